@@ -1,0 +1,452 @@
+/*
+ * ORACLE (test infrastructure, NOT product code).
+ *
+ * CPU restatement of the reference's online log-mel filterbank front end.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * use anything under oracle/.  The shipped path is the HIP kernel in
+ * april_asr_amd/csrc/kernels_fbank.hip.
+ *
+ * Follows (reference file:line):
+ *   src/fbank.c:49-55     povey window           -> orc_make_window
+ *   src/fbank.c:61-95     mel bank table         -> orc_make_melbank
+ *   src/fbank.c:174-306   accept_waveform        -> orc_fbank_accept (+ frame math in orc_fbank_frame)
+ *   src/fbank.c:308-325   flush padding          -> orc_fbank_flush
+ *   src/fbank.c:327-349   pull_segments          -> orc_fbank_pull
+ *   src/fft/pocketfft.c:65-228   twiddle generation (sincos_2pibyn_half, n%4==0 branch)
+ *   src/fft/pocketfft.c:1111-1134 radf2, :1170-1209 radf4, :1730-1764 rfftp_forward,
+ *   :1798-1827 factorisation, :1843-1881 twiddle layout.
+ *
+ * Pinned: bit-exact against the reference's own fbank.c/pocketfft.c compiled
+ * into oracle/_ref/libaprilref.so (tests/test_oracle_fbank.py) and against the
+ * committed golden vectors tests/golden/fbank_*.npz generated from that build.
+ *
+ * Design differences from the reference (behaviour-preserving): the reference
+ * carries a "previous leftover" array and three copy cases; here the stream is
+ * a plain FIFO of samples and frame k is cut at stream offset k*shift.  Power
+ * of two FFT lengths only (factor list of 4s and at most one 2), which is what
+ * every exported model uses (round_pow2 = 1).
+ *
+ * Build with -ffp-contract=off: the reference is built for baseline x86-64
+ * (no FMA contraction) and bit-exactness depends on it.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "orc.h"
+
+/* ------------------------------------------------------------------ */
+/* twiddles: pocketfft.c:65-228 restated for n % 4 == 0               */
+/* ------------------------------------------------------------------ */
+
+/* cos(pi a)-1 and sin(pi a) for |a| <= 0.25 (pocketfft.c:65-90) */
+static void cm1_sin_pi(double a, double *cm1, double *sn)
+{
+    const double s = a * a;
+    double r = -1.0369917389758117e-4;
+    r = fma(r, s, 1.9294935641298806e-3);
+    r = fma(r, s, -2.5806887942825395e-2);
+    r = fma(r, s, 2.3533063028328211e-1);
+    r = fma(r, s, -1.3352627688538006e+0);
+    r = fma(r, s, 4.0587121264167623e+0);
+    r = fma(r, s, -4.9348022005446790e+0);
+    *cm1 = r * s;
+    r = 4.6151442520157035e-4;
+    r = fma(r, s, -7.3700183130883555e-3);
+    r = fma(r, s, 8.2145868949323936e-2);
+    r = fma(r, s, -5.9926452893214921e-1);
+    r = fma(r, s, 2.5501640398732688e+0);
+    r = fma(r, s, -5.1677127800499516e+0);
+    const double s3 = s * a;
+    r = r * s3;
+    *sn = fma(a, 3.1415926535897931e+0, r);
+}
+
+/* (cos,sin)(2 pi i / den) for the first octant, interleaved (pocketfft.c:92-123) */
+static void first_octant(size_t den, double *res)
+{
+    const size_t n = (den + 4) >> 3;
+    if (n == 0) return;
+    res[0] = 1.0; res[1] = 0.0;
+    if (n == 1) return;
+    const size_t blk = (size_t)sqrt((double)n);
+    for (size_t i = 1; i < blk; ++i)
+        cm1_sin_pi((2.0 * (double)i) / (double)den, &res[2 * i], &res[2 * i + 1]);
+    for (size_t start = blk; start < n; start += blk) {
+        double c0, s0;
+        cm1_sin_pi((2.0 * (double)start) / (double)den, &c0, &s0);
+        res[2 * start] = c0 + 1.0;
+        res[2 * start + 1] = s0;
+        size_t end = blk;
+        if (start + end > n) end = n - start;
+        for (size_t i = 1; i < end; ++i) {
+            const double cx = res[2 * i], sx = res[2 * i + 1];
+            res[2 * (start + i)]     = ((c0 * cx - s0 * sx + c0) + cx) + 1.0;
+            res[2 * (start + i) + 1] = (c0 * sx + s0 * cx) + s0 + sx;
+        }
+    }
+    for (size_t i = 1; i < blk; ++i) res[2 * i] += 1.0;
+}
+
+/* table of (cos,sin)(2 pi i / n), i in [0, n/2); n % 4 == 0  (pocketfft.c:172-183,205-214) */
+static void half_circle_table(size_t n, double *res /* 2n doubles of room */)
+{
+    first_octant(n, res);
+    const size_t quart = n >> 2;
+    if ((n & 7) == 0) res[quart] = res[quart + 1] = 0.707106781186547524400844362104849;
+    for (size_t i = 2, j = 2 * quart - 2; i < quart; i += 2, j -= 2) {
+        res[j] = res[i + 1];
+        res[j + 1] = res[i];
+    }
+    const size_t half = n >> 1;
+    for (size_t i = 0; i < half; i += 2) {
+        res[i + half] = -res[i + 1];
+        res[i + half + 1] = res[i];
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* real forward FFT plan (factors 4 and 2 only)                       */
+/* ------------------------------------------------------------------ */
+
+int orc_rfft_plan_init(OrcRfftPlan *p, size_t n)
+{
+    memset(p, 0, sizeof(*p));
+    if (n < 4 || (n & (n - 1)) != 0 || n > ORC_FFT_MAX) return -1;
+    p->n = n;
+    /* pocketfft.c:1798-1812: strip 4s, then one 2 which is swapped to the front */
+    size_t len = n, nf = 0;
+    while ((len % 4) == 0) { p->fct[nf++] = 4; len >>= 2; }
+    if ((len % 2) == 0) {
+        len >>= 1;
+        p->fct[nf++] = 2;
+        size_t t = p->fct[0]; p->fct[0] = p->fct[nf - 1]; p->fct[nf - 1] = t;
+    }
+    if (len != 1) return -1;
+    p->nfct = nf;
+    /* twiddle layout, pocketfft.c:1843-1863 */
+    double *circle = (double *)malloc(2 * n * sizeof(double));
+    if (!circle) return -1;
+    half_circle_table(n, circle);
+    size_t total = 0, l1 = 1;
+    for (size_t k = 0; k < nf; ++k) {
+        size_t ip = p->fct[k], ido = n / (l1 * ip);
+        total += (ip - 1) * (ido - 1);
+        l1 *= ip;
+    }
+    p->tw_store = (double *)calloc(total ? total : 1, sizeof(double));
+    double *ptr = p->tw_store;
+    l1 = 1;
+    for (size_t k = 0; k < nf; ++k) {
+        size_t ip = p->fct[k], ido = n / (l1 * ip);
+        if (k < nf - 1) {
+            p->tw[k] = ptr;
+            ptr += (ip - 1) * (ido - 1);
+            for (size_t j = 1; j < ip; ++j)
+                for (size_t i = 1; i <= (ido - 1) / 2; ++i) {
+                    p->tw[k][(j - 1) * (ido - 1) + 2 * i - 2] = circle[2 * j * l1 * i];
+                    p->tw[k][(j - 1) * (ido - 1) + 2 * i - 1] = circle[2 * j * l1 * i + 1];
+                }
+        }
+        l1 *= ip;
+    }
+    free(circle);
+    return 0;
+}
+
+void orc_rfft_plan_free(OrcRfftPlan *p) { free(p->tw_store); p->tw_store = NULL; }
+
+/* radix-2 real butterfly pass, pocketfft.c:1111-1134 */
+static void pass2(size_t ido, size_t l1, const double *in, double *out, const double *w)
+{
+#define IN2(a, b, c) in[(a) + ido * ((b) + l1 * (c))]
+#define OUT2(a, b, c) out[(a) + ido * ((b) + 2 * (c))]
+    for (size_t k = 0; k < l1; ++k) {
+        OUT2(0, 0, k) = IN2(0, k, 0) + IN2(0, k, 1);
+        OUT2(ido - 1, 1, k) = IN2(0, k, 0) - IN2(0, k, 1);
+    }
+    if ((ido & 1) == 0)
+        for (size_t k = 0; k < l1; ++k) {
+            OUT2(0, 1, k) = -IN2(ido - 1, k, 1);
+            OUT2(ido - 1, 0, k) = IN2(ido - 1, k, 0);
+        }
+    if (ido <= 2) return;
+    for (size_t k = 0; k < l1; ++k)
+        for (size_t i = 2; i < ido; i += 2) {
+            const size_t ic = ido - i;
+            const double wr = w[i - 2], wi = w[i - 1];
+            const double xr = IN2(i - 1, k, 1), xi = IN2(i, k, 1);
+            const double tr2 = wr * xr + wi * xi;
+            const double ti2 = wr * xi - wi * xr;
+            OUT2(i - 1, 0, k) = IN2(i - 1, k, 0) + tr2;
+            OUT2(ic - 1, 1, k) = IN2(i - 1, k, 0) - tr2;
+            OUT2(i, 0, k) = ti2 + IN2(i, k, 0);
+            OUT2(ic, 1, k) = ti2 - IN2(i, k, 0);
+        }
+#undef IN2
+#undef OUT2
+}
+
+/* radix-4 real butterfly pass, pocketfft.c:1170-1209 */
+static void pass4(size_t ido, size_t l1, const double *in, double *out, const double *w)
+{
+    static const double hsqt2 = 0.70710678118654752440;
+#define IN4(a, b, c) in[(a) + ido * ((b) + l1 * (c))]
+#define OUT4(a, b, c) out[(a) + ido * ((b) + 4 * (c))]
+#define W4(x, i) w[(i) + (x) * (ido - 1)]
+    for (size_t k = 0; k < l1; ++k) {
+        const double tr1 = IN4(0, k, 3) + IN4(0, k, 1);
+        OUT4(0, 2, k) = IN4(0, k, 3) - IN4(0, k, 1);
+        const double tr2 = IN4(0, k, 0) + IN4(0, k, 2);
+        OUT4(ido - 1, 1, k) = IN4(0, k, 0) - IN4(0, k, 2);
+        OUT4(0, 0, k) = tr2 + tr1;
+        OUT4(ido - 1, 3, k) = tr2 - tr1;
+    }
+    if ((ido & 1) == 0)
+        for (size_t k = 0; k < l1; ++k) {
+            const double ti1 = -hsqt2 * (IN4(ido - 1, k, 1) + IN4(ido - 1, k, 3));
+            const double tr1 = hsqt2 * (IN4(ido - 1, k, 1) - IN4(ido - 1, k, 3));
+            OUT4(ido - 1, 0, k) = IN4(ido - 1, k, 0) + tr1;
+            OUT4(ido - 1, 2, k) = IN4(ido - 1, k, 0) - tr1;
+            OUT4(0, 3, k) = ti1 + IN4(ido - 1, k, 2);
+            OUT4(0, 1, k) = ti1 - IN4(ido - 1, k, 2);
+        }
+    if (ido <= 2) return;
+    for (size_t k = 0; k < l1; ++k)
+        for (size_t i = 2; i < ido; i += 2) {
+            const size_t ic = ido - i;
+            /* c_j = conj(w_j) * x_j */
+            const double cr2 = W4(0, i - 2) * IN4(i - 1, k, 1) + W4(0, i - 1) * IN4(i, k, 1);
+            const double ci2 = W4(0, i - 2) * IN4(i, k, 1) - W4(0, i - 1) * IN4(i - 1, k, 1);
+            const double cr3 = W4(1, i - 2) * IN4(i - 1, k, 2) + W4(1, i - 1) * IN4(i, k, 2);
+            const double ci3 = W4(1, i - 2) * IN4(i, k, 2) - W4(1, i - 1) * IN4(i - 1, k, 2);
+            const double cr4 = W4(2, i - 2) * IN4(i - 1, k, 3) + W4(2, i - 1) * IN4(i, k, 3);
+            const double ci4 = W4(2, i - 2) * IN4(i, k, 3) - W4(2, i - 1) * IN4(i - 1, k, 3);
+            const double tr1 = cr4 + cr2, tr4 = cr4 - cr2;
+            const double ti1 = ci2 + ci4, ti4 = ci2 - ci4;
+            const double tr2 = IN4(i - 1, k, 0) + cr3, tr3 = IN4(i - 1, k, 0) - cr3;
+            const double ti2 = IN4(i, k, 0) + ci3, ti3 = IN4(i, k, 0) - ci3;
+            OUT4(i - 1, 0, k) = tr2 + tr1;  OUT4(ic - 1, 3, k) = tr2 - tr1;
+            OUT4(i, 0, k) = ti1 + ti2;      OUT4(ic, 3, k) = ti1 - ti2;
+            OUT4(i - 1, 2, k) = tr3 + ti4;  OUT4(ic - 1, 1, k) = tr3 - ti4;
+            OUT4(i, 2, k) = tr4 + ti3;      OUT4(ic, 1, k) = tr4 - ti3;
+        }
+#undef IN4
+#undef OUT4
+#undef W4
+}
+
+/* in-place forward real FFT, FFTPACK half-complex output (pocketfft.c:1730-1764) */
+void orc_rfft_forward(const OrcRfftPlan *p, double *c, double *scratch)
+{
+    const size_t n = p->n;
+    size_t l1 = n;
+    double *a = c, *b = scratch;
+    for (size_t k1 = 0; k1 < p->nfct; ++k1) {
+        const size_t k = p->nfct - k1 - 1;
+        const size_t ip = p->fct[k];
+        const size_t ido = n / l1;
+        l1 /= ip;
+        if (ip == 4) pass4(ido, l1, a, b, p->tw[k]);
+        else         pass2(ido, l1, a, b, p->tw[k]);
+        double *t = a; a = b; b = t;
+    }
+    if (a != c) memcpy(c, a, n * sizeof(double));
+}
+
+/* ------------------------------------------------------------------ */
+/* tables (fbank.c:49-95)                                             */
+/* ------------------------------------------------------------------ */
+
+void orc_make_window(float *out, int n)
+{
+    const double nf = (double)n;
+    for (int i = 0; i < n; ++i)
+        out[i] = (float)pow(0.5 - 0.5 * cos((double)i / nf * 6.283185307), 0.85);
+}
+
+static double mel_of_hz(double f) { return 1127.0 * log(1.0 + f / 700.0); }
+
+void orc_make_melbank(float *tab, int nbins, int nfft_bins, int padded, int rate, int lo_hz, int hi_hz)
+{
+    if (hi_hz == 0) hi_hz = rate / 2;
+    const float bin_hz = (float)rate / (float)padded;
+    const float mlo = (float)mel_of_hz((double)lo_hz);
+    const float mhi = (float)mel_of_hz((double)hi_hz);
+    const float step = (mhi - mlo) / ((float)nbins + 1.0f);
+    for (int m = 0; m < nbins; ++m) {
+        const float left = mlo + (float)m * step;
+        const float center = left + step;
+        const float right = center + step;
+        for (int j = 0; j < nfft_bins; ++j) {
+            const float hz = bin_hz * (float)j;
+            const float mel = (float)mel_of_hz((double)hz);
+            float w = 0.0f;
+            if (mel > left && mel < right)
+                w = (mel <= center) ? (mel - left) / (center - left) : (right - mel) / (right - center);
+            tab[m * nfft_bins + j] = w;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* one frame: fbank.c:228-296                                         */
+/* ------------------------------------------------------------------ */
+
+static const float kFloor = 1.1920928955078125e-07f; /* fbank.c:37 */
+
+void orc_fbank_frame(const OrcFbank *fb, const float *frame /* padded samples */, float *out /* nbins */)
+{
+    const int n = fb->padded;
+    double *d = fb->work;          /* n doubles            */
+    double *r = fb->work + n;      /* n + 1 doubles        */
+    double *scr = fb->work + 2 * n + 1;
+    for (int j = 0; j < n; ++j) d[j] = (double)frame[j];
+    /* DC removal with a float running sum (fbank.c:241-246) */
+    {
+        float sum = 0;
+        for (int j = 0; j < n; ++j) sum += d[j];
+        float mean = sum / n;
+        for (int j = 0; j < n; ++j) d[j] -= mean;
+    }
+    /* pre-emphasis back to front, then the j=0 self term (fbank.c:249-253) */
+    {
+        const float pe = 0.97f;
+        for (int j = n - 1; j > 0; --j) d[j] -= pe * d[j - 1];
+        d[0] -= pe * d[0];
+    }
+    for (int j = 0; j < n; ++j) d[j] *= fb->window[j];
+    /* rfft into r[1..n], then shift so bin k = (r[2k], r[2k+1]) (fbank.c:259-270) */
+    memcpy(r + 1, d, (size_t)n * sizeof(double));
+    orc_rfft_forward(&fb->plan, r + 1, scr);
+    r[0] = r[1];
+    r[1] = 0.0;
+    for (int k = 0; k < fb->nfft_bins; ++k) {
+        float re = (float)r[2 * k], im = (float)r[2 * k + 1];
+        d[k] = re * re + im * im;
+    }
+    for (int m = 0; m < fb->nbins; ++m) {
+        float v = 0.0f;
+        const float *wrow = fb->mel + (size_t)m * fb->nfft_bins;
+        for (int k = 0; k < fb->nfft_bins; ++k) {
+            float p = (float)d[k];
+            v += p * wrow[k];
+        }
+        out[m] = v;
+    }
+    for (int m = 0; m < fb->nbins; ++m) {
+        float v = out[m] > kFloor ? out[m] : kFloor;
+        out[m] = (float)log((double)v);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* online object                                                      */
+/* ------------------------------------------------------------------ */
+
+OrcFbank *orc_fbank_new(int rate, int shift_ms, int len_ms, int nbins, int round_pow2,
+                        int mel_lo, int mel_hi, int seg_count, int seg_step)
+{
+    OrcFbank *fb = (OrcFbank *)calloc(1, sizeof(*fb));
+    fb->shift = shift_ms * rate / 1000;
+    int win = len_ms * rate / 1000;
+    int padded = win;
+    if (round_pow2) { padded = 1; while (padded < win) padded <<= 1; }
+    fb->padded = padded;
+    fb->nfft_bins = padded / 2;
+    fb->nbins = nbins;
+    fb->seg_count = seg_count;
+    fb->seg_step = seg_step;
+    fb->shift_ms = shift_ms;
+    if (orc_rfft_plan_init(&fb->plan, (size_t)padded) != 0) { free(fb); return NULL; }
+    fb->window = (float *)calloc((size_t)padded, sizeof(float));
+    orc_make_window(fb->window, padded);
+    fb->mel = (float *)calloc((size_t)nbins * fb->nfft_bins, sizeof(float));
+    orc_make_melbank(fb->mel, nbins, fb->nfft_bins, padded, rate, mel_lo, mel_hi);
+    fb->ring_frames = seg_count * 32;                 /* fbank.c:147 */
+    fb->ring = (float *)calloc((size_t)fb->ring_frames * nbins, sizeof(float));
+    fb->fifo_cap = 4 * padded + 65536;
+    fb->fifo = (float *)calloc((size_t)fb->fifo_cap, sizeof(float));
+    fb->work = (double *)calloc((size_t)(3 * padded + 2), sizeof(double));
+    return fb;
+}
+
+void orc_fbank_free(OrcFbank *fb)
+{
+    if (!fb) return;
+    orc_rfft_plan_free(&fb->plan);
+    free(fb->window); free(fb->mel); free(fb->ring); free(fb->fifo); free(fb->work);
+    free(fb);
+}
+
+static void push_row(OrcFbank *fb, const float *row, int is_real)
+{
+    memcpy(fb->ring + (size_t)fb->head * fb->nbins, row, (size_t)fb->nbins * sizeof(float));
+    fb->head = (fb->head + 1) % fb->ring_frames;
+    fb->avail += 1;
+    if (is_real) fb->avail_shadow = (long)fb->avail;   /* fbank.c:300 */
+}
+
+/* fbank.c:174-306.  wave == NULL means zeros (fbank.c:175). */
+void orc_fbank_accept(OrcFbank *fb, const float *wave, size_t count)
+{
+    /* The reference processes the call's samples frame by frame and stops
+       (dropping the rest of THIS call) when the ring is full (fbank.c:190-193).
+       FIFO restatement: append, then cut frames while a whole frame is there. */
+    size_t done = 0;
+    float row[256];
+    if (fb->avail + 1 > (size_t)fb->ring_frames) { fb->dropped = 1; return; } /* whole call dropped */
+    while (done < count) {
+        size_t room = (size_t)fb->fifo_cap - fb->fifo_len;
+        size_t take = count - done < room ? count - done : room;
+        if (wave) memcpy(fb->fifo + fb->fifo_len, wave + done, take * sizeof(float));
+        else      memset(fb->fifo + fb->fifo_len, 0, take * sizeof(float));
+        fb->fifo_len += take;
+        done += take;
+        size_t pos = 0;
+        while (fb->fifo_len - pos >= (size_t)fb->padded) {
+            if (fb->avail + 1 > (size_t)fb->ring_frames) {
+                /* ring full: reference warns and returns without saving leftover */
+                fb->fifo_len = 0;
+                fb->dropped = 1;
+                return;
+            }
+            orc_fbank_frame(fb, fb->fifo + pos, row);
+            push_row(fb, row, 1);
+            pos += (size_t)fb->shift;
+        }
+        memmove(fb->fifo, fb->fifo + pos, (fb->fifo_len - pos) * sizeof(float));
+        fb->fifo_len -= pos;
+    }
+}
+
+/* fbank.c:308-325 */
+int orc_fbank_flush(OrcFbank *fb)
+{
+    long lim = -(long)(fb->seg_count * 3);
+    if (fb->avail_shadow < lim) return 0;
+    float row[256];
+    for (int m = 0; m < fb->nbins; ++m) row[m] = (float)log((double)kFloor);
+    while (fb->avail < (size_t)fb->seg_count) push_row(fb, row, 0);
+    return 1;
+}
+
+/* fbank.c:327-349 */
+int orc_fbank_pull(OrcFbank *fb, float *out)
+{
+    if (fb->avail < (size_t)fb->seg_count) return 0;
+    for (int i = 0; i < fb->seg_count; ++i) {
+        int idx = (fb->tail + i) % fb->ring_frames;
+        memcpy(out + (size_t)i * fb->nbins, fb->ring + (size_t)idx * fb->nbins,
+               (size_t)fb->nbins * sizeof(float));
+    }
+    fb->tail = (fb->tail + fb->seg_step) % fb->ring_frames;
+    fb->avail -= (size_t)fb->seg_step;
+    fb->avail_shadow -= fb->seg_step;
+    return 1;
+}
+
+int orc_fbank_stride_ms(const OrcFbank *fb) { return fb->seg_step * fb->shift_ms; }
+const float *orc_fbank_window_ptr(const OrcFbank *fb) { return fb->window; }
+const float *orc_fbank_mel_ptr(const OrcFbank *fb) { return fb->mel; }
+int orc_fbank_padded(const OrcFbank *fb) { return fb->padded; }
