@@ -1,0 +1,407 @@
+"""Writer for synthetic `.april` model files (seeded random weights).
+
+There is no real `aprilv0_en-us.april` in this environment (and no network), so
+tests, smoke() and bench.py generate a model of the same architecture and
+dimensions instead.  The container layout follows the reference's
+`extra/file-format.md` and `extra/export-april.py:374-443`; the three ONNX graphs
+are written in protobuf wire format by hand (no `onnx` package here) and mimic
+what `torch.onnx.export(opset 11)` emits for the icefall
+`lstm_transducer_stateless2` recipe after `convert_scaled_to_non_scaled(is_onnx=True)`
+(reference: `extra/export-april.py:183-331,564`):
+
+  encoder : Conv2dSubsampling (3x Conv2d + DoubleSwish, Linear, BasicNorm) ->
+            L x { LSTM-with-projection written out as Gemm/Split/Sigmoid/Tanh/Mul/MatMul,
+                  residual, FFN (Linear, DoubleSwish, Linear), residual, BasicNorm } ->
+            Linear (joiner.encoder_proj)
+  decoder : Embedding gather -> grouped Conv1d(k=context) -> ReLU -> Linear (joiner.decoder_proj)
+  joiner  : tanh(enc + dec) -> Linear
+
+`variant` knobs change *how* equivalent things are spelled (Gemm vs MatMul+Add,
+folded vs unfolded BasicNorm eps) so the loader's structural weight extraction can
+be tested against more than one spelling.
+"""
+import io
+import struct
+import numpy as np
+
+# ------------------------------------------------------------------ protobuf wire helpers
+FLOAT, INT64 = 1, 7
+A_FLOAT, A_INT, A_STRING, A_TENSOR, A_FLOATS, A_INTS = 1, 2, 3, 4, 6, 7
+
+
+def _varint(n):
+    if n < 0:
+        n += 1 << 64
+    out = bytearray()
+    while True:
+        b = n & 0x7F
+        n >>= 7
+        if n:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _key(field, wt):
+    return _varint((field << 3) | wt)
+
+
+def _f_varint(field, v):
+    return _key(field, 0) + _varint(v)
+
+
+def _f_bytes(field, b):
+    if isinstance(b, str):
+        b = b.encode()
+    if not isinstance(b, bytes):
+        b = bytes(b)
+    return b"".join((_key(field, 2), _varint(len(b)), b))
+
+
+def _f_float(field, v):
+    return _key(field, 5) + struct.pack("<f", v)
+
+
+def tensor_proto(name, arr):
+    arr = np.asarray(arr)
+    if arr.ndim:      # np.ascontiguousarray would promote 0-d to 1-d
+        arr = np.ascontiguousarray(arr)
+    if arr.dtype == np.float32:
+        dt = FLOAT
+    elif arr.dtype == np.int64:
+        dt = INT64
+    else:
+        raise TypeError(arr.dtype)
+    out = b"".join(_f_varint(1, int(d)) for d in arr.shape)
+    out += _f_varint(2, dt)
+    if name:
+        out += _f_bytes(8, name)
+    out += _f_bytes(9, arr.tobytes())
+    return out
+
+
+def _attr(name, value):
+    out = _f_bytes(1, name)
+    if isinstance(value, float):
+        out += _f_float(2, value) + _f_varint(20, A_FLOAT)
+    elif isinstance(value, (int, np.integer)):
+        out += _f_varint(3, int(value)) + _f_varint(20, A_INT)
+    elif isinstance(value, np.ndarray):
+        out += _f_bytes(5, tensor_proto("", value)) + _f_varint(20, A_TENSOR)
+    elif isinstance(value, (list, tuple)):
+        out += b"".join(_f_varint(8, int(v)) for v in value) + _f_varint(20, A_INTS)
+    else:
+        raise TypeError(type(value))
+    return out
+
+
+def node_proto(op, inputs, outputs, name="", **attrs):
+    out = b"".join(_f_bytes(1, i) for i in inputs)
+    out += b"".join(_f_bytes(2, o) for o in outputs)
+    if name:
+        out += _f_bytes(3, name)
+    out += _f_bytes(4, op)
+    out += b"".join(_f_bytes(5, _attr(k, v)) for k, v in attrs.items())
+    return out
+
+
+def value_info(name, elem_type, dims):
+    shape = b"".join(_f_bytes(1, _f_varint(1, int(d))) for d in dims)
+    tensor_type = _f_varint(1, elem_type) + _f_bytes(2, shape)
+    return _f_bytes(1, name) + _f_bytes(2, _f_bytes(1, tensor_type))
+
+
+class GraphBuilder:
+    def __init__(self, name):
+        self.name = name
+        self.nodes, self.inits, self.inputs, self.outputs = [], [], [], []
+        self._n = 0
+
+    def fresh(self, hint="t"):
+        self._n += 1
+        return "%s_%d" % (hint, self._n)
+
+    def init(self, name, arr):
+        self.inits.append(tensor_proto(name, arr))
+        return name
+
+    def node(self, op, inputs, n_out=1, hint=None, **attrs):
+        outs = [self.fresh(hint or op.lower()) for _ in range(n_out)]
+        self.nodes.append(node_proto(op, inputs, outs, name="%s_%d" % (op, len(self.nodes)), **attrs))
+        return outs[0] if n_out == 1 else outs
+
+    def node_named(self, op, inputs, outputs, **attrs):
+        self.nodes.append(node_proto(op, inputs, outputs, name="%s_%d" % (op, len(self.nodes)), **attrs))
+
+    def const(self, arr):
+        return self.node("Constant", [], value=np.asarray(arr))
+
+    def model_bytes(self, opset=11):
+        g = b"".join(_f_bytes(1, n) for n in self.nodes)
+        g += _f_bytes(2, self.name)
+        g += b"".join(_f_bytes(5, t) for t in self.inits)
+        g += b"".join(_f_bytes(11, v) for v in self.inputs)
+        g += b"".join(_f_bytes(12, v) for v in self.outputs)
+        m = _f_varint(1, 6) + _f_bytes(2, "pytorch") + _f_bytes(3, "1.13.1")
+        m += _f_bytes(7, g)
+        m += _f_bytes(8, _f_bytes(1, "") + _f_varint(2, opset))
+        return m
+
+
+# ------------------------------------------------------------------ architecture
+APRILV0_DIMS = dict(n_layers=12, d_model=512, hidden=1024, ffn=2048, joiner=512, vocab=500, mel=80, seg=9,
+                    context=2, dec_groups=128, conv_ch=(8, 32, 128))
+TINY_DIMS = dict(n_layers=2, d_model=64, hidden=128, ffn=128, joiner=64, vocab=40, mel=80, seg=9,
+                 context=2, dec_groups=16, conv_ch=(8, 16, 32))
+LARGE_DIMS = dict(n_layers=16, d_model=768, hidden=1536, ffn=3072, joiner=768, vocab=500, mel=80, seg=9,
+                  context=2, dec_groups=192, conv_ch=(8, 32, 128))
+
+
+def _uniform(rng, shape, fan_in, gain=1.0):
+    b = gain / np.sqrt(float(fan_in))
+    return rng.uniform(-b, b, size=shape).astype(np.float32)
+
+
+def make_weights(dims, seed=2023, joiner_gain=6.0, blank_bias=4.7, blank_id=0):
+    """Seeded weights in PyTorch parameter layout (what the exporter would start from)."""
+    rng = np.random.RandomState(seed)
+    d, H, F, J, V = dims["d_model"], dims["hidden"], dims["ffn"], dims["joiner"], dims["vocab"]
+    c1, c2, c3 = dims["conv_ch"]
+    mel = dims["mel"]
+    f_out = ((mel - 3) // 2 - 1) // 2
+    w = {}
+    w["conv0.w"] = _uniform(rng, (c1, 1, 3, 3), 9);          w["conv0.b"] = _uniform(rng, (c1,), 9)
+    w["conv1.w"] = _uniform(rng, (c2, c1, 3, 3), c1 * 9);    w["conv1.b"] = _uniform(rng, (c2,), c1 * 9)
+    w["conv2.w"] = _uniform(rng, (c3, c2, 3, 3), c2 * 9);    w["conv2.b"] = _uniform(rng, (c3,), c2 * 9)
+    w["embed.w"] = _uniform(rng, (d, c3 * f_out), c3 * f_out); w["embed.b"] = _uniform(rng, (d,), c3 * f_out)
+    w["embed.eps"] = np.float32(0.25)
+    for l in range(dims["n_layers"]):
+        p = "l%d." % l
+        w[p + "w_ih"] = _uniform(rng, (4 * H, d), H); w[p + "b_ih"] = _uniform(rng, (4 * H,), H)
+        w[p + "w_hh"] = _uniform(rng, (4 * H, d), H); w[p + "b_hh"] = _uniform(rng, (4 * H,), H)
+        w[p + "w_hr"] = _uniform(rng, (d, H), H)
+        w[p + "ff1.w"] = _uniform(rng, (F, d), d);    w[p + "ff1.b"] = _uniform(rng, (F,), d)
+        w[p + "ff2.w"] = _uniform(rng, (d, F), F, 0.25); w[p + "ff2.b"] = _uniform(rng, (d,), F, 0.25)
+        w[p + "eps"] = np.float32(rng.uniform(-0.5, 0.5))
+    w["enc_proj.w"] = _uniform(rng, (J, d), d); w["enc_proj.b"] = _uniform(rng, (J,), d)
+    w["emb"] = rng.normal(0, 1.0, size=(V, d)).astype(np.float32)
+    g = dims["dec_groups"]
+    w["dec_conv.w"] = _uniform(rng, (d, d // g, dims["context"]), (d // g) * dims["context"])
+    w["dec_proj.w"] = _uniform(rng, (J, d), d); w["dec_proj.b"] = _uniform(rng, (J,), d)
+    w["out.w"] = _uniform(rng, (V, J), J, joiner_gain); w["out.b"] = _uniform(rng, (V,), J)
+    w["out.b"][blank_id] += np.float32(blank_bias)
+    return w
+
+
+def _double_swish(g, x):
+    one = g.const(np.array(1.0, np.float32))
+    return g.node("Mul", [x, g.node("Sigmoid", [g.node("Sub", [x, one])])])
+
+
+def _basic_norm(g, x, eps_log, name, fold):
+    sq = g.node("Pow", [x, g.const(np.array(2.0, np.float32))])
+    mean = g.node("ReduceMean", [sq], axes=[-1], keepdims=1)
+    if fold:
+        e = g.const(np.array(np.exp(np.float32(eps_log)), np.float32))
+    else:
+        e = g.node("Exp", [g.init(name + ".eps", np.array(eps_log, np.float32))])
+    scale = g.node("Pow", [g.node("Add", [mean, e]), g.const(np.array(-0.5, np.float32))])
+    return g.node("Mul", [x, scale])
+
+
+def _linear3d(g, x, w, b, name):
+    """nn.Linear on a 3-D input: MatMul with the transposed weight as initializer, then Add(bias)."""
+    y = g.node("MatMul", [x, g.init("onnx::MatMul_" + name, np.ascontiguousarray(w.T))])
+    return g.node("Add", [g.init(name + ".bias", b), y]) if b is not None else y
+
+
+def build_encoder(dims, w, variant):
+    g = GraphBuilder("torch_jit")
+    L, d, H = dims["n_layers"], dims["d_model"], dims["hidden"]
+    T, mel = dims["seg"], dims["mel"]
+    g.inputs = [value_info("x", FLOAT, (1, T, mel)), value_info("h", FLOAT, (L, 1, d)), value_info("c", FLOAT, (L, 1, H))]
+    g.outputs = [value_info("encoder_out", FLOAT, (1, 1, dims["joiner"])), value_info("next_h", FLOAT, (L, 1, d)),
+                 value_info("next_c", FLOAT, (L, 1, H))]
+    fold = variant.get("fold_eps", True)
+    t = g.node("Unsqueeze", ["x"], axes=[1])
+    for i, stride in enumerate((1, 2, 2)):
+        attrs = dict(dilations=[1, 1], group=1, kernel_shape=[3, 3], pads=[0, 0, 0, 0], strides=[stride, stride])
+        t = g.node("Conv", [t, g.init("encoder.encoder_embed.conv.%d.weight" % (3 * i), w["conv%d.w" % i]),
+                            g.init("encoder.encoder_embed.conv.%d.bias" % (3 * i), w["conv%d.b" % i])], **attrs)
+        t = _double_swish(g, t)
+    c3 = dims["conv_ch"][2]
+    f_out = ((mel - 3) // 2 - 1) // 2
+    t_out = ((T - 3) // 2 - 1) // 2
+    t = g.node("Transpose", [t], perm=[0, 2, 1, 3])
+    t = g.node("Reshape", [t, g.const(np.array([1, t_out, c3 * f_out], np.int64))])
+    t = _linear3d(g, t, w["embed.w"], w["embed.b"], "encoder.encoder_embed.out")
+    t = _basic_norm(g, t, w["embed.eps"], "encoder.encoder_embed.out_norm", True)
+    src = g.node("Transpose", [t], perm=[1, 0, 2])
+    new_h, new_c = [], []
+    for l in range(L):
+        p = "l%d." % l
+        nm = "encoder.encoder.layers.%d" % l
+        def sl(inp):
+            return g.node("Slice", [inp, g.const(np.array([l], np.int64)), g.const(np.array([l + 1], np.int64)),
+                                    g.const(np.array([0], np.int64)), g.const(np.array([1], np.int64))])
+        h_l, c_l = sl("h"), sl("c")
+        x_t = g.node("Gather", [src, g.const(np.array(0, np.int64))], axis=0)
+        h0 = g.node("Squeeze", [h_l], axes=[0])
+        c0 = g.node("Squeeze", [c_l], axes=[0])
+        if variant.get("lstm_gemm", True):
+            g1 = g.node("Gemm", [x_t, g.init(nm + ".lstm.w_ih", w[p + "w_ih"]), g.init(nm + ".lstm.b_ih", w[p + "b_ih"])],
+                        alpha=1.0, beta=1.0, transB=1)
+            g2 = g.node("Gemm", [h0, g.init(nm + ".lstm.w_hh", w[p + "w_hh"]), g.init(nm + ".lstm.b_hh", w[p + "b_hh"])],
+                        alpha=1.0, beta=1.0, transB=1)
+        else:
+            g1 = g.node("Add", [g.node("MatMul", [x_t, g.init(nm + ".lstm.w_ih_t", np.ascontiguousarray(w[p + "w_ih"].T))]),
+                                g.init(nm + ".lstm.b_ih", w[p + "b_ih"])])
+            g2 = g.node("Add", [g.node("MatMul", [h0, g.init(nm + ".lstm.w_hh_t", np.ascontiguousarray(w[p + "w_hh"].T))]),
+                                g.init(nm + ".lstm.b_hh", w[p + "b_hh"])])
+        gates = g.node("Add", [g1, g2])
+        gi, gf, gg, go = g.node("Split", [gates], n_out=4, axis=1, split=[H] * 4)
+        si, sf, tg, so = g.node("Sigmoid", [gi]), g.node("Sigmoid", [gf]), g.node("Tanh", [gg]), g.node("Sigmoid", [go])
+        c1 = g.node("Add", [g.node("Mul", [sf, c0]), g.node("Mul", [si, tg])])
+        hh = g.node("Mul", [so, g.node("Tanh", [c1])])
+        h1 = g.node("MatMul", [hh, g.init("onnx::MatMul_" + nm + ".lstm.w_hr", np.ascontiguousarray(w[p + "w_hr"].T))])
+        ys = g.node("Concat", [g.node("Unsqueeze", [h1], axes=[0])], axis=0)
+        new_h.append(g.node("Unsqueeze", [h1], axes=[0]))
+        new_c.append(g.node("Unsqueeze", [c1], axes=[0]))
+        src1 = g.node("Add", [ys, src])
+        ff = _linear3d(g, src1, w[p + "ff1.w"], w[p + "ff1.b"], nm + ".feed_forward.0")
+        ff = _double_swish(g, ff)
+        ff = _linear3d(g, ff, w[p + "ff2.w"], w[p + "ff2.b"], nm + ".feed_forward.4")
+        src2 = g.node("Add", [src1, ff])
+        src = _basic_norm(g, src2, w[p + "eps"], nm + ".norm_final", fold)
+    g.node_named("Concat", new_h, ["next_h"], axis=0)
+    g.node_named("Concat", new_c, ["next_c"], axis=0)
+    t = g.node("Transpose", [src], perm=[1, 0, 2])
+    y = g.node("MatMul", [t, g.init("onnx::MatMul_encoder_proj", np.ascontiguousarray(w["enc_proj.w"].T))])
+    g.node_named("Add", [g.init("encoder_proj.bias", w["enc_proj.b"]), y], ["encoder_out"])
+    return g.model_bytes()
+
+
+def build_decoder(dims, w, variant):
+    g = GraphBuilder("torch_jit")
+    d, J, ctx = dims["d_model"], dims["joiner"], dims["context"]
+    g.inputs = [value_info("context", INT64, (1, ctx))]
+    g.outputs = [value_info("decoder_out", FLOAT, (1, 1, J))]
+    e = g.node("Gather", [g.init("decoder.embedding.weight", w["emb"]), "context"], axis=0)
+    e = g.node("Transpose", [e], perm=[0, 2, 1])
+    e = g.node("Conv", [e, g.init("decoder.conv.weight", w["dec_conv.w"])], dilations=[1], group=dims["dec_groups"],
+               kernel_shape=[ctx], pads=[0, 0], strides=[1])
+    e = g.node("Transpose", [e], perm=[0, 2, 1])
+    e = g.node("Relu", [e])
+    y = g.node("MatMul", [e, g.init("onnx::MatMul_decoder_proj", np.ascontiguousarray(w["dec_proj.w"].T))])
+    g.node_named("Add", [g.init("decoder_proj.bias", w["dec_proj.b"]), y], ["decoder_out"])
+    return g.model_bytes()
+
+
+def build_joiner(dims, w, variant):
+    g = GraphBuilder("torch_jit")
+    J, V = dims["joiner"], dims["vocab"]
+    g.inputs = [value_info("encoder_out", FLOAT, (1, 1, J)), value_info("decoder_out", FLOAT, (1, 1, J))]
+    g.outputs = [value_info("logits", FLOAT, (1, 1, V))]
+    t = g.node("Tanh", [g.node("Add", ["encoder_out", "decoder_out"])])
+    y = g.node("MatMul", [t, g.init("onnx::MatMul_output_linear", np.ascontiguousarray(w["out.w"].T))])
+    g.node_named("Add", [g.init("output_linear.bias", w["out.b"]), y], ["logits"])
+    return g.model_bytes()
+
+
+# ------------------------------------------------------------------ vocabulary + params + container
+def make_tokens(vocab, seed=7, punctuation=True):
+    """Deterministic BPE-like vocabulary. id 0 = <blk>; optional punctuation and digits so the
+    reference's punctuation / digit-dot branches (april_session.c:340-358) are reachable."""
+    rng = np.random.RandomState(seed)
+    toks = ["<blk>"]
+    special = [".", ",", "?", "!", " 1", "2", " 3", "4"] if punctuation else []
+    for s in special:
+        if len(toks) < vocab:
+            toks.append(s)
+    letters = "etaoinshrdlucmfwypvbgkqjxz"
+    seen = set(toks)
+    while len(toks) < vocab:
+        n = int(rng.randint(1, 5))
+        s = "".join(letters[int(i)] for i in rng.randint(0, len(letters), size=n))
+        if rng.rand() < 0.45:
+            s = " " + s
+        if s in seen:
+            continue
+        seen.add(s)
+        toks.append(s)
+    return toks
+
+
+def params_block(dims, tokens, blank_id=0, rate=16000, step=4, shift_ms=10, length_ms=25, round_pow2=1, mel_low=20,
+                 mel_high=0):
+    b = io.BytesIO()
+    b.write(b"PARAMS\0\0")
+    for v in (1, dims["seg"], step, dims["mel"], rate, shift_ms, length_ms, round_pow2, mel_low, mel_high, 0,
+              len(tokens), blank_id):
+        b.write(struct.pack("<i", int(v)))
+    for t in tokens:
+        raw = t.encode("utf-8")
+        b.write(struct.pack("<i", len(raw)))
+        b.write(raw)
+    return b.getvalue()
+
+
+def container_bytes(networks, params, name="synthetic", description="seeded synthetic weights", language="en-us",
+                    model_type=1, version=1):
+    """Layout of extra/file-format.md: magic, version, header_size, header, networks..., params."""
+    lang = language.encode("utf-8").ljust(8, b"\0")[:8]
+    nm, ds = name.encode("utf-8"), description.encode("utf-8")
+    header_len = 8 + 8 + len(nm) + 8 + len(ds) + 4 + 16 + 8 + 16 * len(networks)
+    base = 8 + 4 + 8 + header_len
+    offs = []
+    pos = base
+    for n in networks:
+        offs.append(pos)
+        pos += len(n)
+    params_off = pos
+    h = io.BytesIO()
+    h.write(lang)
+    h.write(struct.pack("<Q", len(nm))); h.write(nm)
+    h.write(struct.pack("<Q", len(ds))); h.write(ds)
+    h.write(struct.pack("<I", model_type))
+    h.write(struct.pack("<QQ", params_off, len(params)))
+    h.write(struct.pack("<Q", len(networks)))
+    for o, n in zip(offs, networks):
+        h.write(struct.pack("<QQ", o, len(n)))
+    hb = h.getvalue()
+    assert len(hb) == header_len
+    out = io.BytesIO()
+    out.write(b"APRILMDL")
+    out.write(struct.pack("<I", version))
+    out.write(struct.pack("<Q", header_len))
+    out.write(hb)
+    for n in networks:
+        out.write(n)
+    out.write(params)
+    return out.getvalue()
+
+
+def write_model(path, dims=None, seed=2023, variant=None, punctuation=True, joiner_gain=6.0, blank_bias=4.7,
+                name=None):
+    """Write a synthetic .april file; returns (dims, weights, tokens)."""
+    dims = dict(dims or APRILV0_DIMS)
+    variant = dict(variant or {})
+    w = make_weights(dims, seed=seed, joiner_gain=joiner_gain, blank_bias=blank_bias)
+    toks = make_tokens(dims["vocab"], punctuation=punctuation)
+    nets = [build_encoder(dims, w, variant), build_decoder(dims, w, variant), build_joiner(dims, w, variant)]
+    blob = container_bytes(nets, params_block(dims, toks), name=name or ("synthetic-L%d-d%d" % (dims["n_layers"], dims["d_model"])))
+    with open(path, "wb") as f:
+        f.write(blob)
+    return dims, w, toks
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser(description="write a synthetic .april model")
+    ap.add_argument("out")
+    ap.add_argument("--dims", default="aprilv0", choices=["aprilv0", "tiny", "large"])
+    ap.add_argument("--seed", type=int, default=2023)
+    a = ap.parse_args()
+    write_model(a.out, {"aprilv0": APRILV0_DIMS, "tiny": TINY_DIMS, "large": LARGE_DIMS}[a.dims], seed=a.seed)
+    print("wrote", a.out)

@@ -44,7 +44,7 @@ typedef struct { char *name; int kind; float f; int64_t i; int64_t *ints; int n_
 typedef struct {
     char *op;
     int n_in, n_out;
-    int in[8], out[8];
+    int in[64], out[8];
     Attr *attrs; int n_attrs;
     int is_const;
 } Node;
@@ -182,7 +182,7 @@ static int parse_node(OrcGraph *g, PB b)
     int wt, f; PB sub; uint64_t v;
     int cap_a = 0;
     while ((f = pb_next(&b, &wt, &sub, &v))) {
-        if (f == 1) { char *s = pb_str(&sub); if (nd->n_in >= 8) FAIL("too many inputs"); nd->in[nd->n_in++] = s[0] ? val_id(g, s) : -1; free(s); }
+        if (f == 1) { char *s = pb_str(&sub); if (nd->n_in >= 64) FAIL("too many inputs"); nd->in[nd->n_in++] = s[0] ? val_id(g, s) : -1; free(s); }
         else if (f == 2) { char *s = pb_str(&sub); if (nd->n_out >= 8) FAIL("too many outputs"); nd->out[nd->n_out++] = val_id(g, s); free(s); }
         else if (f == 4) nd->op = pb_str(&sub);
         else if (f == 5) {
@@ -339,7 +339,7 @@ static int bcast_shape(const Ten *a, const Ten *b, int64_t *od, int *orank)
 
 static int binary_op(const char *op, const Ten *a, const Ten *b, Ten *o)
 {
-    int64_t od[MAXR]; int r;
+    int64_t od[MAXR] = {0}; int r;
     if (bcast_shape(a, b, od, &r)) FAIL("%s: shapes not broadcastable", op);
     if (a->dtype != b->dtype) FAIL("%s: dtype mismatch", op);
     ten_alloc(o, a->dtype, r, od);
@@ -445,7 +445,7 @@ static int op_gemm(const Node *nd, const Ten *a, const Ten *b, const Ten *c, Ten
 {
     int tA = (int)attr_i(nd, "transA", 0), tB = (int)attr_i(nd, "transB", 0);
     float alpha = attr_f(nd, "alpha", 1.0f), beta = attr_f(nd, "beta", 1.0f);
-    if (tA || a->rank != 2 || b->rank != 2) FAIL("Gemm: unsupported layout");
+    if (tA || a->rank != 2 || b->rank != 2) FAIL("Gemm: unsupported layout tA=%d ra=%d rb=%d", tA, a->rank, b->rank);
     int64_t M = a->dims[0], K = a->dims[1];
     int64_t N = tB ? b->dims[0] : b->dims[1];
     if ((tB ? b->dims[1] : b->dims[0]) != K) FAIL("Gemm: K mismatch");
@@ -475,7 +475,7 @@ static void copy_elems(Ten *o, size_t oi, const Ten *a, size_t ai, size_t cnt)
 
 static int exec_node(OrcGraph *g, Node *nd)
 {
-    Ten *in[8]; Ten *out[8];
+    Ten *in[64]; Ten *out[8];
     for (int i = 0; i < nd->n_in; ++i) {
         in[i] = nd->in[i] >= 0 ? &g->val[nd->in[i]] : NULL;
         if (in[i] && !in[i]->data) FAIL("%s: input '%s' not computed", nd->op, g->vname[nd->in[i]]);
@@ -610,8 +610,8 @@ static int exec_node(OrcGraph *g, Node *nd)
     }
     if (!strcmp(op, "Slice")) {
         int r = in[0]->rank;
-        int64_t st[MAXR], en[MAXR], sp[MAXR];
-        for (int i = 0; i < r; ++i) { st[i] = 0; en[i] = in[0]->dims[i]; sp[i] = 1; }
+        int64_t st[MAXR], en[MAXR];
+        for (int i = 0; i < r; ++i) { st[i] = 0; en[i] = in[0]->dims[i]; }
         int ns; const int64_t *S, *E, *A = NULL, *P = NULL;
         const Attr *as = attr_find(nd, "starts");
         if (as) { ns = as->n_ints; S = as->ints; E = attr_find(nd, "ends")->ints; const Attr *aa = attr_find(nd, "axes"); A = aa ? aa->ints : NULL; }
@@ -620,9 +620,13 @@ static int exec_node(OrcGraph *g, Node *nd)
             int ax = A ? norm_axis(A[k], r) : k;
             int64_t dim = in[0]->dims[ax], s = S[k], e = E[k], p = P ? P[k] : 1;
             if (p != 1) FAIL("Slice: steps != 1");
-            if (s < 0) s += dim; if (e < 0) e += dim;
-            if (s < 0) s = 0; if (s > dim) s = dim; if (e < 0) e = 0; if (e > dim) e = dim;
-            st[ax] = s; en[ax] = e > s ? e : s; sp[ax] = p;
+            if (s < 0) s += dim;
+            if (e < 0) e += dim;
+            if (s < 0) s = 0;
+            if (s > dim) s = dim;
+            if (e < 0) e = 0;
+            if (e > dim) e = dim;
+            st[ax] = s; en[ax] = e > s ? e : s;
         }
         int64_t d[MAXR]; for (int i = 0; i < r; ++i) d[i] = en[i] - st[i];
         ten_alloc(o, in[0]->dtype, r, d);
