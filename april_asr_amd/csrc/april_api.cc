@@ -1,0 +1,445 @@
+// The exported C ABI: the reference's eleven aam_* / aas_* entry points
+// (include/april_api.h, reference april_api.h:58-196) and the engine-level
+// aprilx_* entry points (include/aprilx_engine.h).
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include "../../include/april_api.h"
+#include "../../include/aprilx_engine.h"
+#include "common.h"
+#include "session.h"
+
+using namespace aprilx;
+
+namespace aprilx { int g_loglevel = LOG_WARNING; }
+
+struct AprilASRModel_i { Model m; };
+struct AprilASRSession_i { Session s; };
+
+namespace {
+bool g_inited = false;
+int g_client_version = 0;
+std::vector<int> g_devices;
+
+int env_int(const char *name, int def)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : def;
+}
+
+bool build_runtime(Model &m, const float *blob_host, const float *blob_device)
+{
+    const ModelParams &P = m.host.params;
+    if (!build_fbank_tables(P.sample_rate, P.frame_shift_ms, P.frame_length_ms, P.mel_features, P.round_pow2 != 0, P.mel_low, P.mel_high, m.ftab)) {
+        LOGE("aam: unsupported frame length (FFT size must be a power of two)");
+        return false;
+    }
+    if (m.layout.dims.embed_in % 16 || m.layout.dims.d_model % 16 || m.layout.dims.hidden % 16 || m.layout.dims.ffn % 16 || m.layout.dims.joiner % 16) {
+        LOGE("aam: layer widths must be multiples of 16 for the MFMA kernels");
+        return false;
+    }
+    if (m.layout.dims.d_model > 2048) { LOGE("aam: d_model > 2048 unsupported by the row-norm kernel"); return false; }
+    m.tok_class = classify_tokens(P);
+    EngineConfig cfg;
+    cfg.max_slots = env_int("APRIL_MAX_SESSIONS", 4096);
+    cfg.max_batch = std::min(cfg.max_slots, env_int("APRIL_MAX_BATCH", 2048));
+    for (int dev : g_devices) {
+        cfg.device = dev;
+        const bool same_dev_blob = blob_device != nullptr;
+        Engine *e = new Engine(cfg, m.layout, blob_host, same_dev_blob ? blob_device : nullptr, P, m.ftab);
+        m.engines.push_back(e);
+        m.scheds.push_back(new Scheduler(&m, e));
+    }
+    return true;
+}
+
+// ---- blob (de)serialisation: [magic][meta_bytes][weight_floats][meta][pad to 256][weights]
+struct BlobHeader { char magic[8]; uint64_t meta_bytes, weight_floats, weights_offset; };
+
+void put(std::string &b, const void *p, size_t n) { b.append((const char *)p, n); }
+template <typename T> void putv(std::string &b, const T &v) { put(b, &v, sizeof v); }
+void puts_(std::string &b, const std::string &s) { uint64_t n = s.size(); putv(b, n); put(b, s.data(), n); }
+
+std::string make_meta(const Model &m)
+{
+    std::string b;
+    puts_(b, m.host.language); puts_(b, m.host.name); puts_(b, m.host.description);
+    const ModelParams &P = m.host.params;
+    int32_t ints[13] = {P.batch_size, P.segment_size, P.segment_step, P.mel_features, P.sample_rate, P.frame_shift_ms, P.frame_length_ms,
+                        P.round_pow2, P.mel_low, P.mel_high, P.snip_edges, P.token_count, P.blank_id};
+    put(b, ints, sizeof ints);
+    uint64_t stride = P.token_stride; putv(b, stride);
+    put(b, P.tokens.data(), P.tokens.size());
+    putv(b, m.layout.dims);
+    uint8_t hb = m.layout.has_dec_conv_b; putv(b, hb);
+    putv(b, m.layout.embed_eps);
+    put(b, m.layout.norm_eps.data(), m.layout.norm_eps.size() * 4);
+    return b;
+}
+
+struct MetaRd {
+    const char *p; size_t n, pos = 0; bool bad = false;
+    void get(void *dst, size_t k) { if (pos + k > n) { bad = true; return; } memcpy(dst, p + pos, k); pos += k; }
+    template <typename T> T val() { T v{}; get(&v, sizeof v); return v; }
+    std::string str() { uint64_t k = val<uint64_t>(); if (bad || pos + k > n) { bad = true; return ""; } std::string s(p + pos, (size_t)k); pos += (size_t)k; return s; }
+};
+
+bool parse_meta(const char *p, size_t n, Model &m)
+{
+    MetaRd r{p, n};
+    m.host.language = r.str(); m.host.name = r.str(); m.host.description = r.str();
+    int32_t ints[13]; r.get(ints, sizeof ints);
+    ModelParams &P = m.host.params;
+    P.batch_size = ints[0]; P.segment_size = ints[1]; P.segment_step = ints[2]; P.mel_features = ints[3]; P.sample_rate = ints[4];
+    P.frame_shift_ms = ints[5]; P.frame_length_ms = ints[6]; P.round_pow2 = ints[7]; P.mel_low = ints[8]; P.mel_high = ints[9];
+    P.snip_edges = ints[10]; P.token_count = ints[11]; P.blank_id = ints[12];
+    P.token_stride = (size_t)r.val<uint64_t>();
+    if (r.bad || P.token_count <= 0 || P.token_count > 16384 || P.token_stride == 0 || P.token_stride > 4096) return false;
+    P.tokens.resize((size_t)P.token_count * P.token_stride);
+    r.get(P.tokens.data(), P.tokens.size());
+    NetDims d = r.val<NetDims>();
+    const bool hb = r.val<uint8_t>() != 0;
+    if (r.bad || d.n_layers <= 0 || d.n_layers > 256) return false;
+    plan_layout(d, hb, m.layout);
+    m.layout.embed_eps = r.val<float>();
+    m.layout.norm_eps.resize((size_t)d.n_layers);
+    r.get(m.layout.norm_eps.data(), (size_t)d.n_layers * 4);
+    m.host.dims = d;
+    return !r.bad;
+}
+
+void free_host_weights(HostModel &h)
+{
+    for (int i = 0; i < 3; ++i) { std::vector<float>().swap(h.conv_w[i]); std::vector<float>().swap(h.conv_b[i]); }
+    std::vector<float>().swap(h.w_embed); std::vector<LayerWeights>().swap(h.layers);
+    std::vector<float>().swap(h.w_encproj); std::vector<float>().swap(h.emb); std::vector<float>().swap(h.dec_conv);
+    std::vector<float>().swap(h.w_decproj); std::vector<float>().swap(h.w_out);
+}
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------ reference ABI
+void aam_api_init(int version)
+{
+    g_client_version = version;                       // stored, never checked (reference src/init.c:34)
+    if (const char *lv = getenv("APRIL_LOG_LEVEL")) {
+        static const char *names[5] = {"DEBUG", "INFO", "WARNING", "ERROR", "NONE"};
+        for (int i = 0; i < 5; ++i) if (strcmp(lv, names[i]) == 0) g_loglevel = i;
+    }
+    g_devices.clear();
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        LOGE("aam_api_init: no HIP device visible; aam_create_model will fail (this build has no CPU path)");
+        g_inited = false;
+        return;
+    }
+    if (const char *dv = getenv("APRIL_GPU_DEVICES")) {
+        std::stringstream ss(dv); std::string item;
+        while (std::getline(ss, item, ',')) if (!item.empty()) { int d = atoi(item.c_str()); if (d >= 0 && d < count) g_devices.push_back(d); }
+    }
+    if (g_devices.empty()) g_devices.push_back(0);
+    g_inited = true;
+}
+
+AprilASRModel aam_create_model(const char *model_path)
+{
+    if (!g_inited) { LOGE("aam: not initialised (call aam_api_init; a HIP device is required)"); return nullptr; }
+    AprilASRModel_i *h = new AprilASRModel_i();
+    std::string err;
+    if (!load_april_file(model_path, h->m.host, err)) { LOGE("aam: failed to load %s: %s", model_path ? model_path : "(null)", err.c_str()); delete h; return nullptr; }
+    plan_layout(h->m.host.dims, !h->m.host.dec_conv_b.empty(), h->m.layout);
+    std::vector<float> blob;
+    pack_weights(h->m.host, h->m.layout, blob);
+    if (!build_runtime(h->m, blob.data(), nullptr)) { delete h; return nullptr; }
+    free_host_weights(h->m.host);
+    LOGI("aam: loaded model %s", h->m.host.name.c_str());
+    return h;
+}
+
+// Host-only load: parse + extract + pack, no GPU objects.  For loader / state-machine tests on
+// machines without a GPU; sessions cannot be created on such a model.
+AprilASRModel aprilx_model_load_host(const char *model_path)
+{
+    AprilASRModel_i *h = new AprilASRModel_i();
+    std::string err;
+    if (!load_april_file(model_path, h->m.host, err)) { LOGE("aam: failed to load %s: %s", model_path ? model_path : "(null)", err.c_str()); delete h; return nullptr; }
+    plan_layout(h->m.host.dims, !h->m.host.dec_conv_b.empty(), h->m.layout);
+    pack_weights(h->m.host, h->m.layout, h->m.host_blob);
+    const ModelParams &P = h->m.host.params;
+    if (!build_fbank_tables(P.sample_rate, P.frame_shift_ms, P.frame_length_ms, P.mel_features, P.round_pow2 != 0, P.mel_low, P.mel_high, h->m.ftab)) { delete h; return nullptr; }
+    h->m.tok_class = classify_tokens(P);
+    free_host_weights(h->m.host);
+    return h;
+}
+
+const char *aam_get_name(AprilASRModel model) { return model->m.host.name.c_str(); }
+const char *aam_get_description(AprilASRModel model) { return model->m.host.description.c_str(); }
+const char *aam_get_language(AprilASRModel model) { return model->m.host.language.c_str(); }
+size_t aam_get_sample_rate(AprilASRModel model) { return (size_t)model->m.host.params.sample_rate; }
+void aam_free(AprilASRModel model) { if (model) delete model; }
+
+AprilASRSession aas_create_session(AprilASRModel model, AprilConfig config)
+{
+    if (!model) return nullptr;
+    if (config.handler == nullptr) {                   // reference src/april_session.c:81-85
+        LOGE("No handler provided! A handler is required, please provide a handler");
+        return nullptr;
+    }
+    Model &m = model->m;
+    if (m.engines.empty()) { LOGE("aas: model was loaded host-only (no GPU engine); cannot create sessions"); return nullptr; }
+    size_t best = 0;
+    for (size_t i = 1; i < m.engines.size(); ++i) if (m.engines[i]->live_slots() < m.engines[best]->live_slots()) best = i;
+    const int slot = m.engines[best]->alloc_slot();
+    if (slot < 0) { LOGE("aas: no free session slot (APRIL_MAX_SESSIONS)"); return nullptr; }
+    AprilASRSession_i *h = new AprilASRSession_i();
+    Session &s = h->s;
+    s.model = &m; s.eng = m.engines[best]; s.sched = m.scheds[best]; s.slot = slot;
+    s.handler = config.handler; s.userdata = config.userdata;
+    s.sync_mode = (config.flags & (APRIL_CONFIG_FLAG_ASYNC_RT_BIT | APRIL_CONFIG_FLAG_ASYNC_NO_RT_BIT)) == 0;   // :28
+    s.realtime_flag = (config.flags & APRIL_CONFIG_FLAG_ASYNC_RT_BIT) != 0;
+    s.fb.shift = m.ftab.shift; s.fb.padded = m.ftab.padded;
+    s.fb.seg_count = m.host.params.segment_size; s.fb.seg_step = m.host.params.segment_step;
+    s.fb.ring_frames = s.eng->ring_frames();
+    s.greedy.init(&m.host.params, &m.tok_class);
+    s.sched->attach(&s);
+    return h;
+}
+
+void aas_feed_pcm16(AprilASRSession session, short *pcm16, size_t short_count)
+{
+    Session *s = &session->s;
+    const short *p = pcm16;
+    s->sched->submit(1, &s, &p, &short_count, false, s->sync_mode);
+    if (s->sync_mode) s->sched->deliver_sync_events(s);
+}
+
+void aas_flush(AprilASRSession session)
+{
+    Session *s = &session->s;
+    s->sched->submit(1, &s, nullptr, nullptr, true, s->sync_mode);
+    if (s->sync_mode) s->sched->deliver_sync_events(s);
+}
+
+float aas_realtime_get_speedup(AprilASRSession session) { (void)session; return 1.0f; }
+
+void aas_free(AprilASRSession session)
+{
+    if (!session) return;
+    Session *s = &session->s;
+    s->sched->detach(s);
+    s->eng->free_slot(s->slot);
+    delete session;
+}
+
+// ------------------------------------------------------------------ engine-level ABI
+int aprilx_model_dims(AprilASRModel model, AprilxDims *o)
+{
+    if (!model || !o) return -1;
+    const NetDims &d = model->m.layout.dims;
+    const ModelParams &P = model->m.host.params;
+    o->n_layers = d.n_layers; o->d_model = d.d_model; o->hidden = d.hidden; o->ffn = d.ffn; o->joiner = d.joiner; o->vocab = d.vocab;
+    o->mel = d.mel; o->seg = d.seg; o->seg_step = P.segment_step; o->context = d.context;
+    o->fft_size = model->m.ftab.padded; o->frame_shift = model->m.ftab.shift; o->sample_rate = P.sample_rate; o->blank_id = P.blank_id;
+    o->n_devices = (int)model->m.engines.size();
+    int64_t n = 0; int cin = 1;
+    for (int i = 0; i < 3; ++i) { n += (int64_t)d.conv_ch[i] * cin * 9 + d.conv_ch[i]; cin = d.conv_ch[i]; }
+    n += (int64_t)d.embed_in * d.d_model + d.d_model;
+    n += (int64_t)d.n_layers * ((int64_t)2 * d.d_model * 4 * d.hidden + 8 * d.hidden + (int64_t)d.hidden * d.d_model + (int64_t)2 * d.d_model * d.ffn + d.ffn + d.d_model + 1);
+    n += (int64_t)d.d_model * d.joiner + d.joiner + (int64_t)d.vocab * d.d_model + (int64_t)d.d_model * (d.d_model / d.dec_groups) * d.context;
+    n += (int64_t)d.d_model * d.joiner + d.joiner + (int64_t)d.joiner * d.vocab + d.vocab;
+    o->param_count = n;
+    return 0;
+}
+
+const char *aprilx_model_token(AprilASRModel model, int32_t id)
+{
+    if (!model || id < 0 || id >= model->m.host.params.token_count) return nullptr;
+    return model->m.host.params.token((size_t)id);
+}
+
+size_t aprilx_model_blob_size(AprilASRModel model)
+{
+    const std::string meta = make_meta(model->m);
+    const size_t woff = (sizeof(BlobHeader) + meta.size() + 255) & ~(size_t)255;
+    return woff + model->m.layout.total * 4;
+}
+
+int aprilx_model_export_blob(AprilASRModel model, void *dst, size_t dst_size)
+{
+    const std::string meta = make_meta(model->m);
+    BlobHeader hd;
+    memcpy(hd.magic, "APXBLOB1", 8);
+    hd.meta_bytes = meta.size(); hd.weight_floats = model->m.layout.total;
+    hd.weights_offset = (sizeof(BlobHeader) + meta.size() + 255) & ~(size_t)255;
+    if (dst_size < hd.weights_offset + hd.weight_floats * 4) return -1;
+    memset(dst, 0, (size_t)hd.weights_offset);
+    memcpy(dst, &hd, sizeof hd);
+    memcpy((char *)dst + sizeof hd, meta.data(), meta.size());
+    if (model->m.engines.empty()) { memcpy((char *)dst + hd.weights_offset, model->m.host_blob.data(), hd.weight_floats * 4); return 0; }
+    Engine *e = model->m.engines[0];
+    HIP_CHECK(hipSetDevice(e->device()));
+    HIP_CHECK(hipMemcpy((char *)dst + hd.weights_offset, e->weights_device(), hd.weight_floats * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+AprilASRModel aprilx_model_from_blob(const void *blob, size_t size, int blob_is_device_ptr)
+{
+    if (!g_inited) { LOGE("aprilx: not initialised"); return nullptr; }
+    BlobHeader hd;
+    if (size < sizeof hd) return nullptr;
+    if (blob_is_device_ptr) { HIP_CHECK(hipSetDevice(g_devices[0])); HIP_CHECK(hipMemcpy(&hd, blob, sizeof hd, hipMemcpyDeviceToHost)); }
+    else memcpy(&hd, blob, sizeof hd);
+    if (memcmp(hd.magic, "APXBLOB1", 8) != 0 || hd.weights_offset + hd.weight_floats * 4 > size || sizeof hd + hd.meta_bytes > hd.weights_offset) { LOGE("aprilx: bad blob"); return nullptr; }
+    std::string meta((size_t)hd.meta_bytes, '\0');
+    if (blob_is_device_ptr) HIP_CHECK(hipMemcpy(&meta[0], (const char *)blob + sizeof hd, meta.size(), hipMemcpyDeviceToHost));
+    else memcpy(&meta[0], (const char *)blob + sizeof hd, meta.size());
+    AprilASRModel_i *h = new AprilASRModel_i();
+    if (!parse_meta(meta.data(), meta.size(), h->m) || h->m.layout.total != hd.weight_floats) { LOGE("aprilx: blob metadata invalid"); delete h; return nullptr; }
+    const float *w = (const float *)((const char *)blob + hd.weights_offset);
+    std::vector<float> staged;
+    const float *host_w = nullptr, *dev_w = nullptr;
+    if (blob_is_device_ptr) {
+        if (g_devices.size() == 1) dev_w = w;
+        else { staged.resize((size_t)hd.weight_floats); HIP_CHECK(hipMemcpy(staged.data(), w, staged.size() * 4, hipMemcpyDeviceToHost)); host_w = staged.data(); }
+    } else host_w = w;
+    if (!build_runtime(h->m, host_w, dev_w)) { delete h; return nullptr; }
+    return h;
+}
+
+void aprilx_feed_many(size_t n, AprilASRSession *sessions, const short *const *pcm16, const size_t *short_counts)
+{
+    if (n == 0) return;
+    // group by scheduler (GPU); each group is submitted at once so the sessions step together
+    std::vector<Scheduler *> scheds;
+    for (size_t i = 0; i < n; ++i) { Scheduler *sc = sessions[i]->s.sched; if (std::find(scheds.begin(), scheds.end(), sc) == scheds.end()) scheds.push_back(sc); }
+    std::vector<std::vector<Session *>> groups(scheds.size());
+    std::vector<std::vector<const short *>> gp(scheds.size());
+    std::vector<std::vector<size_t>> gc(scheds.size());
+    for (size_t i = 0; i < n; ++i) {
+        size_t k = (size_t)(std::find(scheds.begin(), scheds.end(), sessions[i]->s.sched) - scheds.begin());
+        groups[k].push_back(&sessions[i]->s); gp[k].push_back(pcm16[i]); gc[k].push_back(short_counts[i]);
+    }
+    // queue on every GPU first (no wait), then wait, so GPUs run concurrently
+    for (size_t k = 0; k < scheds.size(); ++k) scheds[k]->submit((int)groups[k].size(), groups[k].data(), gp[k].data(), gc[k].data(), false, false);
+    for (size_t i = 0; i < n; ++i) aprilx_session_drain(sessions[i]);
+    for (size_t i = 0; i < n; ++i) if (sessions[i]->s.sync_mode) sessions[i]->s.sched->deliver_sync_events(&sessions[i]->s);
+}
+
+void aprilx_flush_many(size_t n, AprilASRSession *sessions)
+{
+    for (size_t i = 0; i < n; ++i) { Session *s = &sessions[i]->s; s->sched->submit(1, &s, nullptr, nullptr, true, false); }
+    for (size_t i = 0; i < n; ++i) aprilx_session_drain(sessions[i]);
+    for (size_t i = 0; i < n; ++i) if (sessions[i]->s.sync_mode) sessions[i]->s.sched->deliver_sync_events(&sessions[i]->s);
+}
+
+void aprilx_session_drain(AprilASRSession session)
+{
+    Session *s = &session->s;
+    s->sched->submit(0, nullptr, nullptr, nullptr, false, false);   // wake-up only
+    s->sched->wait_idle(s);
+}
+
+int aprilx_run_encoder(AprilASRModel model, int n, const float *x, const float *h, const float *c, float *eout, float *h2, float *c2)
+{
+    if (!model || n <= 0 || model->m.engines.empty()) return -1;
+    model->m.engines[0]->debug_encoder(n, x, h, c, eout, h2, c2);
+    return 0;
+}
+int aprilx_run_decoder(AprilASRModel model, int n, const int64_t *context, float *dout)
+{
+    if (!model || n <= 0 || model->m.engines.empty()) return -1;
+    model->m.engines[0]->debug_decoder(n, context, dout);
+    return 0;
+}
+int aprilx_run_joiner(AprilASRModel model, int n, const float *eout, const float *dout, float *logits)
+{
+    if (!model || n <= 0 || model->m.engines.empty()) return -1;
+    model->m.engines[0]->debug_joiner(n, eout, dout, logits);
+    return 0;
+}
+int aprilx_run_fbank(AprilASRModel model, int n_frames, const int16_t *pcm_frames, float *out)
+{
+    if (!model || model->m.engines.empty() || n_frames <= 0 || n_frames > model->m.engines[0]->ring_frames()) return -1;
+    model->m.engines[0]->debug_fbank(n_frames, pcm_frames, out);
+    return 0;
+}
+
+void aprilx_session_trace_logits(AprilASRSession session, float *buf, size_t cap_floats, size_t *used_floats)
+{
+    Session *s = &session->s;
+    s->sched->wait_idle(s);
+    s->trace_buf = buf; s->trace_cap = cap_floats; s->trace_used = used_floats;
+}
+
+uint64_t aprilx_session_chunks(AprilASRSession session) { return session->s.chunks; }
+
+void aprilx_model_stats(AprilASRModel model, int device_index, AprilxStats *out)
+{
+    memset(out, 0, sizeof *out);
+    if (!model || device_index < 0 || device_index >= (int)model->m.scheds.size()) return;
+    const SchedStats st = model->m.scheds[(size_t)device_index]->stats();
+    out->ticks = st.ticks; out->steps = st.steps; out->chunks = st.chunks; out->rounds = st.rounds; out->frames = st.frames; out->max_batch_seen = st.max_batch_seen;
+    Engine *e = model->m.engines[(size_t)device_index];
+    for (int i = 0; i < 6; ++i) { out->kernel_ms[i] = e->timing(i).ms; out->kernel_launches[i] = (uint64_t)e->timing(i).launches; }
+}
+
+void aprilx_model_profile(AprilASRModel model, int enable)
+{
+    for (Engine *e : model->m.engines) { e->set_profiling(enable != 0); if (enable) e->reset_timing(); }
+}
+
+struct AprilxGreedy_i {
+    Greedy g; AprilRecognitionResultHandler handler; void *ud; std::vector<Event> ev;
+    void flush_events() { for (auto &e : ev) handler(ud, (AprilResultType)e.type, e.tokens.size(), e.tokens.empty() ? nullptr : e.tokens.data()); ev.clear(); }
+};
+
+AprilxGreedy aprilx_greedy_create(AprilASRModel model, AprilRecognitionResultHandler handler, void *userdata)
+{
+    if (!model || !handler) return nullptr;
+    AprilxGreedy_i *g = new AprilxGreedy_i();
+    g->g.init(&model->m.host.params, &model->m.tok_class);
+    g->g.reset_context_to_blank();
+    g->handler = handler; g->ud = userdata;
+    return g;
+}
+int aprilx_greedy_step(AprilxGreedy g, int32_t idx, float max_val, float blank_val, float early_emit, size_t now_ms, int32_t *ctx_out)
+{
+    JointResult r{idx, max_val, blank_val};
+    const bool blank = g->g.on_joint(r, early_emit, now_ms, g->ev);
+    g->flush_events();
+    if (ctx_out) { ctx_out[0] = g->g.ctx[0]; ctx_out[1] = g->g.ctx[1]; }
+    return blank ? 1 : 0;
+}
+void aprilx_greedy_finish(AprilxGreedy g) { g->g.finish_flush(g->ev); g->flush_events(); }
+void aprilx_greedy_free(AprilxGreedy g) { delete g; }
+
+int aprilx_model_fbank_tables(AprilASRModel model, float *window, float *mel)
+{
+    if (!model) return -1;
+    const FbankHostTables &t = model->m.ftab;
+    if (window) memcpy(window, t.window.data(), t.window.size() * 4);
+    if (mel) memcpy(mel, t.mel.data(), t.mel.size() * 4);
+    return t.padded;
+}
+
+int aprilx_probe_file(const char *path, char *err, size_t err_cap)
+{
+    FILE *fd = fopen(path, "rb");
+    std::string e;
+    if (!fd) e = "cannot open file";
+    else {
+        fseek(fd, 0, SEEK_END); long sz = ftell(fd); fseek(fd, 0, SEEK_SET);
+        std::vector<uint8_t> blob(sz > 0 ? (size_t)sz : 0);
+        size_t got = blob.empty() ? 0 : fread(blob.data(), 1, blob.size(), fd);
+        fclose(fd);
+        ContainerInfo info;
+        if (got != blob.size()) e = "short read";
+        else if (parse_container(blob, info, e)) { if (err && err_cap) err[0] = 0; return 0; }
+    }
+    if (err && err_cap) { strncpy(err, e.c_str(), err_cap - 1); err[err_cap - 1] = 0; }
+    return -1;
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+// Online log-mel filterbank on gfx950: one wavefront per 10 ms frame, batched over
+// sessions x new frames.  Bit-compatible restatement of the reference's per-frame
+// arithmetic (src/fbank.c:228-296) including its FFT (src/fft/pocketfft.c radf4 /
+// radf2 passes, :1111-1134,1170-1209,1730-1764): fp64 butterflies in the same
+// operation order, fp32 power and mel accumulation in the same order, compiled
+// with -ffp-contract=off (the reference is built without FMA contraction).
+//
+// Data flow per frame: the frame's `padded` PCM16 samples are read from the staged
+// HBM buffer (coalesced 2-byte loads), windowed into LDS as fp64, the radix passes
+// ping-pong between two LDS buffers (one butterfly task per lane per step), power
+// goes back to LDS as fp32, each of the first `nbins` lanes walks its triangular
+// mel filter sequentially, and the log row is written to the session's feature ring
+// in HBM.  Padding rows (flush) are rows of log(kEps) (src/fbank.c:308-325).
+//
+// DC removal: the reference keeps a *float* running sum of the frame (fbank.c:241-246).
+// Samples are k/32768 with integer k, so for padded <= 512 every partial sum is an
+// exact multiple of 2^-15 below 2^9 and the float sum is exact; it equals the integer
+// sum of the PCM samples / 32768, which is what the wave reduction computes.  For
+// larger frames lane 0 replays the sequential float chain.
+#include "kernels.h"
+
+namespace aprilx {
+
+__device__ __forceinline__ float pcm_to_float(int16_t s) { return (float)s / 32768.0f; }   // april_session.c:520-522
+
+// radix-4 pass: cc = in[(a) + ido*((b) + l1*(c))], ch = out[(a) + ido*((b) + 4*(c))]
+__device__ void fft_pass4(int ido, int l1, const double *in, double *out, const double *w, int lane)
+{
+    const double hsqt2 = 0.70710678118654752440;
+#define CC(a, b, c) in[(a) + ido * ((b) + l1 * (c))]
+#define CH(a, b, c) out[(a) + ido * ((b) + 4 * (c))]
+#define WA(x, i) w[(i) + (x) * (ido - 1)]
+    for (int k = lane; k < l1; k += 64) {
+        const double tr1 = CC(0, k, 3) + CC(0, k, 1);
+        CH(0, 2, k) = CC(0, k, 3) - CC(0, k, 1);
+        const double tr2 = CC(0, k, 0) + CC(0, k, 2);
+        CH(ido - 1, 1, k) = CC(0, k, 0) - CC(0, k, 2);
+        CH(0, 0, k) = tr2 + tr1;
+        CH(ido - 1, 3, k) = tr2 - tr1;
+    }
+    if ((ido & 1) == 0) {
+        for (int k = lane; k < l1; k += 64) {
+            const double ti1 = -hsqt2 * (CC(ido - 1, k, 1) + CC(ido - 1, k, 3));
+            const double tr1 = hsqt2 * (CC(ido - 1, k, 1) - CC(ido - 1, k, 3));
+            CH(ido - 1, 0, k) = CC(ido - 1, k, 0) + tr1;
+            CH(ido - 1, 2, k) = CC(ido - 1, k, 0) - tr1;
+            CH(0, 3, k) = ti1 + CC(ido - 1, k, 2);
+            CH(0, 1, k) = ti1 - CC(ido - 1, k, 2);
+        }
+    }
+    if (ido > 2) {
+        const int nq = (ido - 1) / 2;                 // i = 2, 4, ... < ido
+        for (int t = lane; t < l1 * nq; t += 64) {
+            const int k = t / nq, i = 2 + 2 * (t % nq), ic = ido - i;
+            const double cr2 = WA(0, i - 2) * CC(i - 1, k, 1) + WA(0, i - 1) * CC(i, k, 1);
+            const double ci2 = WA(0, i - 2) * CC(i, k, 1) - WA(0, i - 1) * CC(i - 1, k, 1);
+            const double cr3 = WA(1, i - 2) * CC(i - 1, k, 2) + WA(1, i - 1) * CC(i, k, 2);
+            const double ci3 = WA(1, i - 2) * CC(i, k, 2) - WA(1, i - 1) * CC(i - 1, k, 2);
+            const double cr4 = WA(2, i - 2) * CC(i - 1, k, 3) + WA(2, i - 1) * CC(i, k, 3);
+            const double ci4 = WA(2, i - 2) * CC(i, k, 3) - WA(2, i - 1) * CC(i - 1, k, 3);
+            const double tr1 = cr4 + cr2, tr4 = cr4 - cr2;
+            const double ti1 = ci2 + ci4, ti4 = ci2 - ci4;
+            const double tr2 = CC(i - 1, k, 0) + cr3, tr3 = CC(i - 1, k, 0) - cr3;
+            const double ti2 = CC(i, k, 0) + ci3, ti3 = CC(i, k, 0) - ci3;
+            CH(i - 1, 0, k) = tr2 + tr1;  CH(ic - 1, 3, k) = tr2 - tr1;
+            CH(i, 0, k) = ti1 + ti2;      CH(ic, 3, k) = ti1 - ti2;
+            CH(i - 1, 2, k) = tr3 + ti4;  CH(ic - 1, 1, k) = tr3 - ti4;
+            CH(i, 2, k) = tr4 + ti3;      CH(ic, 1, k) = tr4 - ti3;
+        }
+    }
+#undef CC
+#undef CH
+#undef WA
+}
+
+__device__ void fft_pass2(int ido, int l1, const double *in, double *out, const double *w, int lane)
+{
+#define CC(a, b, c) in[(a) + ido * ((b) + l1 * (c))]
+#define CH(a, b, c) out[(a) + ido * ((b) + 2 * (c))]
+    for (int k = lane; k < l1; k += 64) {
+        CH(0, 0, k) = CC(0, k, 0) + CC(0, k, 1);
+        CH(ido - 1, 1, k) = CC(0, k, 0) - CC(0, k, 1);
+    }
+    if ((ido & 1) == 0) {
+        for (int k = lane; k < l1; k += 64) {
+            CH(0, 1, k) = -CC(ido - 1, k, 1);
+            CH(ido - 1, 0, k) = CC(ido - 1, k, 0);
+        }
+    }
+    if (ido > 2) {
+        const int nq = (ido - 1) / 2;
+        for (int t = lane; t < l1 * nq; t += 64) {
+            const int k = t / nq, i = 2 + 2 * (t % nq), ic = ido - i;
+            const double tr2 = w[i - 2] * CC(i - 1, k, 1) + w[i - 1] * CC(i, k, 1);
+            const double ti2 = w[i - 2] * CC(i, k, 1) - w[i - 1] * CC(i - 1, k, 1);
+            CH(i - 1, 0, k) = CC(i - 1, k, 0) + tr2;
+            CH(ic - 1, 1, k) = CC(i - 1, k, 0) - tr2;
+            CH(i, 0, k) = ti2 + CC(i, k, 0);
+            CH(ic, 1, k) = ti2 - CC(i, k, 0);
+        }
+    }
+#undef CC
+#undef CH
+}
+
+__global__ __launch_bounds__(64) void fbank_kernel(FbankArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    const int lane = threadIdx.x;
+    const FbankFrameDesc d = a.desc[blockIdx.x];
+    const int n = a.t.padded, nbins = a.t.nbins, nfft = n >> 1;
+    float *out = a.ring + ((size_t)d.slot * a.ring_frames + d.ring_row) * nbins;
+    if (d.pcm_off < 0) {
+        for (int m = lane; m < nbins; m += 64) out[m] = a.pad_value;
+        return;
+    }
+    const int16_t *pcm = a.pcm + d.pcm_off;
+    double *A = sh, *B = sh + n;
+
+    // DC offset (fbank.c:241-246)
+    float mean;
+    if (n <= 512) {
+        int part = 0;
+        for (int j = lane; j < n; j += 64) part += (int)pcm[j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        const float sum = (float)part / 32768.0f;
+        mean = sum / (float)n;
+    } else {
+        float sum = 0.0f;
+        if (lane == 0) for (int j = 0; j < n; ++j) sum = (float)((double)sum + (double)pcm_to_float(pcm[j]));
+        sum = __shfl(sum, 0);
+        mean = sum / (float)n;
+    }
+    // subtract mean, pre-emphasis (back-to-front form of fbank.c:249-253 is order independent), window
+    const double pe = (double)0.97f;
+    for (int j = lane; j < n; j += 64) {
+        const double dj = (double)pcm_to_float(pcm[j]) - (double)mean;
+        const double dp = j > 0 ? (double)pcm_to_float(pcm[j - 1]) - (double)mean : dj;
+        double v = dj - pe * dp;
+        v *= (double)a.t.window[j];
+        A[j] = v;
+    }
+    __syncthreads();
+
+    // forward real FFT: factors are consumed last to first (pocketfft.c:1741-1760)
+    double *src = A, *dst = B;
+    int l1 = n;
+    for (int k1 = 0; k1 < a.t.nfct; ++k1) {
+        const int k = a.t.nfct - k1 - 1;
+        const int ip = a.t.fct[k];
+        const int ido = n / l1;
+        l1 /= ip;
+        if (ip == 4) fft_pass4(ido, l1, src, dst, a.t.tw[k], lane);
+        else fft_pass2(ido, l1, src, dst, a.t.tw[k], lane);
+        __syncthreads();
+        double *t = src; src = dst; dst = t;
+    }
+    // src = half-complex spectrum r0, r1,i1, ..., r_{n/2}; power of bins 0..n/2-1 (fbank.c:259-280)
+    float *pw = reinterpret_cast<float *>(dst);
+    for (int k = lane; k < nfft; k += 64) {
+        const float re = (float)(k == 0 ? src[0] : src[2 * k - 1]);
+        const float im = (float)(k == 0 ? 0.0 : src[2 * k]);
+        pw[k] = re * re + im * im;
+    }
+    __syncthreads();
+    const float kFloor = 1.1920928955078125e-07f;
+    for (int m = lane; m < nbins; m += 64) {
+        const float *w = a.t.mel + (size_t)m * nfft;
+        float val = 0.0f;
+        const int hi = a.t.mel_hi[m];
+        for (int k = a.t.mel_lo[m]; k < hi; ++k) val += pw[k] * w[k];
+        const float v = kFloor > val ? kFloor : val;
+        out[m] = (float)log((double)v);
+    }
+}
+
+void launch_fbank(const FbankArgs &a, hipStream_t s)
+{
+    if (a.n_frames <= 0) return;
+    const size_t lds = sizeof(double) * 2 * (size_t)a.t.padded;
+    hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)a.n_frames), dim3(64), lds, s, a);
+}
+
+}  // namespace aprilx

@@ -1,0 +1,493 @@
+// See model_loader.h.
+//
+// Container layout: reference extra/file-format.md; validation rules restate
+// src/file/model_file.c:58-129 and src/params.c:46-112.  Unlike the reference
+// (model_file.c:164-166 reads PARAMS from the current FILE position) the params
+// block is located through its header entry.
+//
+// Weight extraction is STRUCTURAL: torch.onnx names most MatMul weights
+// "onnx::MatMul_###", so nothing is looked up by name.  The walker lists the
+// weight-bearing nodes (Conv / MatMul / Gemm with a constant operand) in graph
+// order and checks the surrounding operators (DoubleSwish constant, BasicNorm
+// epsilon, gate split order i,f,g,o, state lineage of the recurrent matmul)
+// against what the HIP kernels implement; anything else is rejected with a message.
+#include "model_loader.h"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include "common.h"
+#include "onnx_reader.h"
+
+namespace aprilx {
+
+size_t HostModel::param_count() const
+{
+    size_t n = 0;
+    for (int i = 0; i < 3; ++i) n += conv_w[i].size() + conv_b[i].size();
+    n += w_embed.size() + b_embed.size();
+    for (auto &l : layers) n += l.w_gates.size() + 2 * l.b_gates.size() + l.w_hr.size() + l.w_ff1.size() + l.b_ff1.size() + l.w_ff2.size() + l.b_ff2.size() + 1;
+    n += w_encproj.size() + b_encproj.size() + emb.size() + dec_conv.size() + dec_conv_b.size() + w_decproj.size() + b_decproj.size() + w_out.size() + b_out.size();
+    return n;
+}
+
+// ---------------------------------------------------------------- container
+namespace {
+struct Rd {
+    const uint8_t *p; size_t n, pos = 0; bool bad = false;
+    uint64_t le(int bytes) {
+        if (pos + (size_t)bytes > n) { bad = true; pos = n; return 0; }
+        uint64_t v = 0;
+        for (int i = 0; i < bytes; ++i) v |= (uint64_t)p[pos + i] << (8 * i);
+        pos += (size_t)bytes;
+        return v;
+    }
+    int32_t i32() { return (int32_t)(uint32_t)le(4); }
+    bool str(std::string &s) {
+        uint64_t len = le(8);
+        if (bad || len > n - pos) { bad = true; return false; }
+        s.assign((const char *)p + pos, (size_t)len);
+        pos += (size_t)len;
+        return true;
+    }
+};
+
+bool parse_params(Rd &r, ModelParams &o, std::string &err)
+{
+    static const char magic[8] = {'P', 'A', 'R', 'A', 'M', 'S', 0, 0};
+    if (r.pos + 8 > r.n || memcmp(r.p + r.pos, magic, 8) != 0) { err = "params: bad magic"; return false; }
+    r.pos += 8;
+    o.batch_size = r.i32(); o.segment_size = r.i32(); o.segment_step = r.i32(); o.mel_features = r.i32();
+    o.sample_rate = r.i32(); o.frame_shift_ms = r.i32(); o.frame_length_ms = r.i32(); o.round_pow2 = r.i32() != 0;
+    o.mel_low = r.i32(); o.mel_high = r.i32(); o.snip_edges = r.i32() != 0; o.token_count = r.i32(); o.blank_id = r.i32();
+    if (r.bad) { err = "params: truncated"; return false; }
+#define PCHECK(c) if (!(c)) { err = "params: check failed: " #c; return false; }
+    PCHECK(o.batch_size == 1);
+    PCHECK(o.segment_size > 0 && o.segment_size < 100);
+    PCHECK(o.segment_step > 0 && o.segment_step < 100 && o.segment_step <= o.segment_size);
+    PCHECK(o.mel_features > 0 && o.mel_features < 256);
+    PCHECK(o.sample_rate > 0 && o.sample_rate < 144000);
+    PCHECK(o.token_count > 0 && o.token_count < 16384);
+    PCHECK(o.blank_id >= 0 && o.blank_id < o.token_count);
+    PCHECK(o.frame_shift_ms > 0 && o.frame_shift_ms <= o.frame_length_ms);
+    PCHECK(o.frame_length_ms > 0 && o.frame_length_ms <= 5000);
+    PCHECK(o.mel_low > 0 && o.mel_low < o.sample_rate);
+    PCHECK(o.mel_high == 0 || o.mel_high > o.mel_low);
+#undef PCHECK
+    const size_t start = r.pos;
+    size_t longest = 0;
+    for (int i = 0; i < o.token_count; ++i) {
+        int32_t len = r.i32();
+        if (r.bad || len < 0 || (size_t)len > r.n - r.pos) { err = "params: token table truncated"; return false; }
+        if ((size_t)len > longest) longest = (size_t)len;
+        r.pos += (size_t)len;
+    }
+    o.token_stride = longest + 1;
+    o.tokens.assign((size_t)o.token_count * o.token_stride, 0);
+    r.pos = start;
+    for (int i = 0; i < o.token_count; ++i) {
+        int32_t len = r.i32();
+        memcpy(o.tokens.data() + o.token_stride * (size_t)i, r.p + r.pos, (size_t)len);
+        r.pos += (size_t)len;
+    }
+    return true;
+}
+}  // namespace
+
+bool parse_container(const std::vector<uint8_t> &blob, ContainerInfo &info, std::string &err)
+{
+    Rd r{blob.data(), blob.size()};
+    if (r.n < 20 || memcmp(r.p, "APRILMDL", 8) != 0) { err = "not an .april file (magic)"; return false; }
+    r.pos = 8;
+    uint32_t version = (uint32_t)r.le(4);
+    if (version != 1) { err = "unsupported .april version " + std::to_string(version); return false; }
+    (void)r.le(8);   // header_size
+    if (r.pos + 8 > r.n) { err = "truncated header"; return false; }
+    char lang[9]; memcpy(lang, r.p + r.pos, 8); lang[8] = 0; r.pos += 8;
+    info.language = lang;
+    if (!r.str(info.name) || !r.str(info.description)) { err = "truncated header strings"; return false; }
+    info.model_type = (uint32_t)r.le(4);
+    if (!(info.model_type > 0 && info.model_type < 2)) { err = "unexpected model type " + std::to_string(info.model_type); return false; }
+    info.params_off = r.le(8); info.params_size = r.le(8);
+    if (r.bad || info.params_off + info.params_size > r.n) { err = "params out of bounds of file"; return false; }
+    uint64_t nn = r.le(8);
+    if (r.bad || nn > 8) { err = "too many networks"; return false; }
+    for (uint64_t i = 0; i < nn; ++i) {
+        uint64_t off = r.le(8), sz = r.le(8);
+        if (r.bad || off + sz > r.n) { err = "network " + std::to_string(i) + " out of bounds of file"; return false; }
+        info.net_off.push_back(off); info.net_size.push_back(sz);
+    }
+    Rd pr{blob.data(), blob.size(), (size_t)info.params_off};
+    return parse_params(pr, info.params, err);
+}
+
+// ---------------------------------------------------------------- graph view
+namespace {
+
+struct Linear {
+    int K = 0, N = 0;
+    std::vector<float> W;      // K x N
+    std::vector<float> b;      // N or empty
+    std::string in_value, out_value;
+    int node = -1;
+};
+
+struct View {
+    const OGraph &g;
+    std::string err;
+    explicit View(const OGraph &g_) : g(g_) {}
+
+    const ONode *producer(const std::string &v) const {
+        auto it = g.producer.find(v);
+        return it == g.producer.end() ? nullptr : &g.nodes[it->second];
+    }
+    std::vector<const ONode *> consumers(const std::string &v) const {
+        std::vector<const ONode *> r;
+        auto range = g.consumers.equal_range(v);
+        for (auto it = range.first; it != range.second; ++it) r.push_back(&g.nodes[it->second]);
+        return r;
+    }
+    // constant tensor behind a value name (initializer, Constant node, or a constant pushed
+    // through Identity/Cast/Unsqueeze/Squeeze/Reshape/Exp)
+    bool const_floats(const std::string &v, std::vector<float> &out, std::vector<int64_t> *dims = nullptr, int depth = 0) const {
+        if (depth > 8) return false;
+        auto it = g.inits.find(v);
+        if (it != g.inits.end()) {
+            if (it->second.dtype == 1) out = it->second.f;
+            else { out.clear(); for (auto x : it->second.i) out.push_back((float)x); }
+            if (dims) *dims = it->second.dims;
+            return true;
+        }
+        const ONode *p = producer(v);
+        if (!p) return false;
+        if (p->op == "Constant") {
+            const OAttr *a = p->attr("value");
+            if (a && a->has_t) {
+                if (a->t.dtype == 1) out = a->t.f;
+                else { out.clear(); for (auto x : a->t.i) out.push_back((float)x); }
+                if (dims) *dims = a->t.dims;
+                return true;
+            }
+            if ((a = p->attr("value_float"))) { out = {a->f}; if (dims) dims->clear(); return true; }
+            return false;
+        }
+        if (p->op == "Identity" || p->op == "Cast" || p->op == "Unsqueeze" || p->op == "Squeeze" || p->op == "Reshape")
+            return const_floats(p->in[0], out, dims, depth + 1);
+        if (p->op == "Exp") {
+            if (!const_floats(p->in[0], out, dims, depth + 1)) return false;
+            for (auto &x : out) x = expf(x);
+            return true;
+        }
+        return false;
+    }
+    bool is_const(const std::string &v) const { std::vector<float> t; return const_floats(v, t); }
+
+    // follow layout-only operators upwards to the value that carries the data
+    std::string lineage(std::string v) const {
+        for (int guard = 0; guard < 64; ++guard) {
+            const ONode *p = producer(v);
+            if (!p) return v;
+            const std::string &op = p->op;
+            if (op == "Unsqueeze" || op == "Squeeze" || op == "Reshape" || op == "Transpose" || op == "Identity" ||
+                op == "Cast" || op == "Slice" || op == "Flatten" || (op == "Concat" && p->in.size() == 1) ||
+                (op == "Gather" && p->in.size() == 2 && is_const(p->in[1])) || (op == "Split" && p->out.size() == 1))
+                v = p->in[0];
+            else return v;
+        }
+        return v;
+    }
+
+    bool weighted(const ONode &n) const {
+        if (n.op == "Conv") return n.in.size() >= 2 && g.inits.count(n.in[1]);
+        if (n.op == "MatMul") return n.in.size() == 2 && g.inits.count(n.in[1]) && g.inits.at(n.in[1]).dims.size() == 2;
+        if (n.op == "Gemm") return n.in.size() >= 2 && g.inits.count(n.in[1]);
+        return false;
+    }
+
+    bool linear_at(int idx, Linear &L) {
+        const ONode &n = g.nodes[idx];
+        L.node = idx;
+        L.in_value = n.in[0];
+        const OTensor &w = g.inits.at(n.in[1]);
+        if (w.dtype != 1 || w.dims.size() != 2) { err = "linear weight must be a 2-D float tensor (" + n.name + ")"; return false; }
+        if (n.op == "MatMul") {
+            L.K = (int)w.dims[0]; L.N = (int)w.dims[1];
+            L.W = w.f;
+            L.out_value = n.out[0];
+            for (const ONode *c : consumers(n.out[0])) {
+                if (c->op != "Add" || c->in.size() != 2) continue;
+                const std::string &other = c->in[0] == n.out[0] ? c->in[1] : c->in[0];
+                std::vector<float> b;
+                if (const_floats(other, b) && (int)b.size() == L.N) { L.b = b; L.out_value = c->out[0]; break; }
+            }
+            return true;
+        }
+        if (n.op == "Gemm") {
+            const bool tB = n.attr_i("transB", 0) != 0;
+            if (n.attr_i("transA", 0) != 0) { err = "Gemm transA unsupported"; return false; }
+            const OAttr *al = n.attr("alpha"), *be = n.attr("beta");
+            if ((al && al->f != 1.0f) || (be && be->f != 1.0f)) { err = "Gemm alpha/beta != 1 unsupported"; return false; }
+            L.K = (int)(tB ? w.dims[1] : w.dims[0]);
+            L.N = (int)(tB ? w.dims[0] : w.dims[1]);
+            L.W.resize((size_t)L.K * L.N);
+            if (tB) { for (int nn = 0; nn < L.N; ++nn) for (int k = 0; k < L.K; ++k) L.W[(size_t)k * L.N + nn] = w.f[(size_t)nn * L.K + k]; }
+            else L.W = w.f;
+            if (n.in.size() > 2 && !n.in[2].empty()) {
+                std::vector<float> b;
+                if (!const_floats(n.in[2], b) || (int)b.size() != L.N) { err = "Gemm bias must be a constant of length N"; return false; }
+                L.b = b;
+            }
+            L.out_value = n.out[0];
+            return true;
+        }
+        err = "not a linear node";
+        return false;
+    }
+
+    // y -> y * sigmoid(y - 1); returns the product's value name
+    bool double_swish(const std::string &y, std::string &out) {
+        for (const ONode *c : consumers(y)) {
+            float shift = 0; bool ok = false;
+            std::vector<float> k;
+            if (c->op == "Sub" && c->in[0] == y && const_floats(c->in[1], k) && k.size() == 1) { shift = k[0]; ok = true; }
+            if (c->op == "Add" && c->in.size() == 2) {
+                const std::string &o = c->in[0] == y ? c->in[1] : c->in[0];
+                if (const_floats(o, k) && k.size() == 1) { shift = -k[0]; ok = true; }
+            }
+            if (!ok) continue;
+            if (fabsf(shift - 1.0f) > 1e-6f) { err = "activation is x*sigmoid(x-c) with c != 1"; return false; }
+            for (const ONode *s : consumers(c->out[0])) if (s->op == "Sigmoid")
+                for (const ONode *m : consumers(s->out[0])) if (m->op == "Mul" && (m->in[0] == y || m->in[1] == y)) { out = m->out[0]; return true; }
+        }
+        err = "expected DoubleSwish (x * sigmoid(x - 1)) after '" + y + "'";
+        return false;
+    }
+
+    // y -> y * (mean(y^2) + eps)^-0.5 ; returns eps and the output value
+    bool basic_norm(const std::string &y, float &eps, std::string &out) {
+        for (const ONode *c : consumers(y)) {
+            bool sq = false;
+            std::vector<float> k;
+            if (c->op == "Pow" && c->in[0] == y && const_floats(c->in[1], k) && k.size() == 1 && k[0] == 2.0f) sq = true;
+            if (c->op == "Mul" && c->in[0] == y && c->in[1] == y) sq = true;
+            if (!sq) continue;
+            for (const ONode *rm : consumers(c->out[0])) if (rm->op == "ReduceMean")
+                for (const ONode *ad : consumers(rm->out[0])) if (ad->op == "Add") {
+                    const std::string &o = ad->in[0] == rm->out[0] ? ad->in[1] : ad->in[0];
+                    std::vector<float> e;
+                    if (!const_floats(o, e) || e.size() != 1) continue;
+                    for (const ONode *pw : consumers(ad->out[0])) {
+                        std::vector<float> ex;
+                        if (pw->op == "Pow" && const_floats(pw->in[1], ex) && ex.size() == 1 && ex[0] == -0.5f)
+                            for (const ONode *m : consumers(pw->out[0])) if (m->op == "Mul" && (m->in[0] == y || m->in[1] == y)) { eps = e[0]; out = m->out[0]; return true; }
+                    }
+                }
+        }
+        err = "expected BasicNorm (x * (mean(x^2)+eps)^-0.5) after '" + y + "'";
+        return false;
+    }
+};
+
+bool fail(std::string &err, const std::string &m) { err = m; return false; }
+
+bool extract_encoder(const OGraph &g, const ModelParams &P, HostModel &M, std::string &err)
+{
+    View v(g);
+    if (g.inputs.size() != 3 || g.outputs.size() != 3) return fail(err, "encoder must have 3 inputs and 3 outputs");
+    const auto &xi = g.inputs[0], &hi = g.inputs[1], &ci = g.inputs[2];
+    if (xi.dims.size() != 3 || hi.dims.size() != 3 || ci.dims.size() != 3) return fail(err, "encoder inputs must be rank 3");
+    NetDims &D = M.dims;
+    if (xi.dims[0] != P.batch_size || xi.dims[1] != P.segment_size || xi.dims[2] != P.mel_features)
+        return fail(err, "encoder input x does not match PARAMS (batch, segment_size, mel_features)");
+    D.seg = (int)xi.dims[1]; D.mel = (int)xi.dims[2];
+    D.n_layers = (int)hi.dims[0]; D.d_model = (int)hi.dims[2]; D.hidden = (int)ci.dims[2];
+    if (hi.dims[1] != 1 || ci.dims[1] != 1 || ci.dims[0] != hi.dims[0]) return fail(err, "state tensors must be (L,1,*)");
+    if (g.outputs[0].dims.size() != 3) return fail(err, "encoder_out must be rank 3");
+    D.joiner = (int)g.outputs[0].dims[2];
+
+    std::vector<int> wn;
+    for (size_t i = 0; i < g.nodes.size(); ++i) if (v.weighted(g.nodes[i])) wn.push_back((int)i);
+    const int L = D.n_layers;
+    if ((int)wn.size() != 3 + 1 + 5 * L + 1)
+        return fail(err, "encoder: expected " + std::to_string(5 + 5 * L) + " weight-bearing nodes, found " + std::to_string(wn.size()));
+
+    // --- conv stack
+    int H = D.seg, W = D.mel, C = 1;
+    std::string cur;
+    for (int i = 0; i < 3; ++i) {
+        const ONode &n = g.nodes[wn[i]];
+        if (n.op != "Conv") return fail(err, "encoder: node " + std::to_string(i) + " of the embed stack is not Conv");
+        const OTensor &w = g.inits.at(n.in[1]);
+        if (w.dims.size() != 4 || w.dims[2] != 3 || w.dims[3] != 3 || w.dims[1] != C) return fail(err, "embed conv must be 3x3 over " + std::to_string(C) + " channels");
+        if (n.attr_i("group", 1) != 1) return fail(err, "embed conv group != 1");
+        int st = 1;
+        if (auto a = n.attr("strides")) { if (a->ints.size() != 2 || a->ints[0] != a->ints[1]) return fail(err, "embed conv strides"); st = (int)a->ints[0]; }
+        if (auto a = n.attr("pads")) for (auto p : a->ints) if (p != 0) return fail(err, "embed conv padding unsupported");
+        if (auto a = n.attr("dilations")) for (auto p : a->ints) if (p != 1) return fail(err, "embed conv dilation unsupported");
+        D.conv_ch[i] = (int)w.dims[0]; D.conv_stride[i] = st;
+        M.conv_w[i] = w.f;
+        if (n.in.size() > 2 && !n.in[2].empty()) { if (!v.const_floats(n.in[2], M.conv_b[i]) || (int)M.conv_b[i].size() != D.conv_ch[i]) return fail(err, "embed conv bias"); }
+        else M.conv_b[i].assign((size_t)D.conv_ch[i], 0.0f);
+        H = (H - 3) / st + 1; W = (W - 3) / st + 1; C = D.conv_ch[i];
+        if (!v.double_swish(n.out[0], cur)) return fail(err, "encoder embed: " + v.err);
+    }
+    if (H != 1) return fail(err, "embed stack must reduce the segment to one frame (got " + std::to_string(H) + ")");
+    D.f_out = W; D.embed_in = C * W;
+
+    Linear lin;
+    if (!v.linear_at(wn[3], lin)) return fail(err, "encoder embed linear: " + v.err);
+    if (lin.K != D.embed_in || lin.N != D.d_model) return fail(err, "encoder embed linear has unexpected shape");
+    M.w_embed = lin.W; M.b_embed = lin.b.empty() ? std::vector<float>((size_t)lin.N, 0.0f) : lin.b;
+    if (!v.basic_norm(lin.out_value, M.embed_norm_eps, cur)) return fail(err, "encoder embed: " + v.err);
+
+    // --- layers
+    M.layers.resize((size_t)L);
+    const int d = D.d_model, Hh = D.hidden;
+    for (int l = 0; l < L; ++l) {
+        LayerWeights &lw = M.layers[(size_t)l];
+        const int base = 4 + 5 * l;
+        Linear a, b, hr, f1, f2;
+        if (!v.linear_at(wn[base], a) || !v.linear_at(wn[base + 1], b) || !v.linear_at(wn[base + 2], hr) ||
+            !v.linear_at(wn[base + 3], f1) || !v.linear_at(wn[base + 4], f2))
+            return fail(err, "encoder layer " + std::to_string(l) + ": " + v.err);
+        const bool a_is_h = v.lineage(a.in_value) == hi.name, b_is_h = v.lineage(b.in_value) == hi.name;
+        if (a_is_h == b_is_h) return fail(err, "encoder layer " + std::to_string(l) + ": cannot tell input and recurrent gate matmuls apart");
+        const Linear &ih = a_is_h ? b : a, &hh = a_is_h ? a : b;
+        if (ih.K != d || hh.K != d || ih.N != 4 * Hh || hh.N != 4 * Hh) return fail(err, "encoder layer " + std::to_string(l) + ": gate matmul shapes");
+        // gates = ih + hh -> Split(4) -> sigmoid, sigmoid, tanh, sigmoid
+        {
+            const ONode *sum = nullptr;
+            for (const ONode *c : v.consumers(ih.out_value)) if (c->op == "Add" && (c->in[0] == hh.out_value || c->in[1] == hh.out_value)) sum = c;
+            if (!sum) return fail(err, "encoder layer " + std::to_string(l) + ": gate pre-activations are not summed by one Add");
+            const ONode *split = nullptr;
+            for (const ONode *c : v.consumers(sum->out[0])) if (c->op == "Split") split = c;
+            if (!split || split->out.size() != 4) return fail(err, "encoder layer " + std::to_string(l) + ": expected Split into 4 gates");
+            static const char *want[4] = {"Sigmoid", "Sigmoid", "Tanh", "Sigmoid"};
+            for (int k = 0; k < 4; ++k) {
+                auto cs = v.consumers(split->out[k]);
+                if (cs.size() != 1 || cs[0]->op != want[k]) return fail(err, "encoder layer " + std::to_string(l) + ": gate order is not i,f,g,o");
+            }
+        }
+        lw.w_gates.resize((size_t)2 * d * 4 * Hh);
+        memcpy(lw.w_gates.data(), ih.W.data(), ih.W.size() * 4);
+        memcpy(lw.w_gates.data() + ih.W.size(), hh.W.data(), hh.W.size() * 4);
+        lw.b_gates.assign((size_t)4 * Hh, 0.0f);
+        for (int k = 0; k < 4 * Hh; ++k) lw.b_gates[(size_t)k] = (ih.b.empty() ? 0.0f : ih.b[(size_t)k]) + (hh.b.empty() ? 0.0f : hh.b[(size_t)k]);
+        if (hr.K != Hh || hr.N != d || !hr.b.empty()) return fail(err, "encoder layer " + std::to_string(l) + ": projection matmul shape");
+        lw.w_hr = hr.W;
+        if (f1.K != d || f2.N != d || f1.N != f2.K) return fail(err, "encoder layer " + std::to_string(l) + ": feed-forward shapes");
+        if (l == 0) D.ffn = f1.N; else if (D.ffn != f1.N) return fail(err, "feed-forward width differs between layers");
+        lw.w_ff1 = f1.W; lw.b_ff1 = f1.b.empty() ? std::vector<float>((size_t)f1.N, 0.0f) : f1.b;
+        lw.w_ff2 = f2.W; lw.b_ff2 = f2.b.empty() ? std::vector<float>((size_t)f2.N, 0.0f) : f2.b;
+        std::string act;
+        if (!v.double_swish(f1.out_value, act)) return fail(err, "encoder layer " + std::to_string(l) + ": " + v.err);
+        // residual add after ff2, then BasicNorm
+        bool normed = false;
+        for (const ONode *c : v.consumers(f2.out_value)) if (c->op == "Add") {
+            std::string o;
+            if (v.basic_norm(c->out[0], lw.norm_eps, o)) { normed = true; break; }
+        }
+        if (!normed) return fail(err, "encoder layer " + std::to_string(l) + ": " + v.err);
+    }
+    Linear ep;
+    if (!v.linear_at(wn.back(), ep)) return fail(err, "encoder_proj: " + v.err);
+    if (ep.K != d || ep.N != D.joiner) return fail(err, "encoder_proj shape");
+    if (ep.out_value != g.outputs[0].name) return fail(err, "encoder_proj does not produce the first graph output");
+    M.w_encproj = ep.W; M.b_encproj = ep.b.empty() ? std::vector<float>((size_t)ep.N, 0.0f) : ep.b;
+    return true;
+}
+
+bool extract_decoder(const OGraph &g, HostModel &M, std::string &err)
+{
+    View v(g);
+    NetDims &D = M.dims;
+    if (g.inputs.size() != 1 || g.outputs.size() != 1) return fail(err, "decoder must have 1 input and 1 output");
+    if (g.inputs[0].dims.size() != 2 || g.inputs[0].dims[0] != 1) return fail(err, "Currently, only batch size 1 models are supported (decoder context)");
+    D.context = (int)g.inputs[0].dims[1];
+    if (D.context != 2) return fail(err, "decoder context size must be 2 (reference src/april_session.c:322,297 assume it)");
+    const ONode *gather = nullptr, *conv = nullptr; bool relu = false; int mm = -1;
+    for (size_t i = 0; i < g.nodes.size(); ++i) {
+        const ONode &n = g.nodes[i];
+        if (n.op == "Gather" && g.inits.count(n.in[0]) && g.inits.at(n.in[0]).dims.size() == 2) gather = &n;
+        else if (n.op == "Conv") conv = &n;
+        else if (n.op == "Relu") relu = true;
+        else if (v.weighted(n) && n.op != "Conv") mm = (int)i;
+    }
+    if (!gather || !conv || !relu || mm < 0) return fail(err, "decoder: expected Gather(embedding) -> Conv -> Relu -> Linear");
+    const OTensor &emb = g.inits.at(gather->in[0]);
+    if ((int)emb.dims[1] != D.d_model && D.d_model) { /* decoder_dim may differ from encoder d_model; keep its own */ }
+    M.emb = emb.f;
+    const int V = (int)emb.dims[0], dd = (int)emb.dims[1];
+    const OTensor &cw = g.inits.at(conv->in[1]);
+    if (cw.dims.size() != 3 || cw.dims[0] != dd || cw.dims[2] != D.context) return fail(err, "decoder conv weight shape");
+    D.dec_groups = (int)conv->attr_i("group", 1);
+    if (cw.dims[1] * D.dec_groups != dd) return fail(err, "decoder conv groups do not divide channels");
+    M.dec_conv = cw.f;
+    if (conv->in.size() > 2 && !conv->in[2].empty()) { if (!v.const_floats(conv->in[2], M.dec_conv_b)) return fail(err, "decoder conv bias"); }
+    Linear p;
+    if (!v.linear_at(mm, p)) return fail(err, "decoder_proj: " + v.err);
+    if (p.K != dd) return fail(err, "decoder_proj input width");
+    if (p.out_value != g.outputs[0].name) return fail(err, "decoder_proj does not produce the graph output");
+    M.w_decproj = p.W; M.b_decproj = p.b.empty() ? std::vector<float>((size_t)p.N, 0.0f) : p.b;
+    if (dd != D.d_model) return fail(err, "decoder embedding width must equal encoder d_model in this engine");
+    if (p.N != D.joiner) return fail(err, "decoder_out width differs from encoder_out width");
+    D.vocab = V;
+    return true;
+}
+
+bool extract_joiner(const OGraph &g, HostModel &M, std::string &err)
+{
+    View v(g);
+    NetDims &D = M.dims;
+    if (g.inputs.size() != 2 || g.outputs.size() != 1) return fail(err, "joiner must have 2 inputs and 1 output");
+    bool tanh_seen = false; int mm = -1;
+    for (size_t i = 0; i < g.nodes.size(); ++i) {
+        if (g.nodes[i].op == "Tanh") tanh_seen = true;
+        if (v.weighted(g.nodes[i])) mm = (int)i;
+    }
+    if (!tanh_seen || mm < 0) return fail(err, "joiner: expected tanh(enc + dec) -> Linear");
+    Linear o;
+    if (!v.linear_at(mm, o)) return fail(err, "joiner output linear: " + v.err);
+    if (o.K != D.joiner) return fail(err, "joiner input width");
+    if (o.N != D.vocab) return fail(err, "joiner vocabulary differs from the decoder embedding table");
+    if (o.out_value != g.outputs[0].name) return fail(err, "joiner linear does not produce the graph output");
+    if (g.outputs[0].dims.size() != 3) return fail(err, "logits must be rank 3");
+    M.w_out = o.W; M.b_out = o.b.empty() ? std::vector<float>((size_t)o.N, 0.0f) : o.b;
+    return true;
+}
+
+}  // namespace
+
+bool load_april_file(const char *path, HostModel &out, std::string &err)
+{
+    FILE *fd = fopen(path, "rb");
+    if (!fd) { err = std::string("cannot open ") + path; return false; }
+    fseek(fd, 0, SEEK_END);
+    long sz = ftell(fd);
+    fseek(fd, 0, SEEK_SET);
+    std::vector<uint8_t> blob(sz > 0 ? (size_t)sz : 0);
+    size_t got = blob.empty() ? 0 : fread(blob.data(), 1, blob.size(), fd);
+    fclose(fd);
+    if (got != blob.size()) { err = "short read"; return false; }
+
+    ContainerInfo info;
+    if (!parse_container(blob, info, err)) return false;
+    // reference src/april_model.c:36-40
+    if (info.model_type != 1 || info.net_off.size() != 3) { err = "Model has unknown model type, or the wrong number of networks"; return false; }
+    out.language = info.language; out.name = info.name; out.description = info.description;
+    out.params = info.params;
+
+    OGraph enc, dec, joi;
+    std::string e;
+    if (!parse_onnx(blob.data() + info.net_off[0], (size_t)info.net_size[0], enc, e)) { err = "encoder graph: " + e; return false; }
+    if (!parse_onnx(blob.data() + info.net_off[1], (size_t)info.net_size[1], dec, e)) { err = "decoder graph: " + e; return false; }
+    if (!parse_onnx(blob.data() + info.net_off[2], (size_t)info.net_size[2], joi, e)) { err = "joiner graph: " + e; return false; }
+    if (!extract_encoder(enc, out.params, out, err)) return false;
+    if (!extract_decoder(dec, out, err)) return false;
+    if (!extract_joiner(joi, out, err)) return false;
+    // reference src/april_model.c:99-102
+    if (out.dims.vocab != out.params.token_count) { err = "logits width differs from PARAMS token_count"; return false; }
+    return true;
+}
+
+}  // namespace aprilx

@@ -1,0 +1,449 @@
+// See session.h.
+#include "session.h"
+#include <algorithm>
+#include <cstring>
+#include "common.h"
+
+namespace aprilx {
+
+// ---------------------------------------------------------------- token classes
+std::vector<uint8_t> classify_tokens(const ModelParams &p)
+{
+    std::vector<uint8_t> c((size_t)p.token_count, 0);
+    for (int i = 0; i < p.token_count; ++i) {
+        const char *t = p.token((size_t)i);
+        uint8_t f = 0;
+        if (t[0] == ' ') f |= TK_WORD_START;                                   // april_session.c:338
+        const bool single = t[0] != 0 && t[1] == 0;
+        if (single && (t[0] == '.' || t[0] == '!' || t[0] == '?')) f |= TK_SENT_END;   // :341
+        if (single && t[0] == ',') f |= TK_COMMA;                              // :342
+        if (t[0] == '.') f |= TK_DOT;
+        if (t[0] >= '0' && t[0] <= '9') f |= TK_DIGIT_START;                   // :347
+        c[(size_t)i] = f;
+    }
+    return c;
+}
+
+// ---------------------------------------------------------------- greedy search + result state machine
+void Greedy::init(const ModelParams *p, const std::vector<uint8_t> *cls)
+{
+    P_ = p; cls_ = cls;
+    memset(active_, 0, sizeof active_);
+    for (int &i : active_id_) i = -1;
+    head_ = last_call_head_ = 0;
+    emitted_silence_ = true;                       // april_session.c:64
+    last_emit_ms_ = 0;
+    ctx[0] = ctx[1] = 0;
+    ctx_dirty = false;
+}
+
+void Greedy::call(int type, size_t count, std::vector<Event> &out)
+{
+    Event e; e.type = type;
+    e.tokens.assign(active_, active_ + count);
+    out.push_back(std::move(e));
+}
+
+void Greedy::push_ctx(int tok) { ctx[0] = ctx[1]; ctx[1] = tok; ctx_dirty = true; }   // :181-196 (context_size == 2)
+
+void Greedy::reset_context_to_blank() { push_ctx(P_->blank_id); push_ctx(P_->blank_id); }   // :432-438
+
+void Greedy::clear_context()
+{
+    if (ctx[0] == P_->blank_id) return;            // :297 (tests element 0, quirk kept)
+    push_ctx(P_->blank_id); push_ctx(P_->blank_id);
+}
+
+void Greedy::finalize_all(std::vector<Event> &out)
+{
+    if (head_ == 0) return;                         // :199-211
+    call(APRIL_RESULT_RECOGNITION_FINAL, head_, out);
+    last_call_head_ = head_;
+    head_ = 0;
+}
+
+void Greedy::finalize_before_word(const AprilToken &incoming, std::vector<Event> &out)
+{
+    if (head_ == 0) return;                         // :213-255
+    if (incoming.flags & APRIL_TOKEN_FLAG_WORD_BOUNDARY_BIT) { finalize_all(out); return; }
+    size_t start = kMaxActive;
+    for (size_t i = head_ - 1; i > 2; --i)
+        if (active_[i].flags & APRIL_TOKEN_FLAG_WORD_BOUNDARY_BIT) { start = i; break; }
+    if (start == (size_t)kMaxActive) { finalize_all(out); return; }
+    call(APRIL_RESULT_RECOGNITION_FINAL, start, out);
+    memmove(active_, active_ + start, sizeof(AprilToken) * (head_ - start));
+    memmove(active_id_, active_id_ + start, sizeof(int) * (head_ - start));
+    head_ -= start;
+}
+
+void Greedy::emit_silence(std::vector<Event> &out)
+{
+    if (emitted_silence_) return;                   // :257-268
+    emitted_silence_ = true;
+    Event e; e.type = APRIL_RESULT_SILENCE;
+    out.push_back(std::move(e));
+}
+
+bool Greedy::emit_partial(const AprilToken *tok, int tok_id, bool force, std::vector<Event> &out)
+{
+    if (tok) {                                      // :270-294
+        if (!force && last_call_head_ == head_ + 1 && active_id_[head_] == tok_id) return false;
+        active_[head_] = *tok;
+        active_id_[head_] = tok_id;
+        ++head_;
+    } else if (!force && last_call_head_ == head_) {
+        return false;
+    }
+    call(APRIL_RESULT_RECOGNITION_PARTIAL, head_, out);
+    last_call_head_ = head_;
+    return true;
+}
+
+bool Greedy::on_joint(const JointResult &r, float early_emit, size_t now_ms, std::vector<Event> &out)
+{
+    const int blank = P_->blank_id;
+    int best = r.idx;
+    float best_v = r.max_val;
+    if (best < 0) { best = blank == 0 ? 1 : 0; best_v = -9999999999.0f; }   // no logit beat the initial value (NaNs)
+    const float blank_v = r.blank_val;
+
+    const bool cleared = ctx[1] == blank;           // :322
+    const bool same = ctx[1] == best;               // :326
+    if (same) early_emit = 0.0f;
+    bool is_blank = (blank_v - early_emit) > best_v;    // :329-330
+
+    const uint8_t tc = (*cls_)[(size_t)best];
+    AprilToken tok;
+    tok.token = P_->token((size_t)best);
+    tok.logprob = best_v;
+    tok.flags = (AprilTokenFlagBits)0;
+    tok.time_ms = now_ms;
+    tok.reserved = nullptr;
+    int flags = 0;
+    if (tc & TK_WORD_START) flags |= APRIL_TOKEN_FLAG_WORD_BOUNDARY_BIT;
+    bool eos = (tc & TK_SENT_END) != 0;
+    bool punct = eos || (tc & TK_COMMA);
+    if (punct && head_ > 0) {                       // :345-351 "10.0" is not a sentence end
+        const uint8_t lc = (*cls_)[(size_t)active_id_[head_ - 1]];
+        if ((lc & TK_DIGIT_START) && (tc & TK_DOT)) { eos = false; punct = false; }
+    }
+    if (eos) flags |= APRIL_TOKEN_FLAG_SENTENCE_END_BIT;
+    tok.flags = (AprilTokenFlagBits)flags;
+    if (!cleared && punct && !same && best_v > (blank_v - 3.5f)) is_blank = false;   // :356-358
+
+    if (!is_blank) {                                // :361-400
+        last_emit_ms_ = now_ms;
+        push_ctx(best);
+        bool fin = head_ >= (size_t)(kMaxActive - 1);
+        if (head_ > 0 && (flags & APRIL_TOKEN_FLAG_WORD_BOUNDARY_BIT)) {
+            AprilToken &prev = active_[head_ - 1];
+            const bool prev_eos = ((*cls_)[(size_t)active_id_[head_ - 1]] & TK_SENT_END) != 0;
+            if (prev_eos && !(prev.flags & APRIL_TOKEN_FLAG_SENTENCE_END_BIT))
+                prev.flags = (AprilTokenFlagBits)(prev.flags | APRIL_TOKEN_FLAG_SENTENCE_END_BIT);
+            if (prev_eos) fin = true;
+        }
+        if (fin) finalize_before_word(tok, out);
+        if (head_ >= (size_t)(kMaxActive - 1)) { LOGE("No room left even after finalizing previous words"); head_ = 0; }
+        emit_partial(&tok, best, true, out);
+        emitted_silence_ = false;
+    } else {                                        // :401-426
+        const size_t gap = now_ms - last_emit_ms_;
+        const float decayed = best_v - (float)gap / 3000.0f;
+        const bool confident = !same && decayed > (blank_v - 4.0f);
+        if (gap >= 2200) {
+            finalize_all(out);
+            clear_context();
+            emit_silence(out);
+        } else if (confident) {
+            tok.logprob -= 8.0f;
+            if (emit_partial(&tok, best, false, out)) --head_;
+        } else {
+            emit_partial(nullptr, -1, false, out);
+        }
+    }
+    return is_blank;
+}
+
+void Greedy::finish_flush(std::vector<Event> &out)
+{
+    finalize_all(out);
+    clear_context();
+    emit_silence(out);
+}
+
+void FrameBook::compact()
+{
+    if (fifo_pos > 0 && (fifo_pos >= 8192 || fifo_pos == fifo.size())) {
+        fifo.erase(fifo.begin(), fifo.begin() + (long)fifo_pos);
+        fifo_pos = 0;
+    }
+}
+
+// ---------------------------------------------------------------- model
+Model::~Model()
+{
+    for (auto *s : scheds) delete s;
+    for (auto *e : engines) delete e;
+}
+
+// ---------------------------------------------------------------- scheduler
+static constexpr size_t kAsyncRingSamples = 48000;     // reference src/audio_provider.c:31 (3 s at 16 kHz)
+
+Scheduler::Scheduler(Model *m, Engine *e) : model_(m), eng_(e) { thread_ = std::thread([this] { loop(); }); }
+
+Scheduler::~Scheduler()
+{
+    { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+    cv_work_.notify_all();
+    if (thread_.joinable()) thread_.join();
+}
+
+void Scheduler::attach(Session *s)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    sessions_.push_back(s);
+}
+
+void Scheduler::detach(Session *s)
+{
+    std::unique_lock<std::mutex> lk(mu_);
+    s->closing = true;
+    cv_done_.wait(lk, [&] { return !s->busy; });
+    sessions_.erase(std::remove(sessions_.begin(), sessions_.end(), s), sessions_.end());
+    s->inbox.clear();
+}
+
+SchedStats Scheduler::stats() { std::lock_guard<std::mutex> g(mu_); return stats_; }
+
+void Scheduler::submit(int n, Session *const *ss, const short *const *pcm, const size_t *counts, bool flush, bool wait)
+{
+    std::vector<Session *> overflowed;
+    std::vector<uint64_t> tickets((size_t)n, 0);
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (int i = 0; i < n; ++i) {
+            Session *s = ss[i];
+            if (s->closing) continue;
+            if (flush) s->flush_requested = true;
+            else {
+                const size_t cnt = counts[i];
+                if (!s->sync_mode && s->inbox_samples + cnt > kAsyncRingSamples) { overflowed.push_back(s); continue; }   // april_session.c:482-492
+                if (cnt) { s->inbox.emplace_back(pcm[i], pcm[i] + cnt); s->inbox_samples += cnt; }
+            }
+            tickets[(size_t)i] = ++s->submitted;
+        }
+    }
+    cv_work_.notify_one();
+    for (Session *s : overflowed) s->handler(s->userdata, APRIL_RESULT_ERROR_CANT_KEEP_UP, 0, nullptr);
+    if (!wait) return;
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] {
+        for (int i = 0; i < n; ++i) if (tickets[(size_t)i] && ss[i]->completed < tickets[(size_t)i] && !ss[i]->closing) return false;
+        return true;
+    });
+}
+
+void Scheduler::wait_idle(Session *s)
+{
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] { return s->closing || (s->completed >= s->submitted && !s->busy && s->inbox.empty() && !s->flush_requested); });
+}
+
+void Scheduler::deliver_sync_events(Session *s)
+{
+    std::vector<Event> ev;
+    { std::lock_guard<std::mutex> g(mu_); ev.swap(s->done_events); }
+    for (auto &e : ev) s->handler(s->userdata, (AprilResultType)e.type, e.tokens.size(), e.tokens.empty() ? nullptr : e.tokens.data());
+}
+
+void Scheduler::loop()
+{
+    HIP_CHECK(hipSetDevice(eng_->device()));
+    std::vector<Session *> work;
+    std::vector<uint64_t> taken;
+    for (;;) {
+        work.clear(); taken.clear();
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_work_.wait(lk, [&] {
+                if (stop_) return true;
+                for (Session *s : sessions_) if (!s->closing && (!s->inbox.empty() || s->flush_requested)) return true;
+                return false;
+            });
+            if (stop_) return;
+            for (Session *s : sessions_) {
+                if (s->closing || (s->inbox.empty() && !s->flush_requested)) continue;
+                s->busy = true;
+                bool fed = false;
+                for (auto &chunk : s->inbox) { s->fb.fifo.insert(s->fb.fifo.end(), chunk.begin(), chunk.end()); fed = true; }
+                s->inbox.clear(); s->inbox_samples = 0;
+                if (fed) s->was_flushed = false;                                  // april_session.c:510
+                if (s->flush_requested) {                                           // :547-552
+                    s->flush_requested = false;
+                    if (!s->was_flushed && s->flush_phase == 0) { s->was_flushed = true; s->flush_phase = 1; }
+                }
+                work.push_back(s);
+                taken.push_back(s->submitted);
+            }
+        }
+        process(work);
+        // async sessions: deliver on this (library) thread, outside the lock
+        for (Session *s : work) if (!s->sync_mode) {
+            for (auto &e : s->events) s->handler(s->userdata, (AprilResultType)e.type, e.tokens.size(), e.tokens.empty() ? nullptr : e.tokens.data());
+            s->events.clear();
+        }
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (size_t i = 0; i < work.size(); ++i) {
+                Session *s = work[i];
+                if (s->sync_mode) { for (auto &e : s->events) s->done_events.push_back(std::move(e)); s->events.clear(); }
+                s->completed = taken[i];
+                s->busy = false;
+            }
+            stats_.ticks++;
+        }
+        cv_done_.notify_all();
+    }
+}
+
+void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
+{
+    desc_.clear(); pcm_stage_.clear();
+    std::vector<Session *> need_decode;
+    for (Session *s : work) {
+        FrameBook &fb = s->fb;
+        // new real frames: frame k covers stream samples [k*shift, k*shift + padded)  (fbank.c:195-236)
+        if (fb.can_cut()) {
+            const size_t base = pcm_stage_.size();
+            const size_t first = fb.fifo_pos;
+            int cut = 0;
+            while (fb.can_cut() && cut < 96) {
+                FbankFrameDesc d; d.slot = s->slot; d.ring_row = fb.head; d.pcm_off = (int)(base + (size_t)cut * fb.shift);
+                desc_.push_back(d);
+                fb.head = (fb.head + 1) % fb.ring_frames;
+                fb.avail += 1;
+                fb.avail_shadow = fb.avail;                       // fbank.c:300
+                fb.fifo_pos += (size_t)fb.shift;
+                ++cut;
+            }
+            const size_t last_end = first + (size_t)(cut - 1) * fb.shift + (size_t)fb.padded;
+            pcm_stage_.insert(pcm_stage_.end(), fb.fifo.begin() + (long)first, fb.fifo.begin() + (long)last_end);
+            fb.compact();
+            progressed = true;
+            continue;
+        }
+        if (fb.chunk_ready() || s->flush_phase == 0) continue;
+        // drained: flush state machine (april_session.c:552-563, fbank.c:308-325)
+        switch (s->flush_phase) {
+        case 1: case 3:
+            if (fb.flush_allowed()) {
+                while (fb.avail < fb.seg_count) {
+                    FbankFrameDesc d; d.slot = s->slot; d.ring_row = fb.head; d.pcm_off = -1;
+                    desc_.push_back(d);
+                    fb.head = (fb.head + 1) % fb.ring_frames;
+                    fb.avail += 1;                                // padding does not touch the shadow counter
+                }
+            } else {
+                s->flush_phase += 1;
+            }
+            progressed = true;
+            break;
+        case 2:
+            fb.fifo.insert(fb.fifo.end(), (size_t)2 * 3200, (int16_t)0);      // april_session.c:555-556
+            s->flush_phase = 3;
+            progressed = true;
+            break;
+        case 4:
+            s->greedy.finish_flush(s->events);
+            if (s->greedy.ctx_dirty) need_decode.push_back(s);
+            s->flush_phase = 0;
+            progressed = true;
+            break;
+        default: break;
+        }
+    }
+    if (!desc_.empty()) {
+        eng_->fbank((int)desc_.size(), desc_.data(), pcm_stage_.data(), pcm_stage_.size());
+        stats_.frames += desc_.size();
+    }
+    if (!need_decode.empty()) {
+        slots_.clear(); ctx_.clear();
+        for (Session *s : need_decode) { slots_.push_back(s->slot); ctx_.push_back(s->greedy.ctx[0]); ctx_.push_back(s->greedy.ctx[1]); s->greedy.ctx_dirty = false; }
+        eng_->decode((int)slots_.size(), slots_.data(), ctx_.data());
+    }
+}
+
+void Scheduler::step_chunks(std::vector<Session *> &ready)
+{
+    const int n = (int)ready.size();
+    const NetDims &d = eng_->dims();
+    // first use of a session: context = [blank, blank], run the decoder (april_session.c:432-438)
+    slots_.clear(); ctx_.clear();
+    for (Session *s : ready) if (!s->dout_ready) {
+        s->greedy.reset_context_to_blank();
+        s->greedy.ctx_dirty = false;
+        s->dout_ready = true;
+        slots_.push_back(s->slot); ctx_.push_back(s->greedy.ctx[0]); ctx_.push_back(s->greedy.ctx[1]);
+    }
+    if (!slots_.empty()) eng_->decode((int)slots_.size(), slots_.data(), ctx_.data());
+
+    slots_.clear(); tails_.clear();
+    const int stride_ms = model_->host.params.segment_step * model_->host.params.frame_shift_ms;
+    for (Session *s : ready) {
+        FrameBook &fb = s->fb;
+        slots_.push_back(s->slot);
+        tails_.push_back(fb.tail);                                  // fbank.c:327-349
+        fb.tail = (fb.tail + fb.seg_step) % fb.ring_frames;
+        fb.avail -= fb.seg_step;
+        fb.avail_shadow -= fb.seg_step;
+        s->now_ms += (size_t)stride_ms;                             // april_session.c:442-443
+        s->chunks++;
+    }
+    eng_->encode(n, slots_.data(), tails_.data());
+    stats_.steps++; stats_.chunks += (uint64_t)n;
+    if ((uint64_t)n > stats_.max_batch_seen) stats_.max_batch_seen = (uint64_t)n;
+
+    std::vector<Session *> rows(ready), next, dec;
+    for (int round = 0; round < 3 && !rows.empty(); ++round) {
+        const int m = (int)rows.size();
+        slots_.resize((size_t)m);
+        bool want_logits = false;
+        for (int i = 0; i < m; ++i) { slots_[(size_t)i] = rows[(size_t)i]->slot; if (rows[(size_t)i]->trace_buf) want_logits = true; }
+        jr_.resize((size_t)m);
+        if (want_logits) logit_stage_.resize((size_t)m * d.vocab);
+        eng_->joint(m, slots_.data(), jr_.data(), want_logits ? logit_stage_.data() : nullptr);
+        stats_.rounds++;
+        next.clear(); dec.clear();
+        for (int i = 0; i < m; ++i) {
+            Session *s = rows[(size_t)i];
+            if (s->trace_buf && *s->trace_used + (size_t)d.vocab <= s->trace_cap) {
+                memcpy(s->trace_buf + *s->trace_used, logit_stage_.data() + (size_t)i * d.vocab, (size_t)d.vocab * 4);
+                *s->trace_used += (size_t)d.vocab;
+            }
+            const bool blank = s->greedy.on_joint(jr_[(size_t)i], round == 0 ? 1.0f : 0.0f, s->now_ms, s->events);   // :449-454
+            if (s->greedy.ctx_dirty) { dec.push_back(s); s->greedy.ctx_dirty = false; }
+            if (!blank) next.push_back(s);
+        }
+        if (!dec.empty()) {
+            slots_.clear(); ctx_.clear();
+            for (Session *s : dec) { slots_.push_back(s->slot); ctx_.push_back(s->greedy.ctx[0]); ctx_.push_back(s->greedy.ctx[1]); }
+            eng_->decode((int)slots_.size(), slots_.data(), ctx_.data());
+        }
+        rows.swap(next);
+    }
+}
+
+void Scheduler::process(std::vector<Session *> &work)
+{
+    std::vector<Session *> ready;
+    for (;;) {
+        bool progressed = false;
+        cut_frames(work, progressed);
+        ready.clear();
+        for (Session *s : work) if (s->fb.chunk_ready()) ready.push_back(s);
+        if (!ready.empty()) { step_chunks(ready); progressed = true; }
+        if (!progressed) break;
+    }
+}
+
+}  // namespace aprilx

@@ -1,0 +1,165 @@
+// Host-side session runtime for the GPU engine.
+//
+//   Greedy      the per-session transducer search + partial/final/silence state machine
+//               (reference src/april_session.c:199-429), driven by 12-byte JointResults
+//               instead of 500-float logit rows.
+//   FrameBook   bookkeeping twin of the reference's OnlineFBank ring (src/fbank.c:98-127,
+//               174-349): which frames exist, where they live in the HBM ring, flush padding.
+//               The samples themselves only pass through (PCM16 FIFO -> pinned staging).
+//   Scheduler   one stepping thread per GPU: gathers every session that has work, cuts new
+//               frames (one fbank launch for all sessions), and advances all sessions with a
+//               ready chunk in lock-step: one batched encoder pass, then up to three masked
+//               joiner/decoder rounds (reference src/april_session.c:431-476, batched).
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include "../../include/april_api.h"
+#include "engine.h"
+#include "model_loader.h"
+
+namespace aprilx {
+
+enum TokClass : uint8_t {
+    TK_WORD_START = 1,      // text[0] == ' '
+    TK_SENT_END = 2,        // single char . ! ?
+    TK_COMMA = 4,           // single char ,
+    TK_DOT = 8,             // text[0] == '.'
+    TK_DIGIT_START = 16     // text[0] in '0'..'9'
+};
+std::vector<uint8_t> classify_tokens(const ModelParams &p);
+
+struct Event {
+    int type;                         // AprilResultType
+    std::vector<AprilToken> tokens;
+};
+
+class Greedy {
+public:
+    static constexpr int kMaxActive = 72;     // reference src/april_session.h:30
+    void init(const ModelParams *p, const std::vector<uint8_t> *cls);
+    // consume one joiner result; returns true when the round resolved to blank (chunk done)
+    bool on_joint(const JointResult &r, float early_emit, size_t now_ms, std::vector<Event> &out);
+    // end of flush: FINAL, clear context, SILENCE (reference src/april_session.c:561-563)
+    void finish_flush(std::vector<Event> &out);
+    void reset_context_to_blank();            // first use: context = [blank, blank]
+    int ctx[2] = {0, 0};
+    bool ctx_dirty = false;                   // decoder must be re-run for this session
+
+private:
+    void push_ctx(int tok);
+    void clear_context();
+    void finalize_all(std::vector<Event> &out);
+    void finalize_before_word(const AprilToken &incoming, std::vector<Event> &out);
+    void emit_silence(std::vector<Event> &out);
+    bool emit_partial(const AprilToken *tok, int tok_id, bool force, std::vector<Event> &out);
+    void call(int type, size_t count, std::vector<Event> &out);
+
+    const ModelParams *P_ = nullptr;
+    const std::vector<uint8_t> *cls_ = nullptr;
+    AprilToken active_[kMaxActive];
+    int active_id_[kMaxActive];
+    size_t head_ = 0, last_call_head_ = 0;
+    bool emitted_silence_ = true;
+    size_t last_emit_ms_ = 0;
+};
+
+struct FrameBook {
+    int shift = 0, padded = 0, seg_count = 0, seg_step = 0, ring_frames = 0;
+    int head = 0, tail = 0;
+    long avail = 0, avail_shadow = 0;
+    std::vector<int16_t> fifo;      // samples not yet fully consumed by framing
+    size_t fifo_pos = 0;            // start of the next frame inside fifo
+    bool chunk_ready() const { return avail >= seg_count; }
+    bool can_cut() const { return fifo.size() - fifo_pos >= (size_t)padded && avail + 1 <= ring_frames; }
+    bool flush_allowed() const { return avail_shadow >= -(long)(seg_count * 3); }
+    void compact();
+};
+
+class Scheduler;
+struct Model;
+
+struct Session {
+    Model *model = nullptr;
+    Scheduler *sched = nullptr;
+    Engine *eng = nullptr;
+    int slot = -1;
+    AprilRecognitionResultHandler handler = nullptr;
+    void *userdata = nullptr;
+    bool sync_mode = true, realtime_flag = false;
+
+    // ---- guarded by Scheduler::mu_
+    std::deque<std::vector<int16_t>> inbox;   // queued feeds
+    size_t inbox_samples = 0;
+    bool flush_requested = false;
+    bool busy = false;                        // owned by the stepping thread right now
+    bool closing = false;
+    uint64_t submitted = 0, completed = 0;    // work tickets
+    std::vector<Event> done_events;           // sync sessions: events waiting for the caller thread
+
+    // ---- owned by the stepping thread while busy
+    FrameBook fb;
+    Greedy greedy;
+    bool dout_ready = false;
+    bool was_flushed = false;
+    int flush_phase = 0;                      // 0 none, 1 pad-drain, 2 zeros, 3 pad-drain, 4 finish
+    size_t now_ms = 0;
+    uint64_t chunks = 0;
+    std::vector<Event> events;                // produced during the current tick
+    // tracing (tests): every joiner call appends `vocab` floats
+    float *trace_buf = nullptr; size_t trace_cap = 0; size_t *trace_used = nullptr;
+};
+
+struct SchedStats { uint64_t ticks = 0, steps = 0, chunks = 0, rounds = 0, frames = 0, max_batch_seen = 0; };
+
+class Scheduler {
+public:
+    Scheduler(Model *m, Engine *e);
+    ~Scheduler();
+    void attach(Session *s);
+    void detach(Session *s);                       // waits until the session is idle
+    // queue work for n sessions at once and (for sync sessions / wait=true) block until it is done
+    void submit(int n, Session *const *ss, const short *const *pcm, const size_t *counts, bool flush, bool wait);
+    void deliver_sync_events(Session *s);          // caller-thread delivery for sync sessions
+    void wait_idle(Session *s);                    // everything queued so far has been processed
+    SchedStats stats();
+    Engine *engine() { return eng_; }
+
+private:
+    void loop();
+    void process(std::vector<Session *> &work);
+    void cut_frames(std::vector<Session *> &work, bool &progressed);
+    void step_chunks(std::vector<Session *> &ready);
+
+    Model *model_;
+    Engine *eng_;
+    std::mutex mu_;
+    std::condition_variable cv_work_, cv_done_;
+    std::vector<Session *> sessions_;
+    bool stop_ = false;
+    std::thread thread_;
+    SchedStats stats_;
+    // scratch reused across ticks
+    std::vector<FbankFrameDesc> desc_;
+    std::vector<int16_t> pcm_stage_;
+    std::vector<int> slots_, tails_, ctx_;
+    std::vector<JointResult> jr_;
+    std::vector<float> logit_stage_;
+};
+
+struct Model {
+    HostModel host;                           // params, tokens, names (weights freed after upload)
+    PackedLayout layout;
+    FbankHostTables ftab;
+    std::vector<uint8_t> tok_class;
+    std::vector<Engine *> engines;
+    std::vector<Scheduler *> scheds;
+    std::vector<float> host_blob;             // only for host-only models (no engine): packed weights
+    std::mutex mu;
+    ~Model();
+};
+
+}  // namespace aprilx

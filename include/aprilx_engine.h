@@ -1,0 +1,102 @@
+/*
+ * aprilx_engine.h -- engine-level C ABI of libaprilasr.so (MI355X build).
+ *
+ * The reference runs its networks through ONNXRuntime's C API behind
+ * src/ort_util.{h,c}: one g_ort->Run per graph per session per chunk, batch 1
+ * (src/april_session.c:145,160,176).  This header is the batched replacement of
+ * that inner boundary plus the few knobs a multi-session / multi-GPU host needs.
+ * Plain pointers and sizes only; every function cites what it replaces.
+ *
+ * All functions are safe to call from any thread; sessions must not be fed from
+ * two threads at once (same rule as the reference).
+ */
+#ifndef APRILX_ENGINE_H
+#define APRILX_ENGINE_H
+#include "april_api.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Dimensions read from the model's graphs (reference src/april_model.h:35-41). */
+typedef struct AprilxDims {
+    int32_t n_layers, d_model, hidden, ffn, joiner, vocab, mel, seg, seg_step, context;
+    int32_t fft_size, frame_shift, sample_rate, blank_id, n_devices;
+    int64_t param_count;
+} AprilxDims;
+APRIL_EXPORT int aprilx_model_dims(AprilASRModel model, AprilxDims *out);
+/* token text by id (reference src/params.c:31-33 get_token) */
+APRIL_EXPORT const char *aprilx_model_token(AprilASRModel model, int32_t id);
+
+/* ---- weight distribution (multi-GPU, one process per GPU) -------------------------------
+ * Rank 0 parses the .april file (aam_create_model) and exports ONE self-describing blob
+ * (header + params + packed weights).  The host broadcasts it (RCCL over xGMI) and every
+ * other rank builds its model from the blob without touching the file.  Replaces nothing in
+ * the reference (it has no multi-device path); placed next to aam_create_model
+ * (reference april_api.h:61).                                                            */
+APRIL_EXPORT size_t aprilx_model_blob_size(AprilASRModel model);
+APRIL_EXPORT int aprilx_model_export_blob(AprilASRModel model, void *dst, size_t dst_size);
+/* `blob` may be a host pointer or a device pointer on the calling process's GPU */
+APRIL_EXPORT AprilASRModel aprilx_model_from_blob(const void *blob, size_t size, int blob_is_device_ptr);
+
+/* ---- batched session driving ------------------------------------------------------------
+ * aas_feed_pcm16 / aas_flush (reference april_api.h:183,186) for n sessions in ONE call, so
+ * that all of them advance in the same GPU steps.  Blocks until the work is done; handlers
+ * of synchronous sessions run on the calling thread before it returns.                    */
+APRIL_EXPORT void aprilx_feed_many(size_t n, AprilASRSession *sessions, const short *const *pcm16, const size_t *short_counts);
+APRIL_EXPORT void aprilx_flush_many(size_t n, AprilASRSession *sessions);
+/* block until an asynchronous session has consumed everything queued so far */
+APRIL_EXPORT void aprilx_session_drain(AprilASRSession session);
+
+/* ---- direct network evaluation (parity tests) -------------------------------------------
+ * Same tensors as the three ORT Run calls, with a leading batch of n independent sessions:
+ *   encoder: x[n][seg][mel], h[n][L][d_model], c[n][L][hidden] -> eout[n][joiner], h2, c2
+ *            (reference src/april_session.c:131-148)
+ *   decoder: context[n][2] int64 -> dout[n][joiner]              (:151-163)
+ *   joiner : eout[n][joiner], dout[n][joiner] -> logits[n][vocab] (:166-179)
+ *   fbank  : n frames of fft_size PCM16 samples -> n rows of `mel` log energies
+ *            (reference src/fbank.c:228-296 per frame)
+ * These use state slots 0..n-1 directly and must not be mixed with live sessions.        */
+APRIL_EXPORT int aprilx_run_encoder(AprilASRModel model, int n, const float *x, const float *h, const float *c,
+                                    float *eout, float *h2, float *c2);
+APRIL_EXPORT int aprilx_run_decoder(AprilASRModel model, int n, const int64_t *context, float *dout);
+APRIL_EXPORT int aprilx_run_joiner(AprilASRModel model, int n, const float *eout, const float *dout, float *logits);
+APRIL_EXPORT int aprilx_run_fbank(AprilASRModel model, int n_frames, const int16_t *pcm_frames, float *out);
+
+/* ---- tracing / statistics ---------------------------------------------------------------*/
+/* every joiner evaluation of this session appends `vocab` floats to buf (tests only) */
+APRIL_EXPORT void aprilx_session_trace_logits(AprilASRSession session, float *buf, size_t cap_floats, size_t *used_floats);
+APRIL_EXPORT uint64_t aprilx_session_chunks(AprilASRSession session);
+
+typedef struct AprilxStats {
+    uint64_t ticks, steps, chunks, rounds, frames, max_batch_seen;
+    /* per kernel class: accumulated ms and launch counts while profiling is enabled
+       0 gates GEMM+LSTM cell, 1 other encoder GEMMs, 2 row epilogues, 3 conv front end, 4 fbank, 5 decoder+joiner */
+    double kernel_ms[6];
+    uint64_t kernel_launches[6];
+} AprilxStats;
+APRIL_EXPORT void aprilx_model_stats(AprilASRModel model, int device_index, AprilxStats *out);
+/* bracket every launch with hipEvents on the engine's stream (measurement runs only) */
+APRIL_EXPORT void aprilx_model_profile(AprilASRModel model, int enable);
+
+/* state machine alone, for host-logic tests: feed (idx, max, blank) triples, receive events */
+typedef struct AprilxGreedy_i *AprilxGreedy;
+APRIL_EXPORT AprilxGreedy aprilx_greedy_create(AprilASRModel model, AprilRecognitionResultHandler handler, void *userdata);
+/* returns 1 when the round resolved to blank; ctx_out receives the 2-token context */
+APRIL_EXPORT int aprilx_greedy_step(AprilxGreedy g, int32_t idx, float max_val, float blank_val, float early_emit,
+                                    size_t now_ms, int32_t *ctx_out);
+APRIL_EXPORT void aprilx_greedy_finish(AprilxGreedy g);
+APRIL_EXPORT void aprilx_greedy_free(AprilxGreedy g);
+
+/* parse + weight extraction + packing without creating any GPU object (loader tests; no sessions) */
+APRIL_EXPORT AprilASRModel aprilx_model_load_host(const char *model_path);
+/* fbank tables as the device sees them (window[fft_size], mel[mel][fft_size/2]); returns fft_size */
+APRIL_EXPORT int aprilx_model_fbank_tables(AprilASRModel model, float *window, float *mel);
+
+/* container-only parse (no GPU): 0 on success, otherwise -1 and a message in err */
+APRIL_EXPORT int aprilx_probe_file(const char *path, char *err, size_t err_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

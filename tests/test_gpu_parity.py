@@ -1,0 +1,210 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(april_asr_amd/libaprilasr.so), against the CPU oracle on the same seeded inputs.
+
+Bars: fbank bit-exact; network outputs within 1e-4 per call (fp32, different summation order);
+full-session logits within 1e-3 and the callback transcript token-for-token
+(BASELINE.json north_star: "token-for-token ... logits within 1e-3 fp32").
+"""
+import numpy as np
+import pytest
+
+from conftest import speech_like_pcm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu_tiny(tiny_model):
+    import april_asr_amd as A
+    m = A.Model(tiny_model["path"])
+    yield m
+    m.close()
+
+
+@pytest.fixture(scope="module")
+def orc_tiny(tiny_model):
+    from oracle import orc_py as O
+    m = O.Model(tiny_model["path"])
+    yield m
+    m.close()
+
+
+@pytest.fixture(scope="module")
+def gpu_v0(v0_model):
+    import april_asr_amd as A
+    m = A.Model(v0_model["path"])
+    yield m
+    m.close()
+
+
+@pytest.fixture(scope="module")
+def orc_v0(v0_model):
+    from oracle import orc_py as O
+    m = O.Model(v0_model["path"])
+    yield m
+    m.close()
+
+
+def test_native_library_is_loaded(gpu_tiny):
+    """The product path is the in-tree HIP library; nothing here can fall back to the CPU."""
+    with open("/proc/self/maps") as f:
+        assert "april_asr_amd/libaprilasr.so" in f.read()
+    assert gpu_tiny.dims.n_devices >= 1
+
+
+# ------------------------------------------------------------------ fbank
+def test_fbank_kernel_bit_exact(gpu_tiny):
+    from oracle import orc_py as O
+    rng = np.random.RandomState(1)
+    n = gpu_tiny.dims.fft_size
+    frames = [O.lcg_pcm16_fast(n * 64, seed=99).reshape(64, n),
+              rng.randint(-32768, 32768, size=(64, n)).astype(np.int16),
+              (rng.randint(-300, 300, size=(16, n))).astype(np.int16),
+              np.zeros((2, n), np.int16),
+              np.full((2, n), -32768, np.int16), np.full((2, n), 32767, np.int16)]
+    pcm = np.concatenate(frames)
+    got = gpu_tiny.run_fbank(pcm)
+    fb = O.OrcFbank()
+    want = np.stack([fb.frame(pcm[i].astype(np.float32) / np.float32(32768.0)) for i in range(pcm.shape[0])])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), \
+        "max |diff| = %g" % np.abs(got - want).max()
+
+
+# ------------------------------------------------------------------ networks, one call
+@pytest.mark.parametrize("which", ["tiny", "v0"])
+def test_encoder_matches_oracle(which, request):
+    gm = request.getfixturevalue("gpu_" + which); om = request.getfixturevalue("orc_" + which)
+    d = gm.dims
+    rng = np.random.RandomState(5)
+    n = 3
+    x = rng.uniform(-16, 8, size=(n, d.seg, d.mel)).astype(np.float32)
+    h = rng.uniform(-0.5, 0.5, size=(n, d.n_layers, d.d_model)).astype(np.float32)
+    c = rng.uniform(-1, 1, size=(n, d.n_layers, d.hidden)).astype(np.float32)
+    eout, h2, c2 = gm.run_encoder(x, h, c)
+    for i in range(n):
+        e0, h0, c0 = om.encoder(x[i:i + 1], h[i][:, None, :], c[i][:, None, :])
+        assert np.abs(eout[i] - e0.ravel()).max() < 1e-4
+        assert np.abs(h2[i] - h0[:, 0, :]).max() < 1e-4
+        assert np.abs(c2[i] - c0[:, 0, :]).max() < 1e-4
+
+
+@pytest.mark.parametrize("which", ["tiny", "v0"])
+def test_decoder_and_joiner_match_oracle(which, request):
+    gm = request.getfixturevalue("gpu_" + which); om = request.getfixturevalue("orc_" + which)
+    d = gm.dims
+    rng = np.random.RandomState(6)
+    ctx = rng.randint(0, d.vocab, size=(5, 2)).astype(np.int64)
+    dout = gm.run_decoder(ctx)
+    for i in range(5):
+        assert np.abs(dout[i] - om.decoder(ctx[i]).ravel()).max() < 1e-5
+    e = rng.uniform(-2, 2, size=(5, d.joiner)).astype(np.float32)
+    lg = gm.run_joiner(e, dout)
+    for i in range(5):
+        assert np.abs(lg[i] - om.joiner(e[i].reshape(1, 1, -1), dout[i].reshape(1, 1, -1)).ravel()).max() < 1e-4
+
+
+def test_encoder_batch_invariant_bitwise(gpu_tiny):
+    """A row's result does not depend on the batch it is in (fixed reduction order)."""
+    d = gpu_tiny.dims
+    rng = np.random.RandomState(7)
+    n = 37
+    x = rng.uniform(-16, 8, size=(n, d.seg, d.mel)).astype(np.float32)
+    h = rng.uniform(-0.5, 0.5, size=(n, d.n_layers, d.d_model)).astype(np.float32)
+    c = rng.uniform(-1, 1, size=(n, d.n_layers, d.hidden)).astype(np.float32)
+    e_all, h_all, c_all = gpu_tiny.run_encoder(x, h, c)
+    for i in (0, 16, 36):
+        e1, h1, c1 = gpu_tiny.run_encoder(x[i:i + 1], h[i:i + 1], c[i:i + 1])
+        assert np.array_equal(e1[0], e_all[i]) and np.array_equal(h1[0], h_all[i]) and np.array_equal(c1[0], c_all[i])
+
+
+# ------------------------------------------------------------------ full sessions
+def run_oracle(om, pcm, chunk):
+    from oracle import orc_py as O
+    s = O.Session(om, trace_logits=8000)
+    for i in range(0, pcm.size, chunk):
+        s.feed(pcm[i:i + chunk])
+    s.flush()
+    ev = [(t, [(om.token(i).encode(), lp, fl, ms) for (i, lp, fl, ms) in toks]) for t, toks in s.events]
+    lg = s.logits().copy(); n = s.chunks()
+    s.close()
+    return ev, lg, n
+
+
+def run_gpu(gm, pcm, chunk, asynchronous=False):
+    import april_asr_amd as A
+    ev = []
+    s = A.Session(gm, lambda t, toks: ev.append((t, toks)), asynchronous=asynchronous, no_rt=asynchronous, raw_events=True)
+    s.trace_logits(8000)
+    for i in range(0, pcm.size, chunk):
+        s.feed_pcm16(pcm[i:i + chunk])
+        if asynchronous:
+            s.drain()
+    s.flush()
+    if asynchronous:
+        s.drain()
+    lg = s.traced_logits().copy(); n = s.chunks()
+    s.close()
+    return ev, lg, n
+
+
+def assert_same_transcript(want, got, tol=1e-3):
+    assert len(want) == len(got), "callback count %d vs %d" % (len(want), len(got))
+    for k, ((t0, k0), (t1, k1)) in enumerate(zip(want, got)):
+        assert t0 == t1, "callback %d type %d vs %d" % (k, t0, t1)
+        assert len(k0) == len(k1), "callback %d token count" % k
+        for a, b in zip(k0, k1):
+            assert a[0] == b[0] and a[2] == b[2] and a[3] == b[3], "callback %d token %r vs %r" % (k, a, b)
+            assert abs(a[1] - b[1]) < tol
+
+
+@pytest.mark.parametrize("chunk", [1600, 512, 16000 * 6])
+def test_session_transcript_tiny(gpu_tiny, orc_tiny, chunk):
+    pcm = np.concatenate([speech_like_pcm(3.0, seed=1), np.zeros(16000 * 3, np.int16)])
+    want, lg0, n0 = run_oracle(orc_tiny, pcm, 1600)
+    got, lg1, n1 = run_gpu(gpu_tiny, pcm, chunk)
+    assert n0 == n1
+    assert lg0.shape == lg1.shape and np.abs(lg0 - lg1).max() < 1e-3
+    assert_same_transcript(want, got)
+
+
+def test_session_transcript_tiny_async(gpu_tiny, orc_tiny):
+    from oracle import orc_py as O
+    pcm = O.lcg_pcm16_fast(16000 * 3, seed=4)
+    want, lg0, _ = run_oracle(orc_tiny, pcm, 1600)
+    got, lg1, _ = run_gpu(gpu_tiny, pcm, 1600, asynchronous=True)
+    assert lg0.shape == lg1.shape and np.abs(lg0 - lg1).max() < 1e-3
+    assert_same_transcript(want, got)
+
+
+def test_session_transcript_v0(gpu_v0, orc_v0):
+    """aprilv0 dimensions, 4 s of audio + flush (the oracle needs ~0.1 s per chunk)."""
+    pcm = speech_like_pcm(4.0, seed=3, silence=(1.0, 1.6))
+    want, lg0, n0 = run_oracle(orc_v0, pcm, 1600)
+    got, lg1, n1 = run_gpu(gpu_v0, pcm, 1600)
+    assert n0 == n1
+    assert lg0.shape == lg1.shape and np.abs(lg0 - lg1).max() < 1e-3, np.abs(lg0 - lg1).max()
+    assert_same_transcript(want, got)
+
+
+def test_many_sessions_equal_single(gpu_tiny):
+    """64 sessions fed together (different inputs) == each one alone, bit for bit (logits and callbacks)."""
+    import april_asr_amd as A
+    from oracle import orc_py as O
+    n = 64
+    pcms = [O.lcg_pcm16_fast(16000 * 2, seed=100 + i) for i in range(n)]
+    evs = [[] for _ in range(n)]
+    sess = [A.Session(gpu_tiny, (lambda k: (lambda t, toks: evs[k].append((t, toks))))(i), raw_events=True) for i in range(n)]
+    for s in sess:
+        s.trace_logits(400)
+    grp = A.SessionGroup(sess)
+    for o in range(0, 32000, 1600):
+        grp.feed([p[o:o + 1600] for p in pcms])
+    grp.flush()
+    st = gpu_tiny.stats()
+    assert st.max_batch_seen == n
+    for i in (0, 17, 63):
+        ev1, lg1, _ = run_gpu(gpu_tiny, pcms[i], 1600)
+        assert np.array_equal(lg1, sess[i].traced_logits())
+        assert ev1 == evs[i]
+    for s in sess:
+        s.close()
