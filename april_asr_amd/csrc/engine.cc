@@ -411,6 +411,20 @@ void Engine::joint(int n, const int *slots, JointResult *out, float *logits_out)
 }
 
 // ---------------------------------------------------------------- debug / parity entry points
+// The debug calls borrow slots 0..n-1; give them back zeroed (what a new session expects).
+void Engine::zero_slots(int n)
+{
+    const NetDims &d = L_.dims;
+    const size_t S = (size_t)cfg_.max_slots;
+    for (int l = 0; l < d.n_layers; ++l) {
+        HIP_CHECK(hipMemsetAsync(h_ + (size_t)l * S * d.d_model, 0, (size_t)n * d.d_model * 4, stream_));
+        HIP_CHECK(hipMemsetAsync(c_ + (size_t)l * S * d.hidden, 0, (size_t)n * d.hidden * 4, stream_));
+    }
+    HIP_CHECK(hipMemsetAsync(eout_, 0, (size_t)n * d.joiner * 4, stream_));
+    HIP_CHECK(hipMemsetAsync(dout_, 0, (size_t)n * d.joiner * 4, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
 void Engine::debug_encoder(int n, const float *x, const float *h, const float *c, float *eout, float *h2, float *c2)
 {
     HIP_CHECK(hipSetDevice(cfg_.device));
@@ -439,6 +453,7 @@ void Engine::debug_encoder(int n, const float *x, const float *h, const float *c
         }
     }
     (void)hipFree(xd);
+    zero_slots(n);
 }
 
 void Engine::debug_decoder(int n, const int64_t *ctx, float *dout)
@@ -449,6 +464,7 @@ void Engine::debug_decoder(int n, const int64_t *ctx, float *dout)
     decode(n, slots.data(), c32.data());
     sync();
     HIP_CHECK(hipMemcpy(dout, dout_, (size_t)n * d.joiner * 4, hipMemcpyDeviceToHost));
+    zero_slots(n);
 }
 
 void Engine::debug_joiner(int n, const float *eout, const float *dout, float *logits)
@@ -461,6 +477,7 @@ void Engine::debug_joiner(int n, const float *eout, const float *dout, float *lo
     for (int i = 0; i < n; ++i) slots[(size_t)i] = i;
     std::vector<JointResult> jr((size_t)n);
     joint(n, slots.data(), jr.data(), logits);
+    zero_slots(n);
 }
 
 void Engine::debug_fbank(int n_frames, const int16_t *pcm_frames, float *out)

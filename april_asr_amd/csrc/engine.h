@@ -91,6 +91,7 @@ public:
 
 private:
     void upload_tables(const FbankHostTables &ft);
+    void zero_slots(int n);
     void run_encoder_rows(int n, const int *d_slots, const int *d_tails, const float *x_direct);
     void timed_begin(int cls);
     void timed_end(int cls);

@@ -396,6 +396,21 @@ def write_model(path, dims=None, seed=2023, variant=None, punctuation=True, join
     return dims, w, toks
 
 
+def lcg_pcm16(n, seed=12345):
+    """Seeded white-noise PCM16: s = s*1664525 + 1013904223 (mod 2^32), sample = (int16)(s >> 16).
+    Vectorised: A[k] = a^k and S[k] = 1 + a + ... + a^(k-1) built by doubling, x_k = A[k] x_0 + c S[k]."""
+    a, c = 1664525, 1013904223
+    M = np.uint64(0xFFFFFFFF)
+    A = np.array([a], np.uint64); S = np.array([1], np.uint64)
+    while A.size < n:
+        am, sm = A[-1], S[-1]
+        A = np.concatenate([A, (am * A) & M])
+        S = np.concatenate([S, (sm + ((am * S) & M)) & M])
+    A, S = A[:n], S[:n]
+    x = (((A * np.uint64(seed)) & M) + ((np.uint64(c) * S) & M)) & M
+    return ((x >> np.uint64(16)) & np.uint64(0xFFFF)).astype(np.uint16).view(np.int16)
+
+
 if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser(description="write a synthetic .april model")

@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- streaming RNN-T hot path on MI355X, through the C ABI (libaprilasr.so).
+
+Metric (BASELINE.json): real-time factor / concurrent sessions at RTF <= 0.1 for
+aprilv0_en-us-sized weights, 16 kHz mono PCM16.  One "step" = every one of the B concurrent
+sessions on a GPU is fed 100 ms (1600 samples, parec-style) in ONE batched call and processed
+to completion (fbank -> 12-layer LSTM encoder -> joiner/greedy/decoder rounds -> callbacks).
+  value        = audio seconds processed per wall second, whole job (all GPUs)
+  rtf          = wall / audio per session  (every session advances together)
+Weak scaling: B sessions per GPU; sessions never talk to each other; the only collective is
+the RCCL broadcast of the packed weight blob at model load (rank 0 parses the .april file).
+
+Launch: python bench.py --gpus 1 --steps K --warmup W
+        python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Data: synthetic (seeded LCG noise PCM per session; seeded random weights at aprilv0 dims --
+there is no real model/audio offline).  Override with APRIL_MODEL=/path/model.april.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+HBM_PEAK_GBS = 8000.0              # spec; ~6300 measured achievable
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--sessions", type=int, default=int(os.environ.get("BENCH_SESSIONS", "256")), help="concurrent sessions per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=10)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ["APRIL_GPU_DEVICES"] = str(local_rank)
+    os.environ.setdefault("APRIL_MAX_SESSIONS", "4096")
+    os.environ.setdefault("APRIL_MAX_BATCH", "4096")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import april_asr_amd as A
+    from april_asr_amd import synth_model as SM
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    # ---------------- model: rank 0 parses the file, everyone else receives the packed blob over RCCL
+    t_load0 = time.time()
+    bcast_ms = None
+    if rank == 0:
+        path = os.environ.get("APRIL_MODEL")
+        if not path:
+            path = os.path.join(tempfile.gettempdir(), "bench_aprilv0_synth.april")
+            if not os.path.exists(path):
+                SM.write_model(path, SM.APRILV0_DIMS)
+        model = A.Model(path)
+    if world > 1:
+        if rank == 0:
+            blob = torch.from_numpy(model.export_blob()).to(dev)
+            size = torch.tensor([blob.numel()], dtype=torch.int64, device=dev)
+        else:
+            size = torch.zeros(1, dtype=torch.int64, device=dev)
+        dist.broadcast(size, 0)
+        if rank != 0:
+            blob = torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(); t0 = time.time()
+        dist.broadcast(blob, 0)                      # the one collective: weights over xGMI
+        torch.cuda.synchronize(); bcast_ms = (time.time() - t0) * 1e3
+        if rank != 0:
+            model = A.Model.from_blob(None, device_ptr=blob.data_ptr(), size=blob.numel())
+        del blob
+    load_s = time.time() - t_load0
+    d = model.dims
+
+    # ---------------- sessions + synthetic audio
+    B = args.sessions
+    n_steps = args.warmup + args.steps
+    step_samples = 1600
+    counts = [0]
+
+    def on_result(t, toks):
+        counts[0] += 1
+
+    def make_group(nsess, seed0):
+        sess = [A.Session(model, on_result, raw_events=True) for _ in range(nsess)]
+        return sess, A.SessionGroup(sess)
+
+    def pcm_for(nsess, nst, seed0):
+        # one LCG stream per session: seed 12345 + global session id
+        return [SM.lcg_pcm16(step_samples * nst, seed=12345 + seed0 + i) for i in range(nsess)]
+
+    sess, grp = make_group(B, rank * B)
+    pcm = pcm_for(B, n_steps, rank * B)
+
+    def run_steps(group, pcms, s0, s1):
+        for s in range(s0, s1):
+            group.feed([p[s * step_samples:(s + 1) * step_samples] for p in pcms])
+
+    run_steps(grp, pcm, 0, args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(grp, pcm, args.warmup, n_steps)
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    st = model.stats()
+    audio_per_session = args.steps * step_samples / 16000.0
+    value = world * B * audio_per_session / elapsed
+    rtf = elapsed / audio_per_session
+
+    # ---------------- roofline of the dominant kernel (gates GEMM + fused LSTM cell), live hipEvent timing
+    roofline = None
+    if rank == 0:
+        more = pcm_for(B, args.profile_steps, 10_000_000)
+        model.profile(True)
+        run_steps(grp, more, 0, args.profile_steps)
+        sp = model.stats()
+        model.profile(False)
+        launches = sp.kernel_launches[0]
+        if launches:
+            avg_ms = sp.kernel_ms[0] / launches
+            rows = sp.chunks - st.chunks        # session-chunks processed while profiling
+            steps_prof = sp.steps - st.steps
+            rows_per_launch = rows / max(1, steps_prof)
+            flops = 2.0 * rows_per_launch * (2 * d.d_model) * (4 * d.hidden)
+            wbytes = (2 * d.d_model) * (4 * d.hidden) * 4
+            sbytes = rows_per_launch * (d.d_model * 4 * 2 + d.hidden * 4 * 3)      # x,h read; c read+write; u write
+            tf = flops / (avg_ms * 1e-3) / 1e12
+            gbs = (wbytes + sbytes) / (avg_ms * 1e-3) / 1e9
+            frac_mfma, frac_hbm = tf / FP32_MFMA_PEAK_TFLOPS, gbs / HBM_PEAK_GBS
+            if frac_mfma >= frac_hbm:
+                roofline = {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(frac_mfma, 4), "traffic": None}
+            else:
+                roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(frac_hbm, 4), "traffic": None}
+            roofline.update({"kernel": "gemm_f32_kernel<EPI_LSTM> (LSTM gates [B,1024]x[1024,4096] + cell)",
+                             "avg_launch_us": round(avg_ms * 1e3, 2), "rows_per_launch": round(rows_per_launch, 1),
+                             "launches": int(launches), "alt_frac_hbm": round(frac_hbm, 4), "alt_frac_mfma": round(frac_mfma, 4),
+                             "class_ms": {k: round(sp.kernel_ms[i], 3) for i, k in enumerate(
+                                 ["gates", "gemm_other", "row", "conv", "fbank", "dec_joint"])}})
+    for s in sess:
+        s.close()
+
+    # ---------------- concurrency sweep (outside the timed region): RTF at other batch sizes
+    sweep = None
+    if rank == 0 and not args.no_sweep:
+        sweep = {}
+        for nb in (1, 16, 64, 1024, 2048):
+            ss, gg = make_group(nb, 0)
+            pp = pcm_for(nb, 12, 20_000_000)
+            run_steps(gg, pp, 0, 4)
+            torch.cuda.synchronize(); a = time.perf_counter()
+            run_steps(gg, pp, 4, 12)
+            torch.cuda.synchronize(); b = time.perf_counter()
+            sweep[str(nb)] = round((b - a) / (8 * 0.1), 5)
+            for s in ss:
+                s.close()
+        sweep[str(B)] = round(rtf, 5)
+
+    # ---------------- CPU baseline: the oracle (plain-C port, 1 thread) on the host, bounded sample
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import orc_py as O          # checker/baseline only; never on the measured path
+        path = os.environ.get("APRIL_MODEL") or os.path.join(tempfile.gettempdir(), "bench_aprilv0_synth.april")
+        om = O.Model(path)
+        osess = O.Session(om)
+        sample_s = 6.0
+        p = SM.lcg_pcm16(int(16000 * sample_s), seed=12345)
+        a = time.perf_counter()
+        for o in range(0, p.size, step_samples):
+            osess.feed(p[o:o + step_samples])
+        b = time.perf_counter()
+        cpu = {"value": round(sample_s / (b - a), 4), "unit": "audio_seconds_per_second", "cores": 1, "kind": "port",
+               "sample": "oracle/liborc.so (plain-C restatement, 1 thread, 1 session), %.0f s of 16 kHz LCG-noise PCM16 in 100 ms feeds, "
+                         "%d chunks, no flush; ONNXRuntime (the reference's backend) is not installed here" % (sample_s, osess.chunks()),
+               "rtf": round((b - a) / sample_s, 4), "host_cpus": os.cpu_count()}
+        osess.close(); om.close()
+
+    if rank == 0:
+        max_ok = None
+        if sweep:
+            ok = [int(k) for k, v in sweep.items() if v <= 0.1]
+            max_ok = max(ok) if ok else 0
+        out = {
+            "metric": "audio_seconds_per_second (concurrent 16 kHz sessions x 1/RTF), aprilv0_en-us-sized streaming RNN-T",
+            "value": round(value, 2), "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "aprilv0_en-us dims (synthetic seeded weights), %d concurrent streaming sessions per GPU, "
+                                   "100 ms PCM16 feeds via aprilx_feed_many (BASELINE configs[2]; configs[3] at 8 GPUs)" % B,
+                       "sessions_per_gpu": B, "feed_ms": 100, "params": int(d.param_count), "parallelism": "sessions sharded, dp%d" % world},
+            "rtf": round(rtf, 5), "sessions_total": world * B,
+            "max_sessions_per_gpu_rtf_le_0.1_tested": max_ok, "rtf_by_sessions_per_gpu": sweep,
+            "callbacks": counts[0], "model_load_s": round(load_s, 2), "weight_broadcast_ms": bcast_ms,
+            "engine_steps": int(st.steps), "max_batch_seen": int(st.max_batch_seen),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    model.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
