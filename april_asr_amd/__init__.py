@@ -112,9 +112,9 @@ class Model:
         return w, mel
 
     @classmethod
-    def from_blob(cls, blob, device_ptr: int = 0, size: int = 0):
+    def from_blob(cls, blob, device_ptr: int = 0, size: int = 0, init_gpu: bool = True):
         """Build a model from an exported blob: a uint8 ndarray (host) or (device_ptr, size)."""
-        L = _ffi.init()
+        L = _ffi.init() if (device_ptr or init_gpu) else _ffi.lib()
         if device_ptr:
             h = L.aprilx_model_from_blob(C.c_void_p(device_ptr), size, 1)
         else:
@@ -122,7 +122,11 @@ class Model:
             h = L.aprilx_model_from_blob(blob.ctypes.data, blob.size, 0)
         if not h:
             raise Exception("Failed to build model from blob")
-        return cls(_handle=h)
+        m = cls.__new__(cls)
+        m._L = L; m._handle = h
+        m.dims = _ffi.AprilxDims()
+        L.aprilx_model_dims(h, C.byref(m.dims))
+        return m
 
     def run_encoder(self, x, h, c):
         d = self.dims

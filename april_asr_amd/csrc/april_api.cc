@@ -286,7 +286,11 @@ int aprilx_model_export_blob(AprilASRModel model, void *dst, size_t dst_size)
 
 AprilASRModel aprilx_model_from_blob(const void *blob, size_t size, int blob_is_device_ptr)
 {
-    if (!g_inited) { LOGE("aprilx: not initialised"); return nullptr; }
+    // Without an initialised GPU runtime (aam_api_init not called / no device) a HOST blob still
+    // yields a host-only model: metadata + packed weights, no engine, no sessions (loader tests,
+    // and the gloo leg of the broadcast path on CPU-only machines).
+    const bool host_only = !g_inited;
+    if (host_only && blob_is_device_ptr) { LOGE("aprilx: device blob without an initialised GPU runtime"); return nullptr; }
     BlobHeader hd;
     if (size < sizeof hd) return nullptr;
     if (blob_is_device_ptr) { HIP_CHECK(hipSetDevice(g_devices[0])); HIP_CHECK(hipMemcpy(&hd, blob, sizeof hd, hipMemcpyDeviceToHost)); }
@@ -298,6 +302,13 @@ AprilASRModel aprilx_model_from_blob(const void *blob, size_t size, int blob_is_
     AprilASRModel_i *h = new AprilASRModel_i();
     if (!parse_meta(meta.data(), meta.size(), h->m) || h->m.layout.total != hd.weight_floats) { LOGE("aprilx: blob metadata invalid"); delete h; return nullptr; }
     const float *w = (const float *)((const char *)blob + hd.weights_offset);
+    if (host_only) {
+        const ModelParams &P = h->m.host.params;
+        h->m.host_blob.assign(w, w + hd.weight_floats);
+        if (!build_fbank_tables(P.sample_rate, P.frame_shift_ms, P.frame_length_ms, P.mel_features, P.round_pow2 != 0, P.mel_low, P.mel_high, h->m.ftab)) { delete h; return nullptr; }
+        h->m.tok_class = classify_tokens(P);
+        return h;
+    }
     std::vector<float> staged;
     const float *host_w = nullptr, *dev_w = nullptr;
     if (blob_is_device_ptr) {

@@ -1,0 +1,150 @@
+"""Weight extraction + MFMA packing (host-only load, no GPU): the packed blob the engine uploads must
+contain exactly the weights the synthetic exporter wrote, whatever ONNX spelling was used."""
+import struct
+
+import numpy as np
+import pytest
+
+import april_asr_amd as A
+from april_asr_amd import synth_model as SM
+
+
+def split_blob(blob):
+    magic, meta_bytes, wfloats, woff = struct.unpack("<8sQQQ", blob[:32].tobytes())
+    assert magic == b"APXBLOB1"
+    return np.frombuffer(blob[woff:woff + wfloats * 4].tobytes(), np.float32)
+
+
+def unpack_mfma(p, K, N, Npad):
+    """inverse of the kernel layout: Wp[((t*KB+kb)*64+lane)*4+j] = W[kb*16+(lane>>4)*4+j][t*16+(lane&15)]"""
+    KB, NT = K // 16, Npad // 16
+    a = p[:Npad * K].reshape(NT, KB, 64, 4)
+    W = np.zeros((K, Npad), np.float32)
+    lane = np.arange(64)
+    for j in range(4):
+        k = (np.arange(KB)[:, None] * 16 + (lane >> 4)[None, :] * 4 + j)            # [KB,64]
+        n = (np.arange(NT)[:, None, None] * 16 + (lane & 15)[None, None, :])        # [NT,1,64]
+        W[np.broadcast_to(k[None], (NT, KB, 64)), np.broadcast_to(n, (NT, KB, 64))] = a[..., j]
+    return W[:, :N]
+
+
+def layout_offsets(d):
+    """mirror of plan_layout (engine.cc): 64-float aligned sections in a fixed order"""
+    off = [0]
+
+    def take(n):
+        o = off[0]
+        off[0] = (o + n + 63) & ~63
+        return o
+    L = {}
+    cin = 1
+    for i, c in enumerate(d["conv_ch"]):
+        L["conv_w%d" % i] = take(c * cin * 9); L["conv_b%d" % i] = take(c); cin = c
+    f_out = ((d["mel"] - 3) // 2 - 1) // 2
+    ein = d["conv_ch"][2] * f_out
+    L["w_embed"] = take(ein * d["d_model"]); L["b_embed"] = take(d["d_model"])
+    for l in range(d["n_layers"]):
+        L["wg%d" % l] = take(2 * d["d_model"] * 4 * d["hidden"]); L["bg%d" % l] = take(4 * d["hidden"])
+        L["whr%d" % l] = take(d["hidden"] * d["d_model"])
+        L["wff1%d" % l] = take(d["d_model"] * d["ffn"]); L["bff1%d" % l] = take(d["ffn"])
+        L["wff2%d" % l] = take(d["ffn"] * d["d_model"]); L["bff2%d" % l] = take(d["d_model"])
+    L["w_encproj"] = take(d["d_model"] * d["joiner"]); L["b_encproj"] = take(d["joiner"])
+    L["emb"] = take(d["vocab"] * d["d_model"])
+    L["dec_conv"] = take(d["d_model"] * (d["d_model"] // d["dec_groups"]) * d["context"]); L["dec_conv_b"] = take(d["d_model"])
+    L["w_decproj"] = take(d["d_model"] * d["joiner"]); L["b_decproj"] = take(d["joiner"])
+    vp = (d["vocab"] + 15) & ~15
+    L["w_out"] = take(d["joiner"] * vp); L["b_out"] = take(vp)
+    return L, ein, vp
+
+
+def check_blob(w, d, wts):
+    L, ein, vp = layout_offsets(d)
+    D, H, F, J, V = d["d_model"], d["hidden"], d["ffn"], d["joiner"], d["vocab"]
+    for i in range(3):
+        assert np.array_equal(w[L["conv_w%d" % i]:][:wts["conv%d.w" % i].size], wts["conv%d.w" % i].ravel())
+        assert np.array_equal(w[L["conv_b%d" % i]:][:wts["conv%d.b" % i].size], wts["conv%d.b" % i])
+    assert np.array_equal(unpack_mfma(w[L["w_embed"]:], ein, D, D), wts["embed.w"].T)
+    assert np.array_equal(w[L["b_embed"]:][:D], wts["embed.b"])
+    for l in range(d["n_layers"]):
+        p = "l%d." % l
+        Wg = unpack_mfma(w[L["wg%d" % l]:], 2 * D, 4 * H, 4 * H)                 # columns unit-major: u*4+g
+        src = np.concatenate([wts[p + "w_ih"].T, wts[p + "w_hh"].T], 0)           # [2D][4H], gate-major
+        want = src.reshape(2 * D, 4, H).transpose(0, 2, 1).reshape(2 * D, 4 * H)
+        assert np.array_equal(Wg, want)
+        bsum = (wts[p + "b_ih"] + wts[p + "b_hh"]).reshape(4, H).T.ravel()
+        assert np.array_equal(w[L["bg%d" % l]:][:4 * H], bsum)
+        assert np.array_equal(unpack_mfma(w[L["whr%d" % l]:], H, D, D), wts[p + "w_hr"].T)
+        assert np.array_equal(unpack_mfma(w[L["wff1%d" % l]:], D, F, F), wts[p + "ff1.w"].T)
+        assert np.array_equal(unpack_mfma(w[L["wff2%d" % l]:], F, D, D), wts[p + "ff2.w"].T)
+        assert np.array_equal(w[L["bff1%d" % l]:][:F], wts[p + "ff1.b"]) and np.array_equal(w[L["bff2%d" % l]:][:D], wts[p + "ff2.b"])
+    assert np.array_equal(unpack_mfma(w[L["w_encproj"]:], D, J, J), wts["enc_proj.w"].T)
+    assert np.array_equal(w[L["emb"]:][:V * D], wts["emb"].ravel())
+    assert np.array_equal(w[L["dec_conv"]:][:wts["dec_conv.w"].size], wts["dec_conv.w"].ravel())
+    assert np.array_equal(unpack_mfma(w[L["w_decproj"]:], D, J, J), wts["dec_proj.w"].T)
+    out = unpack_mfma(w[L["w_out"]:], J, vp, vp)
+    assert np.array_equal(out[:, :V], wts["out.w"].T) and not out[:, V:].any()
+    assert np.array_equal(w[L["b_out"]:][:V], wts["out.b"])
+
+
+def test_extraction_and_packing(built, tiny_model):
+    m = A.Model.load_host_only(tiny_model["path"])
+    d = tiny_model["dims"]
+    assert (m.dims.n_layers, m.dims.d_model, m.dims.hidden, m.dims.ffn, m.dims.joiner, m.dims.vocab) == \
+           (d["n_layers"], d["d_model"], d["hidden"], d["ffn"], d["joiner"], d["vocab"])
+    assert (m.dims.seg, m.dims.seg_step, m.dims.mel, m.dims.context, m.dims.fft_size, m.dims.frame_shift) == (9, 4, 80, 2, 512, 160)
+    check_blob(split_blob(m.export_blob()), d, tiny_model["weights"])
+    m.close()
+
+
+def test_alternative_onnx_spelling_gives_identical_blob(built, tiny_model, tiny_model_variant):
+    """MatMul+Add instead of Gemm for the LSTM gates, BasicNorm eps as Exp(initializer)."""
+    a = A.Model.load_host_only(tiny_model["path"]); b = A.Model.load_host_only(tiny_model_variant["path"])
+    ba, bb = a.export_blob(), b.export_blob()
+    assert np.array_equal(split_blob(ba), split_blob(bb))
+    a.close(); b.close()
+
+
+def test_blob_roundtrip_host(built, tiny_model):
+    a = A.Model.load_host_only(tiny_model["path"])
+    blob = a.export_blob()
+    b = A.Model.from_blob(blob, init_gpu=False)
+    assert np.array_equal(blob, b.export_blob())
+    assert b.get_name() == a.get_name() and b.dims.param_count == a.dims.param_count
+    assert [b.token(i) for i in range(b.dims.vocab)] == tiny_model["tokens"]
+    a.close(); b.close()
+
+
+def test_param_count_aprilv0_dims():
+    """84.18 M parameters at aprilv0 dimensions (SURVEY.md Appendix C cross-check), from shapes alone."""
+    d = SM.APRILV0_DIMS
+    D, H, F, J, V = d["d_model"], d["hidden"], d["ffn"], d["joiner"], d["vocab"]
+    embed = 8 * 9 + 8 + 32 * 8 * 9 + 32 + 128 * 32 * 9 + 128 + 2304 * D + D
+    layer = 2 * 4 * H * D + 2 * 4 * H + H * D + D * F + F + F * D + D + 1
+    total = embed + 12 * layer + D * J + J + V * D + D * (D // d["dec_groups"]) * 2 + D * J + J + J * V + V
+    assert embed == 1219568 and layer == 6826497 and total == 84179440
+
+
+@pytest.mark.parametrize("breakage", ["wrong_gate_act", "swish_const", "no_norm"])
+def test_unsupported_graphs_are_rejected(built, tmp_path, breakage, capfd):
+    """The loader verifies the operators around each weight instead of trusting positions."""
+    import april_asr_amd.synth_model as S
+    dims = dict(S.TINY_DIMS)
+    w = S.make_weights(dims)
+    toks = S.make_tokens(dims["vocab"])
+    orig_ds, orig_bn = S._double_swish, S._basic_norm
+    try:
+        if breakage == "swish_const":
+            S._double_swish = lambda g, x: g.node("Mul", [x, g.node("Sigmoid", [g.node("Sub", [x, g.const(np.array(2.0, np.float32))])])])
+        if breakage == "no_norm":
+            S._basic_norm = lambda g, x, e, n, f: g.node("Identity", [x])
+        enc = S.build_encoder(dims, w, {})
+        if breakage == "wrong_gate_act":
+            enc = enc.replace(b"\x22\x04Tanh", b"\x22\x04Relu", 1)      # op_type field (4) of the first Tanh node
+    finally:
+        S._double_swish, S._basic_norm = orig_ds, orig_bn
+    blob = S.container_bytes([enc, S.build_decoder(dims, w, {}), S.build_joiner(dims, w, {})], S.params_block(dims, toks))
+    p = tmp_path / "bad.april"
+    p.write_bytes(blob)
+    with pytest.raises(Exception):
+        A.Model.load_host_only(str(p))
+    assert "failed to load" in capfd.readouterr().err

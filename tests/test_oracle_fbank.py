@@ -1,0 +1,98 @@
+"""Pins the fbank oracle (oracle/orc_fbank.c): bit-exact against the committed golden vectors
+(generated from the reference's compiled fbank.c/pocketfft.c by tests/golden/make_golden.py) and,
+where /root/reference exists, against the compiled reference itself on more chunkings."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc_py as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def wave(pcm):
+    return pcm.astype(np.float32) / np.float32(32768.0)
+
+
+def run(fb, pcm, seg):
+    feed = []
+    w = wave(pcm)
+    for i in range(0, w.size, seg):
+        fb.accept(w[i:i + seg])
+        feed += fb.pull_all()
+    p1 = []
+    while fb.flush():
+        p1 += fb.pull_all()
+    fb.accept_zeros(3200); fb.accept_zeros(3200)
+    p2 = []
+    while fb.flush():
+        p2 += fb.pull_all()
+    return np.array(feed), np.array(p1), np.array(p2)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_golden_lcg_chunks(built):
+    g = np.load(os.path.join(G, "fbank_lcg.npz"))
+    pcm = O.lcg_pcm16_fast(160000, seed=int(g["seed"]))
+    feed, p1, p2 = run(O.OrcFbank(), pcm[:16000], 3200)
+    assert np.array_equal(bits(feed), bits(g["feed_1s"]))
+    assert np.array_equal(bits(p1), bits(g["flush1_1s"])) and np.array_equal(bits(p2), bits(g["flush2_1s"]))
+    feed, p1, p2 = run(O.OrcFbank(), pcm, 3200)
+    # 248 chunks while feeding 10 s, 9 after the first flush drain, 28 in total
+    assert len(feed) == int(g["n_feed_10s"]) == 248
+    assert len(p1) == int(g["n_flush1_10s"]) == 9 and len(p1) + len(p2) == int(g["n_flush_total_10s"]) == 28
+    assert feed.astype(np.float64).sum() == float(g["sum_feed_10s"])
+    assert np.array_equal(bits(feed[0]), bits(g["first_chunk_10s"]))
+    assert np.array_equal(bits(p2[-1]), bits(g["last_flush_chunk_10s"]))
+    assert p2[-1][-1][-1] == np.float32(-15.9423847)
+
+
+def test_golden_tables(built):
+    g = np.load(os.path.join(G, "fbank_lcg.npz"))
+    fb = O.OrcFbank()
+    assert np.array_equal(bits(fb.window()), bits(g["window"]))
+    assert np.array_equal(bits(fb.mel()), bits(g["mel"]))
+
+
+def test_golden_single_frames(built):
+    g = np.load(os.path.join(G, "fbank_frames.npz"))
+    fb = O.OrcFbank()
+    got = np.stack([fb.frame(wave(p)) for p in g["pcm"]])
+    assert np.array_equal(bits(got), bits(g["logmel"]))
+
+
+@pytest.mark.parametrize("seg", [1600, 512, 333, 7, 160000])
+def test_chunking_invariance(built, seg):
+    """G3: the same PCM fed in any call sizes gives identical chunks (fbank.c leftover logic == FIFO)."""
+    pcm = O.lcg_pcm16_fast(24000, seed=777)
+    a = run(O.OrcFbank(), pcm, 3200)
+    b = run(O.OrcFbank(), pcm, seg)
+    for x, y in zip(a, b):
+        assert np.array_equal(bits(x), bits(y))
+
+
+@pytest.mark.skipif(not O.ref_available(), reason="compiled reference (oracle/_ref) not present")
+@pytest.mark.parametrize("seg,seed", [(3200, 1), (1600, 2), (512, 3), (100, 4), (48000, 5)])
+def test_against_compiled_reference(built, seg, seed):
+    rng = np.random.RandomState(seed)
+    pcm = np.concatenate([O.lcg_pcm16_fast(20000, seed=seed), np.zeros(3000, np.int16),
+                          rng.randint(-2000, 2000, size=9000).astype(np.int16)])
+    a = run(O.OrcFbank(), pcm, seg)
+    b = run(O.RefFbank(), pcm, seg)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and np.array_equal(bits(x), bits(y))
+
+
+@pytest.mark.skipif(not O.ref_available(), reason="compiled reference (oracle/_ref) not present")
+def test_other_geometry_against_reference(built):
+    """8 kHz (256-point FFT: factors 4,4,4,4) and 40 mel bins."""
+    kw = dict(rate=8000, nbins=40, seg_count=9, seg_step=4)
+    pcm = O.lcg_pcm16_fast(16000, seed=9)
+    a = run(O.OrcFbank(**kw), pcm, 800)
+    b = run(O.RefFbank(**kw), pcm, 800)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and np.array_equal(bits(x), bits(y))
