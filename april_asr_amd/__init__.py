@@ -262,5 +262,22 @@ class SessionGroup:
             self._counts[i] = a.size
         self._L.aprilx_feed_many(len(keep), self._handles, self._ptrs, self._counts)
 
+    def plan(self, pcms: Sequence[np.ndarray], step_samples: int):
+        """Pre-build the pointer/count arrays for feeding `step_samples` per session per call, so the
+        per-step host cost is one library call (what a C/C++ host would do)."""
+        n = len(self.sessions)
+        self._plan_keep = [np.ascontiguousarray(p, np.int16) for p in pcms]
+        steps = min(p.size for p in self._plan_keep) // step_samples
+        self._plan = []
+        for s in range(steps):
+            ptrs = (C.c_void_p * n)(*[p.ctypes.data + 2 * s * step_samples for p in self._plan_keep])
+            cnts = (C.c_size_t * n)(*([step_samples] * n))
+            self._plan.append((ptrs, cnts))
+        return steps
+
+    def feed_planned(self, step: int):
+        ptrs, cnts = self._plan[step]
+        self._L.aprilx_feed_many(len(self.sessions), self._handles, ptrs, cnts)
+
     def flush(self):
         self._L.aprilx_flush_many(len(self.sessions), self._handles)

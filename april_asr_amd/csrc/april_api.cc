@@ -35,7 +35,7 @@ bool build_runtime(Model &m, const float *blob_host, const float *blob_device)
         LOGE("aam: unsupported frame length (FFT size must be a power of two)");
         return false;
     }
-    if (m.layout.dims.embed_in % 16 || m.layout.dims.d_model % 16 || m.layout.dims.hidden % 16 || m.layout.dims.ffn % 16 || m.layout.dims.joiner % 16) {
+    if (m.layout.dims.embed_in % 16 || m.layout.dims.d_model % 16 || m.layout.dims.hidden % 16 || m.layout.dims.ffn % 16 || m.layout.dims.joiner % 16 || m.layout.dims.conv_ch[2] % 16) {
         LOGE("aam: layer widths must be multiples of 16 for the MFMA kernels");
         return false;
     }

@@ -16,8 +16,11 @@ void plan_layout(const NetDims &d, bool has_dec_conv_b, PackedLayout &L)
     L.vocab_pad = (d.vocab + 15) & ~15;
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off = align64(off + n); return o; };
-    int cin = 1;
-    for (int i = 0; i < 3; ++i) { L.conv_w[i] = take((size_t)d.conv_ch[i] * cin * 9); L.conv_b[i] = take((size_t)d.conv_ch[i]); cin = d.conv_ch[i]; }
+    // conv 0/1: OIHW as exported; conv 2 runs as an im2col GEMM: MFMA-packed [k3][conv_ch[2]], k = ci*9 + i*3 + j
+    L.k3 = (d.conv_ch[1] * 9 + 15) & ~15;
+    L.conv_w[0] = take((size_t)d.conv_ch[0] * 9); L.conv_b[0] = take((size_t)d.conv_ch[0]);
+    L.conv_w[1] = take((size_t)d.conv_ch[1] * d.conv_ch[0] * 9); L.conv_b[1] = take((size_t)d.conv_ch[1]);
+    L.conv_w[2] = take((size_t)L.k3 * d.conv_ch[2]); L.conv_b[2] = take((size_t)d.conv_ch[2]);
     L.w_embed = take((size_t)d.embed_in * d.d_model); L.b_embed = take((size_t)d.d_model);
     L.layers.resize((size_t)d.n_layers);
     for (auto &l : L.layers) {
@@ -59,10 +62,23 @@ void pack_weights(const HostModel &m, PackedLayout &L, std::vector<float> &blob)
     blob.assign(L.total, 0.0f);
     float *B = blob.data();
     for (int i = 0; i < 3; ++i) {
-        memcpy(B + L.conv_w[i], m.conv_w[i].data(), m.conv_w[i].size() * 4);
+        if (i < 2) memcpy(B + L.conv_w[i], m.conv_w[i].data(), m.conv_w[i].size() * 4);
         memcpy(B + L.conv_b[i], m.conv_b[i].data(), m.conv_b[i].size() * 4);
     }
-    pack_mfma(m.w_embed.data(), d.embed_in, d.d_model, d.d_model, nullptr, B + L.w_embed);
+    {   // third conv as a K x N matrix: W3[k][o] = w[o][ci][i][j], k = ci*9 + i*3 + j (zero rows up to k3)
+        const int kreal = d.conv_ch[1] * 9, c2 = d.conv_ch[2];
+        std::vector<float> w3((size_t)L.k3 * c2, 0.0f);
+        for (int o = 0; o < c2; ++o) for (int k = 0; k < kreal; ++k) w3[(size_t)k * c2 + o] = m.conv_w[2][(size_t)o * kreal + k];
+        pack_mfma(w3.data(), L.k3, c2, c2, nullptr, B + L.conv_w[2]);
+    }
+    {   // the conv GEMM leaves its output position-major ([f][c]); the graph flattens channel-major (c*f_out + f):
+        // permute the embed linear's input rows instead of transposing activations
+        const int c2 = d.conv_ch[2], F = d.f_out;
+        std::vector<float> we((size_t)d.embed_in * d.d_model);
+        for (int c = 0; c < c2; ++c) for (int f = 0; f < F; ++f)
+            memcpy(&we[((size_t)f * c2 + c) * d.d_model], &m.w_embed[((size_t)c * F + f) * d.d_model], (size_t)d.d_model * 4);
+        pack_mfma(we.data(), d.embed_in, d.d_model, d.d_model, nullptr, B + L.w_embed);
+    }
     memcpy(B + L.b_embed, m.b_embed.data(), (size_t)d.d_model * 4);
     L.embed_eps = m.embed_norm_eps;
     L.norm_eps.resize((size_t)d.n_layers);
@@ -137,6 +153,8 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     const size_t ws_n = (size_t)std::max({kz_embed_ * d.d_model, kz_hr_ * d.d_model, kz_ff2_ * d.d_model, kz_proj_ * d.joiner, kz_out_ * L_.vocab_pad});
     ws_ = dmalloc<float>(ws_n * MB);
     xin_ = dmalloc<float>(MB * d.embed_in);
+    a3_ = dmalloc<float>(MB * d.f_out * L_.k3);
+    HIP_CHECK(hipMemset(a3_, 0, MB * d.f_out * L_.k3 * 4));      // padded k columns (if any) stay zero
     xa_ = dmalloc<float>(MB * d.d_model);
     xb_ = dmalloc<float>(MB * d.d_model);
     u_ = dmalloc<float>(MB * d.hidden);
@@ -162,7 +180,7 @@ Engine::~Engine()
     (void)hipSetDevice(cfg_.device);
     (void)hipStreamSynchronize(stream_);
     for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    for (void *p : {(void *)w_, (void *)h_, (void *)c_, (void *)ring_, (void *)eout_, (void *)dout_, (void *)ws_, (void *)xin_, (void *)xa_,
+    for (void *p : {(void *)w_, (void *)h_, (void *)c_, (void *)ring_, (void *)eout_, (void *)dout_, (void *)ws_, (void *)xin_, (void *)a3_, (void *)xa_,
                     (void *)xb_, (void *)u_, (void *)ff_, (void *)de_, (void *)logits_, (void *)joint_d_, (void *)ds_enc_, (void *)ds_dec_,
                     (void *)ds_joi_, (void *)ds_desc_, (void *)ds_pcm_})
         if (p) (void)hipFree(p);
@@ -291,8 +309,14 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
     ca.ring = ring_; ca.ring_frames = ring_frames_; ca.mel = d.mel; ca.seg = d.seg;
     ca.slot_idx = d_slots; ca.ring_tail = d_tails; ca.x_direct = x_direct;
     for (int i = 0; i < 3; ++i) { ca.w[i] = w_ + L_.conv_w[i]; ca.b[i] = w_ + L_.conv_b[i]; ca.ch[i] = d.conv_ch[i]; ca.stride[i] = d.conv_stride[i]; }
-    ca.out = xin_; ca.ldo = d.embed_in; ca.M = n;
+    ca.ch1_per_group = (d.conv_ch[1] % 8 == 0) ? 8 : d.conv_ch[1];
+    ca.out = a3_; ca.ldo = L_.k3; ca.M = n;
     timed_begin(T_CONV); launch_conv_embed(ca, stream_); timed_end(T_CONV);
+    {   // third conv: [n*f_out, k3] x [k3, c2] + bias, DoubleSwish -> xin[n][f_out*c2]
+        GemmArgs g; g.a0 = a3_; g.lda0 = L_.k3; g.K0 = L_.k3; g.wp = w_ + L_.conv_w[2];
+        g.M = n * d.f_out; g.N = d.conv_ch[2]; g.K = L_.k3; g.kz = 1; g.epi = EPI_BIAS_DSWISH; g.out = xin_; g.ldo = d.conv_ch[2]; g.bias = w_ + L_.conv_b[2];
+        timed_begin(T_CONV); launch_gemm(g, stream_); timed_end(T_CONV);
+    }
 
     // embed linear + bias + BasicNorm
     {

@@ -28,6 +28,7 @@ namespace aprilx {
 struct PackedLayout {
     NetDims dims;
     size_t conv_w[3], conv_b[3];
+    int k3 = 0;                              // K of the third conv as a GEMM (conv_ch[1]*9 rounded up to 16)
     size_t w_embed, b_embed;
     struct Layer { size_t wg, bg, whr, wff1, bff1, wff2, bff2; };
     std::vector<Layer> layers;
@@ -105,7 +106,7 @@ private:
     float *h_ = nullptr, *c_ = nullptr, *ring_ = nullptr, *eout_ = nullptr, *dout_ = nullptr;
     int ring_frames_ = 0;
     // work buffers
-    float *xin_ = nullptr, *xa_ = nullptr, *xb_ = nullptr, *u_ = nullptr, *ff_ = nullptr, *ws_ = nullptr, *de_ = nullptr;
+    float *xin_ = nullptr, *a3_ = nullptr, *xa_ = nullptr, *xb_ = nullptr, *u_ = nullptr, *ff_ = nullptr, *ws_ = nullptr, *de_ = nullptr;
     float *logits_ = nullptr;
     JointResult *joint_d_ = nullptr;
     // staging (pinned host + device mirrors), one region per call type

@@ -70,7 +70,7 @@ struct RowArgs {
 };
 void launch_row(const RowArgs &r, hipStream_t s);
 
-// ---------------------------------------------------------------- encoder front (conv stack)
+// ---------------------------------------------------------------- encoder front (conv 1+2, im2col for conv 3)
 struct ConvEmbedArgs {
     const float *ring = nullptr;           // [slots][ring_frames][mel]
     int ring_frames = 0, mel = 0, seg = 0;
@@ -79,8 +79,9 @@ struct ConvEmbedArgs {
     const float *w[3] = {nullptr, nullptr, nullptr};
     const float *b[3] = {nullptr, nullptr, nullptr};
     int ch[3] = {0, 0, 0};
+    int ch1_per_group = 0;                 // second-conv channels per workgroup (grid.y = ch[1] / this)
     int stride[3] = {1, 2, 2};
-    float *out = nullptr; int ldo = 0;     // [M][ch2 * f_out]
+    float *out = nullptr; int ldo = 0;     // im2col rows of the third conv: [M * f_out][ldo], k = ci*9 + i*3 + j
     int M = 0;
     const float *x_direct = nullptr;       // debug path: x given as [M][seg][mel] instead of the ring
 };

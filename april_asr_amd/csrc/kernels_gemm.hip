@@ -90,29 +90,46 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
             b[nt] = stream_once ? __builtin_nontemporal_load(wbase[nt] + (size_t)kb * 64) : wbase[nt][(size_t)kb * 64];
     };
 
+    // Register-staged software pipeline: DEPTH k-blocks of loads are in flight per wave while the
+    // MFMAs of the oldest stage issue.  Small batches (MT == 1) are HBM-bound weight streams and want
+    // many bytes in flight per CU (6 x 4 waves x (1+NT) KiB); large tiles are MFMA-bound and need
+    // only enough depth to cover L2 latency.
+    constexpr int DEPTH = (MT == 1) ? 6 : (MT == 2 ? 3 : 2);
     if (wb0 < wb1) {
-        f32x4 a_cur[MT], b_cur[NT], a_nxt[MT], b_nxt[NT];
-        load_a(wb0, a_cur);
-        load_b(wb0, b_cur);
-        for (int kb = wb0; kb < wb1; ++kb) {
-            const bool more = kb + 1 < wb1;
-            if (more) { load_a(kb + 1, a_nxt); load_b(kb + 1, b_nxt); }
+        f32x4 a_st[DEPTH][MT], b_st[DEPTH][NT];
+        const int last = wb1 - 1;
+        // Loads are UNCONDITIONAL (indices clamped to the wave's last block) so the loop body is
+        // straight-line code and the compiler can keep counted s_waitcnt vmcnt(N) instead of draining.
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) { const int kb = min(wb0 + s, last); load_a(kb, a_st[s]); load_b(kb, b_st[s]); }
+        auto compute = [&](const f32x4 (&a)[MT], const f32x4 (&b)[NT]) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt].x, b_cur[nt].x, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt].y, b_cur[nt].y, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt].z, b_cur[nt].z, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt].w, b_cur[nt].w, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
                 }
-            if (more) {
+        };
+        int kb0 = wb0;
+        for (; kb0 + DEPTH <= wb1; kb0 += DEPTH) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) b_cur[nt] = b_nxt[nt];
+            for (int s = 0; s < DEPTH; ++s) {
+                compute(a_st[s], b_st[s]);
+                // pin the refill right behind its stage's MFMAs: left alone, the scheduler sinks all
+                // refills to the loop end and the next iteration waits out a full memory latency
+                __builtin_amdgcn_sched_barrier(0);
+                const int nk = min(kb0 + DEPTH + s, last);
+                load_a(nk, a_st[s]); load_b(nk, b_st[s]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        const int rem = wb1 - kb0;       // < DEPTH; stage s already holds block kb0 + s
+#pragma unroll
+        for (int s = 0; s < DEPTH - 1; ++s)
+            if (s < rem) compute(a_st[s], b_st[s]);
     }
 
     // ---- meet in LDS: red[wave][row][col]

@@ -37,9 +37,14 @@ __global__ __launch_bounds__(256) void row_kernel(RowArgs r)
     const int tid = threadIdx.x;
     const int slot = r.slot_idx ? r.slot_idx[m] : m;
 
+    // all slab loads are issued before the first add (kz <= 8, checked on the host); adds in slab order
     auto slab_sum = [&](int n) {
-        float s = r.ws[(size_t)m * r.N + n];
-        for (int z = 1; z < r.kz; ++z) s += r.ws[((size_t)z * r.m_stride + m) * r.N + n];
+        float v[8];
+#pragma unroll
+        for (int z = 0; z < 8; ++z) v[z] = z < r.kz ? r.ws[((size_t)z * r.m_stride + m) * r.N + n] : 0.0f;
+        float s = v[0];
+#pragma unroll
+        for (int z = 1; z < 8; ++z) if (z < r.kz) s += v[z];
         return s;
     };
 
@@ -124,26 +129,29 @@ void launch_row(const RowArgs &r, hipStream_t s)
 }
 
 // ---------------------------------------------------------------- conv front end
-// Conv2d(1->c0,k3) -> DoubleSwish -> Conv2d(c0->c1,k3,s) -> DoubleSwish -> Conv2d(c1->c2,k3,s)
-// -> DoubleSwish, output flattened as [channel][freq] (the graph's Transpose+Reshape before the
-// embed Linear).  One workgroup per session; the 9 x mel chunk is gathered from the session's
-// feature ring in HBM (coalesced 320-byte rows) into LDS, both intermediate maps live in LDS.
-// Accumulation order per output: input channel, then kernel row, then kernel column; bias last
-// (same as the oracle's Conv).
-__global__ __launch_bounds__(256) void conv_embed_kernel(ConvEmbedArgs a)
+// Conv2d(1->c0,k3,s0) -> DoubleSwish -> Conv2d(c0->c1,k3,s1) -> DoubleSwish, then the receptive
+// fields of the third convolution written out as GEMM rows (im2col): the third conv (72 % of the
+// front end's FLOPs) runs on the MFMA GEMM with a fused bias+DoubleSwish epilogue.
+//   grid = (sessions, channel groups of conv 2); each workgroup gathers the 9 x mel chunk from the
+//   session's feature ring in HBM (coalesced 320-byte rows) into LDS, recomputes the cheap first
+//   conv, computes its group of second-conv channels into LDS and writes, for every output
+//   position ow of conv 3, the slice k = ci*9 + i*3 + j of row (session*W3 + ow):
+//       A3[row][k] = act2[ci][i][ow*s2 + j]           (H2 == 3 == kernel height, so H3 == 1)
+// Accumulation order per conv output: input channel, kernel row, kernel column; bias last.
+__global__ __launch_bounds__(256) void conv12_kernel(ConvEmbedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int m = blockIdx.x;
+    const int m = blockIdx.x, grp = blockIdx.y;
     const int tid = threadIdx.x;
     const int H0 = a.seg, W0 = a.mel;
     const int s0 = a.stride[0], s1 = a.stride[1], s2 = a.stride[2];
     const int H1 = (H0 - 3) / s0 + 1, W1 = (W0 - 3) / s0 + 1;
     const int H2 = (H1 - 3) / s1 + 1, W2 = (W1 - 3) / s1 + 1;
-    const int W3 = (W2 - 3) / s2 + 1;          // H3 == 1 (checked at load)
-    const int c0 = a.ch[0], c1 = a.ch[1], c2 = a.ch[2];
+    const int W3 = (W2 - 3) / s2 + 1;
+    const int c0 = a.ch[0], cg = a.ch1_per_group;
     float *x = lds;                              // H0*W0
     float *a1 = x + H0 * W0;                     // c0*H1*W1
-    float *a2 = a1 + c0 * H1 * W1;               // c1*H2*W2
+    float *a2 = a1 + c0 * H1 * W1;               // cg*H2*W2
 
     if (a.x_direct) {
         for (int i = tid; i < H0 * W0; i += 256) x[i] = a.x_direct[(size_t)m * H0 * W0 + i];
@@ -169,8 +177,9 @@ __global__ __launch_bounds__(256) void conv_embed_kernel(ConvEmbedArgs a)
         a1[o] = dswish_dev(acc);
     }
     __syncthreads();
-    for (int o = tid; o < c1 * H2 * W2; o += 256) {
-        const int c = o / (H2 * W2), oh = (o / W2) % H2, ow = o % W2;
+    for (int o = tid; o < cg * H2 * W2; o += 256) {
+        const int cl = o / (H2 * W2), oh = (o / W2) % H2, ow = o % W2;
+        const int c = grp * cg + cl;
         const float *w = a.w[1] + (size_t)c * c0 * 9;
         float acc = 0.0f;
         for (int ci = 0; ci < c0; ++ci) {
@@ -184,19 +193,12 @@ __global__ __launch_bounds__(256) void conv_embed_kernel(ConvEmbedArgs a)
         a2[o] = dswish_dev(acc);
     }
     __syncthreads();
-    for (int o = tid; o < c2 * W3; o += 256) {
-        const int c = o / W3, ow = o % W3;
-        const float *w = a.w[2] + (size_t)c * c1 * 9;
-        float acc = 0.0f;
-        for (int ci = 0; ci < c1; ++ci) {
-            const float *src = a2 + ci * H2 * W2 + ow * s2;
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) acc += src[i * W2 + j] * w[ci * 9 + i * 3 + j];
-        }
-        acc += a.b[2][c];
-        a.out[(size_t)m * a.ldo + o] = dswish_dev(acc);
+    // im2col slice of this channel group: consecutive threads write consecutive k (coalesced runs of cg*9 floats)
+    const int kslice = cg * 9;
+    for (int e = tid; e < W3 * kslice; e += 256) {
+        const int ow = e / kslice, kl = e % kslice;
+        const int cl = kl / 9, i = (kl % 9) / 3, j = kl % 3;
+        a.out[((size_t)m * W3 + ow) * a.ldo + grp * kslice + kl] = a2[cl * H2 * W2 + i * W2 + ow * s2 + j];
     }
 }
 
@@ -204,8 +206,8 @@ void launch_conv_embed(const ConvEmbedArgs &a, hipStream_t s)
 {
     const int H1 = (a.seg - 3) / a.stride[0] + 1, W1 = (a.mel - 3) / a.stride[0] + 1;
     const int H2 = (H1 - 3) / a.stride[1] + 1, W2 = (W1 - 3) / a.stride[1] + 1;
-    const size_t lds = sizeof(float) * ((size_t)a.seg * a.mel + (size_t)a.ch[0] * H1 * W1 + (size_t)a.ch[1] * H2 * W2);
-    hipLaunchKernelGGL(conv_embed_kernel, dim3((unsigned)a.M), dim3(256), lds, s, a);
+    const size_t lds = sizeof(float) * ((size_t)a.seg * a.mel + (size_t)a.ch[0] * H1 * W1 + (size_t)a.ch1_per_group * H2 * W2);
+    hipLaunchKernelGGL(conv12_kernel, dim3((unsigned)a.M, (unsigned)(a.ch[1] / a.ch1_per_group)), dim3(256), lds, s, a);
 }
 
 // ---------------------------------------------------------------- decoder front end

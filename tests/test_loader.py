@@ -37,9 +37,12 @@ def layout_offsets(d):
         off[0] = (o + n + 63) & ~63
         return o
     L = {}
-    cin = 1
-    for i, c in enumerate(d["conv_ch"]):
-        L["conv_w%d" % i] = take(c * cin * 9); L["conv_b%d" % i] = take(c); cin = c
+    c0, c1, c2 = d["conv_ch"]
+    k3 = (c1 * 9 + 15) & ~15
+    L["conv_w0"] = take(c0 * 9); L["conv_b0"] = take(c0)
+    L["conv_w1"] = take(c1 * c0 * 9); L["conv_b1"] = take(c1)
+    L["conv_w2"] = take(k3 * c2); L["conv_b2"] = take(c2)
+    L["k3"] = k3
     f_out = ((d["mel"] - 3) // 2 - 1) // 2
     ein = d["conv_ch"][2] * f_out
     L["w_embed"] = take(ein * d["d_model"]); L["b_embed"] = take(d["d_model"])
@@ -61,9 +64,15 @@ def check_blob(w, d, wts):
     L, ein, vp = layout_offsets(d)
     D, H, F, J, V = d["d_model"], d["hidden"], d["ffn"], d["joiner"], d["vocab"]
     for i in range(3):
-        assert np.array_equal(w[L["conv_w%d" % i]:][:wts["conv%d.w" % i].size], wts["conv%d.w" % i].ravel())
+        if i < 2:
+            assert np.array_equal(w[L["conv_w%d" % i]:][:wts["conv%d.w" % i].size], wts["conv%d.w" % i].ravel())
         assert np.array_equal(w[L["conv_b%d" % i]:][:wts["conv%d.b" % i].size], wts["conv%d.b" % i])
-    assert np.array_equal(unpack_mfma(w[L["w_embed"]:], ein, D, D), wts["embed.w"].T)
+    c0, c1, c2 = d["conv_ch"]
+    w3 = unpack_mfma(w[L["conv_w2"]:], L["k3"], c2, c2)                # third conv as [k = ci*9+i*3+j][out channel]
+    assert np.array_equal(w3[:c1 * 9], wts["conv2.w"].reshape(c2, c1 * 9).T) and not w3[c1 * 9:].any()
+    f_out = ein // c2
+    we = unpack_mfma(w[L["w_embed"]:], ein, D, D)                      # rows permuted to position-major (f*c2 + c)
+    assert np.array_equal(we.reshape(f_out, c2, D), wts["embed.w"].T.reshape(c2, f_out, D).transpose(1, 0, 2))
     assert np.array_equal(w[L["b_embed"]:][:D], wts["embed.b"])
     for l in range(d["n_layers"]):
         p = "l%d." % l
