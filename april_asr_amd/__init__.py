@@ -177,7 +177,9 @@ _HANDLER = _ffi.HANDLER(_dispatch)
 
 class Session:
     def __init__(self, model: Model, callback: Callable[[Result, List[Token]], None], asynchronous: bool = False,
-                 no_rt: bool = False, speaker_name: str = "", raw_events: bool = False):
+                 no_rt: bool = False, speaker_name: str = "", raw_events: bool = False, counters=None):
+        """`counters`: a uint64 ndarray of 6 entries; when given, results are only counted by a C handler inside the
+        library (calls, partial, final, cant_keep_up, silence, tokens) and `callback` is never invoked."""
         self._L = model._L
         self.model = model
         self.callback = callback
@@ -186,8 +188,13 @@ class Session:
         cfg.flags = (2 if no_rt else 1) if asynchronous else 0
         if speaker_name:
             cfg.speaker = _ffi.AprilSpeakerID.from_buffer_copy(struct.pack("@q", hash(speaker_name)) * 2)
-        cfg.handler = _HANDLER
-        cfg.userdata = id(self)
+        if counters is not None:
+            self._counters = counters
+            cfg.handler = C.cast(self._L.aprilx_counting_handler, _ffi.HANDLER)
+            cfg.userdata = counters.ctypes.data
+        else:
+            cfg.handler = _HANDLER
+            cfg.userdata = id(self)
         self._handle = self._L.aas_create_session(model._handle, cfg)
         if not self._handle:
             raise Exception("Failed to create session")

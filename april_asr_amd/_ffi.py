@@ -37,7 +37,7 @@ class AprilxDims(C.Structure):
 
 class AprilxStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("ticks", "steps", "chunks", "rounds", "frames", "max_batch_seen")] + \
-               [("kernel_ms", C.c_double * 6), ("kernel_launches", C.c_uint64 * 6)]
+               [("kernel_ms", C.c_double * 6), ("kernel_launches", C.c_uint64 * 6), ("host_ms", C.c_double * 8)]
 
 
 EXPORTED_REFERENCE_SYMBOLS = [
@@ -50,7 +50,7 @@ EXPORTED_ENGINE_SYMBOLS = [
     "aprilx_model_from_blob", "aprilx_feed_many", "aprilx_flush_many", "aprilx_session_drain",
     "aprilx_run_encoder", "aprilx_run_decoder", "aprilx_run_joiner", "aprilx_run_fbank",
     "aprilx_session_trace_logits", "aprilx_session_chunks", "aprilx_model_stats", "aprilx_model_profile",
-    "aprilx_greedy_create", "aprilx_greedy_step", "aprilx_greedy_finish", "aprilx_greedy_free", "aprilx_probe_file", "aprilx_model_load_host", "aprilx_model_fbank_tables",
+    "aprilx_greedy_create", "aprilx_greedy_step", "aprilx_greedy_finish", "aprilx_greedy_free", "aprilx_probe_file", "aprilx_model_load_host", "aprilx_model_fbank_tables", "aprilx_counting_handler",
 ]
 
 _lib = None

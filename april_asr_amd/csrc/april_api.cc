@@ -35,8 +35,8 @@ bool build_runtime(Model &m, const float *blob_host, const float *blob_device)
         LOGE("aam: unsupported frame length (FFT size must be a power of two)");
         return false;
     }
-    if (m.layout.dims.embed_in % 16 || m.layout.dims.d_model % 16 || m.layout.dims.hidden % 16 || m.layout.dims.ffn % 16 || m.layout.dims.joiner % 16 || m.layout.dims.conv_ch[2] % 16) {
-        LOGE("aam: layer widths must be multiples of 16 for the MFMA kernels");
+    if (m.layout.dims.embed_in % 64 || m.layout.dims.d_model % 64 || m.layout.dims.hidden % 64 || m.layout.dims.ffn % 64 || m.layout.dims.joiner % 64 || m.layout.dims.conv_ch[2] % 16) {
+        LOGE("aam: layer widths must be multiples of 64 for the MFMA kernels");
         return false;
     }
     if (m.layout.dims.d_model > 2048) { LOGE("aam: d_model > 2048 unsupported by the row-norm kernel"); return false; }
@@ -392,6 +392,7 @@ void aprilx_model_stats(AprilASRModel model, int device_index, AprilxStats *out)
     if (!model || device_index < 0 || device_index >= (int)model->m.scheds.size()) return;
     const SchedStats st = model->m.scheds[(size_t)device_index]->stats();
     out->ticks = st.ticks; out->steps = st.steps; out->chunks = st.chunks; out->rounds = st.rounds; out->frames = st.frames; out->max_batch_seen = st.max_batch_seen;
+    for (int i = 0; i < 8; ++i) out->host_ms[i] = st.host_ms[i];
     Engine *e = model->m.engines[(size_t)device_index];
     for (int i = 0; i < 6; ++i) { out->kernel_ms[i] = e->timing(i).ms; out->kernel_launches[i] = (uint64_t)e->timing(i).launches; }
 }
@@ -425,6 +426,17 @@ int aprilx_greedy_step(AprilxGreedy g, int32_t idx, float max_val, float blank_v
 }
 void aprilx_greedy_finish(AprilxGreedy g) { g->g.finish_flush(g->ev); g->flush_events(); }
 void aprilx_greedy_free(AprilxGreedy g) { delete g; }
+
+// A handler implemented in C for load generators: userdata -> uint64_t[6] {calls, partial, final, cant_keep_up, silence, tokens}
+void aprilx_counting_handler(void *userdata, AprilResultType type, size_t count, const AprilToken *tokens)
+{
+    (void)tokens;
+    uint64_t *c = (uint64_t *)userdata;
+    if (!c) return;
+    __atomic_fetch_add(&c[0], 1, __ATOMIC_RELAXED);
+    if ((int)type >= 1 && (int)type <= 4) __atomic_fetch_add(&c[(int)type], 1, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&c[5], (uint64_t)count, __ATOMIC_RELAXED);
+}
 
 int aprilx_model_fbank_tables(AprilASRModel model, float *window, float *mel)
 {

@@ -1,6 +1,7 @@
 // See engine.h.
 #include "engine.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include "common.h"
 
@@ -17,7 +18,7 @@ void plan_layout(const NetDims &d, bool has_dec_conv_b, PackedLayout &L)
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off = align64(off + n); return o; };
     // conv 0/1: OIHW as exported; conv 2 runs as an im2col GEMM: MFMA-packed [k3][conv_ch[2]], k = ci*9 + i*3 + j
-    L.k3 = (d.conv_ch[1] * 9 + 15) & ~15;
+    L.k3 = (d.conv_ch[1] * 9 + 63) & ~63;          // K of every GEMM is a multiple of 64 (4 waves x 16-wide blocks)
     L.conv_w[0] = take((size_t)d.conv_ch[0] * 9); L.conv_b[0] = take((size_t)d.conv_ch[0]);
     L.conv_w[1] = take((size_t)d.conv_ch[1] * d.conv_ch[0] * 9); L.conv_b[1] = take((size_t)d.conv_ch[1]);
     L.conv_w[2] = take((size_t)L.k3 * d.conv_ch[2]); L.conv_b[2] = take((size_t)d.conv_ch[2]);
@@ -116,7 +117,7 @@ static int pick_kz(int K, int N)
 {
     int kz = 256 / std::max(1, N / 16);
     kz = std::max(1, std::min(kz, 8));
-    while (kz > 1 && (K / 16) / kz < 4) kz >>= 1;
+    while (kz > 1 && ((K / 16) / kz < 4 || (K / 16) % (4 * kz) != 0)) kz >>= 1;   // every wave gets whole blocks of every slab
     return kz;
 }
 
@@ -169,6 +170,7 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     logits_h_ = hmalloc<float>(MB * d.vocab);
 
     upload_tables(ft);
+    use_graphs_ = !(getenv("APRIL_NO_GRAPHS") && atoi(getenv("APRIL_NO_GRAPHS")));
     free_.reserve(S);
     for (int i = cfg_.max_slots - 1; i >= 0; --i) free_.push_back(i);
     LOGI("engine: device %d, %d slots, max batch %d, weights %.1f MB, kz(embed,hr,ff2,proj,out)=%d,%d,%d,%d,%d",
@@ -180,6 +182,7 @@ Engine::~Engine()
     (void)hipSetDevice(cfg_.device);
     (void)hipStreamSynchronize(stream_);
     for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto &g : enc_graphs_) (void)hipGraphExecDestroy(g.second);
     for (void *p : {(void *)w_, (void *)h_, (void *)c_, (void *)ring_, (void *)eout_, (void *)dout_, (void *)ws_, (void *)xin_, (void *)a3_, (void *)xa_,
                     (void *)xb_, (void *)u_, (void *)ff_, (void *)de_, (void *)logits_, (void *)joint_d_, (void *)ds_enc_, (void *)ds_dec_,
                     (void *)ds_joi_, (void *)ds_desc_, (void *)ds_pcm_})
@@ -323,7 +326,7 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
         GemmArgs g; g.a0 = xin_; g.lda0 = d.embed_in; g.K0 = d.embed_in; g.wp = w_ + L_.w_embed;
         g.M = n; g.N = d.d_model; g.K = d.embed_in; g.kz = kz_embed_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
         timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
-        RowArgs r; r.mode = ROW_NORM; r.ws = ws_; r.kz = kz_embed_; r.m_stride = ws_mstride_; r.N = d.d_model; r.M = n;
+        RowArgs r; r.mode = ROW_NORM; r.ws = ws_; r.kz = gemm_partials(n, d.d_model, kz_embed_); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = n;
         r.bias = w_ + L_.b_embed; r.out = xa_; r.ldo = d.d_model; r.eps = L_.embed_eps;
         timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
     }
@@ -342,7 +345,7 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
             GemmArgs g; g.a0 = u_; g.lda0 = d.hidden; g.K0 = d.hidden; g.wp = w_ + o.whr;
             g.M = n; g.N = d.d_model; g.K = d.hidden; g.kz = kz_hr_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
             timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
-            RowArgs r; r.mode = ROW_HR; r.ws = ws_; r.kz = kz_hr_; r.m_stride = ws_mstride_; r.N = d.d_model; r.M = n;
+            RowArgs r; r.mode = ROW_HR; r.ws = ws_; r.kz = gemm_partials(n, d.d_model, kz_hr_); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = n;
             r.resid = xa_; r.ldr = d.d_model; r.out = xb_; r.ldo = d.d_model; r.slot_idx = d_slots; r.state = h_l; r.ld_state = d.d_model;
             timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
         }
@@ -355,7 +358,7 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
             GemmArgs g; g.a0 = ff_; g.lda0 = d.ffn; g.K0 = d.ffn; g.wp = w_ + o.wff2;
             g.M = n; g.N = d.d_model; g.K = d.ffn; g.kz = kz_ff2_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
             timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
-            RowArgs r; r.mode = ROW_NORM; r.ws = ws_; r.kz = kz_ff2_; r.m_stride = ws_mstride_; r.N = d.d_model; r.M = n;
+            RowArgs r; r.mode = ROW_NORM; r.ws = ws_; r.kz = gemm_partials(n, d.d_model, kz_ff2_); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = n;
             r.bias = w_ + o.bff2; r.resid = xb_; r.ldr = d.d_model; r.out = xa_; r.ldo = d.d_model; r.eps = L_.norm_eps[(size_t)l];
             timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
         }
@@ -364,7 +367,7 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
         GemmArgs g; g.a0 = xa_; g.lda0 = d.d_model; g.K0 = d.d_model; g.wp = w_ + L_.w_encproj;
         g.M = n; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
         timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
-        RowArgs r; r.mode = ROW_BIAS_STORE; r.ws = ws_; r.kz = kz_proj_; r.m_stride = ws_mstride_; r.N = d.joiner; r.M = n;
+        RowArgs r; r.mode = ROW_BIAS_STORE; r.ws = ws_; r.kz = gemm_partials(n, d.joiner, kz_proj_); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = n;
         r.bias = w_ + L_.b_encproj; r.out = eout_; r.ldo = d.joiner; r.slot_idx = d_slots;
         timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
     }
@@ -379,6 +382,27 @@ void Engine::encode(int n, const int *slots, const int *ring_tails)
         if (o > 0) sync();                               // staging region reuse
         memcpy(hs_enc_, slots + o, (size_t)m * 4);
         memcpy(hs_enc_ + MB, ring_tails + o, (size_t)m * 4);
+        // The whole per-chunk chain (2 index uploads + ~90 kernels) is replayed from a hipGraph captured once per
+        // batch size: at small batches the chain is launch-bound on the host (~3.5 us per launch), the replay is not.
+        // Kernel arguments depend only on m; the slot/tail indices travel through the fixed pinned buffer.
+        if (use_graphs_ && !profiling_) {
+            auto it = enc_graphs_.find(m);
+            if (it == enc_graphs_.end()) {
+                if (enc_graphs_.size() >= 128) { for (auto &g : enc_graphs_) (void)hipGraphExecDestroy(g.second); enc_graphs_.clear(); }
+                hipGraph_t graph = nullptr;
+                hipGraphExec_t exec = nullptr;
+                HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+                HIP_CHECK(hipMemcpyAsync(ds_enc_, hs_enc_, (size_t)m * 4, hipMemcpyHostToDevice, stream_));
+                HIP_CHECK(hipMemcpyAsync(ds_enc_ + MB, hs_enc_ + MB, (size_t)m * 4, hipMemcpyHostToDevice, stream_));
+                run_encoder_rows(m, ds_enc_, ds_enc_ + MB, nullptr);
+                HIP_CHECK(hipStreamEndCapture(stream_, &graph));
+                HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                HIP_CHECK(hipGraphDestroy(graph));
+                it = enc_graphs_.emplace(m, exec).first;
+            }
+            HIP_CHECK(hipGraphLaunch(it->second, stream_));
+            continue;
+        }
         HIP_CHECK(hipMemcpyAsync(ds_enc_, hs_enc_, (size_t)m * 4, hipMemcpyHostToDevice, stream_));
         HIP_CHECK(hipMemcpyAsync(ds_enc_ + MB, hs_enc_ + MB, (size_t)m * 4, hipMemcpyHostToDevice, stream_));
         run_encoder_rows(m, ds_enc_, ds_enc_ + MB, nullptr);
@@ -404,7 +428,7 @@ void Engine::decode(int n, const int *slots, const int *ctx)
         GemmArgs g; g.a0 = de_; g.lda0 = d.d_model; g.K0 = d.d_model; g.wp = w_ + L_.w_decproj;
         g.M = m; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
         timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
-        RowArgs r; r.mode = ROW_BIAS_STORE; r.ws = ws_; r.kz = kz_proj_; r.m_stride = ws_mstride_; r.N = d.joiner; r.M = m;
+        RowArgs r; r.mode = ROW_BIAS_STORE; r.ws = ws_; r.kz = gemm_partials(m, d.joiner, kz_proj_); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = m;
         r.bias = w_ + L_.b_decproj; r.out = dout_; r.ldo = d.joiner; r.slot_idx = ds_dec_;
         timed_begin(T_DEC); launch_row(r, stream_); timed_end(T_DEC);
     }
@@ -423,7 +447,7 @@ void Engine::joint(int n, const int *slots, JointResult *out, float *logits_out)
         GemmArgs g; g.a0 = eout_; g.a0b = dout_; g.lda0 = d.joiner; g.aidx0 = ds_joi_; g.K0 = d.joiner; g.a_op = AOP_TANH_ADD;
         g.wp = w_ + L_.w_out; g.M = m; g.N = L_.vocab_pad; g.K = d.joiner; g.kz = kz_out_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
         timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
-        RowArgs r; r.mode = ROW_ARGMAX; r.ws = ws_; r.kz = kz_out_; r.m_stride = ws_mstride_; r.N = L_.vocab_pad; r.M = m; r.n_valid = d.vocab;
+        RowArgs r; r.mode = ROW_ARGMAX; r.ws = ws_; r.kz = gemm_partials(m, L_.vocab_pad, kz_out_); r.m_stride = ws_mstride_; r.N = L_.vocab_pad; r.M = m; r.n_valid = d.vocab;
         r.bias = w_ + L_.b_out; r.blank = P_.blank_id; r.joint = joint_d_; r.logits_dump = logits_out ? logits_ : nullptr;
         timed_begin(T_DEC); launch_row(r, stream_); timed_end(T_DEC);
         HIP_CHECK(hipMemcpyAsync(joint_h_, joint_d_, (size_t)m * sizeof(JointResult), hipMemcpyDeviceToHost, stream_));

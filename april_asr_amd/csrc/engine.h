@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -28,7 +29,7 @@ namespace aprilx {
 struct PackedLayout {
     NetDims dims;
     size_t conv_w[3], conv_b[3];
-    int k3 = 0;                              // K of the third conv as a GEMM (conv_ch[1]*9 rounded up to 16)
+    int k3 = 0;                              // K of the third conv as a GEMM (conv_ch[1]*9 rounded up to 64)
     size_t w_embed, b_embed;
     struct Layer { size_t wg, bg, whr, wff1, bff1, wff2, bff2; };
     std::vector<Layer> layers;
@@ -128,6 +129,9 @@ private:
     // gemm split factors (fixed per shape => batch-invariant numerics)
     int kz_embed_ = 1, kz_hr_ = 1, kz_ff2_ = 1, kz_proj_ = 1, kz_out_ = 1;
     int ws_mstride_ = 0;
+    // encoder launch chains captured per batch size
+    bool use_graphs_ = true;
+    std::map<int, hipGraphExec_t> enc_graphs_;
     // profiling
     bool profiling_ = false;
     struct Ev { hipEvent_t a, b; int cls; };

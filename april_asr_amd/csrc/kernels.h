@@ -18,8 +18,9 @@ namespace aprilx {
 // output element: K is cut into `kz` slabs (grid.z); inside a slab the four waves of
 // the workgroup each own a contiguous quarter and run one in-order fp32 FMA chain
 // (that is what the MFMA does); the four chains are added ((p0+p1)+p2)+p3.  With
-// kz > 1 the slab results go to a workspace and are added in slab order by the row
-// kernel that follows.
+// kz > 1 slab results are combined PAIRWISE in slab order (balanced tree): a workgroup may
+// own 1, 2, 4 or all slabs of its tile (more as the batch grows and tiles alone fill the
+// chip); what is left goes to a workspace and the row kernel that follows finishes the same tree.
 enum GemmEpilogue {
     EPI_PARTIAL = 0,      // ws[z][m][n] = slab sum                         (consumer: row kernels)
     EPI_LSTM = 1,         // columns are unit-major (unit*4 + gate i,f,g,o): cell update, c in place, u out
@@ -35,7 +36,8 @@ struct GemmArgs {
     int a_op = AOP_NONE;
     const float *wp = nullptr;             // packed weights
     int M = 0, N = 0, K = 0;               // N multiple of 16, K multiple of 16
-    int kz = 1;
+    int kz = 1;                            // K slabs (power of two); canonical summation unit
+    int zs = 1;                            // slabs handled per workgroup (set by launch_gemm)
     int epi = EPI_PARTIAL;
     float *out = nullptr; int ldo = 0;     // EPI_PARTIAL: workspace [kz][m_stride][N]; others: [M][ldo]
     int m_stride = 0;
@@ -43,8 +45,12 @@ struct GemmArgs {
     float *c_state = nullptr;              // EPI_LSTM: [slots][hidden] for this layer
     const int *slot_idx = nullptr;         // EPI_LSTM: row -> slot
     int hidden = 0;
+    int skew = 0;                          // start delay (x 4096 cycles) for every second generation of workgroups
+    int debug = 0;                         // measurement only: 1 = skip the MFMA main loop, 2 = skip the epilogue math
 };
 void launch_gemm(const GemmArgs &g, hipStream_t s);
+// number of partial planes launch_gemm will write for an EPI_PARTIAL GEMM of this shape (kz / slabs-per-workgroup)
+int gemm_partials(int M, int N, int kz);
 
 // ---------------------------------------------------------------- row kernels (one workgroup per row)
 enum RowMode {

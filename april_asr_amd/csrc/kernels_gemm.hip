@@ -13,12 +13,17 @@
 // Replaces the ORT MatMul/Gemm nodes of the encoder/decoder/joiner graphs
 // (reference call sites src/april_session.c:145,160,176).
 #include "kernels.h"
+#include <cstdlib>
 
 namespace aprilx {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sigma and tanh on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each); absolute error ~1e-7,
+// far inside the 1e-4 per-call parity tolerance, and ~10x fewer VALU instructions than libm's expf/tanhf --
+// the epilogue runs while the matrix pipe of the CU idles, so its length is throughput
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * fast_sigmoid(2.0f * x) - 1.0f; }
 
 template <int MT, int NT>
 struct TileCfg {
@@ -38,11 +43,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
     // M-blocks that share one weight column on the same XCD (same x mod 8).
     const int nt0 = blockIdx.x * NT;
     const int m0 = blockIdx.y * Cfg::BM;
-    const int z = blockIdx.z;
+    const int zg = blockIdx.z;                 // this workgroup owns slabs [zg*zs, (zg+1)*zs)
+    if (g.skew > 0) {
+        // Two workgroups share a CU.  Dispatched together they run in lock-step: both stream MFMAs (halving each
+        // other's rate), then both sit in their epilogues while the matrix pipe idles.  Delaying every second
+        // "generation" of workgroups once, by about one epilogue, interleaves the phases for the rest of the launch.
+        // Placement is only a heuristic here (speed, never correctness).
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if ((lin >> 8) & 1) for (int i = 0; i < g.skew; ++i) __builtin_amdgcn_s_sleep(64);
+    }
     const int KB = g.K >> 4;
-    const int zb0 = (int)(((long)KB * z) / g.kz), zb1 = (int)(((long)KB * (z + 1)) / g.kz);
-    const int nb = zb1 - zb0;
-    const int wb0 = zb0 + (nb * wave) / 4, wb1 = zb0 + (nb * (wave + 1)) / 4;
 
     const int mrow = lane & 15, kq = lane >> 4;
 
@@ -62,11 +72,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
     for (int nt = 0; nt < NT; ++nt) wbase[nt] = reinterpret_cast<const f32x4 *>(g.wp) + ((size_t)(nt0 + nt) * KB) * 64 + lane;
     const bool stream_once = gridDim.y == 1;   // weights read by exactly one workgroup: bypass-friendly loads
 
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // after the LDS meet every thread owns QPT groups of 4 consecutive columns ("quads") of the tile
+    constexpr int QROW = Cfg::BN / 4, NQ = Cfg::BM * QROW, QPT = (NQ + 255) / 256;
+    f32x4 lvl[4][QPT];                                 // pairwise (balanced-tree) slab accumulation, level b holds 2^b slabs
+    constexpr int PLANE = Cfg::BM * Cfg::LDR;
+    auto summed4 = [&](int o) {                        // ((p0+p1)+p2)+p3 of four consecutive columns
+        const f32x4 p0 = *reinterpret_cast<const f32x4 *>(red + o), p1 = *reinterpret_cast<const f32x4 *>(red + PLANE + o);
+        const f32x4 p2 = *reinterpret_cast<const f32x4 *>(red + 2 * PLANE + o), p3 = *reinterpret_cast<const f32x4 *>(red + 3 * PLANE + o);
+        return ((p0 + p1) + p2) + p3;
+    };
 
     auto load_a = [&](int kb, f32x4 (&a)[MT]) {
         const int k = kb * 16 + kq * 4;
@@ -89,97 +103,172 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
         for (int nt = 0; nt < NT; ++nt)
             b[nt] = stream_once ? __builtin_nontemporal_load(wbase[nt] + (size_t)kb * 64) : wbase[nt][(size_t)kb * 64];
     };
+    // K blocks: KB = K/16 is a multiple of 4*kz (checked on the host), so every wave owns exactly c blocks of every
+    // slab: slab z, wave w -> blocks [(4z + w) c, (4z + w + 1) c).  A workgroup walks zs consecutive slabs.
+    const int c = g.debug == 1 ? 0 : KB / (4 * g.kz);
+    const int T = g.zs * c;                            // blocks this wave processes in total
 
-    // Register-staged software pipeline: DEPTH k-blocks of loads are in flight per wave while the
-    // MFMAs of the oldest stage issue.  Small batches (MT == 1) are HBM-bound weight streams and want
-    // many bytes in flight per CU (6 x 4 waves x (1+NT) KiB); large tiles are MFMA-bound and need
-    // only enough depth to cover L2 latency.
+    // Register-staged software pipeline: DEPTH k-blocks of loads are in flight per wave while the MFMAs of the
+    // oldest stage issue.  Small batches (MT == 1) are HBM-bound weight streams and want many bytes in flight per
+    // CU (6 x 4 waves x (1+NT) KiB); large tiles are MFMA-bound and need only enough depth to cover L2 latency.
+    // The prefetch stream runs ahead ACROSS slab boundaries, so the pipeline never restarts inside a workgroup;
+    // loads in the main loop are unconditional (the fetch position parks on the last block) so the loop body is
+    // straight-line code and the compiler keeps counted s_waitcnt vmcnt(N) instead of draining.
     constexpr int DEPTH = (MT == 1) ? 6 : (MT == 2 ? 3 : 2);
-    if (wb0 < wb1) {
-        f32x4 a_st[DEPTH][MT], b_st[DEPTH][NT];
-        const int last = wb1 - 1;
-        // Loads are UNCONDITIONAL (indices clamped to the wave's last block) so the loop body is
-        // straight-line code and the compiler can keep counted s_waitcnt vmcnt(N) instead of draining.
+    f32x4 a_st[DEPTH][MT], b_st[DEPTH][NT];
+    int ld_base = (4 * (zg * g.zs) + wave) * c, ld_off = 0, ld_cnt = 0;
+    auto ld_next = [&]() {
+        const int kb = ld_base + ld_off;
+        if (ld_cnt + 1 < T) { ++ld_cnt; if (++ld_off == c) { ld_off = 0; ld_base += 4 * c; } }
+        return kb;
+    };
+    f32x4 acc[MT][NT];
+    auto zero_acc = [&]() {
 #pragma unroll
-        for (int s = 0; s < DEPTH; ++s) { const int kb = min(wb0 + s, last); load_a(kb, a_st[s]); load_b(kb, b_st[s]); }
-        auto compute = [&](const f32x4 (&a)[MT], const f32x4 (&b)[NT]) {
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto compute = [&](const f32x4 (&a)[MT], const f32x4 (&b)[NT]) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
+            }
+    };
+    int slab_done = 0;                                 // slabs finished so far by this workgroup
+    // quarter chains meet in LDS (red[wave][row][col]) and are added ((p0+p1)+p2)+p3; slab sums are combined
+    // pairwise in slab order (balanced tree), so owning 1, 2, 4 or 8 slabs per workgroup -- chosen from the batch
+    // size -- yields the same bits
+    auto meet = [&]() {
+        if (slab_done > 0) __syncthreads();            // previous slab's reads of red[] are done
+        float *mine = red + (size_t)wave * PLANE;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    mine[(mt * 16 + kq * 4 + r) * Cfg::LDR + nt * 16 + mrow] = acc[mt][nt][r];
+        __syncthreads();
+        if (EPI == EPI_PARTIAL) {
+            f32x4 v[QPT];
+#pragma unroll
+            for (int i = 0; i < QPT; ++i) {
+                const int q = threadIdx.x + i * 256;
+                v[i] = q < NQ ? summed4((q / QROW) * Cfg::LDR + (q % QROW) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            bool carry = true;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (carry) {
+                    if ((slab_done >> b) & 1) {
+#pragma unroll
+                        for (int i = 0; i < QPT; ++i) v[i] = lvl[b][i] + v[i];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < QPT; ++i) lvl[b][i] = v[i];
+                        carry = false;
+                    }
                 }
-        };
-        int kb0 = wb0;
-        for (; kb0 + DEPTH <= wb1; kb0 += DEPTH) {
+            }
+        }
+        ++slab_done;
+    };
+
+    zero_acc();
+    if (T > 0) {
+        {
+            int first[DEPTH];
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) first[s] = ld_next();
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) load_b(first[s], b_st[s]);      // weights first: they do not wait for row indices
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) load_a(first[s], a_st[s]);
+        }
+        int in_slab = 0, i = 0;
+        for (; i + DEPTH <= T; i += DEPTH) {
 #pragma unroll
             for (int s = 0; s < DEPTH; ++s) {
                 compute(a_st[s], b_st[s]);
-                // pin the refill right behind its stage's MFMAs: left alone, the scheduler sinks all
-                // refills to the loop end and the next iteration waits out a full memory latency
+                // pin the refill right behind its stage's MFMAs: left alone, the scheduler sinks all refills to the
+                // loop end and the next iteration waits out a full memory latency
                 __builtin_amdgcn_sched_barrier(0);
-                const int nk = min(kb0 + DEPTH + s, last);
-                load_a(nk, a_st[s]); load_b(nk, b_st[s]);
+                const int nk = ld_next();
+                load_b(nk, b_st[s]); load_a(nk, a_st[s]);
                 __builtin_amdgcn_sched_barrier(0);
+                if (++in_slab == c) { in_slab = 0; meet(); if (slab_done < g.zs) zero_acc(); }
             }
         }
-        const int rem = wb1 - kb0;       // < DEPTH; stage s already holds block kb0 + s
 #pragma unroll
         for (int s = 0; s < DEPTH - 1; ++s)
-            if (s < rem) compute(a_st[s], b_st[s]);
+            if (i + s < T) {
+                compute(a_st[s], b_st[s]);
+                if (++in_slab == c) { in_slab = 0; meet(); if (slab_done < g.zs) zero_acc(); }
+            }
+    } else {
+        for (int z = 0; z < g.zs; ++z) meet();         // measurement mode without the main loop
     }
 
-    // ---- meet in LDS: red[wave][row][col]
-    float *mine = red + (size_t)wave * Cfg::BM * Cfg::LDR;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                mine[(mt * 16 + kq * 4 + r) * Cfg::LDR + nt * 16 + mrow] = acc[mt][nt][r];
-    __syncthreads();
-
-    constexpr int PLANE = Cfg::BM * Cfg::LDR;
-    auto summed = [&](int row, int col) {
-        const int o = row * Cfg::LDR + col;
-        return ((red[o] + red[PLANE + o]) + red[2 * PLANE + o]) + red[3 * PLANE + o];
-    };
-
     if (EPI == EPI_PARTIAL) {
-        for (int e = threadIdx.x; e < Cfg::BM * Cfg::BN; e += 256) {
-            const int row = e / Cfg::BN, col = e % Cfg::BN;
+        int top = 0;
+        while ((1 << top) < g.zs) ++top;               // the total of zs (power of two) slabs sits at level log2(zs)
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * 256;
+            const int row = q / QROW, col = (q % QROW) * 4;
             const int m = m0 + row;
-            if (m < g.M) g.out[((size_t)z * g.m_stride + m) * g.N + nt0 * 16 + col] = summed(row, col);
+            f32x4 t = lvl[0][i];
+            if (top == 1) t = lvl[1][i]; else if (top == 2) t = lvl[2][i]; else if (top == 3) t = lvl[3][i];
+            if (q < NQ && m < g.M) *reinterpret_cast<f32x4 *>(g.out + ((size_t)zg * g.m_stride + m) * g.N + nt0 * 16 + col) = t;
         }
     } else if (EPI == EPI_BIAS_DSWISH) {
-        for (int e = threadIdx.x; e < Cfg::BM * Cfg::BN; e += 256) {
-            const int row = e / Cfg::BN, col = e % Cfg::BN;
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * 256;
+            const int row = q / QROW, col = (q % QROW) * 4;
             const int m = m0 + row, n = nt0 * 16 + col;
-            if (m < g.M) {
-                const float y = summed(row, col) + g.bias[n];
-                g.out[(size_t)m * g.ldo + n] = y * sigmoidf_(y - 1.0f);
+            if (q < NQ && m < g.M) {
+                const f32x4 y = summed4(row * Cfg::LDR + col) + *reinterpret_cast<const f32x4 *>(g.bias + n);
+                f32x4 o;
+                o.x = y.x * fast_sigmoid(y.x - 1.0f); o.y = y.y * fast_sigmoid(y.y - 1.0f);
+                o.z = y.z * fast_sigmoid(y.z - 1.0f); o.w = y.w * fast_sigmoid(y.w - 1.0f);
+                *reinterpret_cast<f32x4 *>(g.out + (size_t)m * g.ldo + n) = o;
             }
         }
-    } else {   // EPI_LSTM: 4 consecutive columns = gates i,f,g,o of one hidden unit
-        constexpr int UN = Cfg::BN / 4;
-        for (int e = threadIdx.x; e < Cfg::BM * UN; e += 256) {
-            const int row = e / UN, ul = e % UN;
-            const int m = m0 + row;
-            if (m >= g.M) continue;
+    } else {   // EPI_LSTM: each 4-column group = gates i,f,g,o of one hidden unit
+        // all dependent global loads (slot -> c) of the thread's QPT units are issued up front
+        int qm[QPT], qunit[QPT], qo[QPT];
+        bool qok[QPT];
+        float *cptr[QPT];
+        float cprev[QPT];
+        f32x4 qb[QPT];
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * 256;
+            const int row = q / QROW, ul = q % QROW;
+            qm[i] = m0 + row;
+            qok[i] = q < NQ && qm[i] < g.M;
             const int n = nt0 * 16 + ul * 4;
-            const int unit = n >> 2;
-            const float gi = summed(row, ul * 4 + 0) + g.bias[n + 0];
-            const float gf = summed(row, ul * 4 + 1) + g.bias[n + 1];
-            const float gg = summed(row, ul * 4 + 2) + g.bias[n + 2];
-            const float go = summed(row, ul * 4 + 3) + g.bias[n + 3];
-            float *cp = g.c_state + (size_t)g.slot_idx[m] * g.hidden + unit;
-            const float c_new = sigmoidf_(gf) * (*cp) + sigmoidf_(gi) * tanhf(gg);
-            *cp = c_new;
-            g.out[(size_t)m * g.ldo + unit] = sigmoidf_(go) * tanhf(c_new);
+            qunit[i] = n >> 2;
+            qo[i] = row * Cfg::LDR + ul * 4;
+            const int slot = qok[i] ? g.slot_idx[qm[i]] : 0;
+            cptr[i] = g.c_state + (size_t)slot * g.hidden + qunit[i];
+            qb[i] = *reinterpret_cast<const f32x4 *>(g.bias + n);
+        }
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) cprev[i] = qok[i] ? *cptr[i] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const f32x4 gt = summed4(qo[i]) + qb[i];
+            const float c_new = fast_sigmoid(gt.y) * cprev[i] + fast_sigmoid(gt.x) * fast_tanh(gt.z);
+            const float u = g.debug == 2 ? gt.x + gt.y + gt.z + gt.w : fast_sigmoid(gt.w) * fast_tanh(c_new);
+            if (qok[i]) { *cptr[i] = c_new; g.out[(size_t)qm[i] * g.ldo + qunit[i]] = u; }
         }
     }
 }
@@ -188,7 +277,7 @@ template <int MT, int NT>
 static void dispatch(const GemmArgs &g, hipStream_t s)
 {
     using Cfg = TileCfg<MT, NT>;
-    dim3 grid((unsigned)(g.N / Cfg::BN), (unsigned)((g.M + Cfg::BM - 1) / Cfg::BM), (unsigned)g.kz);
+    dim3 grid((unsigned)(g.N / Cfg::BN), (unsigned)((g.M + Cfg::BM - 1) / Cfg::BM), (unsigned)(g.kz / g.zs));
     const size_t lds = (size_t)Cfg::LDS_FLOATS * sizeof(float);
 #define LAUNCH(E, A) hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, E, A>), grid, dim3(256), lds, s, g)
     if (g.epi == EPI_PARTIAL) { if (g.a_op == AOP_TANH_ADD) LAUNCH(EPI_PARTIAL, AOP_TANH_ADD); else LAUNCH(EPI_PARTIAL, AOP_NONE); }
@@ -198,13 +287,40 @@ static void dispatch(const GemmArgs &g, hipStream_t s)
 }
 
 // Tile choice depends on M only through occupancy; numerics are tile-independent.
-void launch_gemm(const GemmArgs &g, hipStream_t s)
+int gemm_partials(int M, int N, int kz)
 {
+    // same tile choice as launch_gemm; slabs per workgroup grow once the output tiles alone fill the chip
+    const int ntiles = N / 16;
+    const int mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+    const int mblocks = (M + mt * 16 - 1) / (mt * 16);
+    int nt = 4;
+    while (nt > 1 && ((ntiles % nt) != 0 || (long)(ntiles / nt) * mblocks * kz < 256)) nt >>= 1;
+    const long tiles = (long)(ntiles / nt) * mblocks;
+    int zs = 1;
+    while (zs < kz && tiles * (kz / (zs * 2)) >= 256) zs *= 2;
+    return kz / zs;
+}
+
+void launch_gemm(const GemmArgs &g_in, hipStream_t s)
+{
+    GemmArgs g = g_in;
+    static const int dbg = getenv("APRIL_GEMM_DEBUG") ? atoi(getenv("APRIL_GEMM_DEBUG")) : 0;
+    g.debug = dbg;
+    static const int skew = getenv("APRIL_GEMM_SKEW") ? atoi(getenv("APRIL_GEMM_SKEW")) : 2;
+    g.skew = (long)g.N / 64 * ((g.M + 63) / 64) * (g.kz / g.zs) >= 512 ? skew : 0;
+    g.zs = g.epi == EPI_PARTIAL ? g.kz / gemm_partials(g.M, g.N, g.kz) : 1;
     const int ntiles = g.N / 16;
     int mt = g.M <= 16 ? 1 : (g.M <= 32 ? 2 : 4);
-    const int mblocks = (g.M + mt * 16 - 1) / (mt * 16);
+    int mblocks = (g.M + mt * 16 - 1) / (mt * 16);
     int nt = 4;
     while (nt > 1 && ((ntiles % nt) != 0 || (long)(ntiles / nt) * mblocks * g.kz < 256)) nt >>= 1;
+    // fused-epilogue GEMMs (one slab): prefer two resident workgroups per CU over the biggest tile,
+    // so one workgroup's prologue/epilogue overlaps the other's MFMA stream
+    static const int tune = getenv("APRIL_GEMM_TUNE") ? atoi(getenv("APRIL_GEMM_TUNE")) : 0;
+    if (tune && g.epi != EPI_PARTIAL && mt == 4 && (long)(ntiles / nt) * mblocks < 512) {
+        if (tune == 1) { mt = 2; mblocks = (g.M + 31) / 32; }
+        else if (tune == 2 && nt == 4) nt = 2;
+    }
     if (mt == 1) { if (nt == 4) dispatch<1, 4>(g, s); else if (nt == 2) dispatch<1, 2>(g, s); else dispatch<1, 1>(g, s); }
     else if (mt == 2) { if (nt == 4) dispatch<2, 4>(g, s); else if (nt == 2) dispatch<2, 2>(g, s); else dispatch<2, 1>(g, s); }
     else { if (nt == 4) dispatch<4, 4>(g, s); else if (nt == 2) dispatch<4, 2>(g, s); else dispatch<4, 1>(g, s); }

@@ -7,7 +7,7 @@
 
 namespace aprilx {
 
-__device__ __forceinline__ float sigmoid_dev(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoid_dev(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 __device__ __forceinline__ float dswish_dev(float y) { return y * sigmoid_dev(y - 1.0f); }
 
 // fixed-order block sum over 256 threads: xor-shuffle tree inside each wave, then 4 wave sums in order
@@ -37,15 +37,16 @@ __global__ __launch_bounds__(256) void row_kernel(RowArgs r)
     const int tid = threadIdx.x;
     const int slot = r.slot_idx ? r.slot_idx[m] : m;
 
-    // all slab loads are issued before the first add (kz <= 8, checked on the host); adds in slab order
+    // r.kz partial planes (1, 2, 4 or 8; each already a balanced-tree sum of consecutive K slabs): finish the tree.
+    // All loads are issued before the first add.
     auto slab_sum = [&](int n) {
         float v[8];
 #pragma unroll
         for (int z = 0; z < 8; ++z) v[z] = z < r.kz ? r.ws[((size_t)z * r.m_stride + m) * r.N + n] : 0.0f;
-        float s = v[0];
-#pragma unroll
-        for (int z = 1; z < 8; ++z) if (z < r.kz) s += v[z];
-        return s;
+        if (r.kz == 1) return v[0];
+        if (r.kz == 2) return v[0] + v[1];
+        if (r.kz == 4) return (v[0] + v[1]) + (v[2] + v[3]);
+        return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     };
 
     if (MODE == ROW_HR) {

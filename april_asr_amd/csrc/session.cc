@@ -2,9 +2,17 @@
 #include "session.h"
 #include <algorithm>
 #include <cstring>
+#include <chrono>
 #include "common.h"
 
 namespace aprilx {
+
+namespace {
+struct Lap {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    double operator()() { auto n = std::chrono::steady_clock::now(); double ms = std::chrono::duration<double, std::milli>(n - t).count(); t = n; return ms; }
+};
+}  // namespace
 
 // ---------------------------------------------------------------- token classes
 std::vector<uint8_t> classify_tokens(const ModelParams &p)
@@ -263,6 +271,7 @@ void Scheduler::loop()
     std::vector<uint64_t> taken;
     for (;;) {
         work.clear(); taken.clear();
+        Lap lap;
         {
             std::unique_lock<std::mutex> lk(mu_);
             cv_work_.wait(lk, [&] {
@@ -271,6 +280,7 @@ void Scheduler::loop()
                 return false;
             });
             if (stop_) return;
+            lap();
             for (Session *s : sessions_) {
                 if (s->closing || (s->inbox.empty() && !s->flush_requested)) continue;
                 s->busy = true;
@@ -286,7 +296,9 @@ void Scheduler::loop()
                 taken.push_back(s->submitted);
             }
         }
+        stats_.host_ms[0] += lap();
         process(work);
+        lap();
         // async sessions: deliver on this (library) thread, outside the lock
         for (Session *s : work) if (!s->sync_mode) {
             for (auto &e : s->events) s->handler(s->userdata, (AprilResultType)e.type, e.tokens.size(), e.tokens.empty() ? nullptr : e.tokens.data());
@@ -301,6 +313,7 @@ void Scheduler::loop()
                 s->busy = false;
             }
             stats_.ticks++;
+            stats_.host_ms[7] += lap();
         }
         cv_done_.notify_all();
     }
@@ -308,6 +321,7 @@ void Scheduler::loop()
 
 void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
 {
+    Lap lap;
     desc_.clear(); pcm_stage_.clear();
     std::vector<Session *> need_decode;
     for (Session *s : work) {
@@ -362,9 +376,11 @@ void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
         default: break;
         }
     }
+    stats_.host_ms[1] += lap();
     if (!desc_.empty()) {
         eng_->fbank((int)desc_.size(), desc_.data(), pcm_stage_.data(), pcm_stage_.size());
         stats_.frames += desc_.size();
+        stats_.host_ms[2] += lap();
     }
     if (!need_decode.empty()) {
         slots_.clear(); ctx_.clear();
@@ -375,6 +391,7 @@ void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
 
 void Scheduler::step_chunks(std::vector<Session *> &ready)
 {
+    Lap lap;
     const int n = (int)ready.size();
     const NetDims &d = eng_->dims();
     // first use of a session: context = [blank, blank], run the decoder (april_session.c:432-438)
@@ -400,6 +417,7 @@ void Scheduler::step_chunks(std::vector<Session *> &ready)
         s->chunks++;
     }
     eng_->encode(n, slots_.data(), tails_.data());
+    stats_.host_ms[3] += lap();
     stats_.steps++; stats_.chunks += (uint64_t)n;
     if ((uint64_t)n > stats_.max_batch_seen) stats_.max_batch_seen = (uint64_t)n;
 
@@ -411,7 +429,9 @@ void Scheduler::step_chunks(std::vector<Session *> &ready)
         for (int i = 0; i < m; ++i) { slots_[(size_t)i] = rows[(size_t)i]->slot; if (rows[(size_t)i]->trace_buf) want_logits = true; }
         jr_.resize((size_t)m);
         if (want_logits) logit_stage_.resize((size_t)m * d.vocab);
+        lap();
         eng_->joint(m, slots_.data(), jr_.data(), want_logits ? logit_stage_.data() : nullptr);
+        stats_.host_ms[4] += lap();
         stats_.rounds++;
         next.clear(); dec.clear();
         for (int i = 0; i < m; ++i) {
@@ -424,10 +444,12 @@ void Scheduler::step_chunks(std::vector<Session *> &ready)
             if (s->greedy.ctx_dirty) { dec.push_back(s); s->greedy.ctx_dirty = false; }
             if (!blank) next.push_back(s);
         }
+        stats_.host_ms[5] += lap();
         if (!dec.empty()) {
             slots_.clear(); ctx_.clear();
             for (Session *s : dec) { slots_.push_back(s->slot); ctx_.push_back(s->greedy.ctx[0]); ctx_.push_back(s->greedy.ctx[1]); }
             eng_->decode((int)slots_.size(), slots_.data(), ctx_.data());
+            stats_.host_ms[6] += lap();
         }
         rows.swap(next);
     }

@@ -113,7 +113,12 @@ struct Session {
     float *trace_buf = nullptr; size_t trace_cap = 0; size_t *trace_used = nullptr;
 };
 
-struct SchedStats { uint64_t ticks = 0, steps = 0, chunks = 0, rounds = 0, frames = 0, max_batch_seen = 0; };
+struct SchedStats {
+    uint64_t ticks = 0, steps = 0, chunks = 0, rounds = 0, frames = 0, max_batch_seen = 0;
+    // host wall time of the stepping thread by phase (ms): 0 collect, 1 cut frames (host), 2 fbank call, 3 encode launch,
+    // 4 joint (launch + wait for the GPU), 5 decisions, 6 decode launch, 7 deliver/complete
+    double host_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
 
 class Scheduler {
 public:

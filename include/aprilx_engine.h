@@ -74,6 +74,9 @@ typedef struct AprilxStats {
        0 gates GEMM+LSTM cell, 1 other encoder GEMMs, 2 row epilogues, 3 conv front end, 4 fbank, 5 decoder+joiner */
     double kernel_ms[6];
     uint64_t kernel_launches[6];
+    /* host wall time of the GPU's stepping thread by phase (ms): 0 collect work, 1 frame bookkeeping, 2 fbank call,
+       3 encoder launch, 4 joiner launch + wait for the GPU, 5 greedy decisions, 6 decoder launch, 7 completion */
+    double host_ms[8];
 } AprilxStats;
 APRIL_EXPORT void aprilx_model_stats(AprilASRModel model, int device_index, AprilxStats *out);
 /* bracket every launch with hipEvents on the engine's stream (measurement runs only) */
@@ -87,6 +90,10 @@ APRIL_EXPORT int aprilx_greedy_step(AprilxGreedy g, int32_t idx, float max_val, 
                                     size_t now_ms, int32_t *ctx_out);
 APRIL_EXPORT void aprilx_greedy_finish(AprilxGreedy g);
 APRIL_EXPORT void aprilx_greedy_free(AprilxGreedy g);
+
+/* A result handler implemented in C, for load generators and benchmarks (a Python or JNI callback costs more than
+   the GPU step at thousands of sessions).  userdata -> uint64_t[6]: calls, partial, final, cant_keep_up, silence, tokens */
+APRIL_EXPORT void aprilx_counting_handler(void *userdata, AprilResultType type, size_t count, const AprilToken *tokens);
 
 /* parse + weight extraction + packing without creating any GPU object (loader tests; no sessions) */
 APRIL_EXPORT AprilASRModel aprilx_model_load_host(const char *model_path);

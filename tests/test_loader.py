@@ -38,7 +38,7 @@ def layout_offsets(d):
         return o
     L = {}
     c0, c1, c2 = d["conv_ch"]
-    k3 = (c1 * 9 + 15) & ~15
+    k3 = (c1 * 9 + 63) & ~63
     L["conv_w0"] = take(c0 * 9); L["conv_b0"] = take(c0)
     L["conv_w1"] = take(c1 * c0 * 9); L["conv_b1"] = take(c1)
     L["conv_w2"] = take(k3 * c2); L["conv_b2"] = take(c2)
