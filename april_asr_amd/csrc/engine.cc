@@ -185,10 +185,11 @@ Engine::~Engine()
     for (auto &g : enc_graphs_) (void)hipGraphExecDestroy(g.second);
     for (void *p : {(void *)w_, (void *)h_, (void *)c_, (void *)ring_, (void *)eout_, (void *)dout_, (void *)ws_, (void *)xin_, (void *)a3_, (void *)xa_,
                     (void *)xb_, (void *)u_, (void *)ff_, (void *)de_, (void *)logits_, (void *)joint_d_, (void *)ds_enc_, (void *)ds_dec_,
-                    (void *)ds_joi_, (void *)ds_desc_, (void *)ds_pcm_})
+                    (void *)ds_joi_, (void *)ds_desc_[0], (void *)ds_desc_[1], (void *)ds_pcm_[0], (void *)ds_pcm_[1]})
         if (p) (void)hipFree(p);
-    for (void *p : {(void *)hs_enc_, (void *)hs_dec_, (void *)hs_joi_, (void *)joint_h_, (void *)logits_h_, (void *)hs_desc_, (void *)hs_pcm_})
+    for (void *p : {(void *)hs_enc_, (void *)hs_dec_, (void *)hs_joi_, (void *)joint_h_, (void *)logits_h_, (void *)hs_desc_[0], (void *)hs_desc_[1], (void *)hs_pcm_[0], (void *)hs_pcm_[1]})
         if (p) (void)hipHostFree(p);
+    for (int b = 0; b < 2; ++b) if (fb_done_[b]) (void)hipEventDestroy(fb_done_[b]);
     for (void *p : table_allocs_) (void)hipFree(p);
     (void)hipStreamDestroy(stream_);
 }
@@ -227,17 +228,15 @@ int Engine::alloc_slot()
 
 void Engine::free_slot(int slot)
 {
-    // zero the slot's state so the next owner starts from the reference's calloc'd tensors
+    // zero the slot's state so the next owner starts from the reference's calloc'd tensors (april_session.c:40-58).
+    // Two strided 2-D memsets cover all layers; they are stream-ordered ahead of any later use of the slot.
     HIP_CHECK(hipSetDevice(cfg_.device));
     const NetDims &d = L_.dims;
     const size_t S = (size_t)cfg_.max_slots;
-    for (int l = 0; l < d.n_layers; ++l) {
-        HIP_CHECK(hipMemsetAsync(h_ + ((size_t)l * S + slot) * d.d_model, 0, (size_t)d.d_model * 4, stream_));
-        HIP_CHECK(hipMemsetAsync(c_ + ((size_t)l * S + slot) * d.hidden, 0, (size_t)d.hidden * 4, stream_));
-    }
+    HIP_CHECK(hipMemset2DAsync(h_ + (size_t)slot * d.d_model, S * d.d_model * 4, 0, (size_t)d.d_model * 4, (size_t)d.n_layers, stream_));
+    HIP_CHECK(hipMemset2DAsync(c_ + (size_t)slot * d.hidden, S * d.hidden * 4, 0, (size_t)d.hidden * 4, (size_t)d.n_layers, stream_));
     HIP_CHECK(hipMemsetAsync(eout_ + (size_t)slot * d.joiner, 0, (size_t)d.joiner * 4, stream_));
     HIP_CHECK(hipMemsetAsync(dout_ + (size_t)slot * d.joiner, 0, (size_t)d.joiner * 4, stream_));
-    HIP_CHECK(hipStreamSynchronize(stream_));
     std::lock_guard<std::mutex> g(slot_mu_);
     free_.push_back(slot);
     --live_;
@@ -272,34 +271,38 @@ void Engine::collect_timing()
 }
 
 // ---------------------------------------------------------------- fbank
-void Engine::fbank(int n_frames, const FbankFrameDesc *desc, const int16_t *pcm, size_t n_pcm)
+void Engine::fbank(int n_frames, const FbankFrameDesc *desc, const std::pair<const int16_t *, size_t> *parts, size_t n_parts, size_t n_pcm)
 {
     if (n_frames <= 0) return;
     HIP_CHECK(hipSetDevice(cfg_.device));
-    if (n_frames > desc_cap_) {
+    if (n_frames > desc_cap_ || n_pcm > pcm_cap_) {
         sync();
-        if (hs_desc_) { (void)hipHostFree(hs_desc_); (void)hipFree(ds_desc_); }
-        desc_cap_ = std::max(n_frames * 2, 1024);
-        hs_desc_ = hmalloc<FbankFrameDesc>((size_t)desc_cap_); ds_desc_ = dmalloc<FbankFrameDesc>((size_t)desc_cap_);
+        for (int b = 0; b < 2; ++b) {
+            if (hs_desc_[b]) { (void)hipHostFree(hs_desc_[b]); (void)hipFree(ds_desc_[b]); }
+            if (hs_pcm_[b]) { (void)hipHostFree(hs_pcm_[b]); (void)hipFree(ds_pcm_[b]); }
+        }
+        desc_cap_ = std::max({n_frames * 2, desc_cap_, 1024});
+        pcm_cap_ = std::max({n_pcm * 2, pcm_cap_, (size_t)1 << 16});
+        for (int b = 0; b < 2; ++b) {
+            hs_desc_[b] = hmalloc<FbankFrameDesc>((size_t)desc_cap_); ds_desc_[b] = dmalloc<FbankFrameDesc>((size_t)desc_cap_);
+            hs_pcm_[b] = hmalloc<int16_t>(pcm_cap_); ds_pcm_[b] = dmalloc<int16_t>(pcm_cap_);
+            if (!fb_done_[b]) HIP_CHECK(hipEventCreateWithFlags(&fb_done_[b], hipEventDisableTiming));
+        }
     }
-    if (n_pcm > pcm_cap_) {
-        sync();
-        if (hs_pcm_) { (void)hipHostFree(hs_pcm_); (void)hipFree(ds_pcm_); }
-        pcm_cap_ = std::max(n_pcm * 2, (size_t)1 << 16);
-        hs_pcm_ = hmalloc<int16_t>(pcm_cap_); ds_pcm_ = dmalloc<int16_t>(pcm_cap_);
-    }
-    memcpy(hs_desc_, desc, (size_t)n_frames * sizeof(FbankFrameDesc));
-    if (n_pcm) memcpy(hs_pcm_, pcm, n_pcm * sizeof(int16_t));
-    HIP_CHECK(hipMemcpyAsync(ds_desc_, hs_desc_, (size_t)n_frames * sizeof(FbankFrameDesc), hipMemcpyHostToDevice, stream_));
-    if (n_pcm) HIP_CHECK(hipMemcpyAsync(ds_pcm_, hs_pcm_, n_pcm * sizeof(int16_t), hipMemcpyHostToDevice, stream_));
+    const int b = fb_flip_;
+    fb_flip_ ^= 1;
+    HIP_CHECK(hipEventSynchronize(fb_done_[b]));          // the launch that used this pair two calls ago has consumed it
+    memcpy(hs_desc_[b], desc, (size_t)n_frames * sizeof(FbankFrameDesc));
+    size_t off = 0;
+    for (size_t i = 0; i < n_parts; ++i) { memcpy(hs_pcm_[b] + off, parts[i].first, parts[i].second * sizeof(int16_t)); off += parts[i].second; }
+    HIP_CHECK(hipMemcpyAsync(ds_desc_[b], hs_desc_[b], (size_t)n_frames * sizeof(FbankFrameDesc), hipMemcpyHostToDevice, stream_));
+    if (n_pcm) HIP_CHECK(hipMemcpyAsync(ds_pcm_[b], hs_pcm_[b], n_pcm * sizeof(int16_t), hipMemcpyHostToDevice, stream_));
     FbankArgs a;
-    a.t = ft_; a.pcm = ds_pcm_; a.desc = ds_desc_; a.n_frames = n_frames; a.ring = ring_; a.ring_frames = ring_frames_; a.pad_value = pad_value_;
+    a.t = ft_; a.pcm = ds_pcm_[b]; a.desc = ds_desc_[b]; a.n_frames = n_frames; a.ring = ring_; a.ring_frames = ring_frames_; a.pad_value = pad_value_;
     timed_begin(T_FBANK);
     launch_fbank(a, stream_);
     timed_end(T_FBANK);
-    // the pinned staging buffers are reused by the next call: wait for the copies (kernel may still run)
-    HIP_CHECK(hipStreamSynchronize(stream_));
-    if (profiling_) collect_timing();
+    HIP_CHECK(hipEventRecord(fb_done_[b], stream_));       // no host wait here: the encoder launches queue right behind
 }
 
 // ---------------------------------------------------------------- encoder
@@ -534,7 +537,8 @@ void Engine::debug_fbank(int n_frames, const int16_t *pcm_frames, float *out)
     const int padded = ft_.padded;
     std::vector<FbankFrameDesc> desc((size_t)n_frames);
     for (int i = 0; i < n_frames; ++i) { desc[(size_t)i].slot = 0; desc[(size_t)i].ring_row = i; desc[(size_t)i].pcm_off = i * padded; }
-    fbank(n_frames, desc.data(), pcm_frames, (size_t)n_frames * padded);
+    std::pair<const int16_t *, size_t> part(pcm_frames, (size_t)n_frames * padded);
+    fbank(n_frames, desc.data(), &part, 1, (size_t)n_frames * padded);
     sync();
     HIP_CHECK(hipMemcpy(out, ring_, (size_t)n_frames * ft_.nbins * 4, hipMemcpyDeviceToHost));
 }

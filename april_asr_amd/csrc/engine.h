@@ -17,6 +17,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 #include "fbank_tables.h"
 #include "kernels.h"
@@ -71,7 +72,8 @@ public:
     int live_slots() const { return live_; }
 
     // ---- batched hot path; host arrays are copied to pinned staging, all launches go to stream()
-    void fbank(int n_frames, const FbankFrameDesc *desc, const int16_t *pcm, size_t n_pcm);
+    // pcm arrives as `n_parts` windows that are gathered straight into pinned staging (total n_pcm samples)
+    void fbank(int n_frames, const FbankFrameDesc *desc, const std::pair<const int16_t *, size_t> *parts, size_t n_parts, size_t n_pcm);
     void encode(int n, const int *slots, const int *ring_tails);
     void decode(int n, const int *slots, const int *ctx /*[n][context]*/);
     // runs the joiner for n sessions, waits, returns results; logits_out optional [n][vocab] (host)
@@ -116,8 +118,11 @@ private:
     int *hs_joi_ = nullptr, *ds_joi_ = nullptr;      // [max_batch]
     JointResult *joint_h_ = nullptr;
     float *logits_h_ = nullptr;
-    FbankFrameDesc *hs_desc_ = nullptr, *ds_desc_ = nullptr; int desc_cap_ = 0;
-    int16_t *hs_pcm_ = nullptr, *ds_pcm_ = nullptr; size_t pcm_cap_ = 0;
+    // fbank staging is double-buffered so the next call can fill one pair while the previous copy is in flight
+    FbankFrameDesc *hs_desc_[2] = {nullptr, nullptr}, *ds_desc_[2] = {nullptr, nullptr}; int desc_cap_ = 0;
+    int16_t *hs_pcm_[2] = {nullptr, nullptr}, *ds_pcm_[2] = {nullptr, nullptr}; size_t pcm_cap_ = 0;
+    int fb_flip_ = 0;
+    hipEvent_t fb_done_[2] = {nullptr, nullptr};
     // fbank tables on device
     FbankTables ft_;
     std::vector<void *> table_allocs_;

@@ -180,6 +180,31 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
         ++slab_done;
     };
 
+    // EPI_LSTM: the thread's QPT (row, unit) pairs are known up front; their dependent global loads (row -> slot ->
+    // previous cell value) and the gate biases are issued BEFORE the MFMA stream so the epilogue never waits on HBM
+    int qm[QPT], qunit[QPT], qo[QPT];
+    bool qok[QPT];
+    float *cptr[QPT];
+    float cprev[QPT];
+    f32x4 qb[QPT];
+    if (EPI == EPI_LSTM) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * 256;
+            const int row = q / QROW, ul = q % QROW;
+            qm[i] = m0 + row;
+            qok[i] = q < NQ && qm[i] < g.M;
+            const int n = nt0 * 16 + ul * 4;
+            qunit[i] = n >> 2;
+            qo[i] = row * Cfg::LDR + ul * 4;
+            const int slot = qok[i] ? g.slot_idx[qm[i]] : 0;
+            cptr[i] = g.c_state + (size_t)slot * g.hidden + qunit[i];
+            qb[i] = *reinterpret_cast<const f32x4 *>(g.bias + n);
+        }
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) cprev[i] = qok[i] ? *cptr[i] : 0.0f;
+    }
+
     zero_acc();
     if (T > 0) {
         {
@@ -242,27 +267,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
             }
         }
     } else {   // EPI_LSTM: each 4-column group = gates i,f,g,o of one hidden unit
-        // all dependent global loads (slot -> c) of the thread's QPT units are issued up front
-        int qm[QPT], qunit[QPT], qo[QPT];
-        bool qok[QPT];
-        float *cptr[QPT];
-        float cprev[QPT];
-        f32x4 qb[QPT];
-#pragma unroll
-        for (int i = 0; i < QPT; ++i) {
-            const int q = threadIdx.x + i * 256;
-            const int row = q / QROW, ul = q % QROW;
-            qm[i] = m0 + row;
-            qok[i] = q < NQ && qm[i] < g.M;
-            const int n = nt0 * 16 + ul * 4;
-            qunit[i] = n >> 2;
-            qo[i] = row * Cfg::LDR + ul * 4;
-            const int slot = qok[i] ? g.slot_idx[qm[i]] : 0;
-            cptr[i] = g.c_state + (size_t)slot * g.hidden + qunit[i];
-            qb[i] = *reinterpret_cast<const f32x4 *>(g.bias + n);
-        }
-#pragma unroll
-        for (int i = 0; i < QPT; ++i) cprev[i] = qok[i] ? *cptr[i] : 0.0f;
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
             const f32x4 gt = summed4(qo[i]) + qb[i];

@@ -235,8 +235,9 @@ void Scheduler::submit(int n, Session *const *ss, const short *const *pcm, const
             if (flush) s->flush_requested = true;
             else {
                 const size_t cnt = counts[i];
-                if (!s->sync_mode && s->inbox_samples + cnt > kAsyncRingSamples) { overflowed.push_back(s); continue; }   // april_session.c:482-492
-                if (cnt) { s->inbox.emplace_back(pcm[i], pcm[i] + cnt); s->inbox_samples += cnt; }
+                if (!s->sync_mode && s->inbox.size() + cnt > kAsyncRingSamples) { overflowed.push_back(s); continue; }   // april_session.c:482-492
+                if (cnt) s->inbox.insert(s->inbox.end(), pcm[i], pcm[i] + cnt);
+                s->fed = true;
             }
             tickets[(size_t)i] = ++s->submitted;
         }
@@ -254,7 +255,7 @@ void Scheduler::submit(int n, Session *const *ss, const short *const *pcm, const
 void Scheduler::wait_idle(Session *s)
 {
     std::unique_lock<std::mutex> lk(mu_);
-    cv_done_.wait(lk, [&] { return s->closing || (s->completed >= s->submitted && !s->busy && s->inbox.empty() && !s->flush_requested); });
+    cv_done_.wait(lk, [&] { return s->closing || (s->completed >= s->submitted && !s->busy && !s->fed && !s->flush_requested); });
 }
 
 void Scheduler::deliver_sync_events(Session *s)
@@ -276,18 +277,17 @@ void Scheduler::loop()
             std::unique_lock<std::mutex> lk(mu_);
             cv_work_.wait(lk, [&] {
                 if (stop_) return true;
-                for (Session *s : sessions_) if (!s->closing && (!s->inbox.empty() || s->flush_requested)) return true;
+                for (Session *s : sessions_) if (!s->closing && (s->fed || s->flush_requested)) return true;
                 return false;
             });
             if (stop_) return;
             lap();
             for (Session *s : sessions_) {
-                if (s->closing || (s->inbox.empty() && !s->flush_requested)) continue;
+                if (s->closing || (!s->fed && !s->flush_requested)) continue;
                 s->busy = true;
-                bool fed = false;
-                for (auto &chunk : s->inbox) { s->fb.fifo.insert(s->fb.fifo.end(), chunk.begin(), chunk.end()); fed = true; }
-                s->inbox.clear(); s->inbox_samples = 0;
-                if (fed) s->was_flushed = false;                                  // april_session.c:510
+                if (!s->inbox.empty()) { s->fb.fifo.insert(s->fb.fifo.end(), s->inbox.begin(), s->inbox.end()); s->inbox.clear(); }
+                if (s->fed) s->was_flushed = false;                               // april_session.c:510
+                s->fed = false;
                 if (s->flush_requested) {                                           // :547-552
                     s->flush_requested = false;
                     if (!s->was_flushed && s->flush_phase == 0) { s->was_flushed = true; s->flush_phase = 1; }
@@ -322,13 +322,14 @@ void Scheduler::loop()
 void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
 {
     Lap lap;
-    desc_.clear(); pcm_stage_.clear();
+    desc_.clear(); pcm_parts_.clear();
+    size_t staged = 0;
     std::vector<Session *> need_decode;
     for (Session *s : work) {
         FrameBook &fb = s->fb;
         // new real frames: frame k covers stream samples [k*shift, k*shift + padded)  (fbank.c:195-236)
         if (fb.can_cut()) {
-            const size_t base = pcm_stage_.size();
+            const size_t base = staged;
             const size_t first = fb.fifo_pos;
             int cut = 0;
             while (fb.can_cut() && cut < 96) {
@@ -341,8 +342,9 @@ void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
                 ++cut;
             }
             const size_t last_end = first + (size_t)(cut - 1) * fb.shift + (size_t)fb.padded;
-            pcm_stage_.insert(pcm_stage_.end(), fb.fifo.begin() + (long)first, fb.fifo.begin() + (long)last_end);
-            fb.compact();
+            pcm_parts_.emplace_back(fb.fifo.data() + first, last_end - first);
+            staged += last_end - first;
+            s->compact_pending = true;                 // the fifo must not move until the window has been staged
             progressed = true;
             continue;
         }
@@ -378,7 +380,8 @@ void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
     }
     stats_.host_ms[1] += lap();
     if (!desc_.empty()) {
-        eng_->fbank((int)desc_.size(), desc_.data(), pcm_stage_.data(), pcm_stage_.size());
+        eng_->fbank((int)desc_.size(), desc_.data(), pcm_parts_.data(), pcm_parts_.size(), staged);
+        for (Session *s : work) if (s->compact_pending) { s->fb.compact(); s->compact_pending = false; }
         stats_.frames += desc_.size();
         stats_.host_ms[2] += lap();
     }

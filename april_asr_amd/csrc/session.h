@@ -92,8 +92,8 @@ struct Session {
     bool sync_mode = true, realtime_flag = false;
 
     // ---- guarded by Scheduler::mu_
-    std::deque<std::vector<int16_t>> inbox;   // queued feeds
-    size_t inbox_samples = 0;
+    std::vector<int16_t> inbox;               // queued PCM (appended by callers; capacity is reused across feeds)
+    bool fed = false;                         // a feed arrived since the last collection (even an empty one)
     bool flush_requested = false;
     bool busy = false;                        // owned by the stepping thread right now
     bool closing = false;
@@ -104,6 +104,7 @@ struct Session {
     FrameBook fb;
     Greedy greedy;
     bool dout_ready = false;
+    bool compact_pending = false;
     bool was_flushed = false;
     int flush_phase = 0;                      // 0 none, 1 pad-drain, 2 zeros, 3 pad-drain, 4 finish
     size_t now_ms = 0;
@@ -149,7 +150,7 @@ private:
     SchedStats stats_;
     // scratch reused across ticks
     std::vector<FbankFrameDesc> desc_;
-    std::vector<int16_t> pcm_stage_;
+    std::vector<std::pair<const int16_t *, size_t>> pcm_parts_;   // windows to stage, in order
     std::vector<int> slots_, tails_, ctx_;
     std::vector<JointResult> jr_;
     std::vector<float> logit_stage_;
