@@ -230,13 +230,15 @@ void Engine::free_slot(int slot)
 {
     // zero the slot's state so the next owner starts from the reference's calloc'd tensors (april_session.c:40-58).
     // Two strided 2-D memsets cover all layers; they are stream-ordered ahead of any later use of the slot.
-    HIP_CHECK(hipSetDevice(cfg_.device));
-    const NetDims &d = L_.dims;
-    const size_t S = (size_t)cfg_.max_slots;
-    HIP_CHECK(hipMemset2DAsync(h_ + (size_t)slot * d.d_model, S * d.d_model * 4, 0, (size_t)d.d_model * 4, (size_t)d.n_layers, stream_));
-    HIP_CHECK(hipMemset2DAsync(c_ + (size_t)slot * d.hidden, S * d.hidden * 4, 0, (size_t)d.hidden * 4, (size_t)d.n_layers, stream_));
-    HIP_CHECK(hipMemsetAsync(eout_ + (size_t)slot * d.joiner, 0, (size_t)d.joiner * 4, stream_));
-    HIP_CHECK(hipMemsetAsync(dout_ + (size_t)slot * d.joiner, 0, (size_t)d.joiner * 4, stream_));
+    // Teardown-tolerant: sessions may be freed while the process is exiting and the HIP runtime is already gone.
+    if (hipSetDevice(cfg_.device) == hipSuccess) {
+        const NetDims &d = L_.dims;
+        const size_t S = (size_t)cfg_.max_slots;
+        (void)hipMemset2DAsync(h_ + (size_t)slot * d.d_model, S * d.d_model * 4, 0, (size_t)d.d_model * 4, (size_t)d.n_layers, stream_);
+        (void)hipMemset2DAsync(c_ + (size_t)slot * d.hidden, S * d.hidden * 4, 0, (size_t)d.hidden * 4, (size_t)d.n_layers, stream_);
+        (void)hipMemsetAsync(eout_ + (size_t)slot * d.joiner, 0, (size_t)d.joiner * 4, stream_);
+        (void)hipMemsetAsync(dout_ + (size_t)slot * d.joiner, 0, (size_t)d.joiner * 4, stream_);
+    }
     std::lock_guard<std::mutex> g(slot_mu_);
     free_.push_back(slot);
     --live_;

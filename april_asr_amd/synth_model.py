@@ -154,6 +154,10 @@ APRILV0_DIMS = dict(n_layers=12, d_model=512, hidden=1024, ffn=2048, joiner=512,
                     context=2, dec_groups=128, conv_ch=(8, 32, 128))
 TINY_DIMS = dict(n_layers=2, d_model=64, hidden=128, ffn=128, joiner=64, vocab=40, mel=80, seg=9,
                  context=2, dec_groups=16, conv_ch=(8, 16, 32))
+# odd-sized but legal: 3 layers, widths that are multiples of 64 but not powers of two, a vocabulary that is not a
+# multiple of 16 (exercises the padded joiner columns), a different decoder grouping
+MEDIUM_DIMS = dict(n_layers=3, d_model=192, hidden=320, ffn=448, joiner=192, vocab=131, mel=80, seg=9,
+                   context=2, dec_groups=48, conv_ch=(8, 24, 64))
 LARGE_DIMS = dict(n_layers=16, d_model=768, hidden=1536, ffn=3072, joiner=768, vocab=500, mel=80, seg=9,
                   context=2, dec_groups=192, conv_ch=(8, 32, 128))
 

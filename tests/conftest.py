@@ -3,6 +3,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- first, so the process uses ONE HIP runtime (torch's) for both torch and libaprilasr.so
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
@@ -45,6 +46,14 @@ def tiny_model_variant(model_dir, built):
     from april_asr_amd import synth_model as SM
     p = str(model_dir / "tiny_variant.april")
     dims, w, toks = SM.write_model(p, SM.TINY_DIMS, variant=dict(lstm_gemm=False, fold_eps=False))
+    return dict(path=p, dims=dims, weights=w, tokens=toks)
+
+
+@pytest.fixture(scope="session")
+def medium_model(model_dir, built):
+    from april_asr_amd import synth_model as SM
+    p = str(model_dir / "medium.april")
+    dims, w, toks = SM.write_model(p, SM.MEDIUM_DIMS, seed=77)
     return dict(path=p, dims=dims, weights=w, tokens=toks)
 
 

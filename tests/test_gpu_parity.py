@@ -120,7 +120,7 @@ def test_encoder_batch_invariant_bitwise(gpu_tiny):
 # ------------------------------------------------------------------ full sessions
 def run_oracle(om, pcm, chunk):
     from oracle import orc_py as O
-    s = O.Session(om, trace_logits=8000)
+    s = O.Session(om, trace_logits=12000)
     for i in range(0, pcm.size, chunk):
         s.feed(pcm[i:i + chunk])
     s.flush()
@@ -134,7 +134,7 @@ def run_gpu(gm, pcm, chunk, asynchronous=False):
     import april_asr_amd as A
     ev = []
     s = A.Session(gm, lambda t, toks: ev.append((t, toks)), asynchronous=asynchronous, no_rt=asynchronous, raw_events=True)
-    s.trace_logits(8000)
+    s.trace_logits(12000)
     for i in range(0, pcm.size, chunk):
         s.feed_pcm16(pcm[i:i + chunk])
         if asynchronous:
@@ -208,3 +208,155 @@ def test_many_sessions_equal_single(gpu_tiny):
         assert ev1 == evs[i]
     for s in sess:
         s.close()
+
+
+# ------------------------------------------------------------------ more session behaviour
+def test_feed_after_flush_and_double_flush(gpu_tiny, orc_tiny):
+    """flush is idempotent until new audio arrives; feeding after a flush continues the same stream
+    (reference src/april_session.c:510,548-550)."""
+    import april_asr_amd as A
+    from oracle import orc_py as O
+    a = speech_like_pcm(2.0, seed=21); b = speech_like_pcm(1.5, seed=22)
+    so = O.Session(orc_tiny, trace_logits=4000)
+    so.feed(a); so.flush(); so.flush(); so.feed(b); so.flush()
+    want = [(t, [(orc_tiny.token(i).encode(), lp, fl, ms) for (i, lp, fl, ms) in toks]) for t, toks in so.events]
+    ev = []
+    sg = A.Session(gpu_tiny, lambda t, toks: ev.append((t, toks)), raw_events=True)
+    sg.trace_logits(4000)
+    sg.feed_pcm16(a); sg.flush(); sg.flush(); sg.feed_pcm16(b.tobytes()); sg.flush()
+    assert sg.chunks() == so.chunks()
+    assert np.abs(sg.traced_logits() - so.logits()).max() < 1e-3
+    assert_same_transcript(want, ev)
+    sg.close(); so.close()
+
+
+def test_async_overflow_reports_cant_keep_up(gpu_tiny):
+    """More than 48000 queued samples in an asynchronous session: the push is dropped and CANT_KEEP_UP is delivered
+    on the calling thread (reference src/april_session.c:482-492, src/audio_provider.c:31)."""
+    import threading
+    import april_asr_amd as A
+    seen = []
+    s = A.Session(gpu_tiny, lambda t, toks: seen.append((int(t), threading.get_ident())), asynchronous=True, no_rt=True, raw_events=True)
+    big = np.zeros(48001, np.int16)
+    s.feed_pcm16(big)
+    assert (3, threading.get_ident()) in seen
+    s.feed_pcm16(np.zeros(1600, np.int16))
+    s.flush(); s.drain()
+    assert s.get_rt_speedup() == 1.0
+    s.close()
+
+
+def test_async_handler_runs_on_library_thread(gpu_tiny):
+    import threading
+    import april_asr_amd as A
+    from oracle import orc_py as O
+    tids = set()
+    s = A.Session(gpu_tiny, lambda t, toks: tids.add(threading.get_ident()), asynchronous=True, no_rt=True, raw_events=True)
+    s.feed_pcm16(O.lcg_pcm16_fast(16000 * 2, seed=31)); s.flush(); s.drain()
+    assert tids and threading.get_ident() not in tids
+    s.close()
+
+
+def test_concurrent_sync_callers(gpu_tiny):
+    """Different sessions of one model fed from different threads (the reference allows this, concepts.md:41-45):
+    every session's callbacks equal the single-threaded run."""
+    import threading
+    import april_asr_amd as A
+    from oracle import orc_py as O
+    n = 8
+    pcms = [O.lcg_pcm16_fast(16000 * 2, seed=300 + i) for i in range(n)]
+    want = [run_gpu(gpu_tiny, p, 1600)[0] for p in pcms]
+    got = [[] for _ in range(n)]
+
+    def worker(k):
+        s = A.Session(gpu_tiny, lambda t, toks: got[k].append((t, toks)), raw_events=True)
+        for o in range(0, pcms[k].size, 1600):
+            s.feed_pcm16(pcms[k][o:o + 1600])
+        s.flush(); s.close()
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(n)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert got == want
+
+
+def test_model_from_device_blob(gpu_tiny, tiny_model):
+    """The multi-GPU load path on one GPU: export the packed blob, move it to the device the way the RCCL broadcast
+    delivers it, build a second model from the device pointer, same results bit for bit."""
+    import torch
+    import april_asr_amd as A
+    from oracle import orc_py as O
+    blob = torch.from_numpy(gpu_tiny.export_blob()).cuda()
+    torch.cuda.synchronize()
+    m2 = A.Model.from_blob(None, device_ptr=blob.data_ptr(), size=blob.numel())
+    assert m2.get_name() == gpu_tiny.get_name() and m2.dims.param_count == gpu_tiny.dims.param_count
+    pcm = O.lcg_pcm16_fast(16000 * 2, seed=41)
+    e1, l1, _ = run_gpu(gpu_tiny, pcm, 1600)
+    e2, l2, _ = run_gpu(m2, pcm, 1600)
+    assert e1 == e2 and np.array_equal(l1, l2)
+    m2.close()
+
+
+def test_sessions_above_max_batch(tiny_model):
+    """More ready sessions than APRIL_MAX_BATCH: the step is split into sub-batches, results unchanged."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import april_asr_amd as A\n"
+        "from april_asr_amd import synth_model as SM\n"
+        "m = A.Model(%r)\n"
+        "n = 40; pcms = [SM.lcg_pcm16(16000, seed=500 + i) for i in range(n)]\n"
+        "evs = [[] for _ in range(n)]\n"
+        "ss = [A.Session(m, (lambda k: (lambda t, toks: evs[k].append((t, toks))))(i), raw_events=True) for i in range(n)]\n"
+        "g = A.SessionGroup(ss)\n"
+        "for o in range(0, 16000, 1600): g.feed([p[o:o + 1600] for p in pcms])\n"
+        "g.flush()\n"
+        "import pickle; pickle.dump(evs, open(sys.argv[1], 'wb'))\n"
+        "for s in ss: s.close()\n"
+        "m.close()\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), tiny_model["path"]))
+    outs = []
+    for mb in ("16", "2048"):
+        out = os.path.join(os.path.dirname(tiny_model["path"]), "evs_%s.pkl" % mb)
+        env = dict(os.environ, APRIL_MAX_BATCH=mb)
+        subprocess.check_call([sys.executable, "-c", code, out], env=env)
+        import pickle
+        outs.append(pickle.load(open(out, "rb")))
+    assert outs[0] == outs[1] and any(len(e) for e in outs[0])
+
+
+def test_session_60s_aprilv0(gpu_v0, orc_v0):
+    """BASELINE configs[1]: aprilv0 dimensions, one session, 60 s of synthetic 16 kHz PCM16 in 100 ms feeds + flush,
+    token-exact against the CPU oracle, every logit within 1e-3."""
+    pcm = np.concatenate([speech_like_pcm(20.0, seed=5, silence=(8.0, 11.5)), speech_like_pcm(40.0, seed=6, silence=(30.0, 33.0))])
+    want, lg0, n0 = run_oracle(orc_v0, pcm, 1600)
+    got, lg1, n1 = run_gpu(gpu_v0, pcm, 1600)
+    assert n0 == n1 == 1498 + 28
+    assert lg0.shape == lg1.shape
+    assert np.abs(lg0 - lg1).max() < 1e-3, np.abs(lg0 - lg1).max()
+    assert_same_transcript(want, got)
+    assert {t for t, _ in got} >= {1, 2, 4}
+
+
+def test_odd_dimensions_model(medium_model):
+    """3 layers, d=192, hidden=320, ffn=448, vocab=131 (padded to 144 on the device), 24 conv-2 channels
+    (im2col K padded 216 -> 256): network calls and a full session against the oracle."""
+    import april_asr_amd as A
+    from oracle import orc_py as O
+    gm = A.Model(medium_model["path"]); om = O.Model(medium_model["path"])
+    d = gm.dims
+    assert (d.n_layers, d.d_model, d.hidden, d.ffn, d.vocab) == (3, 192, 320, 448, 131)
+    rng = np.random.RandomState(9)
+    x = rng.uniform(-16, 8, size=(2, d.seg, d.mel)).astype(np.float32)
+    h = rng.uniform(-0.5, 0.5, size=(2, d.n_layers, d.d_model)).astype(np.float32)
+    c = rng.uniform(-1, 1, size=(2, d.n_layers, d.hidden)).astype(np.float32)
+    eout, h2, c2 = gm.run_encoder(x, h, c)
+    for i in range(2):
+        e0, h0, c0 = om.encoder(x[i:i + 1], h[i][:, None, :], c[i][:, None, :])
+        assert np.abs(eout[i] - e0.ravel()).max() < 1e-4 and np.abs(h2[i] - h0[:, 0, :]).max() < 1e-4 and np.abs(c2[i] - c0[:, 0, :]).max() < 1e-4
+    pcm = speech_like_pcm(3.0, seed=8, silence=(1.0, 1.4))
+    want, lg0, n0 = run_oracle(om, pcm, 1600)
+    got, lg1, n1 = run_gpu(gm, pcm, 1600)
+    assert n0 == n1 and lg0.shape == lg1.shape and lg1.shape[1] == 131
+    assert np.abs(lg0 - lg1).max() < 1e-3
+    assert_same_transcript(want, got)
+    gm.close(); om.close()
