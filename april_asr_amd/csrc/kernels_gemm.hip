@@ -114,7 +114,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
     // The prefetch stream runs ahead ACROSS slab boundaries, so the pipeline never restarts inside a workgroup;
     // loads in the main loop are unconditional (the fetch position parks on the last block) so the loop body is
     // straight-line code and the compiler keeps counted s_waitcnt vmcnt(N) instead of draining.
-    constexpr int DEPTH = (MT == 1) ? 6 : (MT == 2 ? 3 : 2);
+#ifndef APRIL_DEPTH4
+#define APRIL_DEPTH4 2
+#endif
+    constexpr int DEPTH = (MT == 1) ? 6 : (MT == 2 ? 3 : APRIL_DEPTH4);
     f32x4 a_st[DEPTH][MT], b_st[DEPTH][NT];
     int ld_base = (4 * (zg * g.zs) + wave) * c, ld_off = 0, ld_cnt = 0;
     auto ld_next = [&]() {

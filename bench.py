@@ -43,7 +43,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    os.environ["APRIL_GPU_DEVICES"] = str(local_rank)
+    lanes = int(os.environ.get("APRIL_LANES", "1"))        # engines (stream + stepping thread) per GPU
+    os.environ["APRIL_GPU_DEVICES"] = ",".join([str(local_rank)] * lanes)
     os.environ.setdefault("APRIL_MAX_SESSIONS", "4096")
     os.environ.setdefault("APRIL_MAX_BATCH", "4096")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -160,6 +161,15 @@ def main():
             else:
                 roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(frac_hbm, 4), "traffic": None}
+            # HBM traffic per launch from the committed PMC pass of the same workload (bench.py cannot collect PMC itself)
+            try:
+                tr = json.load(open(os.path.join(ROOT, "profiles", "r01_gates_traffic.json")))
+                if int(tr["sessions_per_gpu"]) == B:
+                    roofline["traffic"] = int(tr["traffic_bytes_per_launch"])
+                    roofline["traffic_source"] = "profiles/r01_gates_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950 x2 read correction)"
+            except Exception:
+                pass
+            roofline["algorithmic_bytes_per_launch"] = int(wbytes + sbytes)
             roofline.update({"kernel": "gemm_f32_kernel<EPI_LSTM> (LSTM gates [B,1024]x[1024,4096] + cell)",
                              "avg_launch_us": round(avg_ms * 1e3, 2), "rows_per_launch": round(rows_per_launch, 1),
                              "launches": int(launches), "alt_frac_hbm": round(frac_hbm, 4), "alt_frac_mfma": round(frac_mfma, 4),

@@ -1,0 +1,53 @@
+"""BASELINE configs[0] equivalent: the ./main-style C++ program (examples/main.cpp) built only against
+include/april_api.h, fed a PCM file, prints the reference's "- partial" / "@ final" lines; the text must
+equal what the oracle's transcript renders to."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import speech_like_pcm
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def render(events, token_text):
+    lines = []
+    for typ, toks in events:
+        if typ == 4:
+            lines.append("")
+        elif typ in (1, 2):
+            lines.append(("@ " if typ == 2 else "- ") + "".join(token_text(t[0]) for t in toks))
+    return lines
+
+
+@pytest.mark.parametrize("container", ["raw", "wav"])
+def test_main_cli_matches_oracle(tiny_model, tmp_path, container):
+    from oracle import orc_py as O
+    exe = str(tmp_path / "main")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "examples", "main.cpp"), "-I", os.path.join(ROOT, "include"),
+                           "-L", os.path.join(ROOT, "april_asr_amd"), "-laprilasr", "-Wl,-rpath," + os.path.join(ROOT, "april_asr_amd"), "-o", exe])
+    pcm = np.concatenate([speech_like_pcm(3.0, seed=12), np.zeros(16000 * 3, np.int16), speech_like_pcm(1.0, seed=13)])
+    path = str(tmp_path / ("audio." + container))
+    with open(path, "wb") as f:
+        if container == "wav":
+            data = pcm.tobytes()
+            f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16)
+                    + b"data" + struct.pack("<I", len(data)))
+            f.write(data)
+        else:
+            f.write(pcm.tobytes())
+    out = subprocess.run([exe, path, tiny_model["path"]], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert out.returncode == 0, out.stderr.decode()
+    got = out.stdout.decode().split("\n")[:-1]
+    om = O.Model(tiny_model["path"])
+    s = O.Session(om)
+    for o in range(0, pcm.size, 1600):
+        s.feed(pcm[o:o + 1600])
+    s.flush()
+    want = render(s.events, om.token)
+    assert got == want and len(got) > 3 and all(l == "" or l[:2] in ("- ", "@ ") for l in got)
+    s.close(); om.close()
