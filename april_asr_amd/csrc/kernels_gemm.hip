@@ -13,17 +13,11 @@
 // Replaces the ORT MatMul/Gemm nodes of the encoder/decoder/joiner graphs
 // (reference call sites src/april_session.c:145,160,176).
 #include "kernels.h"
+#include "device_utils.h"
 #include <cstdlib>
 
 namespace aprilx {
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-// sigma and tanh on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each); absolute error ~1e-7,
-// far inside the 1e-4 per-call parity tolerance, and ~10x fewer VALU instructions than libm's expf/tanhf --
-// the epilogue runs while the matrix pipe of the CU idles, so its length is throughput
-__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * fast_sigmoid(2.0f * x) - 1.0f; }
 
 template <int MT, int NT>
 struct TileCfg {
@@ -314,15 +308,16 @@ void launch_gemm(const GemmArgs &g_in, hipStream_t s)
     static const int dbg = getenv("APRIL_GEMM_DEBUG") ? atoi(getenv("APRIL_GEMM_DEBUG")) : 0;
     g.debug = dbg;
     static const int skew = getenv("APRIL_GEMM_SKEW") ? atoi(getenv("APRIL_GEMM_SKEW")) : 2;
-    g.skew = (long)g.N / 64 * ((g.M + 63) / 64) * (g.kz / g.zs) >= 512 ? skew : 0;
     g.zs = g.epi == EPI_PARTIAL ? g.kz / gemm_partials(g.M, g.N, g.kz) : 1;
+    g.skew = (long)g.N / 64 * ((g.M + 63) / 64) * (g.kz / g.zs) >= 512 ? skew : 0;
     const int ntiles = g.N / 16;
     int mt = g.M <= 16 ? 1 : (g.M <= 32 ? 2 : 4);
     int mblocks = (g.M + mt * 16 - 1) / (mt * 16);
     int nt = 4;
     while (nt > 1 && ((ntiles % nt) != 0 || (long)(ntiles / nt) * mblocks * g.kz < 256)) nt >>= 1;
-    // fused-epilogue GEMMs (one slab): prefer two resident workgroups per CU over the biggest tile,
-    // so one workgroup's prologue/epilogue overlaps the other's MFMA stream
+    // measurement knob (default off): smaller tiles for the fused-epilogue GEMMs so that two workgroups fit per CU.
+    // Measured slower on MI355X (B=256 gates 27 -> 32..36 us): the kernel is limited by operand loads per MFMA,
+    // not by occupancy -- see DESIGN.md section 6.
     static const int tune = getenv("APRIL_GEMM_TUNE") ? atoi(getenv("APRIL_GEMM_TUNE")) : 0;
     if (tune && g.epi != EPI_PARTIAL && mt == 4 && (long)(ntiles / nt) * mblocks < 512) {
         if (tune == 1) { mt = 2; mblocks = (g.M + 31) / 32; }

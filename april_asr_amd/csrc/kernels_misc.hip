@@ -4,23 +4,12 @@
 // intermediates, wavefront shuffles for the row reductions.  Reduction orders are
 // fixed (independent of the batch).
 #include "kernels.h"
+#include "device_utils.h"
 
 namespace aprilx {
 
-__device__ __forceinline__ float sigmoid_dev(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float sigmoid_dev(float x) { return fast_sigmoid(x); }
 __device__ __forceinline__ float dswish_dev(float y) { return y * sigmoid_dev(y - 1.0f); }
-
-// fixed-order block sum over 256 threads: xor-shuffle tree inside each wave, then 4 wave sums in order
-__device__ __forceinline__ float block_sum_256(float v, float *scratch4)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    const int wave = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) scratch4[wave] = v;
-    __syncthreads();
-    return ((scratch4[0] + scratch4[1]) + scratch4[2]) + scratch4[3];
-}
 
 // ---------------------------------------------------------------- row kernel
 // Finishes the split-K GEMMs: s[n] = ((ws[0]+ws[1])+...)+ws[kz-1] in slab order, then the
@@ -37,17 +26,8 @@ __global__ __launch_bounds__(256) void row_kernel(RowArgs r)
     const int tid = threadIdx.x;
     const int slot = r.slot_idx ? r.slot_idx[m] : m;
 
-    // r.kz partial planes (1, 2, 4 or 8; each already a balanced-tree sum of consecutive K slabs): finish the tree.
-    // All loads are issued before the first add.
-    auto slab_sum = [&](int n) {
-        float v[8];
-#pragma unroll
-        for (int z = 0; z < 8; ++z) v[z] = z < r.kz ? r.ws[((size_t)z * r.m_stride + m) * r.N + n] : 0.0f;
-        if (r.kz == 1) return v[0];
-        if (r.kz == 2) return v[0] + v[1];
-        if (r.kz == 4) return (v[0] + v[1]) + (v[2] + v[3]);
-        return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-    };
+    // r.kz partial planes (1, 2, 4 or 8; each already a balanced-tree sum of consecutive K slabs): finish the tree
+    auto slab_sum = [&](int n) { return tree_sum(r.ws, r.kz, r.m_stride, r.N, m, n); };
 
     if (MODE == ROW_HR) {
         for (int n = tid; n < r.N; n += 256) {
