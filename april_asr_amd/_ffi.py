@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaprilasr.so")
+LIB_PATH = os.environ.get("APRIL_ASR_LIB") or os.path.join(_HERE, "libaprilasr.so")
 
 
 class AprilSpeakerID(C.Structure):

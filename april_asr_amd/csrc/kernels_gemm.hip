@@ -50,25 +50,31 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
 
     const int mrow = lane & 15, kq = lane >> 4;
 
-    const float *arow0[MT], *arow0b[MT], *arow1[MT];
+    // Addressing = uniform 64-bit base (SGPRs; advances with the k block) + one 32-bit byte offset per lane and
+    // m-tile (row start + this lane's k quarter), i.e. the saddr form of global_load: no 64-bit vector adds in the loop.
+    // All operands are far below 4 GiB per array.
+    uint32_t aoff0[MT], aoff1[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int row = m0 + mt * 16 + mrow;
         if (row >= g.M) row = g.M - 1;                        // padding rows recompute the last row; never stored
         const int r0 = g.aidx0 ? g.aidx0[row] : row;
-        arow0[mt] = g.a0 + (size_t)r0 * g.lda0;
-        arow0b[mt] = (AOP == AOP_TANH_ADD) ? g.a0b + (size_t)r0 * g.lda0 : nullptr;
-        if (g.K1 > 0) { const int r1 = g.aidx1 ? g.aidx1[row] : row; arow1[mt] = g.a1 + (size_t)r1 * g.lda1; }
-        else arow1[mt] = nullptr;
+        aoff0[mt] = (uint32_t)(((size_t)r0 * g.lda0 + kq * 4) * sizeof(float));
+        aoff1[mt] = 0;
+        if (g.K1 > 0) { const int r1 = g.aidx1 ? g.aidx1[row] : row; aoff1[mt] = (uint32_t)(((size_t)r1 * g.lda1 + kq * 4) * sizeof(float)); }
     }
-    const f32x4 *wbase[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wbase[nt] = reinterpret_cast<const f32x4 *>(g.wp) + ((size_t)(nt0 + nt) * KB) * 64 + lane;
+    const uint32_t boff = (uint32_t)lane * sizeof(f32x4);
     const bool stream_once = gridDim.y == 1;   // weights read by exactly one workgroup: bypass-friendly loads
 
     // after the LDS meet every thread owns QPT groups of 4 consecutive columns ("quads") of the tile
     constexpr int QROW = Cfg::BN / 4, NQ = Cfg::BM * QROW, QPT = (NQ + 255) / 256;
-    f32x4 lvl[4][QPT];                                 // pairwise (balanced-tree) slab accumulation, level b holds 2^b slabs
+    // pairwise (balanced-tree) slab accumulation: level b holds the sum of 2^b consecutive slabs.  A workgroup that owns
+    // zs = 2^t slabs needs t levels; the 64x64 tile is capped at zs = 4 (2 levels, 32 registers) so that it stays
+    // within 256 registers and two workgroups share a CU (launch_gemm / gemm_partials apply the same cap)
+    constexpr int NLVL = (MT == 4 && NT == 4) ? 2 : 3;
+    f32x4 lvl[NLVL][QPT];
+    int top = 0;
+    while ((1 << top) < g.zs) ++top;
     constexpr int PLANE = Cfg::BM * Cfg::LDR;
     auto summed4 = [&](int o) {                        // ((p0+p1)+p2)+p3 of four consecutive columns
         const f32x4 p0 = *reinterpret_cast<const f32x4 *>(red + o), p1 = *reinterpret_cast<const f32x4 *>(red + PLANE + o);
@@ -77,25 +83,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
     };
 
     auto load_a = [&](int kb, f32x4 (&a)[MT]) {
-        const int k = kb * 16 + kq * 4;
+        const bool seg0 = kb * 16 < g.K0;                    // uniform: segment lengths are multiples of 16
+        const char *sb = reinterpret_cast<const char *>(seg0 ? g.a0 : g.a1) + (ptrdiff_t)(seg0 ? kb * 16 : kb * 16 - g.K0) * (ptrdiff_t)sizeof(float);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            if (k < g.K0) {
-                f32x4 v = *reinterpret_cast<const f32x4 *>(arow0[mt] + k);
-                if (AOP == AOP_TANH_ADD) {
-                    const f32x4 w = *reinterpret_cast<const f32x4 *>(arow0b[mt] + k);
-                    v.x = tanhf(v.x + w.x); v.y = tanhf(v.y + w.y); v.z = tanhf(v.z + w.z); v.w = tanhf(v.w + w.w);
-                }
-                a[mt] = v;
-            } else {
-                a[mt] = *reinterpret_cast<const f32x4 *>(arow1[mt] + (k - g.K0));
+            const uint32_t off = seg0 ? aoff0[mt] : aoff1[mt];
+            f32x4 v = *reinterpret_cast<const f32x4 *>(sb + off);
+            if (AOP == AOP_TANH_ADD) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(g.a0b) + (ptrdiff_t)kb * 64 + off);
+                v.x = fast_tanh(v.x + w.x); v.y = fast_tanh(v.y + w.y); v.z = fast_tanh(v.z + w.z); v.w = fast_tanh(v.w + w.w);
             }
+            a[mt] = v;
         }
     };
     auto load_b = [&](int kb, f32x4 (&b)[NT]) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            b[nt] = stream_once ? __builtin_nontemporal_load(wbase[nt] + (size_t)kb * 64) : wbase[nt][(size_t)kb * 64];
+        for (int nt = 0; nt < NT; ++nt) {
+            const char *sb = reinterpret_cast<const char *>(g.wp) + ((size_t)(nt0 + nt) * KB + kb) * (64 * sizeof(f32x4));
+            const f32x4 *pw = reinterpret_cast<const f32x4 *>(sb + boff);
+            b[nt] = stream_once ? __builtin_nontemporal_load(pw) : *pw;
+        }
     };
     // K blocks: KB = K/16 is a multiple of 4*kz (checked on the host), so every wave owns exactly c blocks of every
     // slab: slab z, wave w -> blocks [(4z + w) c, (4z + w + 1) c).  A workgroup walks zs consecutive slabs.
@@ -145,12 +152,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
         if (slab_done > 0) __syncthreads();            // previous slab's reads of red[] are done
         float *mine = red + (size_t)wave * PLANE;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     mine[(mt * 16 + kq * 4 + r) * Cfg::LDR + nt * 16 + mrow] = acc[mt][nt][r];
+            // one m-tile (16 accumulator registers) at a time: left alone, the scheduler copies the whole accumulator
+            // file out of the AGPRs first and the kernel no longer fits two workgroups per CU
+            if (MT == 4) __builtin_amdgcn_sched_barrier(0);
+        }
         __syncthreads();
         if (EPI == EPI_PARTIAL) {
             f32x4 v[QPT];
@@ -161,8 +172,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
             }
             bool carry = true;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                if (carry) {
+            for (int b = 0; b < NLVL; ++b) {
+                if (carry && b < top) {
                     if ((slab_done >> b) & 1) {
 #pragma unroll
                         for (int i = 0; i < QPT; ++i) v[i] = lvl[b][i] + v[i];
@@ -171,6 +182,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
                         for (int i = 0; i < QPT; ++i) lvl[b][i] = v[i];
                         carry = false;
                     }
+                }
+            }
+            if (slab_done + 1 == g.zs) {               // the carry ran through every level: v is the total of the zs slabs
+#pragma unroll
+                for (int i = 0; i < QPT; ++i) {
+                    const int q = threadIdx.x + i * 256;
+                    const int m = m0 + q / QROW;
+                    if (q < NQ && m < g.M)
+                        *reinterpret_cast<f32x4 *>(g.out + ((size_t)zg * g.m_stride + m) * g.N + nt0 * 16 + (q % QROW) * 4) = v[i];
                 }
             }
         }
@@ -208,10 +228,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
             int first[DEPTH];
 #pragma unroll
             for (int s = 0; s < DEPTH; ++s) first[s] = ld_next();
+            // same issue order as the steady state (stage by stage, weights then activations): the compiler merges
+            // the wait counts of the loop entry and the back edge, and any other order here makes every iteration
+            // wait for loads of the NEXT stage (vmcnt(7..4) instead of vmcnt(11..8) at DEPTH 2)
 #pragma unroll
-            for (int s = 0; s < DEPTH; ++s) load_b(first[s], b_st[s]);      // weights first: they do not wait for row indices
-#pragma unroll
-            for (int s = 0; s < DEPTH; ++s) load_a(first[s], a_st[s]);
+            for (int s = 0; s < DEPTH; ++s) {
+                load_b(first[s], b_st[s]); load_a(first[s], a_st[s]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         int in_slab = 0, i = 0;
         for (; i + DEPTH <= T; i += DEPTH) {
@@ -238,17 +262,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
     }
 
     if (EPI == EPI_PARTIAL) {
-        int top = 0;
-        while ((1 << top) < g.zs) ++top;               // the total of zs (power of two) slabs sits at level log2(zs)
-#pragma unroll
-        for (int i = 0; i < QPT; ++i) {
-            const int q = threadIdx.x + i * 256;
-            const int row = q / QROW, col = (q % QROW) * 4;
-            const int m = m0 + row;
-            f32x4 t = lvl[0][i];
-            if (top == 1) t = lvl[1][i]; else if (top == 2) t = lvl[2][i]; else if (top == 3) t = lvl[3][i];
-            if (q < NQ && m < g.M) *reinterpret_cast<f32x4 *>(g.out + ((size_t)zg * g.m_stride + m) * g.N + nt0 * 16 + col) = t;
-        }
+        // stored by the last meet()
     } else if (EPI == EPI_BIAS_DSWISH) {
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
@@ -287,20 +301,38 @@ static void dispatch(const GemmArgs &g, hipStream_t s)
 #undef LAUNCH
 }
 
-// Tile choice depends on M only through occupancy; numerics are tile-independent.
-int gemm_partials(int M, int N, int kz)
+struct TilePlan { int mt, nt, zs; };
+
+// Tile shape and slabs per workgroup.  Depends on M only through occupancy; numerics are tile-independent.
+static TilePlan plan_tiles(int M, int N, int kz, int epi)
 {
-    // same tile choice as launch_gemm; slabs per workgroup grow once the output tiles alone fill the chip
+    // measurement knobs (default 0): 1/2 = smaller tiles for the fused-epilogue GEMMs (measured slower on MI355X:
+    // B=256 gates 27 -> 32..36 us, the kernel is limited by operand loads per MFMA, not by occupancy);
+    // 5 = 64x32 tiles for split-K GEMMs at M > 32
+    static const int tune = getenv("APRIL_GEMM_TUNE") ? atoi(getenv("APRIL_GEMM_TUNE")) : 0;
     const int ntiles = N / 16;
-    const int mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
-    const int mblocks = (M + mt * 16 - 1) / (mt * 16);
-    int nt = 4;
-    while (nt > 1 && ((ntiles % nt) != 0 || (long)(ntiles / nt) * mblocks * kz < 256)) nt >>= 1;
-    const long tiles = (long)(ntiles / nt) * mblocks;
-    int zs = 1;
-    while (zs < kz && tiles * (kz / (zs * 2)) >= 256) zs *= 2;
-    return kz / zs;
+    TilePlan t;
+    t.mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+    int mblocks = (M + t.mt * 16 - 1) / (t.mt * 16);
+    t.nt = 4;
+    while (t.nt > 1 && ((ntiles % t.nt) != 0 || (long)(ntiles / t.nt) * mblocks * kz < 256)) t.nt >>= 1;
+    if (tune && epi != EPI_PARTIAL && t.mt == 4 && (long)(ntiles / t.nt) * mblocks < 512) {
+        if (tune == 1) { t.mt = 2; mblocks = (M + 31) / 32; }
+        else if (tune == 2 && t.nt == 4) t.nt = 2;
+    }
+    if (tune == 5 && epi == EPI_PARTIAL && t.mt == 4 && t.nt == 4) t.nt = 2;
+    t.zs = 1;
+    if (epi == EPI_PARTIAL) {
+        // slabs per workgroup grow once the output tiles alone fill the chip; the 64x64 tile has registers for two
+        // tree levels only (NLVL in the kernel)
+        const long tiles = (long)(ntiles / t.nt) * mblocks;
+        const int zs_max = (t.mt == 4 && t.nt == 4) ? 4 : 8;
+        while (t.zs < kz && t.zs < zs_max && tiles * (kz / (t.zs * 2)) >= 256) t.zs *= 2;
+    }
+    return t;
 }
+
+int gemm_partials(int M, int N, int kz) { return kz / plan_tiles(M, N, kz, EPI_PARTIAL).zs; }
 
 void launch_gemm(const GemmArgs &g_in, hipStream_t s)
 {
@@ -308,21 +340,10 @@ void launch_gemm(const GemmArgs &g_in, hipStream_t s)
     static const int dbg = getenv("APRIL_GEMM_DEBUG") ? atoi(getenv("APRIL_GEMM_DEBUG")) : 0;
     g.debug = dbg;
     static const int skew = getenv("APRIL_GEMM_SKEW") ? atoi(getenv("APRIL_GEMM_SKEW")) : 2;
-    g.zs = g.epi == EPI_PARTIAL ? g.kz / gemm_partials(g.M, g.N, g.kz) : 1;
+    const TilePlan t = plan_tiles(g.M, g.N, g.kz, g.epi);
+    g.zs = t.zs;
     g.skew = (long)g.N / 64 * ((g.M + 63) / 64) * (g.kz / g.zs) >= 512 ? skew : 0;
-    const int ntiles = g.N / 16;
-    int mt = g.M <= 16 ? 1 : (g.M <= 32 ? 2 : 4);
-    int mblocks = (g.M + mt * 16 - 1) / (mt * 16);
-    int nt = 4;
-    while (nt > 1 && ((ntiles % nt) != 0 || (long)(ntiles / nt) * mblocks * g.kz < 256)) nt >>= 1;
-    // measurement knob (default off): smaller tiles for the fused-epilogue GEMMs so that two workgroups fit per CU.
-    // Measured slower on MI355X (B=256 gates 27 -> 32..36 us): the kernel is limited by operand loads per MFMA,
-    // not by occupancy -- see DESIGN.md section 6.
-    static const int tune = getenv("APRIL_GEMM_TUNE") ? atoi(getenv("APRIL_GEMM_TUNE")) : 0;
-    if (tune && g.epi != EPI_PARTIAL && mt == 4 && (long)(ntiles / nt) * mblocks < 512) {
-        if (tune == 1) { mt = 2; mblocks = (g.M + 31) / 32; }
-        else if (tune == 2 && nt == 4) nt = 2;
-    }
+    const int mt = t.mt, nt = t.nt;
     if (mt == 1) { if (nt == 4) dispatch<1, 4>(g, s); else if (nt == 2) dispatch<1, 2>(g, s); else dispatch<1, 1>(g, s); }
     else if (mt == 2) { if (nt == 4) dispatch<2, 4>(g, s); else if (nt == 2) dispatch<2, 2>(g, s); else dispatch<2, 1>(g, s); }
     else { if (nt == 4) dispatch<4, 4>(g, s); else if (nt == 2) dispatch<4, 2>(g, s); else dispatch<4, 1>(g, s); }
