@@ -14,6 +14,7 @@
 // (reference call sites src/april_session.c:145,160,176).
 #include "kernels.h"
 #include "device_utils.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace aprilx {
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
     f32x4 a_st[DEPTH][MT], b_st[DEPTH][NT];
     int ld_base = (4 * (zg * g.zs) + wave) * c, ld_off = 0, ld_cnt = 0;
     auto ld_next = [&]() {
-        const int kb = ld_base + ld_off;
+        const int kb = g.debug == 3 ? 0 : ld_base + ld_off;     // debug 3 (measurement): every block re-reads block 0 (cache-resident operands)
         if (ld_cnt + 1 < T) { ++ld_cnt; if (++ld_off == c) { ld_off = 0; ld_base += 4 * c; } }
         return kb;
     };
@@ -293,7 +294,8 @@ static void dispatch(const GemmArgs &g, hipStream_t s)
 {
     using Cfg = TileCfg<MT, NT>;
     dim3 grid((unsigned)(g.N / Cfg::BN), (unsigned)((g.M + Cfg::BM - 1) / Cfg::BM), (unsigned)(g.kz / g.zs));
-    const size_t lds = (size_t)Cfg::LDS_FLOATS * sizeof(float);
+    static const int ldspad = getenv("APRIL_GEMM_LDSPAD") ? atoi(getenv("APRIL_GEMM_LDSPAD")) : 0;   // measurement: KiB of LDS to request at least (> 80 forces one workgroup per CU)
+    const size_t lds = std::max((size_t)Cfg::LDS_FLOATS * sizeof(float), (size_t)ldspad * 1024);
 #define LAUNCH(E, A) hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, E, A>), grid, dim3(256), lds, s, g)
     if (g.epi == EPI_PARTIAL) { if (g.a_op == AOP_TANH_ADD) LAUNCH(EPI_PARTIAL, AOP_TANH_ADD); else LAUNCH(EPI_PARTIAL, AOP_NONE); }
     else if (g.epi == EPI_LSTM) LAUNCH(EPI_LSTM, AOP_NONE);
