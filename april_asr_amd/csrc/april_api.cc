@@ -44,6 +44,11 @@ bool build_runtime(Model &m, const float *blob_host, const float *blob_device)
     EngineConfig cfg;
     cfg.max_slots = env_int("APRIL_MAX_SESSIONS", 4096);
     cfg.max_batch = std::min(cfg.max_slots, env_int("APRIL_MAX_BATCH", 2048));
+    if (const char *pv = getenv("APRIL_PRECISION")) {
+        const std::string v(pv);
+        if (v == "f16" || v == "fp16" || v == "half") cfg.precision = 1;
+        else if (!(v.empty() || v == "f32" || v == "fp32")) { LOGE("aam: APRIL_PRECISION must be f32 or f16 (got '%s')", pv); return false; }
+    }
     for (int dev : g_devices) {
         cfg.device = dev;
         const bool same_dev_blob = blob_device != nullptr;
@@ -243,6 +248,8 @@ int aprilx_model_dims(AprilASRModel model, AprilxDims *o)
     o->mel = d.mel; o->seg = d.seg; o->seg_step = P.segment_step; o->context = d.context;
     o->fft_size = model->m.ftab.padded; o->frame_shift = model->m.ftab.shift; o->sample_rate = P.sample_rate; o->blank_id = P.blank_id;
     o->n_devices = (int)model->m.engines.size();
+    o->precision = model->m.engines.empty() ? 0 : model->m.engines[0]->precision();
+    o->reserved0 = 0;
     int64_t n = 0; int cin = 1;
     for (int i = 0; i < 3; ++i) { n += (int64_t)d.conv_ch[i] * cin * 9 + d.conv_ch[i]; cin = d.conv_ch[i]; }
     n += (int64_t)d.embed_in * d.d_model + d.d_model;

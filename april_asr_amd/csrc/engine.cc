@@ -131,6 +131,21 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     w_ = dmalloc<float>(L_.total);
     if (blob_device) HIP_CHECK(hipMemcpy(w_, blob_device, L_.total * 4, hipMemcpyDeviceToDevice));
     else HIP_CHECK(hipMemcpy(w_, blob_host, L_.total * 4, hipMemcpyHostToDevice));
+    if (cfg_.precision == 1) {
+        // fp16 operand mode (BASELINE configs[4]): every Linear / LSTM weight matrix gets an fp16 copy in the same
+        // packed element order (round-to-nearest-even, on the device); convolutions, biases, embeddings stay fp32
+        wh_ = dmalloc<uint16_t>(L_.total);
+        const NetDims &d0 = L_.dims;
+        auto cv = [&](size_t off, size_t n) { launch_cvt_f16(w_ + off, wh_ + off, n, nullptr); };
+        cv(L_.w_embed, (size_t)d0.embed_in * d0.d_model);
+        for (const PackedLayout::Layer &o : L_.layers) {
+            cv(o.wg, (size_t)2 * d0.d_model * 4 * d0.hidden); cv(o.whr, (size_t)d0.hidden * d0.d_model);
+            cv(o.wff1, (size_t)d0.d_model * d0.ffn); cv(o.wff2, (size_t)d0.ffn * d0.d_model);
+        }
+        cv(L_.w_encproj, (size_t)d0.d_model * d0.joiner); cv(L_.w_decproj, (size_t)d0.d_model * d0.joiner);
+        cv(L_.w_out, (size_t)d0.joiner * L_.vocab_pad);
+        HIP_CHECK(hipDeviceSynchronize());
+    }
 
     const size_t S = (size_t)cfg_.max_slots, MB = (size_t)cfg_.max_batch;
     ring_frames_ = P_.segment_size * 32;                   // reference src/fbank.c:147
@@ -183,7 +198,7 @@ Engine::~Engine()
     (void)hipStreamSynchronize(stream_);
     for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &g : enc_graphs_) (void)hipGraphExecDestroy(g.second);
-    for (void *p : {(void *)w_, (void *)h_, (void *)c_, (void *)ring_, (void *)eout_, (void *)dout_, (void *)ws_, (void *)xin_, (void *)a3_, (void *)xa_,
+    for (void *p : {(void *)w_, (void *)wh_, (void *)h_, (void *)c_, (void *)ring_, (void *)eout_, (void *)dout_, (void *)ws_, (void *)xin_, (void *)a3_, (void *)xa_,
                     (void *)xb_, (void *)u_, (void *)ff_, (void *)de_, (void *)logits_, (void *)joint_d_, (void *)ds_enc_, (void *)ds_dec_,
                     (void *)ds_joi_, (void *)ds_desc_[0], (void *)ds_desc_[1], (void *)ds_pcm_[0], (void *)ds_pcm_[1]})
         if (p) (void)hipFree(p);
@@ -328,7 +343,7 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
 
     // embed linear + bias + BasicNorm
     {
-        GemmArgs g; g.a0 = xin_; g.lda0 = d.embed_in; g.K0 = d.embed_in; g.wp = w_ + L_.w_embed;
+        GemmArgs g; g.a0 = xin_; g.lda0 = d.embed_in; g.K0 = d.embed_in; lin(g, L_.w_embed);
         g.M = n; g.N = d.d_model; g.K = d.embed_in; g.kz = kz_embed_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
         timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
         RowArgs r; r.mode = ROW_NORM; r.ws = ws_; r.kz = gemm_partials(n, d.d_model, kz_embed_); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = n;
@@ -342,12 +357,12 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
         {   // gates = [x | h_prev] x Wg ; fused LSTM cell
             GemmArgs g; g.a0 = xa_; g.lda0 = d.d_model; g.K0 = d.d_model;
             g.a1 = h_l; g.lda1 = d.d_model; g.aidx1 = d_slots; g.K1 = d.d_model;
-            g.wp = w_ + o.wg; g.M = n; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_LSTM;
+            lin(g, o.wg); g.M = n; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_LSTM;
             g.out = u_; g.ldo = d.hidden; g.bias = w_ + o.bg; g.c_state = c_l; g.slot_idx = d_slots; g.hidden = d.hidden;
             timed_begin(T_GATES); launch_gemm(g, stream_); timed_end(T_GATES);
         }
         {   // h' = u x Whr ; state write + residual
-            GemmArgs g; g.a0 = u_; g.lda0 = d.hidden; g.K0 = d.hidden; g.wp = w_ + o.whr;
+            GemmArgs g; g.a0 = u_; g.lda0 = d.hidden; g.K0 = d.hidden; lin(g, o.whr);
             g.M = n; g.N = d.d_model; g.K = d.hidden; g.kz = kz_hr_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
             timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
             RowArgs r; r.mode = ROW_HR; r.ws = ws_; r.kz = gemm_partials(n, d.d_model, kz_hr_); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = n;
@@ -355,12 +370,12 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
             timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
         }
         {   // FFN up + DoubleSwish
-            GemmArgs g; g.a0 = xb_; g.lda0 = d.d_model; g.K0 = d.d_model; g.wp = w_ + o.wff1;
+            GemmArgs g; g.a0 = xb_; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, o.wff1);
             g.M = n; g.N = d.ffn; g.K = d.d_model; g.kz = 1; g.epi = EPI_BIAS_DSWISH; g.out = ff_; g.ldo = d.ffn; g.bias = w_ + o.bff1;
             timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
         }
         {   // FFN down + bias + residual + BasicNorm
-            GemmArgs g; g.a0 = ff_; g.lda0 = d.ffn; g.K0 = d.ffn; g.wp = w_ + o.wff2;
+            GemmArgs g; g.a0 = ff_; g.lda0 = d.ffn; g.K0 = d.ffn; lin(g, o.wff2);
             g.M = n; g.N = d.d_model; g.K = d.ffn; g.kz = kz_ff2_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
             timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
             RowArgs r; r.mode = ROW_NORM; r.ws = ws_; r.kz = gemm_partials(n, d.d_model, kz_ff2_); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = n;
@@ -369,7 +384,7 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
         }
     }
     {   // encoder_proj -> eout[slot]
-        GemmArgs g; g.a0 = xa_; g.lda0 = d.d_model; g.K0 = d.d_model; g.wp = w_ + L_.w_encproj;
+        GemmArgs g; g.a0 = xa_; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, L_.w_encproj);
         g.M = n; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
         timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
         RowArgs r; r.mode = ROW_BIAS_STORE; r.ws = ws_; r.kz = gemm_partials(n, d.joiner, kz_proj_); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = n;
@@ -430,7 +445,7 @@ void Engine::decode(int n, const int *slots, const int *ctx)
         DecEmbedArgs a; a.emb = w_ + L_.emb; a.conv_w = w_ + L_.dec_conv; a.conv_b = L_.has_dec_conv_b ? w_ + L_.dec_conv_b : nullptr;
         a.ctx = ds_dec_ + MB; a.d = d.d_model; a.groups = d.dec_groups; a.context = d.context; a.vocab = d.vocab; a.M = m; a.out = de_; a.ldo = d.d_model;
         timed_begin(T_DEC); launch_dec_embed(a, stream_); timed_end(T_DEC);
-        GemmArgs g; g.a0 = de_; g.lda0 = d.d_model; g.K0 = d.d_model; g.wp = w_ + L_.w_decproj;
+        GemmArgs g; g.a0 = de_; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, L_.w_decproj);
         g.M = m; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
         timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
         RowArgs r; r.mode = ROW_BIAS_STORE; r.ws = ws_; r.kz = gemm_partials(m, d.joiner, kz_proj_); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = m;
@@ -450,7 +465,7 @@ void Engine::joint(int n, const int *slots, JointResult *out, float *logits_out)
         memcpy(hs_joi_, slots + o, (size_t)m * 4);
         HIP_CHECK(hipMemcpyAsync(ds_joi_, hs_joi_, (size_t)m * 4, hipMemcpyHostToDevice, stream_));
         GemmArgs g; g.a0 = eout_; g.a0b = dout_; g.lda0 = d.joiner; g.aidx0 = ds_joi_; g.K0 = d.joiner; g.a_op = AOP_TANH_ADD;
-        g.wp = w_ + L_.w_out; g.M = m; g.N = L_.vocab_pad; g.K = d.joiner; g.kz = kz_out_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
+        lin(g, L_.w_out); g.M = m; g.N = L_.vocab_pad; g.K = d.joiner; g.kz = kz_out_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
         timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
         RowArgs r; r.mode = ROW_ARGMAX; r.ws = ws_; r.kz = gemm_partials(m, L_.vocab_pad, kz_out_); r.m_stride = ws_mstride_; r.N = L_.vocab_pad; r.M = m; r.n_valid = d.vocab;
         r.bias = w_ + L_.b_out; r.blank = P_.blank_id; r.joint = joint_d_; r.logits_dump = logits_out ? logits_ : nullptr;

@@ -49,6 +49,7 @@ struct EngineConfig {
     int device = 0;
     int max_slots = 4096;
     int max_batch = 2048;
+    int precision = 0;                       // 0: fp32 GEMMs; 1: fp16 weights + fp16-rounded activations, fp32 accumulate (APRIL_PRECISION=f16)
 };
 
 struct KernelTiming { double ms = 0; long launches = 0; };
@@ -65,6 +66,7 @@ public:
     const NetDims &dims() const { return L_.dims; }
     hipStream_t stream() const { return stream_; }
     const float *weights_device() const { return w_; }
+    int precision() const { return cfg_.precision; }
     const PackedLayout &layout() const { return L_; }
 
     int alloc_slot();                 // -1 when full; state zeroed (reference calloc, april_session.c:40-58)
@@ -106,6 +108,8 @@ private:
     ModelParams P_;
     hipStream_t stream_ = nullptr;
     float *w_ = nullptr;                       // packed weights
+    uint16_t *wh_ = nullptr;                   // fp16 copies of the GEMM weight sections (same offsets, in elements), precision 1 only
+    void lin(GemmArgs &g, size_t off) const { if (wh_) { g.wp = wh_ + off; g.wt = 1; } else { g.wp = w_ + off; g.wt = 0; } }
     float *h_ = nullptr, *c_ = nullptr, *ring_ = nullptr, *eout_ = nullptr, *dout_ = nullptr;
     int ring_frames_ = 0;
     // work buffers

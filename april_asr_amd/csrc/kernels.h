@@ -34,7 +34,9 @@ struct GemmArgs {
     const float *a1 = nullptr; int lda1 = 0; const int *aidx1 = nullptr; int K1 = 0;
     const float *a0b = nullptr;            // AOP_TANH_ADD second addend (same ld/idx as a0)
     int a_op = AOP_NONE;
-    const float *wp = nullptr;             // packed weights
+    const void *wp = nullptr;              // packed weights (fp32, or fp16 in the same element order when wt == 1)
+    int wt = 0;                            // 0: fp32 operands, v_mfma_f32_16x16x4_f32; 1: fp16 weights, A rounded to fp16 on load,
+                                           //    v_mfma_f32_16x16x16_f16 with fp32 accumulation (BASELINE configs[4])
     int M = 0, N = 0, K = 0;               // N multiple of 16, K multiple of 16
     int kz = 1;                            // K slabs (power of two); canonical summation unit
     int zs = 1;                            // slabs handled per workgroup (set by launch_gemm)
@@ -103,6 +105,9 @@ struct DecEmbedArgs {
     float *out = nullptr; int ldo = 0;     // relu(conv(emb)) [M][d]
 };
 void launch_dec_embed(const DecEmbedArgs &a, hipStream_t s);
+
+// fp32 -> fp16 (round to nearest even), elementwise; used once at load for the fp16 weight copies
+void launch_cvt_f16(const float *src, void *dst, size_t n, hipStream_t s);
 
 // ---------------------------------------------------------------- fbank
 struct FbankTables {                       // device pointers

@@ -26,10 +26,15 @@ struct TileCfg {
     static constexpr int LDS_FLOATS = 4 * BM * LDR;
 };
 
-template <int MT, int NT, int EPI, int AOP>
+using h4 = __attribute__((ext_vector_type(4))) _Float16;
+template <int WT> struct WQuad { using type = f32x4; };
+template <> struct WQuad<1> { using type = h4; };
+
+template <int MT, int NT, int EPI, int AOP, int WT>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
 {
     using Cfg = TileCfg<MT, NT>;
+    using BQ = typename WQuad<WT>::type;       // one lane's four consecutive k values of a weight tile
     extern __shared__ __attribute__((aligned(16))) float red[];
 
     const int lane = threadIdx.x & 63;
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
         aoff1[mt] = 0;
         if (g.K1 > 0) { const int r1 = g.aidx1 ? g.aidx1[row] : row; aoff1[mt] = (uint32_t)(((size_t)r1 * g.lda1 + kq * 4) * sizeof(float)); }
     }
-    const uint32_t boff = (uint32_t)lane * sizeof(f32x4);
+    const uint32_t boff = (uint32_t)lane * sizeof(BQ);
     const bool stream_once = gridDim.y == 1;   // weights read by exactly one workgroup: bypass-friendly loads
 
     // after the LDS meet every thread owns QPT groups of 4 consecutive columns ("quads") of the tile
@@ -97,11 +102,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
             a[mt] = v;
         }
     };
-    auto load_b = [&](int kb, f32x4 (&b)[NT]) {
+    auto load_b = [&](int kb, BQ (&b)[NT]) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const char *sb = reinterpret_cast<const char *>(g.wp) + ((size_t)(nt0 + nt) * KB + kb) * (64 * sizeof(f32x4));
-            const f32x4 *pw = reinterpret_cast<const f32x4 *>(sb + boff);
+            const char *sb = reinterpret_cast<const char *>(g.wp) + ((size_t)(nt0 + nt) * KB + kb) * (64 * sizeof(BQ));
+            const BQ *pw = reinterpret_cast<const BQ *>(sb + boff);
             b[nt] = stream_once ? __builtin_nontemporal_load(pw) : *pw;
         }
     };
@@ -120,7 +125,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
 #define APRIL_DEPTH4 2
 #endif
     constexpr int DEPTH = (MT == 1) ? 6 : (MT == 2 ? 3 : APRIL_DEPTH4);
-    f32x4 a_st[DEPTH][MT], b_st[DEPTH][NT];
+    f32x4 a_st[DEPTH][MT];
+    BQ b_st[DEPTH][NT];
     int ld_base = (4 * (zg * g.zs) + wave) * c, ld_off = 0, ld_cnt = 0;
     auto ld_next = [&]() {
         const int kb = g.debug == 3 ? 0 : ld_base + ld_off;     // debug 3 (measurement): every block re-reads block 0 (cache-resident operands)
@@ -134,16 +140,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    auto compute = [&](const f32x4 (&a)[MT], const f32x4 (&b)[NT]) {
+    auto compute = [&](const f32x4 (&a)[MT], const BQ (&b)[NT]) {
+        if constexpr (WT == 1) {
+            // the same 16 k values per lane as four fp32 k-steps, in one v_mfma_f32_16x16x16_f16 (fp32 accumulate)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt) {
+                const h4 ah = {(_Float16)a[mt].x, (_Float16)a[mt].y, (_Float16)a[mt].z, (_Float16)a[mt].w};
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, b[nt], acc[mt][nt], 0, 0, 0);
             }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
+                }
+        }
     };
     int slab_done = 0;                                 // slabs finished so far by this workgroup
     // quarter chains meet in LDS (red[wave][row][col]) and are added ((p0+p1)+p2)+p3; slab sums are combined
@@ -296,11 +312,12 @@ static void dispatch(const GemmArgs &g, hipStream_t s)
     dim3 grid((unsigned)(g.N / Cfg::BN), (unsigned)((g.M + Cfg::BM - 1) / Cfg::BM), (unsigned)(g.kz / g.zs));
     static const int ldspad = getenv("APRIL_GEMM_LDSPAD") ? atoi(getenv("APRIL_GEMM_LDSPAD")) : 0;   // measurement: KiB of LDS to request at least (> 80 forces one workgroup per CU)
     const size_t lds = std::max((size_t)Cfg::LDS_FLOATS * sizeof(float), (size_t)ldspad * 1024);
-#define LAUNCH(E, A) hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, E, A>), grid, dim3(256), lds, s, g)
-    if (g.epi == EPI_PARTIAL) { if (g.a_op == AOP_TANH_ADD) LAUNCH(EPI_PARTIAL, AOP_TANH_ADD); else LAUNCH(EPI_PARTIAL, AOP_NONE); }
-    else if (g.epi == EPI_LSTM) LAUNCH(EPI_LSTM, AOP_NONE);
-    else LAUNCH(EPI_BIAS_DSWISH, AOP_NONE);
-#undef LAUNCH
+#define LAUNCH2(E, A) do { if (g.wt == 1) hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, E, A, 1>), grid, dim3(256), lds, s, g); \
+                           else hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, E, A, 0>), grid, dim3(256), lds, s, g); } while (0)
+    if (g.epi == EPI_PARTIAL) { if (g.a_op == AOP_TANH_ADD) LAUNCH2(EPI_PARTIAL, AOP_TANH_ADD); else LAUNCH2(EPI_PARTIAL, AOP_NONE); }
+    else if (g.epi == EPI_LSTM) LAUNCH2(EPI_LSTM, AOP_NONE);
+    else LAUNCH2(EPI_BIAS_DSWISH, AOP_NONE);
+#undef LAUNCH2
 }
 
 struct TilePlan { int mt, nt, zs; };

@@ -5,6 +5,7 @@
 // fixed (independent of the batch).
 #include "kernels.h"
 #include "device_utils.h"
+#include <algorithm>
 
 namespace aprilx {
 
@@ -216,6 +217,18 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(DecEmbedArgs a)
 void launch_dec_embed(const DecEmbedArgs &a, hipStream_t s)
 {
     hipLaunchKernelGGL(dec_embed_kernel, dim3((unsigned)a.M), dim3(256), 0, s, a);
+}
+
+// ---------------------------------------------------------------- fp16 weight copies
+__global__ __launch_bounds__(256) void cvt_f16_kernel(const float *src, _Float16 *dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = (_Float16)src[i];
+}
+
+void launch_cvt_f16(const float *src, void *dst, size_t n, hipStream_t s)
+{
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(cvt_f16_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, src, reinterpret_cast<_Float16 *>(dst), n);
 }
 
 }  // namespace aprilx

@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+FP16_MFMA_PEAK_TFLOPS = 2500.0     # dense fp16 MFMA peak (--precision f16 only)
 HBM_PEAK_GBS = 8000.0              # spec; ~6300 measured achievable
 
 
@@ -38,6 +39,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=10)
+    ap.add_argument("--precision", choices=["f32", "f16"], default="f32",
+                    help="f16 = opt-in fp16-operand mode (BASELINE configs[4]); the headline metric is quoted on f32")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -66,6 +69,8 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if args.precision == "f16":
+        os.environ["APRIL_PRECISION"] = "f16"       # read by the library when a model is created
     # ---------------- model: rank 0 parses the file, everyone else receives the packed blob over RCCL
     t_load0 = time.time()
     bcast_ms = None
@@ -112,16 +117,23 @@ def main():
     sess, grp = make_group(B, rank * B)
     pcm = pcm_for(B, n_steps, rank * B)
 
-    def run_steps(group, pcms, s0, s1):
+    step_wall = []                           # per-step wall time of the timed steps (p50/p99 latency of one 100 ms feed of all sessions)
+
+    def run_steps(group, pcms, s0, s1, record=None):
         if s0 == 0:
             group.plan(pcms, step_samples)       # pointer arrays built outside the timed region
         for s in range(s0, s1):
-            group.feed_planned(s)
+            if record is None:
+                group.feed_planned(s)
+            else:
+                a = time.perf_counter()
+                group.feed_planned(s)
+                record.append(time.perf_counter() - a)
 
     run_steps(grp, pcm, 0, args.warmup)
     barrier()
     t0 = time.perf_counter()
-    run_steps(grp, pcm, args.warmup, n_steps)
+    run_steps(grp, pcm, args.warmup, n_steps, step_wall)
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -154,9 +166,13 @@ def main():
             sbytes = rows_per_launch * (d.d_model * 4 * 2 + d.hidden * 4 * 3)      # x,h read; c read+write; u write
             tf = flops / (avg_ms * 1e-3) / 1e12
             gbs = (wbytes + sbytes) / (avg_ms * 1e-3) / 1e9
-            frac_mfma, frac_hbm = tf / FP32_MFMA_PEAK_TFLOPS, gbs / HBM_PEAK_GBS
+            mfma_peak = FP16_MFMA_PEAK_TFLOPS if d.precision == 1 else FP32_MFMA_PEAK_TFLOPS
+            if d.precision == 1:
+                wbytes //= 2                        # fp16 weight copies
+            gbs = (wbytes + sbytes) / (avg_ms * 1e-3) / 1e9
+            frac_mfma, frac_hbm = tf / mfma_peak, gbs / HBM_PEAK_GBS
             if frac_mfma >= frac_hbm:
-                roofline = {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                roofline = {"bound": "mfma", "achieved": round(tf, 2), "peak": mfma_peak, "unit": "TFLOP/s",
                             "frac": round(frac_mfma, 4), "traffic": None}
             else:
                 roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -164,7 +180,7 @@ def main():
             # HBM traffic per launch from the committed PMC pass of the same workload (bench.py cannot collect PMC itself)
             try:
                 tr = json.load(open(os.path.join(ROOT, "profiles", "r01_gates_traffic.json")))
-                if int(tr["sessions_per_gpu"]) == B:
+                if int(tr["sessions_per_gpu"]) == B and d.precision == 0:
                     roofline["traffic"] = int(tr["traffic_bytes_per_launch"])
                     roofline["traffic_source"] = "profiles/r01_gates_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950 x2 read correction)"
             except Exception:
@@ -222,11 +238,13 @@ def main():
             "metric": "audio_seconds_per_second (concurrent 16 kHz sessions x 1/RTF), aprilv0_en-us-sized streaming RNN-T",
             "value": round(value, 2), "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16" if d.precision == 1 else "f32", "data": "synthetic",
             "config": {"workload": "aprilv0_en-us dims (synthetic seeded weights), %d concurrent streaming sessions per GPU, "
                                    "100 ms PCM16 feeds via aprilx_feed_many (BASELINE configs[2]; configs[3] at 8 GPUs)" % B,
                        "sessions_per_gpu": B, "feed_ms": 100, "params": int(d.param_count), "parallelism": "sessions sharded, dp%d" % world},
             "rtf": round(rtf, 5), "sessions_total": world * B,
+            "step_latency_ms": {"p50": round(float(np.percentile(step_wall, 50)) * 1e3, 3), "p99": round(float(np.percentile(step_wall, 99)) * 1e3, 3),
+                                "max": round(max(step_wall) * 1e3, 3), "what": "wall time of one aprilx_feed_many call (100 ms of audio for every session, callbacks delivered), rank 0"},
             "max_sessions_per_gpu_rtf_le_0.1_tested": max_ok, "rtf_by_sessions_per_gpu": sweep,
             "callbacks": int(counts[0]), "tokens_in_callbacks": int(counts[5]), "model_load_s": round(load_s, 2), "weight_broadcast_ms": bcast_ms,
             "engine_steps": int(st.steps), "host_phase_ms_total": host_ms, "max_batch_seen": int(st.max_batch_seen),

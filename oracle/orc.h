@@ -104,6 +104,10 @@ const char *orc_graph_output_name(const OrcGraph *g, int i);
 int  orc_graph_run(OrcGraph *g, int n_in, const char *const *in_names, const void *const *in_bufs,
                    int n_out, const char *const *out_names, void *const *out_bufs);
 const char *orc_graph_last_error(void);
+/* checker mode for the product's fp16 path: MatMul/Gemm operands rounded to binary16, fp32 accumulate (process-wide) */
+void orc_set_f16_linear(int on);
+int  orc_get_f16_linear(void);
+void orc_round_f16(const float *src, float *dst, size_t n);   /* the rounding it uses (nearest binary16, ties to even) */
 
 /* ---------------- model + session ---------------- */
 typedef struct OrcModel {

@@ -37,6 +37,7 @@ typedef struct {
     int64_t dims[MAXR];
     size_t n;
     void *data;
+    float *h16;          /* fp16-rounded shadow of a constant MatMul/Gemm operand (orc_set_f16_linear), built on first use */
 } Ten;
 
 typedef struct { char *name; int kind; float f; int64_t i; int64_t *ints; int n_ints; Ten t; int has_t; } Attr;
@@ -98,7 +99,7 @@ static void ten_alloc(Ten *t, int dtype, int rank, const int64_t *dims)
     t->data = calloc(t->n ? t->n : 1, dtype == DT_F32 ? 4 : 8);
     t->owns = 1; t->live = 1;
 }
-static void ten_release(Ten *t) { if (t->owns && t->data) free(t->data); t->data = NULL; t->owns = 0; t->live = 0; }
+static void ten_release(Ten *t) { if (t->owns && t->data) free(t->data); if (t->h16) free(t->h16); t->h16 = NULL; t->data = NULL; t->owns = 0; t->live = 0; }
 
 /* TensorProto -> Ten (float32 / int64; int32 widened) */
 static int parse_tensor(PB b, Ten *t, char **name_out)
@@ -427,6 +428,50 @@ static int op_conv(const Node *nd, const Ten *x, const Ten *w, const Ten *bias, 
     return 0;
 }
 
+/* ---- fp16-operand mode (checker for the product's APRIL_PRECISION=f16, BASELINE configs[4]) ----
+ * Every MatMul / Gemm rounds BOTH operands to IEEE binary16 (round to nearest even) and accumulates in fp32, which is
+ * what v_mfma_f32_16x16x16_f16 computes up to summation order.  Conv nodes, biases and everything else stay fp32. */
+static int g_f16_linear = 0;
+void orc_set_f16_linear(int on) { g_f16_linear = on; }
+int orc_get_f16_linear(void) { return g_f16_linear; }
+
+/* float -> nearest binary16 (ties to even) -> float, by bit arithmetic (this gcc has no _Float16) */
+static float f16_round1(float x)
+{
+    uint32_t u; memcpy(&u, &x, 4);
+    const uint32_t sign = u & 0x80000000u; uint32_t a = u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return x;                                  /* inf / nan */
+    if (a < 0x38800000u) {                                           /* below 2^-14: binary16 subnormal, quantum 2^-24 */
+        float m; memcpy(&m, &a, 4);
+        m = rintf(m * 16777216.0f) * (1.0f / 16777216.0f);           /* default rounding mode: nearest even */
+        memcpy(&a, &m, 4);
+    } else {
+        a += 0xfffu + ((a >> 13) & 1u);                              /* keep 10 mantissa bits */
+        a &= ~0x1fffu;
+        if (a >= 0x47800000u) a = 0x7f800000u;                       /* >= 65520 rounds to infinity */
+    }
+    a |= sign;
+    float r; memcpy(&r, &a, 4);
+    return r;
+}
+void orc_round_f16(const float *src, float *dst, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) dst[i] = f16_round1(src[i]);
+}
+static const float *f16_operand(const Ten *t, float **tmp)
+{
+    *tmp = NULL;
+    if (!g_f16_linear) return (const float *)t->data;
+    Ten *m = (Ten *)t;
+    if (t->is_const) {
+        if (!m->h16) { m->h16 = (float *)malloc((t->n ? t->n : 1) * 4); orc_round_f16((const float *)t->data, m->h16, t->n); }
+        return m->h16;
+    }
+    *tmp = (float *)malloc((t->n ? t->n : 1) * 4);
+    orc_round_f16((const float *)t->data, *tmp, t->n);
+    return *tmp;
+}
+
 static int op_matmul(const Ten *a, const Ten *b, Ten *o)
 {
     if (b->rank != 2 || a->rank < 1) FAIL("MatMul: B must be 2-D");
@@ -437,7 +482,10 @@ static int op_matmul(const Ten *a, const Ten *b, Ten *o)
     od[r - 1] = N;
     ten_alloc(o, DT_F32, r, od);
     size_t M = a->n / (size_t)K;
-    for (size_t m = 0; m < M; ++m) mv_kn((const float *)a->data + m * (size_t)K, b->data, (float *)o->data + m * (size_t)N, (size_t)K, (size_t)N);
+    float *ta, *tb;
+    const float *ad = f16_operand(a, &ta), *bd = f16_operand(b, &tb);
+    for (size_t m = 0; m < M; ++m) mv_kn(ad + m * (size_t)K, bd, (float *)o->data + m * (size_t)N, (size_t)K, (size_t)N);
+    free(ta); free(tb);
     return 0;
 }
 
@@ -451,10 +499,12 @@ static int op_gemm(const Node *nd, const Ten *a, const Ten *b, const Ten *c, Ten
     if ((tB ? b->dims[1] : b->dims[0]) != K) FAIL("Gemm: K mismatch");
     int64_t od[2] = {M, N};
     ten_alloc(o, DT_F32, 2, od);
+    float *ta, *tb;
+    const float *ad = f16_operand(a, &ta), *bd = f16_operand(b, &tb);
     for (int64_t m = 0; m < M; ++m) {
         float *y = (float *)o->data + m * N;
-        if (tB) mv_nk((const float *)a->data + m * K, b->data, y, (size_t)K, (size_t)N);
-        else    mv_kn((const float *)a->data + m * K, b->data, y, (size_t)K, (size_t)N);
+        if (tB) mv_nk(ad + m * K, bd, y, (size_t)K, (size_t)N);
+        else    mv_kn(ad + m * K, bd, y, (size_t)K, (size_t)N);
         for (int64_t n = 0; n < N; ++n) {
             float v = alpha == 1.0f ? y[n] : alpha * y[n];
             if (c) {
@@ -464,6 +514,7 @@ static int op_gemm(const Node *nd, const Ten *a, const Ten *b, const Ten *c, Ten
             y[n] = v;
         }
     }
+    free(ta); free(tb);
     return 0;
 }
 

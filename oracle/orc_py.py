@@ -275,6 +275,20 @@ class RefFbank:
             r.append(c)
 
 
+def set_f16_linear(on):
+    """Process-wide checker mode for the product's APRIL_PRECISION=f16: MatMul/Gemm operands rounded to binary16
+    (ties to even), fp32 accumulation; Conv and everything else fp32.  Models loaded before the switch keep any
+    rounded weight copies they already built, so set it before the first network call."""
+    lib().orc_set_f16_linear(1 if on else 0)
+
+
+def round_f16(x):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    lib().orc_round_f16(x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), C.c_size_t(x.size))
+    return y
+
+
 def lcg_pcm16(n, seed=12345):
     """SURVEY.md Appendix E recipe: s = s*1664525 + 1013904223; v = (int16)(s >> 16)."""
     out = np.empty(n, np.int16)

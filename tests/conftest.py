@@ -66,6 +66,16 @@ def v0_model(model_dir, built):
     return dict(path=p, dims=dims, weights=None, tokens=toks)
 
 
+@pytest.fixture(scope="session")
+def large_model(model_dir, built):
+    """BASELINE configs[4] "larger encoder": 16 layers, d_model 768, hidden 1536, ffn 3072, joiner 768 (~250 M parameters,
+    ~1 GB on disk, ~40 s to write)."""
+    from april_asr_amd import synth_model as SM
+    p = str(model_dir / "large.april")
+    dims, w, toks = SM.write_model(p, SM.LARGE_DIMS, seed=5)
+    return dict(path=p, dims=dims, weights=None, tokens=toks)
+
+
 def speech_like_pcm(seconds, seed=0, rate=16000, silence=(0.0, 0.0)):
     """Three seeded sinusoids x 4 Hz envelope + noise at -30 dB, <= 0.5 FS, optional digital silence span."""
     rng = np.random.RandomState(seed)

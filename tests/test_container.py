@@ -139,3 +139,18 @@ def test_fields_match(built, tiny_model):
         R.free_model(rm)
     L.orc_file_free(f)
     m.close()
+
+
+def test_oracle_f16_rounding_matches_ieee_binary16(built):
+    """The checker mode for the fp16 path rounds exactly like an IEEE float32 -> binary16 conversion (ties to even),
+    including subnormals, overflow to infinity and every half-way point."""
+    from oracle import orc_py as O
+    rng = np.random.RandomState(0)
+    x = rng.standard_normal(100000).astype(np.float32) * rng.choice([1e-8, 1e-6, 1e-4, 1e-2, 1, 100, 1e4, 7e4], 100000).astype(np.float32)
+    h = np.arange(0, 0x7c00, dtype=np.uint16).view(np.float16).astype(np.float32)
+    mid = ((h[:-1].astype(np.float64) + h[1:].astype(np.float64)) / 2).astype(np.float32)
+    edge = np.array([0, -0.0, 65504, 65519.99, 65520, 65536, 1e9, -1e9, np.inf, -np.inf, 6.1e-5, 5.96e-8, 2.98e-8, 2.99e-8, 1e-9], np.float32)
+    x = np.concatenate([x, h, -h, mid, -mid, np.nextafter(mid, np.float32(0)), np.nextafter(mid, np.float32(1e9)), edge]).astype(np.float32)
+    with np.errstate(over="ignore"):
+        want = x.astype(np.float16).astype(np.float32)
+    assert np.array_equal(O.round_f16(x), want)

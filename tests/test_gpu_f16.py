@@ -1,0 +1,116 @@
+"""fp16-operand mode (BASELINE configs[4]: "... fp16 MFMA path"), opt-in with APRIL_PRECISION=f16.
+
+Linear/LSTM weights are stored as binary16, activations are rounded to binary16 as they enter a GEMM, products
+accumulate in fp32 (v_mfma_f32_16x16x16_f16); convolutions, biases, norms and the recurrent state stay fp32.
+The checker is the same CPU oracle with MatMul/Gemm operands rounded the same way (orc_set_f16_linear), so what is
+compared is the kernels, not the precision loss.  Tolerances: 2e-3 per network call / 5e-3 on session logits against
+the fp16-rounding oracle (an activation that differs in the last fp32 bit can round to the neighbouring binary16
+value, 2^-11 relative); 5e-2 against the fp32 oracle (the cost of the mode itself, reported, not hidden).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import speech_like_pcm
+from test_gpu_parity import run_gpu, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def f16_models(tiny_model, v0_model):
+    import april_asr_amd as A
+    from oracle import orc_py as O
+    os.environ["APRIL_PRECISION"] = "f16"
+    try:
+        gt, gv = A.Model(tiny_model["path"]), A.Model(v0_model["path"])
+    finally:
+        del os.environ["APRIL_PRECISION"]
+    O.set_f16_linear(True)
+    ot, ov = O.Model(tiny_model["path"]), O.Model(v0_model["path"])
+    yield dict(tiny=(gt, ot), v0=(gv, ov))
+    for m in (gt, gv, ot, ov):
+        m.close()
+    O.set_f16_linear(False)
+
+
+def test_precision_is_reported(f16_models, tiny_model):
+    import april_asr_amd as A
+    assert f16_models["tiny"][0].dims.precision == 1
+    m = A.Model(tiny_model["path"])
+    assert m.dims.precision == 0
+    m.close()
+    os.environ["APRIL_PRECISION"] = "int3"
+    try:
+        with pytest.raises(Exception):
+            A.Model(tiny_model["path"])
+    finally:
+        del os.environ["APRIL_PRECISION"]
+
+
+@pytest.mark.parametrize("which", ["tiny", "v0"])
+def test_f16_networks_match_f16_oracle(f16_models, which):
+    gm, om = f16_models[which]
+    d = gm.dims
+    rng = np.random.RandomState(11)
+    n = 3
+    x = rng.uniform(-16, 8, size=(n, d.seg, d.mel)).astype(np.float32)
+    h = rng.uniform(-0.5, 0.5, size=(n, d.n_layers, d.d_model)).astype(np.float32)
+    c = rng.uniform(-1, 1, size=(n, d.n_layers, d.hidden)).astype(np.float32)
+    eout, h2, c2 = gm.run_encoder(x, h, c)
+    for i in range(n):
+        e0, h0, c0 = om.encoder(x[i:i + 1], h[i][:, None, :], c[i][:, None, :])
+        assert np.abs(eout[i] - e0.ravel()).max() < 2e-3, np.abs(eout[i] - e0.ravel()).max()
+        assert np.abs(h2[i] - h0[:, 0, :]).max() < 2e-3 and np.abs(c2[i] - c0[:, 0, :]).max() < 2e-3
+    ctx = rng.randint(0, d.vocab, size=(n, d.context)).astype(np.int64)
+    dout = gm.run_decoder(ctx)
+    e = rng.uniform(-1, 1, size=(n, d.joiner)).astype(np.float32)
+    lg = gm.run_joiner(e, dout)
+    for i in range(n):
+        assert np.abs(dout[i] - om.decoder(ctx[i]).ravel()).max() < 2e-3
+        l0 = om.joiner(e[i].reshape(1, 1, -1), dout[i].reshape(1, 1, -1))
+        assert np.abs(lg[i] - l0.ravel()).max() < 2e-3
+
+
+def test_f16_batch_invariant_bitwise(f16_models):
+    gm, _ = f16_models["tiny"]
+    d = gm.dims
+    rng = np.random.RandomState(7)
+    n = 37
+    x = rng.uniform(-16, 8, size=(n, d.seg, d.mel)).astype(np.float32)
+    h = rng.uniform(-0.5, 0.5, size=(n, d.n_layers, d.d_model)).astype(np.float32)
+    c = rng.uniform(-1, 1, size=(n, d.n_layers, d.hidden)).astype(np.float32)
+    e_all, h_all, c_all = gm.run_encoder(x, h, c)
+    for i in (0, 16, 36):
+        e1, h1, c1 = gm.run_encoder(x[i:i + 1], h[i:i + 1], c[i:i + 1])
+        assert np.array_equal(e1[0], e_all[i]) and np.array_equal(h1[0], h_all[i]) and np.array_equal(c1[0], c_all[i])
+
+
+@pytest.mark.parametrize("which,secs", [("tiny", 3.0), ("v0", 4.0)])
+def test_f16_session_against_both_oracles(f16_models, which, secs, request):
+    from oracle import orc_py as O
+    gm, om = f16_models[which]
+    pcm = speech_like_pcm(secs, seed=3, silence=(1.0, 1.6))
+    want, lg0, n0 = run_oracle(om, pcm, 1600)                  # fp16-rounding oracle
+    got, lg1, n1 = run_gpu(gm, pcm, 1600)
+    assert n0 == n1 and lg0.shape == lg1.shape
+    err16 = float(np.abs(lg0 - lg1).max())
+    assert err16 < 5e-3, err16
+    # callbacks: same sequence of result types and token ids (log-probabilities within the logit tolerance)
+    assert [t for t, _ in want] == [t for t, _ in got]
+    for (_, k0), (_, k1) in zip(want, got):
+        assert [a[0] for a in k0] == [b[0] for b in k1]
+    # distance to the fp32 reference semantics: reported and bounded
+    O.set_f16_linear(False)
+    try:
+        path = request.getfixturevalue("tiny_model" if which == "tiny" else "v0_model")["path"]
+        o32 = O.Model(path)
+        _, lg32, n32 = run_oracle(o32, pcm, 1600)
+        o32.close()
+    finally:
+        O.set_f16_linear(True)
+    if lg32.shape == lg1.shape:                               # same number of joiner rounds (no token flipped)
+        err32 = float(np.abs(lg32 - lg1).max())
+        print("fp16 mode vs fp32 oracle: max |dlogit| = %.4g (vs fp16-rounding oracle %.4g)" % (err32, err16))
+        assert err32 < 5e-2, err32

@@ -360,3 +360,36 @@ def test_odd_dimensions_model(medium_model):
     assert np.abs(lg0 - lg1).max() < 1e-3
     assert_same_transcript(want, got)
     gm.close(); om.close()
+
+
+def test_config5_larger_encoder_512_sessions(large_model):
+    """BASELINE configs[4] shape (fp32 here): the larger encoder (16 x {768, 1536, 3072}), 512 concurrent sessions in
+    100 ms feeds on one GPU.  Session 0 against the CPU oracle (token-exact, logits within 1e-3); sessions 1 and 511
+    against themselves stepped alone (bit-identical)."""
+    import april_asr_amd as A
+    from oracle import orc_py as O
+    gm = A.Model(large_model["path"]); om = O.Model(large_model["path"])
+    d = gm.dims
+    assert (d.n_layers, d.d_model, d.hidden, d.ffn, d.joiner) == (16, 768, 1536, 3072, 768)
+    n, secs = 512, 0.6
+    pcms = [speech_like_pcm(secs, seed=40)] + [O.lcg_pcm16_fast(int(16000 * secs), seed=300 + i) for i in range(1, n)]
+    evs = [[] for _ in range(n)]
+    sess = [A.Session(gm, (lambda k: (lambda t, toks: evs[k].append((t, toks))))(i), raw_events=True) for i in range(n)]
+    for i in (0, 1, n - 1):
+        sess[i].trace_logits(200)
+    grp = A.SessionGroup(sess)
+    for o in range(0, int(16000 * secs), 1600):
+        grp.feed([p[o:o + 1600] for p in pcms])
+    grp.flush()
+    assert gm.stats().max_batch_seen == n
+    want, lg0, n0 = run_oracle(om, pcms[0], 1600)
+    assert sess[0].chunks() == n0
+    lg = sess[0].traced_logits()
+    assert lg.shape == lg0.shape and np.abs(lg - lg0).max() < 1e-3, np.abs(lg - lg0).max()
+    assert_same_transcript(want, evs[0])
+    for i in (1, n - 1):
+        ev1, lg1, _ = run_gpu(gm, pcms[i], 1600)
+        assert np.array_equal(lg1, sess[i].traced_logits()) and ev1 == evs[i]
+    for s in sess:
+        s.close()
+    gm.close(); om.close()
