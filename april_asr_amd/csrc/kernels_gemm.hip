@@ -14,6 +14,10 @@
 // (reference call sites src/april_session.c:145,160,176).
 #include "kernels.h"
 #include "device_utils.h"
+#include "gemm_mainloop_asm.inc"
+#ifndef APRIL_ASM_NB
+#define APRIL_ASM_NB 2      // operand buffers of the hand-scheduled K loop: 2 keeps two workgroups per CU, 3 needs > 256 registers
+#endif
 #include <algorithm>
 #include <cstdlib>
 
@@ -59,6 +63,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
     // Addressing = uniform 64-bit base (SGPRs; advances with the k block) + one 32-bit byte offset per lane and
     // m-tile (row start + this lane's k quarter), i.e. the saddr form of global_load: no 64-bit vector adds in the loop.
     // All operands are far below 4 GiB per array.
+    // after the LDS meet every thread owns QPT groups of 4 consecutive columns ("quads") of the tile
+    constexpr int QROW = Cfg::BN / 4, NQ = Cfg::BM * QROW, QPT = (NQ + 255) / 256;
     uint32_t aoff0[MT], aoff1[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -72,8 +78,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
     const uint32_t boff = (uint32_t)lane * sizeof(BQ);
     const bool stream_once = gridDim.y == 1;   // weights read by exactly one workgroup: bypass-friendly loads
 
-    // after the LDS meet every thread owns QPT groups of 4 consecutive columns ("quads") of the tile
-    constexpr int QROW = Cfg::BN / 4, NQ = Cfg::BM * QROW, QPT = (NQ + 255) / 256;
     // pairwise (balanced-tree) slab accumulation: level b holds the sum of 2^b consecutive slabs.  A workgroup that owns
     // zs = 2^t slabs needs t levels; the 64x64 tile is capped at zs = 4 (2 levels, 32 registers) so that it stays
     // within 256 registers and two workgroups share a CU (launch_gemm / gemm_partials apply the same cap)
@@ -240,7 +244,52 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
     }
 
     zero_acc();
-    if (T > 0) {
+    bool by_hand = false;
+    // fused-epilogue GEMMs only (one slab, 5..16 blocks per wave): the split-K GEMMs walk several short slabs per
+    // workgroup and rely on the cross-slab prefetch of the compiler-scheduled loop below (measured: no gain there)
+    if constexpr (MT == 4 && NT == 4 && WT == 0 && AOP == AOP_NONE && EPI != EPI_PARTIAL) {
+        if (g.asm_loop && c > 0) {
+            // hand-scheduled K loop (tools/gen_gemm_asm.py): same blocks, same order, same accumulation chains
+            by_hand = true;
+            uint32_t boffs[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) boffs[nt] = boff + (uint32_t)nt * (uint32_t)KB * 1024u;
+            for (int z = 0; z < g.zs; ++z) {
+                const int kb0 = (4 * (zg * g.zs + z) + wave) * c;
+                int done = 0;
+                while (done < c) {
+                    const int kb = kb0 + done;
+                    const bool seg0 = kb * 16 < g.K0;
+                    int n = c - done;
+                    if (seg0 && g.K0 / 16 - kb < n) n = g.K0 / 16 - kb;
+                    const char *ap = reinterpret_cast<const char *>(seg0 ? g.a0 : g.a1) + (ptrdiff_t)(seg0 ? kb * 16 : kb * 16 - g.K0) * 4;
+                    const char *bp = reinterpret_cast<const char *>(g.wp) + ((size_t)nt0 * KB + kb) * 1024;
+                    const uint32_t o0 = seg0 ? aoff0[0] : aoff1[0], o1 = seg0 ? aoff0[1] : aoff1[1];
+                    const uint32_t o2 = seg0 ? aoff0[2] : aoff1[2], o3 = seg0 ? aoff0[3] : aoff1[3];
+#define APRIL_ASM_OPERANDS \
+                    : [c0] "+a"(acc[0][0]), [c1] "+a"(acc[0][1]), [c2] "+a"(acc[0][2]), [c3] "+a"(acc[0][3]), \
+                      [c4] "+a"(acc[1][0]), [c5] "+a"(acc[1][1]), [c6] "+a"(acc[1][2]), [c7] "+a"(acc[1][3]), \
+                      [c8] "+a"(acc[2][0]), [c9] "+a"(acc[2][1]), [c10] "+a"(acc[2][2]), [c11] "+a"(acc[2][3]), \
+                      [c12] "+a"(acc[3][0]), [c13] "+a"(acc[3][1]), [c14] "+a"(acc[3][2]), [c15] "+a"(acc[3][3]) \
+                    : [aoff0] "v"(o0), [aoff1] "v"(o1), [aoff2] "v"(o2), [aoff3] "v"(o3), \
+                      [boff0] "v"(boffs[0]), [boff1] "v"(boffs[1]), [boff2] "v"(boffs[2]), [boff3] "v"(boffs[3]), \
+                      [ap] "s"(ap), [bp] "s"(bp), [nblk] "s"(n)
+#if APRIL_ASM_NB == 3
+                    asm volatile(APRIL_MAINLOOP3_TEXT APRIL_ASM_OPERANDS : APRIL_MAINLOOP3_CLOBBERS);
+#else
+                    asm volatile(APRIL_MAINLOOP2_TEXT APRIL_ASM_OPERANDS : APRIL_MAINLOOP2_CLOBBERS);
+#endif
+#undef APRIL_ASM_OPERANDS
+                    done += n;
+                }
+                meet();
+                if (slab_done < g.zs) zero_acc();
+            }
+        }
+    }
+    if (by_hand) {
+        // K loop done above
+    } else if (T > 0) {
         {
             int first[DEPTH];
 #pragma unroll
@@ -359,8 +408,14 @@ void launch_gemm(const GemmArgs &g_in, hipStream_t s)
     static const int dbg = getenv("APRIL_GEMM_DEBUG") ? atoi(getenv("APRIL_GEMM_DEBUG")) : 0;
     g.debug = dbg;
     static const int skew = getenv("APRIL_GEMM_SKEW") ? atoi(getenv("APRIL_GEMM_SKEW")) : 2;
+    static const int asm_loop = getenv("APRIL_GEMM_ASM") ? atoi(getenv("APRIL_GEMM_ASM")) : 1;     // 0 = compiler-scheduled loop everywhere (A/B)
     const TilePlan t = plan_tiles(g.M, g.N, g.kz, g.epi);
     g.zs = t.zs;
+    // hand-scheduled K loop: measured gains with one workgroup per CU (gates at B <= 256: 24.8 -> 22.9 us) and for the
+    // bias+DoubleSwish GEMMs at any size (FFN-up at B = 1024: 26.5 -> 23.3 us); the LSTM-cell GEMM with two
+    // co-resident workgroups per CU is faster with the compiler-scheduled loop (B = 1024: 83 vs 91 us)
+    const long wgs = (long)(g.N / 64) * ((g.M + 63) / 64);
+    g.asm_loop = asm_loop == 1 ? !(g.epi == EPI_LSTM && wgs >= 512) : (asm_loop != 0);
     g.skew = (long)g.N / 64 * ((g.M + 63) / 64) * (g.kz / g.zs) >= 512 ? skew : 0;
     const int mt = t.mt, nt = t.nt;
     if (mt == 1) { if (nt == 4) dispatch<1, 4>(g, s); else if (nt == 2) dispatch<1, 2>(g, s); else dispatch<1, 1>(g, s); }

@@ -1,6 +1,7 @@
 // Measurement aid: times launch_gemm (the product's GEMM kernel, linked from csrc/build/kernels_gemm.o) on one shape.
 //   build: hipcc --offload-arch=gfx950 -O2 -Iapril_asr_amd/csrc tools/gemm_bench.hip april_asr_amd/csrc/build/kernels_gemm.o -o tools/gemm_bench
-//   usage: tools/gemm_bench M N K [epi=2 (bias+dswish) | 0 (partials, kz given)] [kz=1] [iters=200]
+//   usage: tools/gemm_bench M N K [epi=2 (bias+dswish) | 0 (partials, kz given)] [kz=1] [iters=200] [wcopies=1]
+//   wcopies > 1 cycles through that many copies of W so the weights stream from HBM as in the product (12 layers x 28 MB)
 #include "kernels.h"
 #include <cstdio>
 #include <cstdlib>
@@ -10,27 +11,36 @@ using namespace aprilx;
 int main(int argc, char **argv)
 {
     const int M = atoi(argv[1]), N = atoi(argv[2]), K = atoi(argv[3]);
-    const int epi = argc > 4 ? atoi(argv[4]) : 2, kz = argc > 5 ? atoi(argv[5]) : 1, iters = argc > 6 ? atoi(argv[6]) : 200;
+    const int epi = argc > 4 ? atoi(argv[4]) : 2, kz = argc > 5 ? atoi(argv[5]) : 1, iters = argc > 6 ? atoi(argv[6]) : 200, wc = argc > 7 ? atoi(argv[7]) : 1;
     float *a, *w, *out, *bias;
-    hipMalloc(&a, (size_t)M * K * 4); hipMalloc(&w, (size_t)K * N * 4); hipMalloc(&out, (size_t)8 * M * N * 4); hipMalloc(&bias, (size_t)N * 4);
+    hipMalloc(&a, (size_t)M * K * 4); hipMalloc(&w, (size_t)K * N * 4 * wc); hipMalloc(&out, (size_t)8 * M * N * 4); hipMalloc(&bias, (size_t)N * 4);
     std::vector<float> h((size_t)std::max((size_t)M * K, (size_t)K * N));
     for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u >> 8) & 0xffff) / 65536.0f - 0.5f;
     hipMemcpy(a, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice);
-    hipMemcpy(w, h.data(), (size_t)K * N * 4, hipMemcpyHostToDevice);
+    for (int i = 0; i < wc; ++i) hipMemcpy(w + (size_t)i * K * N, h.data(), (size_t)K * N * 4, hipMemcpyHostToDevice);
     hipMemset(bias, 0, (size_t)N * 4);
     GemmArgs g;
     g.a0 = a; g.lda0 = K; g.K0 = K; g.wp = w; g.M = M; g.N = N; g.K = K; g.kz = kz; g.epi = epi;
     g.out = out; g.ldo = N; g.m_stride = M; g.bias = bias;
+    if (epi == 1) {   // the product's gates call: A = [x | h[slot]] in two K segments, fused LSTM cell (c in place, u out)
+        int *idx; hipMalloc(&idx, (size_t)M * 4);
+        std::vector<int> hi((size_t)M);
+        for (int i = 0; i < M; ++i) hi[(size_t)i] = (int)(((unsigned)i * 2654435761u) % (unsigned)M);   // scattered slots
+        hipMemcpy(idx, hi.data(), (size_t)M * 4, hipMemcpyHostToDevice);
+        float *cst; hipMalloc(&cst, (size_t)M * (N / 4) * 4); hipMemset(cst, 0, (size_t)M * (N / 4) * 4);
+        g.K0 = K / 2; g.lda0 = K / 2; g.a1 = a + (size_t)M * (K / 2); g.lda1 = K / 2; g.aidx1 = idx; g.K1 = K / 2;
+        g.c_state = cst; g.slot_idx = idx; g.hidden = N / 4; g.ldo = N / 4;
+    }
     hipStream_t s; hipStreamCreate(&s);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 20; ++i) launch_gemm(g, s);
     hipStreamSynchronize(s);
     hipEventRecord(e0, s);
-    for (int i = 0; i < iters; ++i) launch_gemm(g, s);
+    for (int i = 0; i < iters; ++i) { g.wp = w + (size_t)(i % wc) * K * N; launch_gemm(g, s); }
     hipEventRecord(e1, s);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
-    printf("M=%d N=%d K=%d epi=%d kz=%d : %.2f us/launch (back-to-back)  %.1f TFLOP/s  %.1f%% of 157.3\n", M, N, K, epi, kz, us, tf, tf / 157.3 * 100);
+    printf("M=%d N=%d K=%d epi=%d kz=%d wc=%d : %.2f us/launch (back-to-back)  %.1f TFLOP/s  %.1f%% of 157.3\n", M, N, K, epi, kz, wc, us, tf, tf / 157.3 * 100);
     return 0;
 }
