@@ -205,6 +205,7 @@ Engine::~Engine()
     for (void *p : {(void *)hs_enc_, (void *)hs_dec_, (void *)hs_joi_, (void *)joint_h_, (void *)logits_h_, (void *)hs_desc_[0], (void *)hs_desc_[1], (void *)hs_pcm_[0], (void *)hs_pcm_[1]})
         if (p) (void)hipHostFree(p);
     for (int b = 0; b < 2; ++b) if (fb_done_[b]) (void)hipEventDestroy(fb_done_[b]);
+    if (dec_done_) (void)hipEventDestroy(dec_done_);
     for (void *p : table_allocs_) (void)hipFree(p);
     (void)hipStreamDestroy(stream_);
 }
@@ -437,7 +438,11 @@ void Engine::decode(int n, const int *slots, const int *ctx)
     const int MB = cfg_.max_batch;
     for (int o = 0; o < n; o += MB) {
         const int m = std::min(MB, n - o);
-        if (o > 0) sync();
+        // two decoder launches can follow each other without a host wait in between (context reset after a flush, then
+        // the first step of a new session): the pinned staging and the device index buffer may not be rewritten
+        // before the previous launch has consumed them
+        if (!dec_done_) HIP_CHECK(hipEventCreateWithFlags(&dec_done_, hipEventDisableTiming));
+        else HIP_CHECK(hipEventSynchronize(dec_done_));
         memcpy(hs_dec_, slots + o, (size_t)m * 4);
         memcpy(hs_dec_ + MB, ctx + (size_t)o * d.context, (size_t)m * d.context * 4);
         HIP_CHECK(hipMemcpyAsync(ds_dec_, hs_dec_, (size_t)m * 4, hipMemcpyHostToDevice, stream_));
@@ -451,6 +456,7 @@ void Engine::decode(int n, const int *slots, const int *ctx)
         RowArgs r; r.mode = ROW_BIAS_STORE; r.ws = ws_; r.kz = gemm_partials(m, d.joiner, kz_proj_); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = m;
         r.bias = w_ + L_.b_decproj; r.out = dout_; r.ldo = d.joiner; r.slot_idx = ds_dec_;
         timed_begin(T_DEC); launch_row(r, stream_); timed_end(T_DEC);
+        HIP_CHECK(hipEventRecord(dec_done_, stream_));
     }
 }
 

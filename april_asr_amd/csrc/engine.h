@@ -127,6 +127,7 @@ private:
     int16_t *hs_pcm_[2] = {nullptr, nullptr}, *ds_pcm_[2] = {nullptr, nullptr}; size_t pcm_cap_ = 0;
     int fb_flip_ = 0;
     hipEvent_t fb_done_[2] = {nullptr, nullptr};
+    hipEvent_t dec_done_ = nullptr;            // last decoder launch has consumed its staged indices
     // fbank tables on device
     FbankTables ft_;
     std::vector<void *> table_allocs_;

@@ -393,3 +393,33 @@ def test_config5_larger_encoder_512_sessions(large_model):
     for s in sess:
         s.close()
     gm.close(); om.close()
+
+
+def test_2048_sessions_one_gpu(gpu_tiny):
+    """BASELINE configs[3]'s session count on ONE GPU (tiny dimensions so that it runs in seconds): 2048 concurrent
+    sessions advance in shared steps of 2048 rows; sampled sessions are bit-identical to themselves stepped alone (size-independent property:
+    batch invariance)."""
+    import april_asr_amd as A
+    from oracle import orc_py as O
+    n = 2048
+    pcms = [O.lcg_pcm16_fast(8000, seed=7000 + i) for i in range(n)]
+    counts = np.zeros(6, np.uint64)
+    evs = {i: [] for i in (0, 1, 777, 2047)}
+    sess = []
+    for i in range(n):
+        if i in evs:
+            sess.append(A.Session(gpu_tiny, (lambda k: (lambda t, toks: evs[k].append((t, toks))))(i), raw_events=True))
+            sess[-1].trace_logits(120)
+        else:
+            sess.append(A.Session(gpu_tiny, None, counters=counts))
+    grp = A.SessionGroup(sess)
+    for o in range(0, 8000, 1600):
+        grp.feed([p[o:o + 1600] for p in pcms])
+    grp.flush()
+    assert gpu_tiny.stats().max_batch_seen == n
+    assert int(counts[0]) > 0
+    for i in evs:
+        ev1, lg1, _ = run_gpu(gpu_tiny, pcms[i], 1600)
+        assert np.array_equal(lg1, sess[i].traced_logits()) and ev1 == evs[i]
+    for s in sess:
+        s.close()
