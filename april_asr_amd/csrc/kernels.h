@@ -49,6 +49,7 @@ struct GemmArgs {
     int hidden = 0;
     int skew = 0;                          // start delay (x 4096 cycles) for every second generation of workgroups
     int asm_loop = 0;                      // != 0: hand-scheduled K loop (gemm_mainloop_asm.inc) in the fused-epilogue 64x64 fp32 tiles
+    unsigned long long *trace = nullptr;   // measurement only: per-workgroup s_memtime stamps [wg][8] (wave 0, lane 0)
     int debug = 0;                         // measurement only: 1 = skip the MFMA main loop, 2 = skip the epilogue math, 3 = all k blocks read block 0
 };
 void launch_gemm(const GemmArgs &g, hipStream_t s);

@@ -43,6 +43,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // measurement only (gemm_bench GEMM_TRACE=1): wave 0 stamps s_memtime at phase boundaries (uniform branch, all lanes store the same value)
+    auto stamp = [&](int i) { if (g.trace && wave == 0) g.trace[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + i] = __builtin_amdgcn_s_memtime(); };
+    stamp(0);
     // XCD-aware mapping: consecutive blockIdx.x land on different XCDs, so keep the
     // M-blocks that share one weight column on the same XCD (same x mod 8).
     const int nt0 = blockIdx.x * NT;
@@ -244,16 +247,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
     }
 
     zero_acc();
+    stamp(1);
     bool by_hand = false;
     // fused-epilogue GEMMs only (one slab, 5..16 blocks per wave): the split-K GEMMs walk several short slabs per
     // workgroup and rely on the cross-slab prefetch of the compiler-scheduled loop below (measured: no gain there)
-    if constexpr (MT == 4 && NT == 4 && WT == 0 && AOP == AOP_NONE && EPI != EPI_PARTIAL) {
+    if constexpr (MT == 4 && (NT == 4 || NT == 2) && WT == 0 && AOP == AOP_NONE && EPI != EPI_PARTIAL) {
         if (g.asm_loop && c > 0) {
             // hand-scheduled K loop (tools/gen_gemm_asm.py): same blocks, same order, same accumulation chains
             by_hand = true;
-            uint32_t boffs[4];
+            uint32_t boffs[NT];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) boffs[nt] = boff + (uint32_t)nt * (uint32_t)KB * 1024u;
+            for (int nt = 0; nt < NT; ++nt) boffs[nt] = boff + (uint32_t)nt * (uint32_t)KB * 1024u;
             for (int z = 0; z < g.zs; ++z) {
                 const int kb0 = (4 * (zg * g.zs + z) + wave) * c;
                 int done = 0;
@@ -266,23 +270,36 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
                     const char *bp = reinterpret_cast<const char *>(g.wp) + ((size_t)nt0 * KB + kb) * 1024;
                     const uint32_t o0 = seg0 ? aoff0[0] : aoff1[0], o1 = seg0 ? aoff0[1] : aoff1[1];
                     const uint32_t o2 = seg0 ? aoff0[2] : aoff1[2], o3 = seg0 ? aoff0[3] : aoff1[3];
-#define APRIL_ASM_OPERANDS \
-                    : [c0] "+a"(acc[0][0]), [c1] "+a"(acc[0][1]), [c2] "+a"(acc[0][2]), [c3] "+a"(acc[0][3]), \
-                      [c4] "+a"(acc[1][0]), [c5] "+a"(acc[1][1]), [c6] "+a"(acc[1][2]), [c7] "+a"(acc[1][3]), \
-                      [c8] "+a"(acc[2][0]), [c9] "+a"(acc[2][1]), [c10] "+a"(acc[2][2]), [c11] "+a"(acc[2][3]), \
-                      [c12] "+a"(acc[3][0]), [c13] "+a"(acc[3][1]), [c14] "+a"(acc[3][2]), [c15] "+a"(acc[3][3]) \
-                    : [aoff0] "v"(o0), [aoff1] "v"(o1), [aoff2] "v"(o2), [aoff3] "v"(o3), \
-                      [boff0] "v"(boffs[0]), [boff1] "v"(boffs[1]), [boff2] "v"(boffs[2]), [boff3] "v"(boffs[3]), \
-                      [ap] "s"(ap), [bp] "s"(bp), [nblk] "s"(n)
+#define APRIL_ASM_IN_A [aoff0] "v"(o0), [aoff1] "v"(o1), [aoff2] "v"(o2), [aoff3] "v"(o3), [ap] "s"(ap), [bp] "s"(bp), [nblk] "s"(n)
+                    if constexpr (NT == 4) {
 #if APRIL_ASM_NB == 3
-                    asm volatile(APRIL_MAINLOOP3_TEXT APRIL_ASM_OPERANDS : APRIL_MAINLOOP3_CLOBBERS);
+                        asm volatile(APRIL_MAINLOOP3_TEXT
 #else
-                    asm volatile(APRIL_MAINLOOP2_TEXT APRIL_ASM_OPERANDS : APRIL_MAINLOOP2_CLOBBERS);
+                        asm volatile(APRIL_MAINLOOP2_TEXT
 #endif
-#undef APRIL_ASM_OPERANDS
+                            : [c0] "+a"(acc[0][0]), [c1] "+a"(acc[0][1]), [c2] "+a"(acc[0][2]), [c3] "+a"(acc[0][3]),
+                              [c4] "+a"(acc[1][0]), [c5] "+a"(acc[1][1]), [c6] "+a"(acc[1][2]), [c7] "+a"(acc[1][3]),
+                              [c8] "+a"(acc[2][0]), [c9] "+a"(acc[2][1]), [c10] "+a"(acc[2][2]), [c11] "+a"(acc[2][3]),
+                              [c12] "+a"(acc[3][0]), [c13] "+a"(acc[3][1]), [c14] "+a"(acc[3][2]), [c15] "+a"(acc[3][3])
+                            : APRIL_ASM_IN_A, [boff0] "v"(boffs[0]), [boff1] "v"(boffs[1]), [boff2] "v"(boffs[NT - 2]), [boff3] "v"(boffs[NT - 1])
+#if APRIL_ASM_NB == 3
+                            : APRIL_MAINLOOP3_CLOBBERS);
+#else
+                            : APRIL_MAINLOOP2_CLOBBERS);
+#endif
+                    } else {
+                        asm volatile(APRIL_MAINLOOP2_NT2_TEXT
+                            : [c0] "+a"(acc[0][0]), [c1] "+a"(acc[0][1]), [c2] "+a"(acc[1][0]), [c3] "+a"(acc[1][1]),
+                              [c4] "+a"(acc[2][0]), [c5] "+a"(acc[2][1]), [c6] "+a"(acc[3][0]), [c7] "+a"(acc[3][1])
+                            : APRIL_ASM_IN_A, [boff0] "v"(boffs[0]), [boff1] "v"(boffs[1])
+                            : APRIL_MAINLOOP2_NT2_CLOBBERS);
+                    }
+#undef APRIL_ASM_IN_A
                     done += n;
                 }
+                stamp(2);
                 meet();
+                stamp(3);
                 if (slab_done < g.zs) zero_acc();
             }
         }
@@ -352,6 +369,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
             if (qok[i]) { *cptr[i] = c_new; g.out[(size_t)qm[i] * g.ldo + qunit[i]] = u; }
         }
     }
+    stamp(4);
 }
 
 template <int MT, int NT>
@@ -416,7 +434,7 @@ void launch_gemm(const GemmArgs &g_in, hipStream_t s)
     // co-resident workgroups per CU is faster with the compiler-scheduled loop (B = 1024: 83 vs 91 us)
     const long wgs = (long)(g.N / 64) * ((g.M + 63) / 64);
     g.asm_loop = asm_loop == 1 ? !(g.epi == EPI_LSTM && wgs >= 512) : (asm_loop != 0);
-    g.skew = (long)g.N / 64 * ((g.M + 63) / 64) * (g.kz / g.zs) >= 512 ? skew : 0;
+    g.skew = (long)(g.N / (16 * t.nt)) * ((g.M + 16 * t.mt - 1) / (16 * t.mt)) * (g.kz / g.zs) >= 512 ? skew : 0;   // two workgroups per CU
     const int mt = t.mt, nt = t.nt;
     if (mt == 1) { if (nt == 4) dispatch<1, 4>(g, s); else if (nt == 2) dispatch<1, 2>(g, s); else dispatch<1, 1>(g, s); }
     else if (mt == 2) { if (nt == 4) dispatch<2, 4>(g, s); else if (nt == 2) dispatch<2, 2>(g, s); else dispatch<2, 1>(g, s); }

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 using namespace aprilx;
 
 int main(int argc, char **argv)
@@ -40,6 +41,23 @@ int main(int argc, char **argv)
     hipEventRecord(e1, s);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (getenv("GEMM_TRACE")) {   // one extra launch with per-workgroup s_memtime stamps
+        const int nwg = 8192;
+        unsigned long long *tr; hipMalloc(&tr, (size_t)nwg * 8 * 8); hipMemset(tr, 0, (size_t)nwg * 8 * 8);
+        g.trace = tr; g.wp = w; launch_gemm(g, s); hipStreamSynchronize(s); g.trace = nullptr;
+        std::vector<unsigned long long> ht((size_t)nwg * 8);
+        hipMemcpy(ht.data(), tr, ht.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0; int n = 0;
+        for (int i = 0; i < nwg; ++i) if (ht[(size_t)i * 8]) { ++n; t0 = std::min(t0, ht[(size_t)i * 8]); t1 = std::max(t1, ht[(size_t)i * 8 + 4]); }
+        double seg[5] = {0, 0, 0, 0, 0}, start_spread = 0;
+        for (int i = 0; i < nwg; ++i) if (ht[(size_t)i * 8]) {
+            const unsigned long long *q = &ht[(size_t)i * 8];
+            seg[0] += (double)(q[1] - q[0]); seg[1] += (double)(q[2] - q[1]); seg[2] += (double)(q[3] - q[2]); seg[3] += (double)(q[4] - q[3]);
+            start_spread += (double)(q[0] - t0);
+        }
+        printf("  trace: %d workgroups, span %llu ticks; mean ticks: setup %.0f | K loop %.0f | meet %.0f | epilogue %.0f | start after first %.0f\n",
+               n, t1 - t0, seg[0] / n, seg[1] / n, seg[2] / n, seg[3] / n, start_spread / n);
+    }
     const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
     printf("M=%d N=%d K=%d epi=%d kz=%d wc=%d : %.2f us/launch (back-to-back)  %.1f TFLOP/s  %.1f%% of 157.3\n", M, N, K, epi, kz, wc, us, tf, tf / 157.3 * 100);
     return 0;
