@@ -43,8 +43,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // measurement only (gemm_bench GEMM_TRACE=1): wave 0 stamps s_memtime at phase boundaries (uniform branch, all lanes store the same value)
+    // measurement only (tools/gemm_bench built with -DAPRIL_GEMM_TRACE, run with GEMM_TRACE=1): wave 0 stamps s_memtime at
+    // phase boundaries (uniform branch, all lanes store the same value); compiled out of the product
+#ifdef APRIL_GEMM_TRACE
     auto stamp = [&](int i) { if (g.trace && wave == 0) g.trace[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + i] = __builtin_amdgcn_s_memtime(); };
+#else
+    auto stamp = [](int) {};
+#endif
     stamp(0);
     // XCD-aware mapping: consecutive blockIdx.x land on different XCDs, so keep the
     // M-blocks that share one weight column on the same XCD (same x mod 8).

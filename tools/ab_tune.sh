@@ -1,3 +1,4 @@
-for shape in "256 4096 1024 1 1" "1024 4096 1024 1 1" "1024 4096 1024 2 1" "2048 4096 1024 1 1" "1024 2048 512 2 1"; do
-  for p in 0 1; do for a in 0 1; do echo -n "PRIO=$p ASM=$a "; GEMM_TRACE=1 APRIL_GEMM_PRIO=$p APRIL_GEMM_ASM=$a timeout 60 tools/gemm_bench_nb2 $shape 96 24 | tr '\n' ' ' | sed 's/trace: [0-9]* workgroups, span [0-9]* ticks; mean ticks://; s/| start after first [0-9]*//'; echo; done; done
-done
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for b in 256 1024; do echo "B=$b"; timeout 300 python bench.py --steps 30 --warmup 5 --sessions $b --no-cpu-baseline --no-sweep --profile-steps 10 2>&1 | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['rtf'], d['roofline']['class_ms'], d['roofline']['avg_launch_us'], d['roofline']['frac'])"; done

@@ -1,5 +1,6 @@
 // Measurement aid: times launch_gemm (the product's GEMM kernel, linked from csrc/build/kernels_gemm.o) on one shape.
-//   build: hipcc --offload-arch=gfx950 -O2 -Iapril_asr_amd/csrc tools/gemm_bench.hip april_asr_amd/csrc/build/kernels_gemm.o -o tools/gemm_bench
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DAPRIL_GEMM_TRACE] -Iapril_asr_amd/csrc -c april_asr_amd/csrc/kernels_gemm.hip -o kg.o
+//          hipcc --offload-arch=gfx950 -O2 -Iapril_asr_amd/csrc -c tools/gemm_bench.hip -o gb.o && hipcc --offload-arch=gfx950 gb.o kg.o -o tools/gemm_bench
 //   usage: tools/gemm_bench M N K [epi=2 (bias+dswish) | 0 (partials, kz given)] [kz=1] [iters=200] [wcopies=1]
 //   wcopies > 1 cycles through that many copies of W so the weights stream from HBM as in the product (12 layers x 28 MB)
 #include "kernels.h"
