@@ -51,6 +51,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
     auto stamp = [](int) {};
 #endif
     stamp(0);
+#ifdef APRIL_GEMM_TRACE
+    if (g.trace && wave == 0) {   // where this workgroup runs: HW_ID (wave/simd/cu/sh/se fields) and XCC_ID
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n s_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+        g.trace[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + 5] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     // XCD-aware mapping: consecutive blockIdx.x land on different XCDs, so keep the
     // M-blocks that share one weight column on the same XCD (same x mod 8).
     const int nt0 = blockIdx.x * NT;

@@ -56,6 +56,18 @@ int main(int argc, char **argv)
             seg[0] += (double)(q[1] - q[0]); seg[1] += (double)(q[2] - q[1]); seg[2] += (double)(q[3] - q[2]); seg[3] += (double)(q[4] - q[3]);
             start_spread += (double)(q[0] - t0);
         }
+        if (getenv("GEMM_TRACE_CU")) {   // timeline of the workgroups that ran on one CU (same XCC clock): ticks relative to the first start there
+            // HW_ID (gfx9): [3:0] wave, [5:4] simd, [7:6] pipe, [11:8] cu, [12] sh, [15:13] se ; XCC_ID [3:0]
+            auto key = [&](int i) { const unsigned long long v = ht[(size_t)i * 8 + 5]; const unsigned hw = (unsigned)v; return ((v >> 32) & 15) << 16 | (hw & 0xff00); };
+            int pick = -1; for (int i = 0; i < nwg; ++i) if (ht[(size_t)i * 8]) { pick = i; break; }
+            const unsigned long long k0 = key(pick);
+            std::vector<int> on; for (int i = 0; i < nwg; ++i) if (ht[(size_t)i * 8] && key(i) == k0) on.push_back(i);
+            std::sort(on.begin(), on.end(), [&](int a, int b) { return ht[(size_t)a * 8] < ht[(size_t)b * 8]; });
+            const unsigned long long base = ht[(size_t)on[0] * 8];
+            printf("  CU key %llx: %zu workgroups\n", k0, on.size());
+            for (int i : on) { const unsigned long long *q = &ht[(size_t)i * 8];
+                printf("    wg %5d  start %7llu  loop %7llu..%7llu  meet-end %7llu  end %7llu\n", i, q[0] - base, q[1] - base, q[2] - base, q[3] - base, q[4] - base); }
+        }
         printf("  trace: %d workgroups, span %llu ticks; mean ticks: setup %.0f | K loop %.0f | meet %.0f | epilogue %.0f | start after first %.0f\n",
                n, t1 - t0, seg[0] / n, seg[1] / n, seg[2] / n, seg[3] / n, start_spread / n);
     }
