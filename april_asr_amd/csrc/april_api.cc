@@ -216,7 +216,7 @@ void aas_feed_pcm16(AprilASRSession session, short *pcm16, size_t short_count)
 {
     Session *s = &session->s;
     const short *p = pcm16;
-    s->sched->submit(1, &s, &p, &short_count, false, s->sync_mode);
+    s->sched->submit(1, &s, &p, &short_count, false, s->sync_mode, /*borrow=*/s->sync_mode);
     if (s->sync_mode) s->sched->deliver_sync_events(s);
 }
 
@@ -340,8 +340,8 @@ void aprilx_feed_many(size_t n, AprilASRSession *sessions, const short *const *p
         groups[k].push_back(&sessions[i]->s); gp[k].push_back(pcm16[i]); gc[k].push_back(short_counts[i]);
     }
     // queue on every GPU first (no wait), then wait, so GPUs run concurrently
-    for (size_t k = 0; k < scheds.size(); ++k) scheds[k]->submit((int)groups[k].size(), groups[k].data(), gp[k].data(), gc[k].data(), false, false);
-    for (size_t i = 0; i < n; ++i) aprilx_session_drain(sessions[i]);
+    for (size_t k = 0; k < scheds.size(); ++k) scheds[k]->submit((int)groups[k].size(), groups[k].data(), gp[k].data(), gc[k].data(), false, false, /*borrow=*/true);
+    for (size_t k = 0; k < scheds.size(); ++k) scheds[k]->wait_idle_many(groups[k].data(), (int)groups[k].size());
     for (size_t i = 0; i < n; ++i) if (sessions[i]->s.sync_mode) sessions[i]->s.sched->deliver_sync_events(&sessions[i]->s);
 }
 

@@ -1,6 +1,7 @@
 // See session.h.
 #include "session.h"
 #include <algorithm>
+#include <tuple>
 #include <cstring>
 #include <chrono>
 #include "common.h"
@@ -219,11 +220,12 @@ void Scheduler::detach(Session *s)
     cv_done_.wait(lk, [&] { return !s->busy; });
     sessions_.erase(std::remove(sessions_.begin(), sessions_.end(), s), sessions_.end());
     s->inbox.clear();
+    s->borrow_ptr = nullptr; s->borrow_cnt = 0;
 }
 
 SchedStats Scheduler::stats() { std::lock_guard<std::mutex> g(mu_); return stats_; }
 
-void Scheduler::submit(int n, Session *const *ss, const short *const *pcm, const size_t *counts, bool flush, bool wait)
+void Scheduler::submit(int n, Session *const *ss, const short *const *pcm, const size_t *counts, bool flush, bool wait, bool borrow)
 {
     std::vector<Session *> overflowed;
     std::vector<uint64_t> tickets((size_t)n, 0);
@@ -235,8 +237,11 @@ void Scheduler::submit(int n, Session *const *ss, const short *const *pcm, const
             if (flush) s->flush_requested = true;
             else {
                 const size_t cnt = counts[i];
-                if (!s->sync_mode && s->inbox.size() + cnt > kAsyncRingSamples) { overflowed.push_back(s); continue; }   // april_session.c:482-492
-                if (cnt) s->inbox.insert(s->inbox.end(), pcm[i], pcm[i] + cnt);
+                if (!s->sync_mode && s->inbox.size() + s->borrow_cnt + cnt > kAsyncRingSamples) { overflowed.push_back(s); continue; }   // april_session.c:482-492
+                if (cnt) {
+                    if (borrow && !s->borrow_cnt && s->inbox.empty()) { s->borrow_ptr = pcm[i]; s->borrow_cnt = cnt; }
+                    else s->inbox.insert(s->inbox.end(), pcm[i], pcm[i] + cnt);
+                }
                 s->fed = true;
             }
             tickets[(size_t)i] = ++s->submitted;
@@ -258,6 +263,18 @@ void Scheduler::wait_idle(Session *s)
     cv_done_.wait(lk, [&] { return s->closing || (s->completed >= s->submitted && !s->busy && !s->fed && !s->flush_requested); });
 }
 
+void Scheduler::wait_idle_many(Session *const *ss, int n)
+{
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] {
+        for (int i = 0; i < n; ++i) {
+            const Session *s = ss[i];
+            if (!(s->closing || (s->completed >= s->submitted && !s->busy && !s->fed && !s->flush_requested))) return false;
+        }
+        return true;
+    });
+}
+
 void Scheduler::deliver_sync_events(Session *s)
 {
     std::vector<Event> ev;
@@ -270,6 +287,7 @@ void Scheduler::loop()
     HIP_CHECK(hipSetDevice(eng_->device()));
     std::vector<Session *> work;
     std::vector<uint64_t> taken;
+    std::vector<std::tuple<Session *, const short *, size_t>> lent;
     for (;;) {
         work.clear(); taken.clear();
         Lap lap;
@@ -285,6 +303,11 @@ void Scheduler::loop()
             for (Session *s : sessions_) {
                 if (s->closing || (!s->fed && !s->flush_requested)) continue;
                 s->busy = true;
+                if (s->borrow_cnt) {
+                    if (s->inbox.empty()) lent.emplace_back(s, s->borrow_ptr, s->borrow_cnt);
+                    else s->fb.fifo.insert(s->fb.fifo.end(), s->borrow_ptr, s->borrow_ptr + s->borrow_cnt);   // something queued behind it: keep the order
+                    s->borrow_ptr = nullptr; s->borrow_cnt = 0;
+                }
                 if (!s->inbox.empty()) { s->fb.fifo.insert(s->fb.fifo.end(), s->inbox.begin(), s->inbox.end()); s->inbox.clear(); }
                 if (s->fed) s->was_flushed = false;                               // april_session.c:510
                 s->fed = false;
@@ -296,6 +319,10 @@ void Scheduler::loop()
                 taken.push_back(s->submitted);
             }
         }
+        // lent PCM: the caller is blocked until `completed` moves, so its buffer is read here, outside the lock (a lent
+        // buffer is only accepted when nothing is queued in front of it, so the order of samples is kept)
+        for (auto &l : lent) std::get<0>(l)->fb.fifo.insert(std::get<0>(l)->fb.fifo.end(), std::get<1>(l), std::get<1>(l) + std::get<2>(l));
+        lent.clear();
         stats_.host_ms[0] += lap();
         process(work);
         lap();

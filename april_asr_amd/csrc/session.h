@@ -93,6 +93,8 @@ struct Session {
 
     // ---- guarded by Scheduler::mu_
     std::vector<int16_t> inbox;               // queued PCM (appended by callers; capacity is reused across feeds)
+    const short *borrow_ptr = nullptr;        // PCM lent by a caller that blocks until the work is done (sync feed, feed_many):
+    size_t borrow_cnt = 0;                    //   copied once, by the stepping thread, outside the lock
     bool fed = false;                         // a feed arrived since the last collection (even an empty one)
     bool flush_requested = false;
     bool busy = false;                        // owned by the stepping thread right now
@@ -128,9 +130,12 @@ public:
     void attach(Session *s);
     void detach(Session *s);                       // waits until the session is idle
     // queue work for n sessions at once and (for sync sessions / wait=true) block until it is done
-    void submit(int n, Session *const *ss, const short *const *pcm, const size_t *counts, bool flush, bool wait);
+    // `borrow`: the caller keeps the PCM buffers alive and unchanged until the sessions are idle again (it blocks in this
+    // call, or drains afterwards), so they are read in place by the stepping thread instead of being copied under the lock
+    void submit(int n, Session *const *ss, const short *const *pcm, const size_t *counts, bool flush, bool wait, bool borrow = false);
     void deliver_sync_events(Session *s);          // caller-thread delivery for sync sessions
     void wait_idle(Session *s);                    // everything queued so far has been processed
+    void wait_idle_many(Session *const *ss, int n);
     SchedStats stats();
     Engine *engine() { return eng_; }
 

@@ -198,7 +198,7 @@ def main():
     sweep = None
     if rank == 0 and not args.no_sweep:
         sweep = {}
-        for nb in (1, 16, 64, 1024, 1280, 1536, 2048):
+        for nb in (1, 16, 64, 1024, 1280, 1536, 1792, 2048):
             ss, gg = make_group(nb, 0)
             pp = pcm_for(nb, 12, 20_000_000)
             run_steps(gg, pp, 0, 4)

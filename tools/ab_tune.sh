@@ -1,4 +1,4 @@
-GEMM_TRACE=1 GEMM_TRACE_CU=1 APRIL_GEMM_PERSIST=1 timeout 60 tools/gemm_bench_nb2 1024 4096 1024 2 1 96 24
-for shape in "1024 4096 1024 1 1" "1024 4096 1024 2 1" "2048 4096 1024 1 1" "1024 2048 512 2 1" "2048 2048 512 2 1" "2048 512 2048 0 8" "2048 512 1024 0 8" "256 4096 1024 1 1"; do
-  for p in 0 1; do echo -n "PERSIST=$p "; APRIL_GEMM_PERSIST=$p timeout 60 tools/gemm_bench_nb2 $shape 96 24; done
-done
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for b in 256 1024 1536; do echo "B=$b"; timeout 300 python bench.py --steps 30 --warmup 5 --sessions $b --no-cpu-baseline --no-sweep --profile-steps 0 2>&1 | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['rtf'], d['host_phase_ms_total'], d['step_latency_ms']['p50'], d['step_latency_ms']['p99'])"; done
