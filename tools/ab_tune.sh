@@ -1,3 +1,5 @@
-for rep in 1 2; do for t in 256 128 64; do for b in 1 256 1024; do echo -n "rep=$rep KZ_TARGET=$t B=$b  "; APRIL_KZ_TARGET=$t timeout 300 python bench.py --steps 30 --warmup 5 --sessions $b --no-cpu-baseline --no-sweep --profile-steps 10 2>&1 | tail -1 | python -c "
-import sys,json
-d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['class_ms'])"; done; done; done
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for cfg in "256 0" "256 1" "1 0" "1024 0"; do set -- $cfg
+  rm -rf /tmp/tr; APRIL_NO_GRAPHS=$2 timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o t -- python bench.py --sessions $1 --steps 10 --warmup 3 --no-sweep --no-cpu-baseline --profile-steps 0 > /tmp/tr.log 2>&1
+  echo "== sessions=$1 NO_GRAPHS=$2"; python tools/gap_summary.py $(ls /tmp/tr/*kernel_trace.csv /tmp/tr/*/*kernel_trace.csv 2>/dev/null | head -1)
+done

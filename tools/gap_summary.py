@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Inter-kernel gaps from a rocprofv3 kernel trace CSV: how much of a chunk step is kernels, how much is the space
+between them.  Gaps above 60 us are host turnarounds (between joiner rounds / feeds) and are reported separately.
+usage: gap_summary.py <..._kernel_trace.csv>"""
+import csv
+import statistics
+import sys
+
+rows = []
+for r in csv.DictReader(open(sys.argv[1])):
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+busy = sum(e - s for s, e, _ in rows)
+gaps = [rows[i + 1][0] - rows[i][1] for i in range(len(rows) - 1)]
+small = [g for g in gaps if g < 60000]
+big = [g for g in gaps if g >= 60000]
+print("kernels %d  busy %.2f ms  span %.2f ms" % (len(rows), busy / 1e6, (rows[-1][1] - rows[0][0]) / 1e6))
+print("gaps < 60 us: n=%d  sum %.2f ms  median %.2f us  mean %.2f us  p90 %.2f us" % (
+    len(small), sum(small) / 1e6, statistics.median(small) / 1e3, statistics.mean(small) / 1e3, sorted(small)[int(len(small) * 0.9)] / 1e3))
+print("gaps >= 60 us (host turnarounds): n=%d  sum %.2f ms" % (len(big), sum(big) / 1e6))
+print("kernel time / (kernel time + small gaps) = %.3f" % (busy / (busy + sum(small))))
