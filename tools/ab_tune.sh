@@ -1,5 +1,4 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for cfg in "256 0" "256 1" "1 0" "1024 0"; do set -- $cfg
-  rm -rf /tmp/tr; APRIL_NO_GRAPHS=$2 timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o t -- python bench.py --sessions $1 --steps 10 --warmup 3 --no-sweep --no-cpu-baseline --profile-steps 0 > /tmp/tr.log 2>&1
-  echo "== sessions=$1 NO_GRAPHS=$2"; python tools/gap_summary.py $(ls /tmp/tr/*kernel_trace.csv /tmp/tr/*/*kernel_trace.csv 2>/dev/null | head -1)
-done
+APRIL_FUSE_ROW_MAX=100000 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for rep in 1 2; do for b in 1 16 256 1024; do for f in 0 100000; do echo -n "rep=$rep B=$b FUSE_ROW_MAX=$f  "; APRIL_FUSE_ROW_MAX=$f timeout 300 python bench.py --steps 30 --warmup 5 --sessions $b --no-cpu-baseline --no-sweep --profile-steps 0 2>&1 | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['step_latency_ms']['p50'])"; done; done; done
