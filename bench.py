@@ -217,7 +217,7 @@ def main():
         path = os.environ.get("APRIL_MODEL") or os.path.join(tempfile.gettempdir(), "bench_aprilv0_synth.april")
         om = O.Model(path)
         osess = O.Session(om)
-        sample_s = 6.0
+        sample_s = 12.0
         p = SM.lcg_pcm16(int(16000 * sample_s), seed=12345)
         a = time.perf_counter()
         for o in range(0, p.size, step_samples):
