@@ -1,4 +1,4 @@
-// fp32 MFMA "skinny" GEMM for gfx950: out[M,N] = A[M,K] x W[K,N], M = sessions
+// MFMA "skinny" GEMM for gfx950: out[M,N] = A[M,K] x W[K,N], M = sessions
 // stepped together (1 .. thousands), W streamed once per workgroup column from a
 // pre-packed HBM layout (see kernels.h).  v_mfma_f32_16x16x4_f32 is an exact
 // in-order fp32 FMA chain, so results do not depend on M or on the tile shape.
@@ -10,6 +10,10 @@
 //   EPI_PARTIAL      slab sums -> workspace (row kernels finish bias/residual/norm)
 //   EPI_LSTM         LSTM cell: sigma/tanh gates, c' written in place, u = sigma(o) tanh(c')
 //   EPI_BIAS_DSWISH  y = acc + b ; y * sigmoid(y - 1)
+// WT = 1 reads fp16 weights and rounds A to fp16 on load (v_mfma_f32_16x16x16_f16, fp32
+// accumulation, same lane<->k mapping and summation structure).  The K loop exists twice with
+// identical arithmetic: compiler-scheduled C++ (all shapes) and a generated hand-scheduled
+// version for the fused-epilogue 64x64 / 64x32 fp32 tiles (gemm_mainloop_asm.inc).
 // Replaces the ORT MatMul/Gemm nodes of the encoder/decoder/joiner graphs
 // (reference call sites src/april_session.c:145,160,176).
 #include "kernels.h"
