@@ -64,6 +64,17 @@ int main(int argc, char **argv)
             std::vector<int> on; for (int i = 0; i < nwg; ++i) if (ht[(size_t)i * 8] && key(i) == k0) on.push_back(i);
             std::sort(on.begin(), on.end(), [&](int a, int b) { return ht[(size_t)a * 8] < ht[(size_t)b * 8]; });
             const unsigned long long base = ht[(size_t)on[0] * 8];
+            {   // all CUs of the same XCC (one clock domain): whole-XCC span and the spread of per-CU spans
+                const unsigned long long xk = k0 >> 16;
+                std::vector<unsigned long long> keys; unsigned long long lo = ~0ull, hi = 0;
+                for (int i = 0; i < nwg; ++i) if (ht[(size_t)i * 8] && (key(i) >> 16) == xk) { keys.push_back(key(i)); lo = std::min(lo, ht[(size_t)i * 8]); hi = std::max(hi, ht[(size_t)i * 8 + 4]); }
+                std::sort(keys.begin(), keys.end()); keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+                std::vector<unsigned long long> spans, starts, ends;
+                for (unsigned long long k : keys) { unsigned long long a = ~0ull, b = 0; for (int i = 0; i < nwg; ++i) if (ht[(size_t)i * 8] && key(i) == k) { a = std::min(a, ht[(size_t)i * 8]); b = std::max(b, ht[(size_t)i * 8 + 4]); } spans.push_back(b - a); starts.push_back(a - lo); ends.push_back(b - lo); }
+                std::sort(spans.begin(), spans.end()); std::sort(starts.begin(), starts.end()); std::sort(ends.begin(), ends.end());
+                printf("  XCC %llu: %zu CUs, whole span %llu cycles; per-CU span min/med/max %llu/%llu/%llu; first start of a CU min/med/max %llu/%llu/%llu; last end min/med/max %llu/%llu/%llu\n",
+                       xk, keys.size(), hi - lo, spans.front(), spans[spans.size() / 2], spans.back(), starts.front(), starts[starts.size() / 2], starts.back(), ends.front(), ends[ends.size() / 2], ends.back());
+            }
             printf("  CU key %llx: %zu workgroups\n", k0, on.size());
             for (int i : on) { const unsigned long long *q = &ht[(size_t)i * 8];
                 printf("    wg %5d  start %7llu  loop %7llu..%7llu  meet-end %7llu  end %7llu\n", i, q[0] - base, q[1] - base, q[2] - base, q[3] - base, q[4] - base); }
