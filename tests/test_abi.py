@@ -85,3 +85,13 @@ def test_fails_loudly_without_gpu(built, tiny_model, capfd):
     assert not L.aam_create_model(tiny_model["path"].encode())
     err = capfd.readouterr().err
     assert "HIP device" in err
+
+
+def test_generated_gemm_loop_is_current():
+    """april_asr_amd/csrc/gemm_mainloop_asm.inc is generated code: it must be what tools/gen_gemm_asm.py prints."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = subprocess.check_output([sys.executable, os.path.join(root, "tools", "gen_gemm_asm.py")]).decode()
+    have = open(os.path.join(root, "april_asr_amd", "csrc", "gemm_mainloop_asm.inc")).read()
+    assert want == have
