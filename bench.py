@@ -196,7 +196,7 @@ def main():
 
     # ---------------- concurrency sweep (outside the timed region): RTF at other batch sizes
     sweep = None
-    if rank == 0 and not args.no_sweep:
+    if rank == 0 and world == 1 and not args.no_sweep:          # single-GPU runs only (the driver computes scaling from per-N values)
         sweep = {}
         for nb in (1, 16, 64, 1024, 1280, 1536, 1792, 2048):
             ss, gg = make_group(nb, 0)
@@ -212,7 +212,7 @@ def main():
 
     # ---------------- CPU baseline: the oracle (plain-C port, 1 thread) on the host, bounded sample
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import orc_py as O          # checker/baseline only; never on the measured path
         path = os.environ.get("APRIL_MODEL") or os.path.join(tempfile.gettempdir(), "bench_aprilv0_synth.april")
         om = O.Model(path)
@@ -250,9 +250,10 @@ def main():
             "engine_steps": int(st.steps), "host_phase_ms_total": host_ms, "max_batch_seen": int(st.max_batch_seen),
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     model.close()
     if world > 1:
+        barrier()                                  # rank 0 runs the roofline pass after the timed region; leave together
         dist.destroy_process_group()
 
 
