@@ -41,13 +41,15 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--precision", choices=["f32", "f16"], default="f32",
                     help="f16 = opt-in fp16-operand mode (BASELINE configs[4]); the headline metric is quoted on f32")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collective backend for the weight broadcast; gloo (host tensors, ranks may share a GPU) exists to "
+                         "exercise the multi-process path on a one-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     lanes = int(os.environ.get("APRIL_LANES", "1"))        # engines (stream + stepping thread) per GPU
-    os.environ["APRIL_GPU_DEVICES"] = ",".join([str(local_rank)] * lanes)
     os.environ.setdefault("APRIL_MAX_SESSIONS", "4096")
     os.environ.setdefault("APRIL_MAX_BATCH", "4096")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -55,6 +57,9 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
+    if args.backend == "gloo":                             # test mode: wrap the ranks onto the GPUs that exist
+        local_rank %= max(1, torch.cuda.device_count())
+    os.environ["APRIL_GPU_DEVICES"] = ",".join([str(local_rank)] * lanes)      # read by the library when it initialises
     import april_asr_amd as A
     from april_asr_amd import synth_model as SM
 
@@ -62,15 +67,18 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)      # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")      # where collective tensors live
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
-    if args.precision == "f16":
-        os.environ["APRIL_PRECISION"] = "f16"       # read by the library when a model is created
     # ---------------- model: rank 0 parses the file, everyone else receives the packed blob over RCCL
     t_load0 = time.time()
     bcast_ms = None
@@ -83,18 +91,21 @@ def main():
         model = A.Model(path)
     if world > 1:
         if rank == 0:
-            blob = torch.from_numpy(model.export_blob()).to(dev)
-            size = torch.tensor([blob.numel()], dtype=torch.int64, device=dev)
+            blob = torch.from_numpy(model.export_blob()).to(cdev)
+            size = torch.tensor([blob.numel()], dtype=torch.int64, device=cdev)
         else:
-            size = torch.zeros(1, dtype=torch.int64, device=dev)
+            size = torch.zeros(1, dtype=torch.int64, device=cdev)
         dist.broadcast(size, 0)
         if rank != 0:
-            blob = torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
+            blob = torch.empty(int(size.item()), dtype=torch.uint8, device=cdev)
         torch.cuda.synchronize(); t0 = time.time()
         dist.broadcast(blob, 0)                      # the one collective: weights over xGMI
         torch.cuda.synchronize(); bcast_ms = (time.time() - t0) * 1e3
         if rank != 0:
-            model = A.Model.from_blob(None, device_ptr=blob.data_ptr(), size=blob.numel())
+            if args.backend == "nccl":
+                model = A.Model.from_blob(None, device_ptr=blob.data_ptr(), size=blob.numel())
+            else:
+                model = A.Model.from_blob(blob.numpy())
         del blob
     load_s = time.time() - t_load0
     d = model.dims
@@ -138,7 +149,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     st = model.stats()
