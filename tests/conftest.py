@@ -8,6 +8,9 @@ import torch  # noqa: F401  -- first, so the process uses ONE HIP runtime (torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+TESTS_DIR = os.path.dirname(os.path.abspath(__file__))
+if TESTS_DIR not in sys.path:
+    sys.path.insert(0, TESTS_DIR)
 
 
 def pytest_configure(config):

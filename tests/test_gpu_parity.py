@@ -423,3 +423,33 @@ def test_2048_sessions_one_gpu(gpu_tiny):
         assert np.array_equal(lg1, sess[i].traced_logits()) and ev1 == evs[i]
     for s in sess:
         s.close()
+
+
+@pytest.mark.parametrize("which", ["tiny", "medium", "v0"])
+def test_networks_match_torch_fp32(which, request):
+    """The HIP kernels against a plain PyTorch fp32 statement of the network (tests/torch_ref.py: torch.nn.LSTM with
+    proj_size, conv2d, linear), independent of the oracle's ONNX interpreter.  Tolerance 1e-4 per network call."""
+    import april_asr_amd as A
+    from april_asr_amd import synth_model as SM
+    import torch_ref as TR
+    mdl = request.getfixturevalue({"tiny": "tiny_model", "medium": "medium_model", "v0": "v0_model"}[which])
+    dims = mdl["dims"]
+    w = mdl["weights"] if mdl["weights"] is not None else SM.make_weights(dims)      # v0 fixture: default seed, not kept in memory
+    gm = A.Model(mdl["path"])
+    d = gm.dims
+    rng = np.random.RandomState(21)
+    n = 3
+    x = rng.uniform(-16, 8, size=(n, d.seg, d.mel)).astype(np.float32)
+    h = rng.uniform(-0.5, 0.5, size=(n, d.n_layers, d.d_model)).astype(np.float32)
+    c = rng.uniform(-1, 1, size=(n, d.n_layers, d.hidden)).astype(np.float32)
+    eout, h2, c2 = gm.run_encoder(x, h, c)
+    ctx = rng.randint(0, d.vocab, size=(n, d.context)).astype(np.int64)
+    dout = gm.run_decoder(ctx)
+    e = rng.uniform(-2, 2, size=(n, d.joiner)).astype(np.float32)
+    lg = gm.run_joiner(e, dout)
+    for i in range(n):
+        e1, h1, c1 = TR.encoder(w, dims, x[i], h[i], c[i])
+        assert np.abs(eout[i] - e1).max() < 1e-4 and np.abs(h2[i] - h1).max() < 1e-4 and np.abs(c2[i] - c1).max() < 1e-4
+        assert np.abs(dout[i] - TR.decoder(w, dims, ctx[i])).max() < 1e-4
+        assert np.abs(lg[i] - TR.joiner(w, dims, e[i], dout[i])).max() < 1e-4
+    gm.close()
