@@ -11,7 +11,9 @@
  * /root/reference and not installed in this image, so this interpreter is a
  * restatement of the published ONNX operator definitions, anchored on the
  * reference's call sites (tensor names/shapes, src/april_session.c:121-128).
- * PARITY UNPINNED versus ORT itself.
+ * PARITY UNPINNED versus ORT itself.  Its operator semantics are cross-checked on a
+ * code-disjoint implementation: a PyTorch fp32 statement of the same architecture
+ * (tests/torch_ref.py, tests/test_oracle_vs_torch.py; agreement within 2e-5).
  *
  * Summation order: every dot product is a plain left-to-right float chain in
  * k (MatMul / Conv) or 8 interleaved partial chains (Gemm with transB=1), one
