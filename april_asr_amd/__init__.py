@@ -128,6 +128,23 @@ class Model:
         L.aprilx_model_dims(h, C.byref(m.dims))
         return m
 
+    def save_blob(self, path: str):
+        """Cache of the parsed + packed weights next to the model (aprilx_model_save_blob)."""
+        if self._L.aprilx_model_save_blob(self._handle, path.encode("utf-8")) != 0:
+            raise RuntimeError("blob save failed")
+
+    @classmethod
+    def load_blob(cls, path: str, init_gpu: bool = True):
+        L = _ffi.init() if init_gpu else _ffi.lib()
+        h = L.aprilx_model_load_blob(path.encode("utf-8"))
+        if not h:
+            raise Exception("Failed to load model blob")
+        m = cls.__new__(cls)
+        m._L = L; m._handle = h
+        m.dims = _ffi.AprilxDims()
+        L.aprilx_model_dims(h, C.byref(m.dims))
+        return m
+
     def run_encoder(self, x, h, c):
         d = self.dims
         x = np.ascontiguousarray(x, np.float32); n = x.shape[0]

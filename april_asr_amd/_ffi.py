@@ -47,7 +47,7 @@ EXPORTED_REFERENCE_SYMBOLS = [
 ]
 EXPORTED_ENGINE_SYMBOLS = [
     "aprilx_model_dims", "aprilx_model_token", "aprilx_model_blob_size", "aprilx_model_export_blob",
-    "aprilx_model_from_blob", "aprilx_feed_many", "aprilx_flush_many", "aprilx_session_drain",
+    "aprilx_model_from_blob", "aprilx_model_save_blob", "aprilx_model_load_blob", "aprilx_feed_many", "aprilx_flush_many", "aprilx_session_drain",
     "aprilx_run_encoder", "aprilx_run_decoder", "aprilx_run_joiner", "aprilx_run_fbank",
     "aprilx_session_trace_logits", "aprilx_session_chunks", "aprilx_model_stats", "aprilx_model_profile",
     "aprilx_greedy_create", "aprilx_greedy_step", "aprilx_greedy_finish", "aprilx_greedy_free", "aprilx_probe_file", "aprilx_model_load_host", "aprilx_model_fbank_tables", "aprilx_counting_handler",
@@ -83,6 +83,8 @@ def lib():
     L.aprilx_model_blob_size.argtypes = [vp]; L.aprilx_model_blob_size.restype = sz
     L.aprilx_model_export_blob.argtypes = [vp, vp, sz]; L.aprilx_model_export_blob.restype = C.c_int
     L.aprilx_model_from_blob.argtypes = [vp, sz, C.c_int]; L.aprilx_model_from_blob.restype = vp
+    L.aprilx_model_save_blob.argtypes = [vp, C.c_char_p]; L.aprilx_model_save_blob.restype = C.c_int
+    L.aprilx_model_load_blob.argtypes = [C.c_char_p]; L.aprilx_model_load_blob.restype = vp
     L.aprilx_feed_many.argtypes = [sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz)]; L.aprilx_feed_many.restype = None
     L.aprilx_flush_many.argtypes = [sz, C.POINTER(vp)]; L.aprilx_flush_many.restype = None
     L.aprilx_session_drain.argtypes = [vp]; L.aprilx_session_drain.restype = None

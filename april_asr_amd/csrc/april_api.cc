@@ -3,6 +3,7 @@
 // aprilx_* entry points (include/aprilx_engine.h).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <sstream>
 #include "../../include/april_api.h"
@@ -289,6 +290,27 @@ int aprilx_model_export_blob(AprilASRModel model, void *dst, size_t dst_size)
     HIP_CHECK(hipSetDevice(e->device()));
     HIP_CHECK(hipMemcpy((char *)dst + hd.weights_offset, e->weights_device(), hd.weight_floats * 4, hipMemcpyDeviceToHost));
     return 0;
+}
+
+int aprilx_model_save_blob(AprilASRModel model, const char *path)
+{
+    if (!model || !path) return -1;
+    std::vector<char> buf(aprilx_model_blob_size(model));
+    if (aprilx_model_export_blob(model, buf.data(), buf.size()) != 0) return -1;
+    FILE *f = fopen(path, "wb");
+    if (!f) { LOGE("aprilx: cannot write '%s'", path); return -1; }
+    const bool ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    return (fclose(f) == 0 && ok) ? 0 : -1;
+}
+
+AprilASRModel aprilx_model_load_blob(const char *path)
+{
+    FILE *f = path ? fopen(path, "rb") : nullptr;
+    if (!f) { LOGE("aprilx: cannot read '%s'", path ? path : "(null)"); return nullptr; }
+    std::vector<char> buf;
+    if (fseek(f, 0, SEEK_END) == 0) { const long n = ftell(f); if (n > 0) { buf.resize((size_t)n); rewind(f); if (fread(buf.data(), 1, buf.size(), f) != buf.size()) buf.clear(); } }
+    fclose(f);
+    return buf.empty() ? nullptr : aprilx_model_from_blob(buf.data(), buf.size(), 0);
 }
 
 AprilASRModel aprilx_model_from_blob(const void *blob, size_t size, int blob_is_device_ptr)

@@ -40,6 +40,11 @@ APRIL_EXPORT size_t aprilx_model_blob_size(AprilASRModel model);
 APRIL_EXPORT int aprilx_model_export_blob(AprilASRModel model, void *dst, size_t dst_size);
 /* `blob` may be a host pointer or a device pointer on the calling process's GPU */
 APRIL_EXPORT AprilASRModel aprilx_model_from_blob(const void *blob, size_t size, int blob_is_device_ptr);
+/* The same blob as a file next to the model: a cache of the parsed + MFMA-packed weights, so that later loads skip the
+ * ONNX parse and the packing (the reference re-parses the .april file at every
+ * aam_create_model, april_model.c:24-107).  save returns 0 on success; load returns NULL on any failure. */
+APRIL_EXPORT int aprilx_model_save_blob(AprilASRModel model, const char *path);
+APRIL_EXPORT AprilASRModel aprilx_model_load_blob(const char *path);
 
 /* ---- batched session driving ------------------------------------------------------------
  * aas_feed_pcm16 / aas_flush (reference april_api.h:183,186) for n sessions in ONE call, so

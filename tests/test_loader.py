@@ -123,6 +123,23 @@ def test_blob_roundtrip_host(built, tiny_model):
     a.close(); b.close()
 
 
+def test_blob_file_cache(built, tiny_model, tmp_path):
+    """save_blob / load_blob: the packed-weight cache file reproduces the model."""
+    a = A.Model.load_host_only(tiny_model["path"])
+    p = str(tmp_path / "tiny.apxblob")
+    a.save_blob(p)
+    b = A.Model.load_blob(p, init_gpu=False)
+    assert np.array_equal(a.export_blob(), b.export_blob())
+    assert b.get_name() == a.get_name() and [b.token(i) for i in range(b.dims.vocab)] == tiny_model["tokens"]
+    with open(p, "r+b") as f:
+        f.write(b"XXXXXXXX")                                   # bad magic
+    with pytest.raises(Exception):
+        A.Model.load_blob(p, init_gpu=False)
+    with pytest.raises(Exception):
+        A.Model.load_blob(str(tmp_path / "missing.apxblob"), init_gpu=False)
+    a.close(); b.close()
+
+
 def test_param_count_aprilv0_dims():
     """84.18 M parameters at aprilv0 dimensions (SURVEY.md Appendix C cross-check), from shapes alone."""
     d = SM.APRILV0_DIMS
