@@ -289,7 +289,7 @@ void Engine::collect_timing()
 }
 
 // ---------------------------------------------------------------- fbank
-void Engine::fbank(int n_frames, const FbankFrameDesc *desc, const std::pair<const int16_t *, size_t> *parts, size_t n_parts, size_t n_pcm)
+void Engine::fbank(int n_frames, const FbankFrameDesc *desc, const std::pair<const int16_t *, size_t> *parts, size_t n_parts, size_t n_pcm, HostPool *pool)
 {
     if (n_frames <= 0) return;
     HIP_CHECK(hipSetDevice(cfg_.device));
@@ -311,8 +311,16 @@ void Engine::fbank(int n_frames, const FbankFrameDesc *desc, const std::pair<con
     fb_flip_ ^= 1;
     HIP_CHECK(hipEventSynchronize(fb_done_[b]));          // the launch that used this pair two calls ago has consumed it
     memcpy(hs_desc_[b], desc, (size_t)n_frames * sizeof(FbankFrameDesc));
-    size_t off = 0;
-    for (size_t i = 0; i < n_parts; ++i) { memcpy(hs_pcm_[b] + off, parts[i].first, parts[i].second * sizeof(int16_t)); off += parts[i].second; }
+    if (pool && n_parts >= 256) {
+        part_off_.resize(n_parts);
+        size_t off = 0;
+        for (size_t i = 0; i < n_parts; ++i) { part_off_[i] = off; off += parts[i].second; }
+        int16_t *dst = hs_pcm_[b];
+        pool->run(n_parts, 64, [&](size_t i) { memcpy(dst + part_off_[i], parts[i].first, parts[i].second * sizeof(int16_t)); });
+    } else {
+        size_t off = 0;
+        for (size_t i = 0; i < n_parts; ++i) { memcpy(hs_pcm_[b] + off, parts[i].first, parts[i].second * sizeof(int16_t)); off += parts[i].second; }
+    }
     HIP_CHECK(hipMemcpyAsync(ds_desc_[b], hs_desc_[b], (size_t)n_frames * sizeof(FbankFrameDesc), hipMemcpyHostToDevice, stream_));
     if (n_pcm) HIP_CHECK(hipMemcpyAsync(ds_pcm_[b], hs_pcm_[b], n_pcm * sizeof(int16_t), hipMemcpyHostToDevice, stream_));
     FbankArgs a;

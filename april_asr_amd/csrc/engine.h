@@ -21,6 +21,7 @@
 #include <vector>
 #include "fbank_tables.h"
 #include "kernels.h"
+#include "host_pool.h"
 #include "model_loader.h"
 
 namespace aprilx {
@@ -75,7 +76,8 @@ public:
 
     // ---- batched hot path; host arrays are copied to pinned staging, all launches go to stream()
     // pcm arrives as `n_parts` windows that are gathered straight into pinned staging (total n_pcm samples)
-    void fbank(int n_frames, const FbankFrameDesc *desc, const std::pair<const int16_t *, size_t> *parts, size_t n_parts, size_t n_pcm);
+    void fbank(int n_frames, const FbankFrameDesc *desc, const std::pair<const int16_t *, size_t> *parts, size_t n_parts, size_t n_pcm,
+               HostPool *pool = nullptr);
     void encode(int n, const int *slots, const int *ring_tails);
     void decode(int n, const int *slots, const int *ctx /*[n][context]*/);
     // runs the joiner for n sessions, waits, returns results; logits_out optional [n][vocab] (host)
@@ -127,6 +129,7 @@ private:
     int16_t *hs_pcm_[2] = {nullptr, nullptr}, *ds_pcm_[2] = {nullptr, nullptr}; size_t pcm_cap_ = 0;
     int fb_flip_ = 0;
     hipEvent_t fb_done_[2] = {nullptr, nullptr};
+    std::vector<size_t> part_off_;             // staging offsets of the PCM windows of one fbank call
     hipEvent_t dec_done_ = nullptr;            // last decoder launch has consumed its staged indices
     // fbank tables on device
     FbankTables ft_;

@@ -198,7 +198,14 @@ Model::~Model()
 // ---------------------------------------------------------------- scheduler
 static constexpr size_t kAsyncRingSamples = 48000;     // reference src/audio_provider.c:31 (3 s at 16 kHz)
 
-Scheduler::Scheduler(Model *m, Engine *e) : model_(m), eng_(e) { thread_ = std::thread([this] { loop(); }); }
+static int host_helpers()
+{
+    const char *v = getenv("APRIL_HOST_THREADS");
+    const int n = v && *v ? atoi(v) : 3;
+    return n < 0 ? 0 : (n > 32 ? 32 : n);
+}
+
+Scheduler::Scheduler(Model *m, Engine *e) : model_(m), eng_(e), pool_(host_helpers()) { thread_ = std::thread([this] { loop(); }); }
 
 Scheduler::~Scheduler()
 {
@@ -321,7 +328,7 @@ void Scheduler::loop()
         }
         // lent PCM: the caller is blocked until `completed` moves, so its buffer is read here, outside the lock (a lent
         // buffer is only accepted when nothing is queued in front of it, so the order of samples is kept)
-        for (auto &l : lent) std::get<0>(l)->fb.fifo.insert(std::get<0>(l)->fb.fifo.end(), std::get<1>(l), std::get<1>(l) + std::get<2>(l));
+        pool_.run(lent.size(), 64, [&](size_t i) { auto &l = lent[i]; std::get<0>(l)->fb.fifo.insert(std::get<0>(l)->fb.fifo.end(), std::get<1>(l), std::get<1>(l) + std::get<2>(l)); });
         lent.clear();
         stats_.host_ms[0] += lap();
         process(work);
@@ -407,8 +414,8 @@ void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
     }
     stats_.host_ms[1] += lap();
     if (!desc_.empty()) {
-        eng_->fbank((int)desc_.size(), desc_.data(), pcm_parts_.data(), pcm_parts_.size(), staged);
-        for (Session *s : work) if (s->compact_pending) { s->fb.compact(); s->compact_pending = false; }
+        eng_->fbank((int)desc_.size(), desc_.data(), pcm_parts_.data(), pcm_parts_.size(), staged, &pool_);
+        pool_.run(work.size(), 64, [&](size_t i) { Session *s = work[i]; if (s->compact_pending) { s->fb.compact(); s->compact_pending = false; } });
         stats_.frames += desc_.size();
         stats_.host_ms[2] += lap();
     }

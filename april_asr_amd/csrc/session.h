@@ -147,6 +147,7 @@ private:
 
     Model *model_;
     Engine *eng_;
+    HostPool pool_;                                // helpers for the per-session host copies (APRIL_HOST_THREADS, default 3)
     std::mutex mu_;
     std::condition_variable cv_work_, cv_done_;
     std::vector<Session *> sessions_;
