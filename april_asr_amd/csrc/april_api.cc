@@ -384,18 +384,19 @@ void aprilx_session_drain(AprilASRSession session)
 int aprilx_run_encoder(AprilASRModel model, int n, const float *x, const float *h, const float *c, float *eout, float *h2, float *c2)
 {
     if (!model || n <= 0 || model->m.engines.empty()) return -1;
+    if (n > model->m.engines[0]->max_batch()) { LOGE("aprilx_run_encoder: n = %d exceeds APRIL_MAX_BATCH = %d", n, model->m.engines[0]->max_batch()); return -1; }
     model->m.engines[0]->debug_encoder(n, x, h, c, eout, h2, c2);
     return 0;
 }
 int aprilx_run_decoder(AprilASRModel model, int n, const int64_t *context, float *dout)
 {
-    if (!model || n <= 0 || model->m.engines.empty()) return -1;
+    if (!model || n <= 0 || model->m.engines.empty() || n > model->m.engines[0]->max_slots()) return -1;
     model->m.engines[0]->debug_decoder(n, context, dout);
     return 0;
 }
 int aprilx_run_joiner(AprilASRModel model, int n, const float *eout, const float *dout, float *logits)
 {
-    if (!model || n <= 0 || model->m.engines.empty()) return -1;
+    if (!model || n <= 0 || model->m.engines.empty() || n > model->m.engines[0]->max_slots()) return -1;
     model->m.engines[0]->debug_joiner(n, eout, dout, logits);
     return 0;
 }

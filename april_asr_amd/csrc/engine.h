@@ -63,6 +63,7 @@ public:
 
     int device() const { return cfg_.device; }
     int max_batch() const { return cfg_.max_batch; }
+    int max_slots() const { return cfg_.max_slots; }
     int ring_frames() const { return ring_frames_; }
     const NetDims &dims() const { return L_.dims; }
     hipStream_t stream() const { return stream_; }

@@ -73,6 +73,8 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     cdev = dev if args.backend == "nccl" else torch.device("cpu")      # where collective tensors live
+    if args.precision == "f16":
+        os.environ["APRIL_PRECISION"] = "f16"       # read by the library when a model is created
 
     def barrier():
         torch.cuda.synchronize()
