@@ -241,6 +241,30 @@ def main():
                          "%d chunks, no flush; ONNXRuntime (the reference's backend) is not installed here" % (sample_s, osess.chunks()),
                "rtf": round((b - a) / sample_s, 4), "host_cpus": os.cpu_count()}
         osess.close(); om.close()
+        # the same port on many cores at once (one process, one session, one thread each -- how the reference would be
+        # scaled on a CPU host: its ORT sessions run intra=inter=1, april_model.c:54-55)
+        import subprocess
+        import sys
+        k = max(1, min(int(os.environ.get("BENCH_CPU_PROCS", "32")), (os.cpu_count() or 1)))
+        start = os.path.join(tempfile.gettempdir(), "bench_cpu_start_%d" % os.getpid())
+        if os.path.exists(start):
+            os.remove(start)
+        worker = os.path.join(ROOT, "oracle", "cpu_worker.py")
+        procs = [subprocess.Popen([sys.executable, worker, path, "6", str(12345 + i), start], stdout=subprocess.PIPE, text=True) for i in range(k)]
+        try:
+            for pr in procs:
+                assert pr.stdout.readline().startswith("ready")
+            open(start, "w").close()
+            times = [float(pr.stdout.readline().split()[1]) for pr in procs]
+            cpu["all_cores"] = {"value": round(k * 6.0 / max(times), 3), "unit": "audio_seconds_per_second", "cores": k,
+                                "sample": "%d processes x (1 session, 1 thread, 6 s of audio) started together; slowest %.2f s, fastest %.2f s" % (k, max(times), min(times))}
+        except Exception as e:                          # the single-core figure above stands on its own
+            cpu["all_cores"] = {"error": repr(e)}
+        finally:
+            for pr in procs:
+                pr.kill() if pr.poll() is None else None
+            if os.path.exists(start):
+                os.remove(start)
 
     if rank == 0:
         max_ok = None
