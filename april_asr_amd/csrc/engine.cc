@@ -248,6 +248,7 @@ void Engine::free_slot(int slot)
     // Two strided 2-D memsets cover all layers; they are stream-ordered ahead of any later use of the slot.
     // Teardown-tolerant: sessions may be freed while the process is exiting and the HIP runtime is already gone.
     if (hipSetDevice(cfg_.device) == hipSuccess) {
+        std::lock_guard<std::mutex> cg(capture_mu_);           // never enqueue into a stream that is being captured (encode())
         const NetDims &d = L_.dims;
         const size_t S = (size_t)cfg_.max_slots;
         (void)hipMemset2DAsync(h_ + (size_t)slot * d.d_model, S * d.d_model * 4, 0, (size_t)d.d_model * 4, (size_t)d.n_layers, stream_);
@@ -420,6 +421,7 @@ void Engine::encode(int n, const int *slots, const int *ring_tails)
                 if (enc_graphs_.size() >= 128) { for (auto &g : enc_graphs_) (void)hipGraphExecDestroy(g.second); enc_graphs_.clear(); }
                 hipGraph_t graph = nullptr;
                 hipGraphExec_t exec = nullptr;
+                std::lock_guard<std::mutex> cg(capture_mu_);       // aas_free on another thread zeroes slots through this stream
                 HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
                 HIP_CHECK(hipMemcpyAsync(ds_enc_, hs_enc_, (size_t)m * 4, hipMemcpyHostToDevice, stream_));
                 HIP_CHECK(hipMemcpyAsync(ds_enc_ + MB, hs_enc_ + MB, (size_t)m * 4, hipMemcpyHostToDevice, stream_));

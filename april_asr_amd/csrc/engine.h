@@ -140,6 +140,7 @@ private:
     std::vector<int> free_;
     int live_ = 0;
     std::mutex slot_mu_;
+    std::mutex capture_mu_;                    // held while stream_ is being captured into a graph, and by other threads' enqueues
     // gemm split factors (fixed per shape => batch-invariant numerics)
     int kz_embed_ = 1, kz_hr_ = 1, kz_ff2_ = 1, kz_proj_ = 1, kz_out_ = 1;
     int ws_mstride_ = 0;

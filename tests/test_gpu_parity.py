@@ -453,3 +453,51 @@ def test_networks_match_torch_fp32(which, request):
         assert np.abs(dout[i] - TR.decoder(w, dims, ctx[i])).max() < 1e-4
         assert np.abs(lg[i] - TR.joiner(w, dims, e[i], dout[i])).max() < 1e-4
     gm.close()
+
+
+def test_session_churn_while_stepping(gpu_tiny):
+    """Sessions are created, fed and freed on one thread while another thread steps a group whose size keeps changing
+    (every new batch size captures a new hipGraph on the engine's stream; aas_free zeroes slots through the same stream).
+    The watched session's transcript and logits must equal the same session run alone."""
+    import threading
+    import april_asr_amd as A
+    from oracle import orc_py as O
+    pcm = O.lcg_pcm16_fast(16000 * 2, seed=4242)
+    want_ev, want_lg, _ = run_gpu(gpu_tiny, pcm, 1600)
+    stop = threading.Event()
+    errors = []
+
+    def churn():
+        rng = np.random.RandomState(5)
+        try:
+            while not stop.is_set():
+                ss = [A.Session(gpu_tiny, lambda t, toks: None) for _ in range(int(rng.randint(1, 6)))]
+                for s in ss:
+                    s.feed_pcm16(O.lcg_pcm16_fast(1600 * int(rng.randint(1, 4)), seed=int(rng.randint(1 << 20))))
+                for s in ss:
+                    s.close()
+        except Exception as e:                      # pragma: no cover
+            errors.append(e)
+
+    th = threading.Thread(target=churn)
+    th.start()
+    try:
+        ev = []
+        watched = A.Session(gpu_tiny, lambda t, toks: ev.append((t, toks)), raw_events=True)
+        watched.trace_logits(400)
+        extras = []
+        for o in range(0, pcm.size, 1600):
+            if (o // 1600) % 3 == 0:                 # the group changes size every few feeds
+                extras.append(A.Session(gpu_tiny, lambda t, toks: None))
+            if (o // 1600) % 5 == 4 and extras:
+                extras.pop().close()
+            grp = A.SessionGroup([watched] + extras)
+            grp.feed([pcm[o:o + 1600]] + [O.lcg_pcm16_fast(1600, seed=o + k) for k in range(len(extras))])
+        watched.flush()
+    finally:
+        stop.set(); th.join()
+    assert not errors
+    assert ev == want_ev and np.array_equal(watched.traced_logits(), want_lg)
+    watched.close()
+    for s in extras:
+        s.close()
