@@ -70,24 +70,29 @@ typedef struct { const uint8_t *p, *end; } PB;
 static uint64_t pb_varint(PB *b)
 {
     uint64_t v = 0; int s = 0;
-    while (b->p < b->end) { uint8_t c = *b->p++; v |= (uint64_t)(c & 0x7f) << s; if (!(c & 0x80)) break; s += 7; }
+    while (b->p < b->end) { uint8_t c = *b->p++; if (s < 64) v |= (uint64_t)(c & 0x7f) << s; if (!(c & 0x80)) break; s += 7; }
     return v;
 }
-/* returns field number, sets wire type; for LEN fields sets sub */
+/* returns field number (0 at the end or on malformed input), sets wire type; for LEN fields sets sub, otherwise sub is
+ * empty.  Never reads or points beyond b->end: model files are untrusted input (tests/test_loader.py fuzzes them). */
 static int pb_next(PB *b, int *wt, PB *sub, uint64_t *v)
 {
+    sub->p = sub->end = b->end;
+    *v = 0;
     if (b->p >= b->end) return 0;
     uint64_t key = pb_varint(b);
     *wt = (int)(key & 7);
     int field = (int)(key >> 3);
+    const size_t left = (size_t)(b->end - b->p);
     switch (*wt) {
     case 0: *v = pb_varint(b); break;
-    case 1: memcpy(v, b->p, 8); b->p += 8; break;
-    case 5: { uint32_t t; memcpy(&t, b->p, 4); *v = t; b->p += 4; break; }
-    case 2: { uint64_t len = pb_varint(b); sub->p = b->p; sub->end = b->p + len; b->p += len; break; }
+    case 1: if (left < 8) { b->p = b->end; return 0; } memcpy(v, b->p, 8); b->p += 8; break;
+    case 5: { if (left < 4) { b->p = b->end; return 0; } uint32_t t; memcpy(&t, b->p, 4); *v = t; b->p += 4; break; }
+    case 2: { uint64_t len = pb_varint(b); if (len > (uint64_t)(b->end - b->p)) { b->p = b->end; return 0; }
+              sub->p = b->p; sub->end = b->p + len; b->p += len; break; }
     default: b->p = b->end; return 0;
     }
-    return field;
+    return field > 0 ? field : 0;
 }
 static char *pb_str(const PB *s) { size_t n = (size_t)(s->end - s->p); char *r = malloc(n + 1); memcpy(r, s->p, n); r[n] = 0; return r; }
 
@@ -128,6 +133,16 @@ static int parse_tensor(PB b, Ten *t, char **name_out)
         else if (f == 9) { raw = sub; have_raw = 1; }
     }
     if (dtype != DT_F32 && dtype != DT_I64 && dtype != DT_I32) { free(fdata); free(idata); FAIL("tensor dtype %d unsupported", dtype); }
+    {   /* the element count must be what the payload holds BEFORE anything is allocated from it */
+        const size_t esz = dtype == DT_I64 ? 8 : 4;
+        const size_t have = have_raw ? (size_t)(raw.end - raw.p) / esz : (dtype == DT_F32 ? nf : ni);
+        size_t want = 1;
+        for (int i = 0; i < rank; ++i) {
+            if (dims[i] < 0 || (dims[i] > 0 && want > ((size_t)1 << 40) / (size_t)dims[i])) { free(fdata); free(idata); FAIL("tensor dims"); }
+            want *= (size_t)dims[i];
+        }
+        if (want != have || (have_raw && (size_t)(raw.end - raw.p) != want * esz)) { free(fdata); free(idata); FAIL("tensor payload size"); }
+    }
     ten_alloc(t, dtype == DT_F32 ? DT_F32 : DT_I64, rank, dims);
     if (dtype == DT_F32) {
         if (have_raw) { if ((size_t)(raw.end - raw.p) != t->n * 4) FAIL("raw size"); memcpy(t->data, raw.p, t->n * 4); }

@@ -174,3 +174,17 @@ def test_unsupported_graphs_are_rejected(built, tmp_path, breakage, capfd):
     with pytest.raises(Exception):
         A.Model.load_host_only(str(p))
     assert "failed to load" in capfd.readouterr().err
+
+
+def test_corrupted_models_never_crash(built, tiny_model, tmp_path):
+    """Model files are untrusted input: 400 corrupted copies (byte flips, header flips, truncations, 0xff runs) must be
+    either rejected or loaded -- never crash the process (product loader and oracle loader, in a subprocess)."""
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_loader_worker.py")
+    for seed in (1, 2):
+        out = subprocess.run([sys.executable, worker, tiny_model["path"], str(tmp_path / "fuzz.april"), str(seed), "200"],
+                             capture_output=True, text=True, errors="replace", timeout=600)
+        assert out.returncode == 0, "loader crashed (seed %d): %s" % (seed, (out.stdout + out.stderr)[-2000:])
+        assert "accepted product=" in out.stdout
