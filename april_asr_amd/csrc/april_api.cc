@@ -107,6 +107,13 @@ bool parse_meta(const char *p, size_t n, Model &m)
     NetDims d = r.val<NetDims>();
     const bool hb = r.val<uint8_t>() != 0;
     if (r.bad || d.n_layers <= 0 || d.n_layers > 256) return false;
+    for (size_t t = 0; t < (size_t)P.token_count; ++t) P.tokens[(t + 1) * P.token_stride - 1] = 0;    // token text is NUL-terminated within its slot
+    auto in = [](long v, long lo, long hi) { return v >= lo && v <= hi; };
+    if (!in(d.d_model, 16, 1 << 16) || !in(d.hidden, 16, 1 << 16) || !in(d.ffn, 16, 1 << 18) || !in(d.joiner, 16, 1 << 16) ||
+        !in(d.vocab, 2, 1 << 20) || d.vocab != P.token_count || !in(d.mel, 8, 1024) || !in(d.seg, 3, 64) || d.context != 2 ||
+        !in(d.dec_groups, 1, d.d_model) || d.d_model % d.dec_groups != 0 || !in(d.f_out, 1, 4096) || !in(d.embed_in, 16, 1 << 22) ||
+        !in(d.conv_ch[0], 1, 4096) || !in(d.conv_ch[1], 1, 4096) || !in(d.conv_ch[2], 1, 4096))
+        return false;
     plan_layout(d, hb, m.layout);
     m.layout.embed_eps = r.val<float>();
     m.layout.norm_eps.resize((size_t)d.n_layers);
@@ -324,7 +331,8 @@ AprilASRModel aprilx_model_from_blob(const void *blob, size_t size, int blob_is_
     if (size < sizeof hd) return nullptr;
     if (blob_is_device_ptr) { HIP_CHECK(hipSetDevice(g_devices[0])); HIP_CHECK(hipMemcpy(&hd, blob, sizeof hd, hipMemcpyDeviceToHost)); }
     else memcpy(&hd, blob, sizeof hd);
-    if (memcmp(hd.magic, "APXBLOB1", 8) != 0 || hd.weights_offset + hd.weight_floats * 4 > size || sizeof hd + hd.meta_bytes > hd.weights_offset) { LOGE("aprilx: bad blob"); return nullptr; }
+    if (memcmp(hd.magic, "APXBLOB1", 8) != 0 || hd.weights_offset > size || hd.weight_floats > (size - hd.weights_offset) / 4 ||
+        hd.meta_bytes > size || sizeof hd + hd.meta_bytes > hd.weights_offset) { LOGE("aprilx: bad blob"); return nullptr; }
     std::string meta((size_t)hd.meta_bytes, '\0');
     if (blob_is_device_ptr) HIP_CHECK(hipMemcpy(&meta[0], (const char *)blob + sizeof hd, meta.size(), hipMemcpyDeviceToHost));
     else memcpy(&meta[0], (const char *)blob + sizeof hd, meta.size());
