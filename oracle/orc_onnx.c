@@ -179,10 +179,10 @@ static int parse_attr(PB b, Attr *a)
     int wt, f; PB sub; uint64_t v;
     int64_t *ints = NULL; int n = 0, cap = 0;
     while ((f = pb_next(&b, &wt, &sub, &v))) {
-        if (f == 1) a->name = pb_str(&sub);
+        if (f == 1) { free(a->name); a->name = pb_str(&sub); }
         else if (f == 2) { uint32_t u = (uint32_t)v; memcpy(&a->f, &u, 4); }
         else if (f == 3) a->i = (int64_t)v;
-        else if (f == 5) { if (parse_tensor(sub, &a->t, NULL)) return -1; a->has_t = 1; }
+        else if (f == 5) { if (a->has_t) { free(a->t.data); a->has_t = 0; } if (parse_tensor(sub, &a->t, NULL)) { free(a->name); free(ints); a->name = NULL; return -1; } a->has_t = 1; }
         else if (f == 8) {
             if (wt == 2) { PB q = sub; while (q.p < q.end) { if (n == cap) { cap = cap ? cap * 2 : 8; ints = realloc(ints, 8 * (size_t)cap); } ints[n++] = (int64_t)pb_varint(&q); } }
             else { if (n == cap) { cap = cap ? cap * 2 : 8; ints = realloc(ints, 8 * (size_t)cap); } ints[n++] = (int64_t)v; }
@@ -200,9 +200,9 @@ static int parse_node(OrcGraph *g, PB b)
     int wt, f; PB sub; uint64_t v;
     int cap_a = 0;
     while ((f = pb_next(&b, &wt, &sub, &v))) {
-        if (f == 1) { char *s = pb_str(&sub); if (nd->n_in >= 64) FAIL("too many inputs"); nd->in[nd->n_in++] = s[0] ? val_id(g, s) : -1; free(s); }
-        else if (f == 2) { char *s = pb_str(&sub); if (nd->n_out >= 8) FAIL("too many outputs"); nd->out[nd->n_out++] = val_id(g, s); free(s); }
-        else if (f == 4) nd->op = pb_str(&sub);
+        if (f == 1) { char *s = pb_str(&sub); if (nd->n_in >= 64) { free(s); FAIL("too many inputs"); } nd->in[nd->n_in++] = s[0] ? val_id(g, s) : -1; free(s); }
+        else if (f == 2) { char *s = pb_str(&sub); if (nd->n_out >= 8) { free(s); FAIL("too many outputs"); } nd->out[nd->n_out++] = val_id(g, s); free(s); }
+        else if (f == 4) { free(nd->op); nd->op = pb_str(&sub); }
         else if (f == 5) {
             if (nd->n_attrs == cap_a) { cap_a = cap_a ? cap_a * 2 : 4; nd->attrs = realloc(nd->attrs, sizeof(Attr) * (size_t)cap_a); }
             if (parse_attr(sub, &nd->attrs[nd->n_attrs])) return -1;
@@ -262,7 +262,7 @@ OrcGraph *orc_graph_parse(const uint8_t *bytes, size_t n)
     while ((f = pb_next(&b, &wt, &sub, &v))) {
         if (f == 5) {
             Ten t; char *nm = NULL;
-            if (parse_tensor(sub, &t, &nm)) { orc_graph_free(g); return NULL; }
+            if (parse_tensor(sub, &t, &nm)) { free(nm); orc_graph_free(g); return NULL; }
             int id = val_id(g, nm ? nm : "");
             g->val[id] = t;
             free(nm);
