@@ -246,6 +246,12 @@ class Session:
     def chunks(self) -> int:
         return int(self._L.aprilx_session_chunks(self._handle))
 
+    def contexts(self):
+        """(host context [2], device search state [ctx0, ctx1, last token, last emission ms]) -- derived independently, must agree"""
+        h = np.zeros(2, np.int32); d = np.zeros(4, np.int32)
+        self._L.aprilx_session_context(self._handle, h.ctypes.data, d.ctypes.data)
+        return h, d
+
     def trace_logits(self, max_rows: int):
         self._trace = np.zeros((max_rows, self.model.dims.vocab), np.float32)
         self._trace_used = C.c_size_t(0)

@@ -37,7 +37,8 @@ class AprilxDims(C.Structure):
 
 class AprilxStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("ticks", "steps", "chunks", "rounds", "frames", "max_batch_seen")] + \
-               [("kernel_ms", C.c_double * 6), ("kernel_launches", C.c_uint64 * 6), ("host_ms", C.c_double * 8)]
+               [("kernel_ms", C.c_double * 6), ("kernel_launches", C.c_uint64 * 6), ("host_ms", C.c_double * 8),
+                ("flights", C.c_uint64), ("replay_mismatch", C.c_uint64), ("kernels_per_step", C.c_uint64)]
 
 
 EXPORTED_REFERENCE_SYMBOLS = [
@@ -49,7 +50,7 @@ EXPORTED_ENGINE_SYMBOLS = [
     "aprilx_model_dims", "aprilx_model_token", "aprilx_model_blob_size", "aprilx_model_export_blob",
     "aprilx_model_from_blob", "aprilx_model_save_blob", "aprilx_model_load_blob", "aprilx_feed_many", "aprilx_flush_many", "aprilx_session_drain",
     "aprilx_run_encoder", "aprilx_run_decoder", "aprilx_run_joiner", "aprilx_run_fbank",
-    "aprilx_session_trace_logits", "aprilx_session_chunks", "aprilx_model_stats", "aprilx_model_profile",
+    "aprilx_session_trace_logits", "aprilx_session_chunks", "aprilx_session_context", "aprilx_model_stats", "aprilx_model_profile",
     "aprilx_greedy_create", "aprilx_greedy_step", "aprilx_greedy_finish", "aprilx_greedy_free", "aprilx_probe_file", "aprilx_model_load_host", "aprilx_model_fbank_tables", "aprilx_counting_handler",
 ]
 
@@ -94,6 +95,7 @@ def lib():
     L.aprilx_run_fbank.argtypes = [vp, C.c_int, vp, vp]; L.aprilx_run_fbank.restype = C.c_int
     L.aprilx_session_trace_logits.argtypes = [vp, vp, sz, C.POINTER(sz)]; L.aprilx_session_trace_logits.restype = None
     L.aprilx_session_chunks.argtypes = [vp]; L.aprilx_session_chunks.restype = C.c_uint64
+    L.aprilx_session_context.argtypes = [vp, vp, vp]; L.aprilx_session_context.restype = None
     L.aprilx_model_stats.argtypes = [vp, C.c_int, C.POINTER(AprilxStats)]; L.aprilx_model_stats.restype = None
     L.aprilx_model_profile.argtypes = [vp, C.c_int]; L.aprilx_model_profile.restype = None
     L.aprilx_greedy_create.argtypes = [vp, HANDLER, vp]; L.aprilx_greedy_create.restype = vp

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <sstream>
+#include <cmath>
 #include "../../include/april_api.h"
 #include "../../include/aprilx_engine.h"
 #include "common.h"
@@ -53,7 +54,7 @@ bool build_runtime(Model &m, const float *blob_host, const float *blob_device)
     for (int dev : g_devices) {
         cfg.device = dev;
         const bool same_dev_blob = blob_device != nullptr;
-        Engine *e = new Engine(cfg, m.layout, blob_host, same_dev_blob ? blob_device : nullptr, P, m.ftab);
+        Engine *e = new Engine(cfg, m.layout, blob_host, same_dev_blob ? blob_device : nullptr, P, m.ftab, m.tok_class);
         m.engines.push_back(e);
         m.scheds.push_back(new Scheduler(&m, e));
     }
@@ -101,7 +102,8 @@ bool parse_meta(const char *p, size_t n, Model &m)
     P.frame_shift_ms = ints[5]; P.frame_length_ms = ints[6]; P.round_pow2 = ints[7]; P.mel_low = ints[8]; P.mel_high = ints[9];
     P.snip_edges = ints[10]; P.token_count = ints[11]; P.blank_id = ints[12];
     P.token_stride = (size_t)r.val<uint64_t>();
-    if (r.bad || P.token_count <= 0 || P.token_count > 16384 || P.token_stride == 0 || P.token_stride > 4096) return false;
+    std::string perr;
+    if (r.bad || !validate_params(P, perr) || P.token_stride == 0 || P.token_stride > 4096) { if (!perr.empty()) LOGE("aprilx: blob %s", perr.c_str()); return false; }
     P.tokens.resize((size_t)P.token_count * P.token_stride);
     r.get(P.tokens.data(), P.tokens.size());
     NetDims d = r.val<NetDims>();
@@ -112,14 +114,20 @@ bool parse_meta(const char *p, size_t n, Model &m)
     if (!in(d.d_model, 16, 1 << 16) || !in(d.hidden, 16, 1 << 16) || !in(d.ffn, 16, 1 << 18) || !in(d.joiner, 16, 1 << 16) ||
         !in(d.vocab, 2, 1 << 20) || d.vocab != P.token_count || !in(d.mel, 8, 1024) || !in(d.seg, 3, 64) || d.context != 2 ||
         !in(d.dec_groups, 1, d.d_model) || d.d_model % d.dec_groups != 0 || !in(d.f_out, 1, 4096) || !in(d.embed_in, 16, 1 << 22) ||
-        !in(d.conv_ch[0], 1, 4096) || !in(d.conv_ch[1], 1, 4096) || !in(d.conv_ch[2], 1, 4096))
+        !in(d.conv_ch[0], 1, 4096) || !in(d.conv_ch[1], 1, 4096) || !in(d.conv_ch[2], 1, 4096) ||
+        d.seg != P.segment_size || d.mel != P.mel_features ||                      // the network input is the PARAMS chunk (april_model.c:65-72)
+        !in(d.conv_stride[0], 1, 8) || !in(d.conv_stride[1], 1, 8) || !in(d.conv_stride[2], 1, 8) ||
+        d.embed_in != d.conv_ch[2] * d.f_out)
         return false;
     plan_layout(d, hb, m.layout);
     m.layout.embed_eps = r.val<float>();
     m.layout.norm_eps.resize((size_t)d.n_layers);
     r.get(m.layout.norm_eps.data(), (size_t)d.n_layers * 4);
     m.host.dims = d;
-    return !r.bad;
+    auto eps_ok = [](float e) { return std::isfinite(e) && e > 0.0f; };
+    if (r.bad || !eps_ok(m.layout.embed_eps)) return false;
+    for (float e : m.layout.norm_eps) if (!eps_ok(e)) return false;
+    return true;
 }
 
 void free_host_weights(HostModel &h)
@@ -235,12 +243,22 @@ void aas_flush(AprilASRSession session)
     if (s->sync_mode) s->sched->deliver_sync_events(s);
 }
 
-float aas_realtime_get_speedup(AprilASRSession session) { (void)session; return 1.0f; }
+// reference src/april_session.c:95-97: the EMA of (processing time x 1.1 / audio time) for ASYNC_RT sessions, 1.0 otherwise.
+// The reference also feeds it to sonic to compress audio when it exceeds 1; this engine never time-compresses (it batches
+// instead), so the value only reports how close the session's GPU is to falling behind real time.
+float aas_realtime_get_speedup(AprilASRSession session)
+{
+    Session *s = &session->s;
+    if (!s->realtime_flag) return 1.0f;
+    s->sched->wait_idle(s);
+    return (float)s->speed_needed;
+}
 
 void aas_free(AprilASRSession session)
 {
     if (!session) return;
     Session *s = &session->s;
+    if (s->sched->on_loop_thread()) { s->sched->detach(s); return; }      // refused with an error message (see Scheduler::detach)
     s->sched->detach(s);
     s->eng->free_slot(s->slot);
     delete session;
@@ -424,6 +442,18 @@ void aprilx_session_trace_logits(AprilASRSession session, float *buf, size_t cap
 
 uint64_t aprilx_session_chunks(AprilASRSession session) { return session->s.chunks; }
 
+void aprilx_session_context(AprilASRSession session, int32_t *host_ctx, int32_t *device_state)
+{
+    Session *s = &session->s;
+    s->sched->wait_idle(s);
+    if (host_ctx) { host_ctx[0] = s->greedy.ctx[0]; host_ctx[1] = s->greedy.ctx[1]; }
+    if (device_state) {
+        GreedyState g;
+        s->eng->read_greedy_state(s->slot, &g);
+        device_state[0] = g.ctx0; device_state[1] = g.ctx1; device_state[2] = g.last_tok; device_state[3] = (int32_t)g.last_emit_ms;
+    }
+}
+
 void aprilx_model_stats(AprilASRModel model, int device_index, AprilxStats *out)
 {
     memset(out, 0, sizeof *out);
@@ -431,7 +461,9 @@ void aprilx_model_stats(AprilASRModel model, int device_index, AprilxStats *out)
     const SchedStats st = model->m.scheds[(size_t)device_index]->stats();
     out->ticks = st.ticks; out->steps = st.steps; out->chunks = st.chunks; out->rounds = st.rounds; out->frames = st.frames; out->max_batch_seen = st.max_batch_seen;
     for (int i = 0; i < 8; ++i) out->host_ms[i] = st.host_ms[i];
+    out->flights = st.flights; out->replay_mismatch = st.replay_mismatch;
     Engine *e = model->m.engines[(size_t)device_index];
+    out->kernels_per_step = (uint64_t)e->kernels_per_step();
     for (int i = 0; i < 6; ++i) { out->kernel_ms[i] = e->timing(i).ms; out->kernel_launches[i] = (uint64_t)e->timing(i).launches; }
 }
 

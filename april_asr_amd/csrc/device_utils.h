@@ -2,6 +2,7 @@
 // here exactly once: the fused (small-batch) and unfused paths must produce the same bits.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "kernels.h"
 
 namespace aprilx {
 
@@ -42,6 +43,29 @@ __device__ __forceinline__ f32x4 tree_sum4(const float *ws, int parts, int m_str
     if (parts == 2) return v[0] + v[1];
     if (parts == 4) return (v[0] + v[1]) + (v[2] + v[3]);
     return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+}
+
+// BasicNorm scale of one row, (mean(y^2) + eps)^-1/2, from the row's sum-of-squares partials (one per SSQ_COLS columns,
+// written by EPI_RESID_SSQ / ROW_RESID_SSQ): partials added in column order, v_rsq_f32 (1 ulp).  EVERY consumer of a
+// normalised row calls this one function, so they all see the same scale.
+__device__ __forceinline__ float row_scale(const RowScale &rs, int row)
+{
+    const float *p = rs.ssq + (size_t)row * rs.groups;
+    float t = p[0];
+    for (int j = 1; j < rs.groups; ++j) t += p[j];
+    return __builtin_amdgcn_rsqf(t * rs.inv_n + rs.eps);
+}
+
+// sum of squares of a 4-column quad, then over the 8 consecutive lanes that own one SSQ_COLS-wide granule of a row
+// (lane groups are 8-aligned; every lane of the wave must call this).  Order: ((q0+q1)+(q2+q3))+((q4+q5)+(q6+q7)) with
+// q = (v0^2 + v1^2) + (v2^2 + v3^2) -- the same in the GEMM epilogue and in the row kernel.
+__device__ __forceinline__ float granule_ssq(const f32x4 &y)
+{
+    float q = (y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w);
+    q += __shfl_xor(q, 1);
+    q += __shfl_xor(q, 2);
+    q += __shfl_xor(q, 4);
+    return q;
 }
 
 // sigma and tanh on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each); absolute error ~1e-7, far inside

@@ -14,7 +14,7 @@ void plan_layout(const NetDims &d, bool has_dec_conv_b, PackedLayout &L)
 {
     L.dims = d;
     L.has_dec_conv_b = has_dec_conv_b;
-    L.vocab_pad = (d.vocab + 15) & ~15;
+    L.vocab_pad = (d.vocab + 31) & ~31;            // a multiple of 32: the joiner GEMM's full-K tiles are 32 columns wide
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off = align64(off + n); return o; };
     // conv 0/1: OIHW as exported; conv 2 runs as an im2col GEMM: MFMA-packed [k3][conv_ch[2]], k = ci*9 + i*3 + j
@@ -122,7 +122,7 @@ static int pick_kz(int K, int N)
 }
 
 Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float *blob_host, const float *blob_device,
-               const ModelParams &params, const FbankHostTables &ft)
+               const ModelParams &params, const FbankHostTables &ft, const std::vector<uint8_t> &tok_class)
     : cfg_(cfg), L_(layout), P_(params)
 {
     HIP_CHECK(hipSetDevice(cfg_.device));
@@ -154,11 +154,19 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     ring_ = dmalloc<float>(S * ring_frames_ * d.mel);
     eout_ = dmalloc<float>(S * d.joiner);
     dout_ = dmalloc<float>(S * d.joiner);
+    gstate_ = dmalloc<GreedyState>(S);
     HIP_CHECK(hipMemset(h_, 0, (size_t)d.n_layers * S * d.d_model * 4));
     HIP_CHECK(hipMemset(c_, 0, (size_t)d.n_layers * S * d.hidden * 4));
     HIP_CHECK(hipMemset(ring_, 0, S * ring_frames_ * d.mel * 4));
     HIP_CHECK(hipMemset(eout_, 0, S * d.joiner * 4));
     HIP_CHECK(hipMemset(dout_, 0, S * d.joiner * 4));
+    {   // every slot starts with context [blank, blank] (april_session.c:432-438), no emission yet (:64-66)
+        std::vector<GreedyState> init(S);
+        for (auto &g : init) { g.ctx0 = P_.blank_id; g.ctx1 = P_.blank_id; g.last_tok = -1; g.last_emit_ms = 0; }
+        HIP_CHECK(hipMemcpy(gstate_, init.data(), S * sizeof(GreedyState), hipMemcpyHostToDevice));
+    }
+    cls_ = dmalloc<uint8_t>((size_t)d.vocab);
+    HIP_CHECK(hipMemcpy(cls_, tok_class.data(), (size_t)d.vocab, hipMemcpyHostToDevice));
 
     kz_embed_ = pick_kz(d.embed_in, d.d_model);
     kz_hr_ = pick_kz(d.hidden, d.d_model);
@@ -171,18 +179,23 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     xin_ = dmalloc<float>(MB * d.embed_in);
     a3_ = dmalloc<float>(MB * d.f_out * L_.k3);
     HIP_CHECK(hipMemset(a3_, 0, MB * d.f_out * L_.k3 * 4));      // padded k columns (if any) stay zero
-    xa_ = dmalloc<float>(MB * d.d_model);
+    y_ = dmalloc<float>(MB * d.d_model);
+    ssq_ = dmalloc<float>(MB * (d.d_model / SSQ_COLS));
     xb_ = dmalloc<float>(MB * d.d_model);
     u_ = dmalloc<float>(MB * d.hidden);
     ff_ = dmalloc<float>(MB * d.ffn);
     de_ = dmalloc<float>(MB * d.d_model);
-    logits_ = dmalloc<float>(MB * d.vocab);
-    joint_d_ = dmalloc<JointResult>(MB);
-    hs_enc_ = hmalloc<int>(2 * MB); ds_enc_ = dmalloc<int>(2 * MB);
-    hs_dec_ = hmalloc<int>(MB * (1 + d.context)); ds_dec_ = dmalloc<int>(MB * (1 + d.context));
-    hs_joi_ = hmalloc<int>(MB); ds_joi_ = dmalloc<int>(MB);
-    joint_h_ = hmalloc<JointResult>(MB);
-    logits_h_ = hmalloc<float>(MB * d.vocab);
+    HIP_CHECK(hipMemset(de_, 0, MB * d.d_model * 4));            // rows whose context did not change are read (never stored) by the decoder projection
+    logits_ = dmalloc<float>(3 * MB * d.vocab);
+    logits_h_ = hmalloc<float>(3 * MB * d.vocab);
+    // step bookkeeping
+    ring_cap_ = std::max<size_t>((size_t)1 << 20, 3 * MB * 8 + 2 * S); ring_h_ = hmalloc<int>(ring_cap_);
+    step_cap_ = 1 << 14; step_off_h_ = hmalloc<int>((size_t)step_cap_); rec_off_h_ = hmalloc<int>((size_t)step_cap_);
+    rec_cap_ = std::max<size_t>((size_t)1 << 20, 3 * MB * 8); rec_d_ = dmalloc<StepRecord>(rec_cap_); rec_h_ = hmalloc<StepRecord>(rec_cap_);
+    counter_d_ = dmalloc<int>(1); rec_off_d_ = dmalloc<int>(1); flags_d_ = dmalloc<int>(4);
+    step_d_ = dmalloc<int>(3 * MB); active_d_ = dmalloc<int>(MB); dirty_d_ = dmalloc<int>(MB);
+    dec_slots_d_ = dmalloc<int>(S);
+    HIP_CHECK(hipMemset(counter_d_, 0, 4)); HIP_CHECK(hipMemset(rec_off_d_, 0, 4)); HIP_CHECK(hipMemset(flags_d_, 0, 16));
 
     upload_tables(ft);
     use_graphs_ = !(getenv("APRIL_NO_GRAPHS") && atoi(getenv("APRIL_NO_GRAPHS")));
@@ -197,15 +210,15 @@ Engine::~Engine()
     (void)hipSetDevice(cfg_.device);
     (void)hipStreamSynchronize(stream_);
     for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    for (auto &g : enc_graphs_) (void)hipGraphExecDestroy(g.second);
-    for (void *p : {(void *)w_, (void *)wh_, (void *)h_, (void *)c_, (void *)ring_, (void *)eout_, (void *)dout_, (void *)ws_, (void *)xin_, (void *)a3_, (void *)xa_,
-                    (void *)xb_, (void *)u_, (void *)ff_, (void *)de_, (void *)logits_, (void *)joint_d_, (void *)ds_enc_, (void *)ds_dec_,
-                    (void *)ds_joi_, (void *)ds_desc_[0], (void *)ds_desc_[1], (void *)ds_pcm_[0], (void *)ds_pcm_[1]})
+    for (auto &g : step_graphs_) (void)hipGraphExecDestroy(g.second);
+    for (void *p : {(void *)w_, (void *)wh_, (void *)h_, (void *)c_, (void *)ring_, (void *)eout_, (void *)dout_, (void *)gstate_, (void *)cls_, (void *)ws_, (void *)xin_,
+                    (void *)a3_, (void *)y_, (void *)ssq_, (void *)xb_, (void *)u_, (void *)ff_, (void *)de_, (void *)logits_, (void *)rec_d_, (void *)counter_d_,
+                    (void *)rec_off_d_, (void *)flags_d_, (void *)step_d_, (void *)active_d_, (void *)dirty_d_, (void *)dec_slots_d_,
+                    (void *)ds_desc_[0], (void *)ds_desc_[1], (void *)ds_pcm_[0], (void *)ds_pcm_[1]})
         if (p) (void)hipFree(p);
-    for (void *p : {(void *)hs_enc_, (void *)hs_dec_, (void *)hs_joi_, (void *)joint_h_, (void *)logits_h_, (void *)hs_desc_[0], (void *)hs_desc_[1], (void *)hs_pcm_[0], (void *)hs_pcm_[1]})
+    for (void *p : {(void *)ring_h_, (void *)step_off_h_, (void *)rec_off_h_, (void *)rec_h_, (void *)logits_h_, (void *)hs_desc_[0], (void *)hs_desc_[1], (void *)hs_pcm_[0], (void *)hs_pcm_[1]})
         if (p) (void)hipHostFree(p);
     for (int b = 0; b < 2; ++b) if (fb_done_[b]) (void)hipEventDestroy(fb_done_[b]);
-    if (dec_done_) (void)hipEventDestroy(dec_done_);
     for (void *p : table_allocs_) (void)hipFree(p);
     (void)hipStreamDestroy(stream_);
 }
@@ -244,17 +257,16 @@ int Engine::alloc_slot()
 
 void Engine::free_slot(int slot)
 {
-    // zero the slot's state so the next owner starts from the reference's calloc'd tensors (april_session.c:40-58).
-    // Two strided 2-D memsets cover all layers; they are stream-ordered ahead of any later use of the slot.
+    // reset the slot so the next owner starts from the reference's calloc'd tensors (april_session.c:40-58) and a
+    // [blank, blank] context: ONE kernel, stream-ordered ahead of any later use of the slot.
     // Teardown-tolerant: sessions may be freed while the process is exiting and the HIP runtime is already gone.
     if (hipSetDevice(cfg_.device) == hipSuccess) {
-        std::lock_guard<std::mutex> cg(capture_mu_);           // never enqueue into a stream that is being captured (encode())
+        std::lock_guard<std::mutex> cg(capture_mu_);           // never enqueue into a stream that is being captured (step())
         const NetDims &d = L_.dims;
-        const size_t S = (size_t)cfg_.max_slots;
-        (void)hipMemset2DAsync(h_ + (size_t)slot * d.d_model, S * d.d_model * 4, 0, (size_t)d.d_model * 4, (size_t)d.n_layers, stream_);
-        (void)hipMemset2DAsync(c_ + (size_t)slot * d.hidden, S * d.hidden * 4, 0, (size_t)d.hidden * 4, (size_t)d.n_layers, stream_);
-        (void)hipMemsetAsync(eout_ + (size_t)slot * d.joiner, 0, (size_t)d.joiner * 4, stream_);
-        (void)hipMemsetAsync(dout_ + (size_t)slot * d.joiner, 0, (size_t)d.joiner * 4, stream_);
+        ZeroSlotArgs z;
+        z.h = h_; z.c = c_; z.n_layers = d.n_layers; z.slots = (size_t)cfg_.max_slots; z.d_model = d.d_model; z.hidden = d.hidden;
+        z.eout = eout_; z.dout = dout_; z.joiner = d.joiner; z.state = gstate_; z.blank = P_.blank_id; z.slot = slot;
+        launch_zero_slot(z, stream_);
     }
     std::lock_guard<std::mutex> g(slot_mu_);
     free_.push_back(slot);
@@ -268,6 +280,7 @@ void Engine::set_profiling(bool on) { sync(); profiling_ = on; }
 void Engine::reset_timing() { for (auto &t : timing_) t = KernelTiming(); }
 void Engine::timed_begin(int cls)
 {
+    ++launch_count_;
     if (!profiling_) return;
     if (ev_used_ == ev_pool_.size()) { Ev e; HIP_CHECK(hipEventCreate(&e.a)); HIP_CHECK(hipEventCreate(&e.b)); e.cls = cls; ev_pool_.push_back(e); }
     ev_pool_[ev_used_].cls = cls;
@@ -333,10 +346,15 @@ void Engine::fbank(int n_frames, const FbankFrameDesc *desc, const std::pair<con
 }
 
 // ---------------------------------------------------------------- encoder
+// Launch count per chunk at batch sizes where the full-K schedule applies: 2 (conv) + 1 (embed) + 4 per layer + 1.
+// BasicNorm never runs as a kernel: EPI_RESID_SSQ leaves y and its per-32-column sums of squares, and every consumer
+// of the normalised row (the next layer's gate GEMM, its residual, encoder_proj) multiplies by row_scale() on the way in.
 void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, const float *x_direct)
 {
     const NetDims &d = L_.dims;
     const size_t S = (size_t)cfg_.max_slots;
+    const int G = d.d_model / SSQ_COLS;
+    auto scale_of = [&](float eps) { RowScale r; r.ssq = ssq_; r.groups = G; r.inv_n = 1.0f / (float)d.d_model; r.eps = eps; return r; };
     // conv front end
     ConvEmbedArgs ca;
     ca.ring = ring_; ca.ring_frames = ring_frames_; ca.mel = d.mel; ca.seg = d.seg;
@@ -350,162 +368,238 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
         g.M = n * d.f_out; g.N = d.conv_ch[2]; g.K = L_.k3; g.kz = 1; g.epi = EPI_BIAS_DSWISH; g.out = xin_; g.ldo = d.conv_ch[2]; g.bias = w_ + L_.conv_b[2];
         timed_begin(T_CONV); launch_gemm(g, stream_); timed_end(T_CONV);
     }
-
-    // embed linear + bias + BasicNorm
-    {
-        GemmArgs g; g.a0 = xin_; g.lda0 = d.embed_in; g.K0 = d.embed_in; lin(g, L_.w_embed);
-        g.M = n; g.N = d.d_model; g.K = d.embed_in; g.kz = kz_embed_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
+    // y = A x W + bias (+ residual) with sums of squares: fused into the GEMM where its tiles own all of K, else split-K + row kernel
+    auto resid_ssq = [&](const float *a, int K, size_t w_off, int kz, const float *bias, const float *resid) {
+        GemmArgs g; g.a0 = a; g.lda0 = K; g.K0 = K; lin(g, w_off);
+        g.M = n; g.N = d.d_model; g.K = K; g.kz = kz;
+        if (gemm_fullk(n, d.d_model, kz)) {
+            g.epi = EPI_RESID_SSQ; g.bias = bias; g.resid = resid; g.ldr = d.d_model; g.out = y_; g.ldo = d.d_model; g.ssq_out = ssq_;
+            timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
+            return;
+        }
+        g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
         timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
-        RowArgs r; r.mode = ROW_NORM; r.ws = ws_; r.kz = gemm_partials(n, d.d_model, kz_embed_); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = n;
-        r.bias = w_ + L_.b_embed; r.out = xa_; r.ldo = d.d_model; r.eps = L_.embed_eps;
+        RowArgs r; r.mode = ROW_RESID_SSQ; r.ws = ws_; r.parts = gemm_partials(n, d.d_model, kz); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = n;
+        r.bias = bias; r.resid = resid; r.ldr = d.d_model; r.out = y_; r.ldo = d.d_model; r.ssq_out = ssq_;
         timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
-    }
+    };
+    // embed linear + bias (BasicNorm deferred)
+    resid_ssq(xin_, d.embed_in, L_.w_embed, kz_embed_, w_ + L_.b_embed, nullptr);
+    float eps_in = L_.embed_eps;                          // epsilon of the BasicNorm that produced this layer's input
     for (int l = 0; l < d.n_layers; ++l) {
         const PackedLayout::Layer &o = L_.layers[(size_t)l];
         float *h_l = h_ + (size_t)l * S * d.d_model;
         float *c_l = c_ + (size_t)l * S * d.hidden;
-        {   // gates = [x | h_prev] x Wg ; fused LSTM cell
-            GemmArgs g; g.a0 = xa_; g.lda0 = d.d_model; g.K0 = d.d_model;
+        const RowScale xs = scale_of(eps_in);
+        {   // gates = [norm(y) | h_prev] x Wg ; fused LSTM cell
+            GemmArgs g; g.a0 = y_; g.lda0 = d.d_model; g.K0 = d.d_model; g.a_op = AOP_SCALE; g.a_scale = xs;
             g.a1 = h_l; g.lda1 = d.d_model; g.aidx1 = d_slots; g.K1 = d.d_model;
             lin(g, o.wg); g.M = n; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_LSTM;
             g.out = u_; g.ldo = d.hidden; g.bias = w_ + o.bg; g.c_state = c_l; g.slot_idx = d_slots; g.hidden = d.hidden;
             timed_begin(T_GATES); launch_gemm(g, stream_); timed_end(T_GATES);
         }
-        {   // h' = u x Whr ; state write + residual
+        {   // h' = u x Whr ; state write + residual: xb = norm(y) + h'
             GemmArgs g; g.a0 = u_; g.lda0 = d.hidden; g.K0 = d.hidden; lin(g, o.whr);
-            g.M = n; g.N = d.d_model; g.K = d.hidden; g.kz = kz_hr_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
-            timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
-            RowArgs r; r.mode = ROW_HR; r.ws = ws_; r.kz = gemm_partials(n, d.d_model, kz_hr_); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = n;
-            r.resid = xa_; r.ldr = d.d_model; r.out = xb_; r.ldo = d.d_model; r.slot_idx = d_slots; r.state = h_l; r.ld_state = d.d_model;
-            timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
+            g.M = n; g.N = d.d_model; g.K = d.hidden; g.kz = kz_hr_;
+            if (gemm_fullk(n, d.d_model, kz_hr_)) {
+                g.epi = EPI_HR; g.state = h_l; g.ld_state = d.d_model; g.slot_idx = d_slots; g.resid = y_; g.ldr = d.d_model; g.r_scale = xs; g.out = xb_; g.ldo = d.d_model;
+                timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
+            } else {
+                g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
+                timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
+                RowArgs r; r.mode = ROW_HR; r.ws = ws_; r.parts = gemm_partials(n, d.d_model, kz_hr_); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = n;
+                r.resid = y_; r.ldr = d.d_model; r.r_scale = xs; r.out = xb_; r.ldo = d.d_model; r.slot_idx = d_slots; r.state = h_l; r.ld_state = d.d_model;
+                timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
+            }
         }
         {   // FFN up + DoubleSwish
             GemmArgs g; g.a0 = xb_; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, o.wff1);
             g.M = n; g.N = d.ffn; g.K = d.d_model; g.kz = 1; g.epi = EPI_BIAS_DSWISH; g.out = ff_; g.ldo = d.ffn; g.bias = w_ + o.bff1;
             timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
         }
-        {   // FFN down + bias + residual + BasicNorm
-            GemmArgs g; g.a0 = ff_; g.lda0 = d.ffn; g.K0 = d.ffn; lin(g, o.wff2);
-            g.M = n; g.N = d.d_model; g.K = d.ffn; g.kz = kz_ff2_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
+        // FFN down + bias + residual -> y (the last reader of the previous y was the projection above)
+        resid_ssq(ff_, d.ffn, o.wff2, kz_ff2_, w_ + o.bff2, xb_);
+        eps_in = L_.norm_eps[(size_t)l];
+    }
+    {   // encoder_proj(norm(y)) -> eout[slot]
+        GemmArgs g; g.a0 = y_; g.lda0 = d.d_model; g.K0 = d.d_model; g.a_op = AOP_SCALE; g.a_scale = scale_of(eps_in); lin(g, L_.w_encproj);
+        g.M = n; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_;
+        if (gemm_fullk(n, d.joiner, kz_proj_)) {
+            g.epi = EPI_SLOT_STORE; g.bias = w_ + L_.b_encproj; g.out = eout_; g.ldo = d.joiner; g.slot_idx = d_slots;
             timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
-            RowArgs r; r.mode = ROW_NORM; r.ws = ws_; r.kz = gemm_partials(n, d.d_model, kz_ff2_); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = n;
-            r.bias = w_ + o.bff2; r.resid = xb_; r.ldr = d.d_model; r.out = xa_; r.ldo = d.d_model; r.eps = L_.norm_eps[(size_t)l];
+        } else {
+            g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
+            timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
+            RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_; r.parts = gemm_partials(n, d.joiner, kz_proj_); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = n;
+            r.bias = w_ + L_.b_encproj; r.out = eout_; r.ldo = d.joiner; r.slot_idx = d_slots;
             timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
         }
     }
-    {   // encoder_proj -> eout[slot]
-        GemmArgs g; g.a0 = xa_; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, L_.w_encproj);
-        g.M = n; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
-        timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
-        RowArgs r; r.mode = ROW_BIAS_STORE; r.ws = ws_; r.kz = gemm_partials(n, d.joiner, kz_proj_); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = n;
-        r.bias = w_ + L_.b_encproj; r.out = eout_; r.ldo = d.joiner; r.slot_idx = d_slots;
-        timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
-    }
 }
 
-void Engine::encode(int n, const int *slots, const int *ring_tails)
+// ---------------------------------------------------------------- decoder / joiner rounds
+DecEmbedParams Engine::dec_params() const
 {
-    HIP_CHECK(hipSetDevice(cfg_.device));
+    const NetDims &d = L_.dims;
+    DecEmbedParams p; p.emb = w_ + L_.emb; p.conv_w = w_ + L_.dec_conv; p.conv_b = L_.has_dec_conv_b ? w_ + L_.dec_conv_b : nullptr;
+    p.d = d.d_model; p.groups = d.dec_groups; p.context = d.context; p.vocab = d.vocab;
+    return p;
+}
+
+// dout[slot] = de x Wp + b for rows with row_mask != 0 (all rows when null)
+void Engine::run_decproj(int n, const int *d_slots, const int *row_mask, const int *run_flag)
+{
+    (void)run_flag;
+    const NetDims &d = L_.dims;
+    GemmArgs g; g.a0 = de_; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, L_.w_decproj);
+    g.M = n; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_;
+    if (gemm_fullk(n, d.joiner, kz_proj_)) {
+        g.epi = EPI_SLOT_STORE; g.bias = w_ + L_.b_decproj; g.out = dout_; g.ldo = d.joiner; g.slot_idx = d_slots; g.row_mask = row_mask;
+        timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
+        return;
+    }
+    g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
+    timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
+    RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_; r.parts = gemm_partials(n, d.joiner, kz_proj_); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = n;
+    r.bias = w_ + L_.b_decproj; r.out = dout_; r.ldo = d.joiner; r.slot_idx = d_slots; r.row_mask = row_mask;
+    timed_begin(T_DEC); launch_row(r, stream_); timed_end(T_DEC);
+}
+
+// The reference's loop "joiner -> process_logits, up to three times, early-emit 1,0,0" (src/april_session.c:449-454)
+// for all rows of the step at once, decisions included: rows that resolved to blank are masked out of the later rounds.
+void Engine::run_greedy_rounds(int n, bool dump_logits)
+{
+    const NetDims &d = L_.dims;
     const int MB = cfg_.max_batch;
-    for (int o = 0; o < n; o += MB) {
-        const int m = std::min(MB, n - o);
-        if (o > 0) sync();                               // staging region reuse
-        memcpy(hs_enc_, slots + o, (size_t)m * 4);
-        memcpy(hs_enc_ + MB, ring_tails + o, (size_t)m * 4);
-        // The whole per-chunk chain (2 index uploads + ~90 kernels) is replayed from a hipGraph captured once per
-        // batch size: at small batches the chain is launch-bound on the host (~3.5 us per launch), the replay is not.
-        // Kernel arguments depend only on m; the slot/tail indices travel through the fixed pinned buffer.
-        if (use_graphs_ && !profiling_) {
-            auto it = enc_graphs_.find(m);
-            if (it == enc_graphs_.end()) {
-                if (enc_graphs_.size() >= 128) { for (auto &g : enc_graphs_) (void)hipGraphExecDestroy(g.second); enc_graphs_.clear(); }
-                hipGraph_t graph = nullptr;
-                hipGraphExec_t exec = nullptr;
-                std::lock_guard<std::mutex> cg(capture_mu_);       // aas_free on another thread zeroes slots through this stream
-                HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-                HIP_CHECK(hipMemcpyAsync(ds_enc_, hs_enc_, (size_t)m * 4, hipMemcpyHostToDevice, stream_));
-                HIP_CHECK(hipMemcpyAsync(ds_enc_ + MB, hs_enc_ + MB, (size_t)m * 4, hipMemcpyHostToDevice, stream_));
-                run_encoder_rows(m, ds_enc_, ds_enc_ + MB, nullptr);
-                HIP_CHECK(hipStreamEndCapture(stream_, &graph));
-                HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-                HIP_CHECK(hipGraphDestroy(graph));
-                it = enc_graphs_.emplace(m, exec).first;
-            }
-            HIP_CHECK(hipGraphLaunch(it->second, stream_));
-            continue;
+    const int *d_slots = step_d_, *d_now = step_d_ + 2 * MB;
+    for (int round = 0; round < 3; ++round) {
+        {   // logits = tanh(eout + dout) x Wout (+ bias in the decision kernel)
+            GemmArgs g; g.a0 = eout_; g.a0b = dout_; g.lda0 = d.joiner; g.aidx0 = d_slots; g.K0 = d.joiner; g.a_op = AOP_TANH_ADD;
+            lin(g, L_.w_out); g.M = n; g.N = L_.vocab_pad; g.K = d.joiner; g.kz = kz_out_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
+            timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
         }
-        HIP_CHECK(hipMemcpyAsync(ds_enc_, hs_enc_, (size_t)m * 4, hipMemcpyHostToDevice, stream_));
-        HIP_CHECK(hipMemcpyAsync(ds_enc_ + MB, hs_enc_ + MB, (size_t)m * 4, hipMemcpyHostToDevice, stream_));
-        run_encoder_rows(m, ds_enc_, ds_enc_ + MB, nullptr);
+        DecideArgs a;
+        a.ws = ws_; a.parts = gemm_partials(n, L_.vocab_pad, kz_out_); a.m_stride = ws_mstride_; a.N = L_.vocab_pad; a.M = n; a.n_valid = d.vocab;
+        a.bias = w_ + L_.b_out; a.blank = P_.blank_id; a.early_emit = round == 0 ? 1.0f : 0.0f;
+        a.slot_idx = d_slots; a.now_ms = d_now; a.active = active_d_; a.dirty = dirty_d_; a.tok_class = cls_; a.state = gstate_;
+        a.rec_ring = rec_d_; a.rec_off = rec_off_d_; a.round = round;
+        a.logits_dump = dump_logits ? logits_ + (size_t)round * MB * d.vocab : nullptr;
+        a.dec = dec_params(); a.de_out = de_; a.ld_de = d.d_model;
+        timed_begin(T_DEC); launch_decide(a, stream_); timed_end(T_DEC);
+        run_decproj(n, d_slots, dirty_d_, nullptr);
     }
 }
 
-// ---------------------------------------------------------------- decoder
-void Engine::decode(int n, const int *slots, const int *ctx)
+void Engine::run_chain(int m, bool dump_logits)
 {
-    HIP_CHECK(hipSetDevice(cfg_.device));
-    const NetDims &d = L_.dims;
     const int MB = cfg_.max_batch;
-    for (int o = 0; o < n; o += MB) {
-        const int m = std::min(MB, n - o);
-        // two decoder launches can follow each other without a host wait in between (context reset after a flush, then
-        // the first step of a new session): the pinned staging and the device index buffer may not be rewritten
-        // before the previous launch has consumed them
-        if (!dec_done_) HIP_CHECK(hipEventCreateWithFlags(&dec_done_, hipEventDisableTiming));
-        else HIP_CHECK(hipEventSynchronize(dec_done_));
-        memcpy(hs_dec_, slots + o, (size_t)m * 4);
-        memcpy(hs_dec_ + MB, ctx + (size_t)o * d.context, (size_t)m * d.context * 4);
-        HIP_CHECK(hipMemcpyAsync(ds_dec_, hs_dec_, (size_t)m * 4, hipMemcpyHostToDevice, stream_));
-        HIP_CHECK(hipMemcpyAsync(ds_dec_ + MB, hs_dec_ + MB, (size_t)m * d.context * 4, hipMemcpyHostToDevice, stream_));
-        DecEmbedArgs a; a.emb = w_ + L_.emb; a.conv_w = w_ + L_.dec_conv; a.conv_b = L_.has_dec_conv_b ? w_ + L_.dec_conv_b : nullptr;
-        a.ctx = ds_dec_ + MB; a.d = d.d_model; a.groups = d.dec_groups; a.context = d.context; a.vocab = d.vocab; a.M = m; a.out = de_; a.ldo = d.d_model;
-        timed_begin(T_DEC); launch_dec_embed(a, stream_); timed_end(T_DEC);
-        GemmArgs g; g.a0 = de_; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, L_.w_decproj);
-        g.M = m; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
-        timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
-        RowArgs r; r.mode = ROW_BIAS_STORE; r.ws = ws_; r.kz = gemm_partials(m, d.joiner, kz_proj_); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = m;
-        r.bias = w_ + L_.b_decproj; r.out = dout_; r.ldo = d.joiner; r.slot_idx = ds_dec_;
-        timed_begin(T_DEC); launch_row(r, stream_); timed_end(T_DEC);
-        HIP_CHECK(hipEventRecord(dec_done_, stream_));
-    }
+    AdvanceArgs a;
+    a.host_ring = ring_h_; a.host_step_off = step_off_h_; a.host_rec_off = rec_off_h_; a.counter = counter_d_;
+    a.dst = step_d_; a.dst_stride = MB; a.active = active_d_; a.rec_off = rec_off_d_; a.m = m;
+    launch_advance(a, stream_);
+    run_encoder_rows(m, step_d_, step_d_ + MB, nullptr);
+    run_greedy_rounds(m, dump_logits);
 }
 
-// ---------------------------------------------------------------- joiner
-void Engine::joint(int n, const int *slots, JointResult *out, float *logits_out)
+void Engine::begin_flight()
 {
     HIP_CHECK(hipSetDevice(cfg_.device));
-    const NetDims &d = L_.dims;
-    const int MB = cfg_.max_batch;
-    for (int o = 0; o < n; o += MB) {
-        const int m = std::min(MB, n - o);
-        memcpy(hs_joi_, slots + o, (size_t)m * 4);
-        HIP_CHECK(hipMemcpyAsync(ds_joi_, hs_joi_, (size_t)m * 4, hipMemcpyHostToDevice, stream_));
-        GemmArgs g; g.a0 = eout_; g.a0b = dout_; g.lda0 = d.joiner; g.aidx0 = ds_joi_; g.K0 = d.joiner; g.a_op = AOP_TANH_ADD;
-        lin(g, L_.w_out); g.M = m; g.N = L_.vocab_pad; g.K = d.joiner; g.kz = kz_out_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
-        timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
-        RowArgs r; r.mode = ROW_ARGMAX; r.ws = ws_; r.kz = gemm_partials(m, L_.vocab_pad, kz_out_); r.m_stride = ws_mstride_; r.N = L_.vocab_pad; r.M = m; r.n_valid = d.vocab;
-        r.bias = w_ + L_.b_out; r.blank = P_.blank_id; r.joint = joint_d_; r.logits_dump = logits_out ? logits_ : nullptr;
-        timed_begin(T_DEC); launch_row(r, stream_); timed_end(T_DEC);
-        HIP_CHECK(hipMemcpyAsync(joint_h_, joint_d_, (size_t)m * sizeof(JointResult), hipMemcpyDeviceToHost, stream_));
-        if (logits_out) HIP_CHECK(hipMemcpyAsync(logits_h_, logits_, (size_t)m * d.vocab * 4, hipMemcpyDeviceToHost, stream_));
+    ring_pos_ = 0; rec_pos_ = 0; steps_ = 0;
+    std::lock_guard<std::mutex> cg(capture_mu_);
+    HIP_CHECK(hipMemsetAsync(counter_d_, 0, 4, stream_));
+}
+
+bool Engine::flight_has_room(int rows, int nsteps) const
+{
+    // + max_slots: decoder refreshes stage their slot lists in the same index ring
+    return steps_ + nsteps <= step_cap_ && ring_pos_ + (size_t)3 * rows + (size_t)cfg_.max_slots <= ring_cap_ && rec_pos_ + (size_t)3 * rows <= rec_cap_;
+}
+
+int Engine::step(int m, const int *slots, const int *ring_tails, const int *now_ms, float *logits_out)
+{
+    if (m <= 0 || m > cfg_.max_batch || !flight_has_room(m, 1)) { LOGE("engine: step of %d rows does not fit (max batch %d)", m, cfg_.max_batch); abort(); }
+    const int k = steps_++;
+    int *blk = ring_h_ + ring_pos_;
+    memcpy(blk, slots, (size_t)m * 4); memcpy(blk + m, ring_tails, (size_t)m * 4); memcpy(blk + 2 * m, now_ms, (size_t)m * 4);
+    step_off_h_[k] = (int)ring_pos_; rec_off_h_[k] = (int)rec_pos_;
+    ring_pos_ += (size_t)3 * m; rec_pos_ += (size_t)3 * m;
+    // The whole per-chunk chain (index fetch + ~55 kernels) is replayed from a hipGraph captured once per batch size:
+    // at small batches the chain is launch-bound on the host (~3.5 us per launch), the replay is not.  Kernel arguments
+    // depend only on m; the step's indices and its record offset reach the kernels through the device step counter.
+    if (use_graphs_ && !profiling_ && !logits_out) {
+        auto it = step_graphs_.find(m);
+        if (it == step_graphs_.end()) {
+            if (step_graphs_.size() >= 128) { for (auto &g : step_graphs_) (void)hipGraphExecDestroy(g.second); step_graphs_.clear(); }
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            std::lock_guard<std::mutex> cg(capture_mu_);       // aas_free on another thread resets slots through this stream
+            HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+            run_chain(m, false);
+            HIP_CHECK(hipStreamEndCapture(stream_, &graph));
+            HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            HIP_CHECK(hipGraphDestroy(graph));
+            it = step_graphs_.emplace(m, exec).first;
+        }
+        std::lock_guard<std::mutex> cg(capture_mu_);
+        HIP_CHECK(hipGraphLaunch(it->second, stream_));
+        return k;
+    }
+    {
+        std::lock_guard<std::mutex> cg(capture_mu_);
+        launch_count_ = 0;
+        run_chain(m, logits_out != nullptr);
+        kernels_per_step_ = launch_count_ + 1;        // + the index fetch
+    }
+    if (logits_out) {
+        const NetDims &d = L_.dims;
+        const size_t MB = (size_t)cfg_.max_batch;
+        for (int r = 0; r < 3; ++r)
+            HIP_CHECK(hipMemcpyAsync(logits_h_ + (size_t)r * m * d.vocab, logits_ + (size_t)r * MB * d.vocab, (size_t)m * d.vocab * 4, hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipMemcpyAsync(rec_h_ + rec_off_h_[k], rec_d_ + rec_off_h_[k], (size_t)3 * m * sizeof(StepRecord), hipMemcpyDeviceToHost, stream_));
         sync();
-        memcpy(out + o, joint_h_, (size_t)m * sizeof(JointResult));
-        if (logits_out) memcpy(logits_out + (size_t)o * d.vocab, logits_h_, (size_t)m * d.vocab * 4);
+        memcpy(logits_out, logits_h_, (size_t)3 * m * d.vocab * 4);
     }
+    return k;
+}
+
+void Engine::decode_rows(int n, const int *slots, int op)
+{
+    if (n <= 0) return;
+    HIP_CHECK(hipSetDevice(cfg_.device));
+    const NetDims &d = L_.dims;
+    const int MB = cfg_.max_batch;
+    std::lock_guard<std::mutex> cg(capture_mu_);
+    for (int o = 0; o < n; o += MB) {
+        const int m = std::min(MB, n - o);
+        if (ring_pos_ + (size_t)m > ring_cap_) { LOGE("engine: index ring exhausted"); abort(); }
+        int *blk = ring_h_ + ring_pos_;                  // staged in the flight's pinned ring: never rewritten before the copy ran
+        memcpy(blk, slots + o, (size_t)m * 4);
+        ring_pos_ += (size_t)m;
+        HIP_CHECK(hipMemcpyAsync(dec_slots_d_, blk, (size_t)m * 4, hipMemcpyHostToDevice, stream_));
+        DecRowsArgs a; a.slot_idx = dec_slots_d_; a.M = m; a.op = op; a.blank = P_.blank_id; a.state = gstate_; a.dec = dec_params(); a.de_out = de_; a.ld_de = d.d_model;
+        timed_begin(T_DEC); launch_dec_rows(a, stream_); timed_end(T_DEC);
+        run_decproj(m, dec_slots_d_, nullptr, nullptr);
+    }
+}
+
+void Engine::end_flight()
+{
+    HIP_CHECK(hipSetDevice(cfg_.device));
+    if (rec_pos_) HIP_CHECK(hipMemcpyAsync(rec_h_, rec_d_, rec_pos_ * sizeof(StepRecord), hipMemcpyDeviceToHost, stream_));
+    sync();
 }
 
 // ---------------------------------------------------------------- debug / parity entry points
-// The debug calls borrow slots 0..n-1; give them back zeroed (what a new session expects).
+// The debug calls borrow slots 0..n-1; give them back reset (what a new session expects).
 void Engine::zero_slots(int n)
 {
     const NetDims &d = L_.dims;
-    const size_t S = (size_t)cfg_.max_slots;
-    for (int l = 0; l < d.n_layers; ++l) {
-        HIP_CHECK(hipMemsetAsync(h_ + (size_t)l * S * d.d_model, 0, (size_t)n * d.d_model * 4, stream_));
-        HIP_CHECK(hipMemsetAsync(c_ + (size_t)l * S * d.hidden, 0, (size_t)n * d.hidden * 4, stream_));
+    for (int i = 0; i < n; ++i) {
+        ZeroSlotArgs z;
+        z.h = h_; z.c = c_; z.n_layers = d.n_layers; z.slots = (size_t)cfg_.max_slots; z.d_model = d.d_model; z.hidden = d.hidden;
+        z.eout = eout_; z.dout = dout_; z.joiner = d.joiner; z.state = gstate_; z.blank = P_.blank_id; z.slot = i;
+        launch_zero_slot(z, stream_);
     }
-    HIP_CHECK(hipMemsetAsync(eout_, 0, (size_t)n * d.joiner * 4, stream_));
-    HIP_CHECK(hipMemsetAsync(dout_, 0, (size_t)n * d.joiner * 4, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
@@ -516,7 +610,7 @@ void Engine::debug_encoder(int n, const float *x, const float *h, const float *c
     const size_t S = (size_t)cfg_.max_slots;
     if (n > cfg_.max_batch || n > cfg_.max_slots) { LOGE("debug_encoder: n too large"); abort(); }
     // uses slots 0..n-1 directly (callers must not have live sessions); state layout is [n][L][*] on the host
-    std::vector<int> slots((size_t)n), tails((size_t)n, 0);
+    std::vector<int> slots((size_t)n);
     for (int i = 0; i < n; ++i) slots[(size_t)i] = i;
     float *xd = dmalloc<float>((size_t)n * d.seg * d.mel);
     HIP_CHECK(hipMemcpy(xd, x, (size_t)n * d.seg * d.mel * 4, hipMemcpyHostToDevice));
@@ -525,9 +619,8 @@ void Engine::debug_encoder(int n, const float *x, const float *h, const float *c
             HIP_CHECK(hipMemcpy(h_ + ((size_t)l * S + i) * d.d_model, h + ((size_t)i * d.n_layers + l) * d.d_model, (size_t)d.d_model * 4, hipMemcpyHostToDevice));
             HIP_CHECK(hipMemcpy(c_ + ((size_t)l * S + i) * d.hidden, c + ((size_t)i * d.n_layers + l) * d.hidden, (size_t)d.hidden * 4, hipMemcpyHostToDevice));
         }
-    memcpy(hs_enc_, slots.data(), (size_t)n * 4);
-    HIP_CHECK(hipMemcpyAsync(ds_enc_, hs_enc_, (size_t)n * 4, hipMemcpyHostToDevice, stream_));
-    run_encoder_rows(n, ds_enc_, ds_enc_, xd);
+    HIP_CHECK(hipMemcpy(step_d_, slots.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    run_encoder_rows(n, step_d_, step_d_, xd);
     sync();
     for (int i = 0; i < n; ++i) {
         HIP_CHECK(hipMemcpy(eout + (size_t)i * d.joiner, eout_ + (size_t)i * d.joiner, (size_t)d.joiner * 4, hipMemcpyDeviceToHost));
@@ -542,12 +635,20 @@ void Engine::debug_encoder(int n, const float *x, const float *h, const float *c
 
 void Engine::debug_decoder(int n, const int64_t *ctx, float *dout)
 {
+    HIP_CHECK(hipSetDevice(cfg_.device));
     const NetDims &d = L_.dims;
+    if (n > cfg_.max_batch) { LOGE("debug_decoder: n too large"); abort(); }
     std::vector<int> slots((size_t)n), c32((size_t)n * d.context);
     for (int i = 0; i < n; ++i) { slots[(size_t)i] = i; for (int t = 0; t < d.context; ++t) c32[(size_t)i * d.context + t] = (int)ctx[(size_t)i * d.context + t]; }
-    decode(n, slots.data(), c32.data());
+    int *ctx_d = dmalloc<int>(c32.size());
+    HIP_CHECK(hipMemcpy(ctx_d, c32.data(), c32.size() * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dec_slots_d_, slots.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    DecEmbedArgs a; a.dec = dec_params(); a.ctx = ctx_d; a.M = n; a.out = de_; a.ldo = d.d_model;
+    launch_dec_embed(a, stream_);
+    run_decproj(n, dec_slots_d_, nullptr, nullptr);
     sync();
     HIP_CHECK(hipMemcpy(dout, dout_, (size_t)n * d.joiner * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(ctx_d);
     zero_slots(n);
 }
 
@@ -555,12 +656,25 @@ void Engine::debug_joiner(int n, const float *eout, const float *dout, float *lo
 {
     const NetDims &d = L_.dims;
     HIP_CHECK(hipSetDevice(cfg_.device));
+    if (n > cfg_.max_batch) { LOGE("debug_joiner: n too large"); abort(); }
     HIP_CHECK(hipMemcpy(eout_, eout, (size_t)n * d.joiner * 4, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dout_, dout, (size_t)n * d.joiner * 4, hipMemcpyHostToDevice));
     std::vector<int> slots((size_t)n);
     for (int i = 0; i < n; ++i) slots[(size_t)i] = i;
-    std::vector<JointResult> jr((size_t)n);
-    joint(n, slots.data(), jr.data(), logits);
+    HIP_CHECK(hipMemcpy(step_d_, slots.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    GemmArgs g; g.a0 = eout_; g.a0b = dout_; g.lda0 = d.joiner; g.aidx0 = step_d_; g.K0 = d.joiner; g.a_op = AOP_TANH_ADD;
+    lin(g, L_.w_out); g.M = n; g.N = L_.vocab_pad; g.K = d.joiner; g.kz = kz_out_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
+    launch_gemm(g, stream_);
+    // logits = tree + bias for all padded columns; the host keeps the first `vocab` of each row
+    float *lg = dmalloc<float>((size_t)n * L_.vocab_pad);
+    RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_; r.parts = gemm_partials(n, L_.vocab_pad, kz_out_); r.m_stride = ws_mstride_; r.N = L_.vocab_pad; r.M = n;
+    r.bias = w_ + L_.b_out; r.out = lg; r.ldo = L_.vocab_pad;
+    launch_row(r, stream_);
+    sync();
+    std::vector<float> host((size_t)n * L_.vocab_pad);
+    HIP_CHECK(hipMemcpy(host.data(), lg, host.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) memcpy(logits + (size_t)i * d.vocab, host.data() + (size_t)i * L_.vocab_pad, (size_t)d.vocab * 4);
+    (void)hipFree(lg);
     zero_slots(n);
 }
 
@@ -574,6 +688,13 @@ void Engine::debug_fbank(int n_frames, const int16_t *pcm_frames, float *out)
     fbank(n_frames, desc.data(), &part, 1, (size_t)n_frames * padded);
     sync();
     HIP_CHECK(hipMemcpy(out, ring_, (size_t)n_frames * ft_.nbins * 4, hipMemcpyDeviceToHost));
+}
+
+void Engine::read_greedy_state(int slot, GreedyState *out)
+{
+    HIP_CHECK(hipSetDevice(cfg_.device));
+    sync();
+    HIP_CHECK(hipMemcpy(out, gstate_ + slot, sizeof(GreedyState), hipMemcpyDeviceToHost));
 }
 
 void Engine::read_ring(int slot, int row, int n_rows, float *out)

@@ -9,8 +9,9 @@
 //   ring   [slots][ring_frames][mel]  log-mel feature ring           (reference OnlineFBank ring)
 //   eout   [slots][joiner]          projected encoder output of the last chunk
 //   dout   [slots][joiner]          projected decoder output of the current token context
+//   gstate [slots]                  greedy-search state (token context, last emission time, last token)
 // plus per-step work buffers sized for `max_batch` rows.  State never leaves HBM
-// between feed calls; per round only 12 bytes per session come back (JointResult).
+// between feed calls; per joiner round 16 bytes per session come back (StepRecord), once per flight.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -58,7 +59,7 @@ struct KernelTiming { double ms = 0; long launches = 0; };
 class Engine {
 public:
     Engine(const EngineConfig &cfg, const PackedLayout &layout, const float *blob_host, const float *blob_device,
-           const ModelParams &params, const FbankHostTables &ft);
+           const ModelParams &params, const FbankHostTables &ft, const std::vector<uint8_t> &tok_class);
     ~Engine();
 
     int device() const { return cfg_.device; }
@@ -75,14 +76,21 @@ public:
     void free_slot(int slot);
     int live_slots() const { return live_; }
 
-    // ---- batched hot path; host arrays are copied to pinned staging, all launches go to stream()
+    // ---- batched hot path (one stepping thread).  A FLIGHT is everything enqueued between two host waits: frames are cut,
+    // chunk steps (encoder + the three joiner/decision/decoder rounds, all on the device) and decoder refreshes are queued
+    // back to back, and the host reads the 16-byte-per-round records once, at end_flight().
     // pcm arrives as `n_parts` windows that are gathered straight into pinned staging (total n_pcm samples)
     void fbank(int n_frames, const FbankFrameDesc *desc, const std::pair<const int16_t *, size_t> *parts, size_t n_parts, size_t n_pcm,
                HostPool *pool = nullptr);
-    void encode(int n, const int *slots, const int *ring_tails);
-    void decode(int n, const int *slots, const int *ctx /*[n][context]*/);
-    // runs the joiner for n sessions, waits, returns results; logits_out optional [n][vocab] (host)
-    void joint(int n, const int *slots, JointResult *out, float *logits_out);
+    void begin_flight();
+    bool flight_has_room(int rows, int nsteps = 1) const;   // `nsteps` more steps with `rows` rows in total fit into the index / record rings
+    // one chunk for m sessions (m <= max_batch): returns the step's index inside the flight.  logits_out (tests): when
+    // non-null the step runs eagerly, waits, and returns the logits of the three rounds [3][m][vocab]
+    int step(int m, const int *slots, const int *ring_tails, const int *now_ms, float *logits_out = nullptr);
+    // decoder output refresh for listed slots from the context held on the device; op 1 = end-of-flush reset first
+    void decode_rows(int n, const int *slots, int op);
+    void end_flight();                          // records -> host, wait
+    const StepRecord *records(int step_index) const { return rec_h_ + rec_off_h_[step_index]; }   // [3][m], valid after end_flight()
     void sync();
 
     // ---- debug / parity entry points (state passed explicitly, like the ORT tensors)
@@ -91,20 +99,26 @@ public:
     void debug_joiner(int n, const float *eout, const float *dout, float *logits);
     void debug_fbank(int n_frames, const int16_t *pcm_frames /*[n][padded]*/, float *out /*[n][nbins]*/);
     void read_ring(int slot, int row, int n_rows, float *out);
+    void read_greedy_state(int slot, GreedyState *out);
 
     // ---- profiling: when enabled every launch of the named classes is bracketed by hipEvents
     void set_profiling(bool on);
     KernelTiming timing(int cls) const { return timing_[cls]; }
     void reset_timing();
     enum { T_GATES = 0, T_GEMM_OTHER = 1, T_ROW = 2, T_CONV = 3, T_FBANK = 4, T_DEC = 5, T_COUNT = 6 };
+    long kernels_per_step() const { return kernels_per_step_; }    // launches of the last eagerly issued chunk chain
 
 private:
     void upload_tables(const FbankHostTables &ft);
     void zero_slots(int n);
     void run_encoder_rows(int n, const int *d_slots, const int *d_tails, const float *x_direct);
+    void run_greedy_rounds(int n, bool dump_logits);
+    void run_decproj(int n, const int *d_slots, const int *row_mask, const int *run_flag);
+    void run_chain(int m, bool dump_logits);     // advance + encoder + greedy rounds with arguments that depend on m only
     void timed_begin(int cls);
     void timed_end(int cls);
     void collect_timing();
+    DecEmbedParams dec_params() const;
 
     EngineConfig cfg_;
     PackedLayout L_;
@@ -114,16 +128,18 @@ private:
     uint16_t *wh_ = nullptr;                   // fp16 copies of the GEMM weight sections (same offsets, in elements), precision 1 only
     void lin(GemmArgs &g, size_t off) const { if (wh_) { g.wp = wh_ + off; g.wt = 1; } else { g.wp = w_ + off; g.wt = 0; } }
     float *h_ = nullptr, *c_ = nullptr, *ring_ = nullptr, *eout_ = nullptr, *dout_ = nullptr;
+    GreedyState *gstate_ = nullptr;            // [slots]
+    uint8_t *cls_ = nullptr;                   // [vocab] token classes
     int ring_frames_ = 0;
     // work buffers
-    float *xin_ = nullptr, *a3_ = nullptr, *xa_ = nullptr, *xb_ = nullptr, *u_ = nullptr, *ff_ = nullptr, *ws_ = nullptr, *de_ = nullptr;
-    float *logits_ = nullptr;
-    JointResult *joint_d_ = nullptr;
-    // staging (pinned host + device mirrors), one region per call type
-    int *hs_enc_ = nullptr, *ds_enc_ = nullptr;      // [2][max_batch]: slots, tails
-    int *hs_dec_ = nullptr, *ds_dec_ = nullptr;      // [max_batch] slots + [max_batch*ctx] ctx
-    int *hs_joi_ = nullptr, *ds_joi_ = nullptr;      // [max_batch]
-    JointResult *joint_h_ = nullptr;
+    float *xin_ = nullptr, *a3_ = nullptr, *y_ = nullptr, *ssq_ = nullptr, *xb_ = nullptr, *u_ = nullptr, *ff_ = nullptr, *ws_ = nullptr, *de_ = nullptr;
+    float *logits_ = nullptr;                  // [3][max_batch][vocab] (traced steps, debug_joiner)
+    // step bookkeeping: pinned host rings (read by the advance kernel) + device mirrors
+    int *ring_h_ = nullptr; size_t ring_cap_ = 0, ring_pos_ = 0;      // index blocks
+    int *step_off_h_ = nullptr, *rec_off_h_ = nullptr; int step_cap_ = 0, steps_ = 0;
+    StepRecord *rec_d_ = nullptr, *rec_h_ = nullptr; size_t rec_cap_ = 0, rec_pos_ = 0;
+    int *counter_d_ = nullptr, *step_d_ = nullptr, *active_d_ = nullptr, *dirty_d_ = nullptr, *rec_off_d_ = nullptr, *flags_d_ = nullptr;
+    int *dec_slots_d_ = nullptr;
     float *logits_h_ = nullptr;
     // fbank staging is double-buffered so the next call can fill one pair while the previous copy is in flight
     FbankFrameDesc *hs_desc_[2] = {nullptr, nullptr}, *ds_desc_[2] = {nullptr, nullptr}; int desc_cap_ = 0;
@@ -131,7 +147,6 @@ private:
     int fb_flip_ = 0;
     hipEvent_t fb_done_[2] = {nullptr, nullptr};
     std::vector<size_t> part_off_;             // staging offsets of the PCM windows of one fbank call
-    hipEvent_t dec_done_ = nullptr;            // last decoder launch has consumed its staged indices
     // fbank tables on device
     FbankTables ft_;
     std::vector<void *> table_allocs_;
@@ -144,9 +159,10 @@ private:
     // gemm split factors (fixed per shape => batch-invariant numerics)
     int kz_embed_ = 1, kz_hr_ = 1, kz_ff2_ = 1, kz_proj_ = 1, kz_out_ = 1;
     int ws_mstride_ = 0;
-    // encoder launch chains captured per batch size
+    // chunk-step launch chains captured per batch size
     bool use_graphs_ = true;
-    std::map<int, hipGraphExec_t> enc_graphs_;
+    std::map<int, hipGraphExec_t> step_graphs_;
+    long kernels_per_step_ = 0, launch_count_ = 0;
     // profiling
     bool profiling_ = false;
     struct Ev { hipEvent_t a, b; int cls; };

@@ -14,19 +14,43 @@ namespace aprilx {
 // ---------------------------------------------------------------- GEMM
 // out[M,N] = A[M,K] x W[K,N]  with W pre-packed for v_mfma_f32_16x16x4_f32:
 //   Wp[((ntile*KB + kb)*64 + lane)*4 + j] = W[kb*16 + (lane>>4)*4 + j][ntile*16 + (lane&15)]
-// so one 16-byte load per lane feeds four MFMA k-steps.  Canonical summation per
-// output element: K is cut into `kz` slabs (grid.z); inside a slab the four waves of
-// the workgroup each own a contiguous quarter and run one in-order fp32 FMA chain
-// (that is what the MFMA does); the four chains are added ((p0+p1)+p2)+p3.  With
-// kz > 1 slab results are combined PAIRWISE in slab order (balanced tree): a workgroup may
-// own 1, 2, 4 or all slabs of its tile (more as the batch grows and tiles alone fill the
-// chip); what is left goes to a workspace and the row kernel that follows finishes the same tree.
+// so one 16-byte load per lane feeds four MFMA k-steps.
+//
+// Canonical summation per output element (a property of the LAYER, never of the batch):
+//   K is cut into `kz` slabs, every slab into 4 contiguous chunks; a chunk is ONE in-order fp32 FMA chain
+//   (that is what the MFMA computes); a slab is ((c0+c1)+c2)+c3; slabs are combined PAIRWISE in slab order
+//   (balanced tree).  Two schedules produce exactly this:
+//     GM_SLAB   the 4 waves of a workgroup own the 4 chunks of a slab and meet in LDS once per slab; a workgroup
+//               walks zs consecutive slabs (1, 2, 4 or 8 as the batch grows), the slab tree lives in registers;
+//               what is left (kz / zs planes) goes to a workspace and a row kernel finishes the same tree.
+//               This is the small-batch schedule: kz x more workgroups stream the weights from HBM.
+//     GM_FULLK  (kz >= 4) wave w owns the contiguous K quarter = slabs [w kz/4, (w+1) kz/4): it closes every chunk
+//               chain in registers (S = ((c0+c1)+c2)+c3, then the first tree level for kz = 8), and the four waves
+//               meet ONCE as (R0+R1)+(R2+R3).  No partial planes; the row work (state write, residual, bias,
+//               sum of squares, slot store) runs in the GEMM epilogue.  Used as soon as output tiles alone give
+//               enough workgroups.
 enum GemmEpilogue {
-    EPI_PARTIAL = 0,      // ws[z][m][n] = slab sum                         (consumer: row kernels)
+    EPI_PARTIAL = 0,      // ws[z][m][n] = tree sum of this workgroup's slabs      (consumer: row kernels; FULLK: one plane)
     EPI_LSTM = 1,         // columns are unit-major (unit*4 + gate i,f,g,o): cell update, c in place, u out
-    EPI_BIAS_DSWISH = 2   // out = y * sigmoid(y - 1), y = acc + bias
+    EPI_BIAS_DSWISH = 2,  // out = y * sigmoid(y - 1), y = acc + bias
+    EPI_HR = 3,           // LSTM projection: state[slot] = acc ; out = resid * rowscale(resid) + acc
+    EPI_RESID_SSQ = 4,    // y = resid + (acc + bias) (resid optional) ; out = y ; ssq[m][n/32] = sum of y^2 over 32 columns
+    EPI_SLOT_STORE = 5    // out[slot] = acc + bias, rows with row_mask[m] == 0 skipped (mask optional)
 };
-enum GemmAOp { AOP_NONE = 0, AOP_TANH_ADD = 1 };   // A element = tanh(a0[row] + a0b[row])  (joiner)
+// A-operand prologues.  AOP_SCALE: rows of segment 0 are multiplied by their BasicNorm scale
+// (sum of squares partials -> (mean + eps)^-1/2) as they are loaded, i.e. the GEMM consumes x = y * scale(y)
+// without a normalisation kernel in between; the product is the same fp32 value a separate kernel would store.
+enum GemmAOp { AOP_NONE = 0, AOP_TANH_ADD = 1, AOP_SCALE = 2 };
+enum GemmMode { GM_SLAB = 0, GM_FULLK = 1 };
+
+constexpr int SSQ_COLS = 32;       // columns per sum-of-squares partial (one granule = 8 consecutive 4-column quads)
+
+struct RowScale {                  // BasicNorm scale of a row from its sum-of-squares partials (see row_scale() in device_utils.h)
+    const float *ssq = nullptr;    // [rows][groups]
+    int groups = 0;                // N / SSQ_COLS
+    float inv_n = 0.0f;            // 1 / N
+    float eps = 0.0f;
+};
 
 struct GemmArgs {
     // A operand as up to two K segments with optional row indirection (slot ids)
@@ -34,51 +58,142 @@ struct GemmArgs {
     const float *a1 = nullptr; int lda1 = 0; const int *aidx1 = nullptr; int K1 = 0;
     const float *a0b = nullptr;            // AOP_TANH_ADD second addend (same ld/idx as a0)
     int a_op = AOP_NONE;
+    RowScale a_scale;                      // AOP_SCALE: scale of segment-0 rows (indexed by batch row)
     const void *wp = nullptr;              // packed weights (fp32, or fp16 in the same element order when wt == 1)
     int wt = 0;                            // 0: fp32 operands, v_mfma_f32_16x16x4_f32; 1: fp16 weights, A rounded to fp16 on load,
                                            //    v_mfma_f32_16x16x16_f16 with fp32 accumulation (BASELINE configs[4])
-    int M = 0, N = 0, K = 0;               // N multiple of 16, K multiple of 16
+    int M = 0, N = 0, K = 0;               // N multiple of 16, K multiple of 64
     int kz = 1;                            // K slabs (power of two); canonical summation unit
     int zs = 1;                            // slabs handled per workgroup (set by launch_gemm)
+    int mode = GM_SLAB;                    // set by launch_gemm
     int epi = EPI_PARTIAL;
-    float *out = nullptr; int ldo = 0;     // EPI_PARTIAL: workspace [kz][m_stride][N]; others: [M][ldo]
+    float *out = nullptr; int ldo = 0;     // EPI_PARTIAL: workspace [planes][m_stride][N]; others: [M][ldo] (EPI_SLOT_STORE: [slots][ldo])
     int m_stride = 0;
     const float *bias = nullptr;
     float *c_state = nullptr;              // EPI_LSTM: [slots][hidden] for this layer
-    const int *slot_idx = nullptr;         // EPI_LSTM: row -> slot
+    const int *slot_idx = nullptr;         // EPI_LSTM / EPI_HR / EPI_SLOT_STORE: row -> slot
     int hidden = 0;
+    float *state = nullptr; int ld_state = 0;     // EPI_HR: h state of this layer [slots][ld_state]
+    const float *resid = nullptr; int ldr = 0;    // EPI_HR / EPI_RESID_SSQ: residual rows [M][ldr]
+    RowScale r_scale;                      // EPI_HR: the residual is y * scale(y)
+    float *ssq_out = nullptr;              // EPI_RESID_SSQ: [M][N / SSQ_COLS]
+    const int *row_mask = nullptr;         // EPI_SLOT_STORE: optional
     int skew = 0;                          // start delay (x 4096 cycles) for every second generation of workgroups
     int asm_loop = 0;                      // != 0: hand-scheduled K loop (gemm_mainloop_asm.inc) in the fused-epilogue 64x64 fp32 tiles
     unsigned long long *trace = nullptr;   // measurement only: per-workgroup s_memtime stamps [wg][8] (wave 0, lane 0)
     int debug = 0;                         // measurement only: 1 = skip the MFMA main loop, 2 = skip the epilogue math, 3 = all k blocks read block 0
 };
 void launch_gemm(const GemmArgs &g, hipStream_t s);
-// number of partial planes launch_gemm will write for an EPI_PARTIAL GEMM of this shape (kz / slabs-per-workgroup)
+// number of partial planes launch_gemm will write for an EPI_PARTIAL GEMM of this shape
 int gemm_partials(int M, int N, int kz);
+// true when launch_gemm runs a GEMM of this shape on the full-K schedule, i.e. the caller may (must, for the row
+// epilogues EPI_HR / EPI_RESID_SSQ / EPI_SLOT_STORE) fuse the row work; false: EPI_PARTIAL + row kernel
+bool gemm_fullk(int M, int N, int kz);
 
-// ---------------------------------------------------------------- row kernels (one workgroup per row)
+// ---------------------------------------------------------------- row kernels (one workgroup per row; small-batch path)
 enum RowMode {
-    ROW_HR = 0,          // s = sum_z ws; h_state[slot] = s; out = resid + s
-    ROW_NORM = 1,        // y = resid + (s + bias); out = y * (mean(y^2) + eps)^-0.5   (resid optional)
-    ROW_BIAS_STORE = 2,  // out[slot] = s + bias
-    ROW_ARGMAX = 3       // logits = s + bias; arg-max over n != blank (lowest index wins), blank logit
+    ROW_HR = 0,          // s = tree(ws); state[slot] = s; out = resid * rowscale(resid) + s
+    ROW_RESID_SSQ = 1,   // y = resid + (s + bias) (resid optional); out = y; ssq partials of y
+    ROW_SLOT_STORE = 2   // out[slot] = s + bias (rows with row_mask == 0 skipped)
 };
-struct JointResult { int32_t idx; float max_val; float blank_val; };
 struct RowArgs {
     int mode = ROW_HR;
-    const float *ws = nullptr; int kz = 1; int m_stride = 0; int N = 0; int M = 0;
-    int n_valid = 0;                       // ROW_ARGMAX: vocabulary size (<= N)
+    const float *ws = nullptr; int parts = 1; int m_stride = 0; int N = 0; int M = 0;
     const float *bias = nullptr;
     const float *resid = nullptr; int ldr = 0;
+    RowScale r_scale;                      // ROW_HR
     float *out = nullptr; int ldo = 0;
     const int *slot_idx = nullptr;         // row -> slot for state / slot-indexed outputs
     float *state = nullptr; int ld_state = 0;   // ROW_HR: h state of this layer
-    float eps = 0.0f;
-    int blank = 0;
-    JointResult *joint = nullptr;
-    float *logits_dump = nullptr;          // optional [M][n_valid]
+    float *ssq_out = nullptr;              // ROW_RESID_SSQ
+    const int *row_mask = nullptr;         // ROW_SLOT_STORE
 };
 void launch_row(const RowArgs &r, hipStream_t s);
+
+// ---------------------------------------------------------------- greedy search on the device
+// Per-slot search state (reference AprilASRSession_i: context tensor, last_emission_time_ms, the class of the
+// last active token; src/april_session.h:32-73).  The host keeps the token list and runs the callbacks; the
+// device keeps what the NEXT network call depends on, so a chunk needs no host decision.
+struct GreedyState { int32_t ctx0, ctx1; int32_t last_tok; uint32_t last_emit_ms; };
+// One joiner round of one session.  flags: 1 = valid (the round ran), 2 = resolved to blank, 4 = context changed
+struct StepRecord { int32_t idx; float max_val; float blank_val; uint32_t flags; };
+enum { REC_VALID = 1, REC_BLANK = 2, REC_CTX = 4 };
+enum TokClassBits { TKC_WORD_START = 1, TKC_SENT_END = 2, TKC_COMMA = 4, TKC_DOT = 8, TKC_DIGIT_START = 16 };
+
+struct DecEmbedParams {
+    const float *emb = nullptr;            // [vocab][d]
+    const float *conv_w = nullptr;         // [d][d/groups][context]
+    const float *conv_b = nullptr;         // optional [d]
+    int d = 0, groups = 0, context = 0, vocab = 0;
+};
+
+// Masked arg-max over the joiner logits + the blank / non-blank decision of src/april_session.c:306-429 that
+// drives the data path (context push, decoder re-run, silence reset) + the decoder front end for rows whose context
+// changed.  One workgroup per row.
+struct DecideArgs {
+    const float *ws = nullptr; int parts = 1; int m_stride = 0; int N = 0; int M = 0;   // logits = tree(ws) + bias
+    int n_valid = 0;                       // vocabulary size (<= N)
+    const float *bias = nullptr;
+    int blank = 0;
+    float early_emit = 0.0f;               // 1.0 in the first round of a chunk, 0.0 afterwards (:449-454)
+    const int *slot_idx = nullptr;         // row -> slot
+    const int *now_ms = nullptr;           // row -> session time of this chunk
+    int *active = nullptr;                 // row -> still searching in this chunk (in/out)
+    int *dirty = nullptr;                  // row -> context changed in this round (out; the decoder projection's row mask)
+    const uint8_t *tok_class = nullptr;    // [vocab] TokClassBits
+    GreedyState *state = nullptr;          // [slots]
+    StepRecord *rec = nullptr;             // [M] records of this round, or null (see rec_ring)
+    StepRecord *rec_ring = nullptr;        // records go to rec_ring[*rec_off + round * M + row] when rec == null
+    const int *rec_off = nullptr; int round = 0;
+    float *logits_dump = nullptr;          // optional [M][n_valid]
+    DecEmbedParams dec;
+    float *de_out = nullptr; int ld_de = 0;   // relu(conv(emb[ctx])) rows for dirty rows
+};
+void launch_decide(const DecideArgs &a, hipStream_t s);
+
+// Decoder front end for listed slots, context taken from the device state.  op 1 first applies the end-of-flush
+// reset (last token forgotten; context cleared to [blank, blank] unless it already starts with blank,
+// src/april_session.c:296-301,561-563).
+struct DecRowsArgs {
+    const int *slot_idx = nullptr; int M = 0;
+    int op = 0; int blank = 0;
+    GreedyState *state = nullptr;
+    DecEmbedParams dec;
+    float *de_out = nullptr; int ld_de = 0;
+};
+void launch_dec_rows(const DecRowsArgs &a, hipStream_t s);
+
+// debug / parity entry point: decoder front end with explicit contexts
+struct DecEmbedArgs {
+    DecEmbedParams dec;
+    const int *ctx = nullptr;              // [M][context]
+    int M = 0;
+    float *out = nullptr; int ldo = 0;
+};
+void launch_dec_embed(const DecEmbedArgs &a, hipStream_t s);
+
+// start of a chunk step inside a launch chain whose arguments are fixed (hipGraph): fetches the step's index block
+// (slots | ring tails | session times, m ints each) from the pinned host ring through the device step counter
+struct AdvanceArgs {
+    const int *host_ring = nullptr;        // pinned, device-readable
+    const int *host_step_off = nullptr;    // pinned: [step] -> offset of the step's block in host_ring
+    const int *host_rec_off = nullptr;     // pinned: [step] -> offset of the step's records in the record ring
+    int *counter = nullptr;                // device: next step
+    int *dst = nullptr; int dst_stride = 0;   // device: [3][dst_stride]
+    int *active = nullptr;                 // device: [m] set to 1
+    int *rec_off = nullptr;                // device: record offset of the current step
+    int m = 0;
+};
+void launch_advance(const AdvanceArgs &a, hipStream_t s);
+
+// slot reset (aas_free / session create): recurrent state, encoder/decoder outputs and the search state of one slot
+struct ZeroSlotArgs {
+    float *h = nullptr, *c = nullptr; int n_layers = 0; size_t slots = 0; int d_model = 0, hidden = 0;
+    float *eout = nullptr, *dout = nullptr; int joiner = 0;
+    GreedyState *state = nullptr; int blank = 0;
+    int slot = 0;
+};
+void launch_zero_slot(const ZeroSlotArgs &a, hipStream_t s);
 
 // ---------------------------------------------------------------- encoder front (conv 1+2, im2col for conv 3)
 struct ConvEmbedArgs {
@@ -96,17 +211,6 @@ struct ConvEmbedArgs {
     const float *x_direct = nullptr;       // debug path: x given as [M][seg][mel] instead of the ring
 };
 void launch_conv_embed(const ConvEmbedArgs &a, hipStream_t s);
-
-// ---------------------------------------------------------------- decoder front
-struct DecEmbedArgs {
-    const float *emb = nullptr;            // [vocab][d]
-    const float *conv_w = nullptr;         // [d][d/groups][context]
-    const float *conv_b = nullptr;         // optional [d]
-    const int *ctx = nullptr;              // [M][context]
-    int d = 0, groups = 0, context = 0, vocab = 0, M = 0;
-    float *out = nullptr; int ldo = 0;     // relu(conv(emb)) [M][d]
-};
-void launch_dec_embed(const DecEmbedArgs &a, hipStream_t s);
 
 // fp32 -> fp16 (round to nearest even), elementwise; used once at load for the fp16 weight copies
 void launch_cvt_f16(const float *src, void *dst, size_t n, hipStream_t s);

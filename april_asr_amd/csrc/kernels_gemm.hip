@@ -3,13 +3,18 @@
 // pre-packed HBM layout (see kernels.h).  v_mfma_f32_16x16x4_f32 is an exact
 // in-order fp32 FMA chain, so results do not depend on M or on the tile shape.
 //
-// Workgroup = 256 threads = 4 waves; the waves split the K range of the
-// workgroup's slab (split-K inside the CU keeps >= 4 independent 16-byte load
-// streams per CU in flight at M <= 16, where the kernel is HBM-bound), partial
-// tiles meet in LDS and the epilogue runs on the summed tile:
-//   EPI_PARTIAL      slab sums -> workspace (row kernels finish bias/residual/norm)
+// Workgroup = 256 threads = 4 waves which split K; partial tiles meet in LDS and the
+// epilogue runs on the summed tile.  Two schedules of the same canonical summation
+// (kernels.h): GM_SLAB (waves split every slab, one LDS meet per slab, slabs across
+// workgroups -> partial planes; the HBM-bound small-batch form) and GM_FULLK (every wave
+// owns a contiguous K quarter, chunk chains and the slab tree are folded in registers,
+// ONE LDS meet, no partial planes; the row work runs in the epilogue).  Epilogues:
+//   EPI_PARTIAL      slab-tree sums -> workspace (row kernels finish bias/residual/...)
 //   EPI_LSTM         LSTM cell: sigma/tanh gates, c' written in place, u = sigma(o) tanh(c')
 //   EPI_BIAS_DSWISH  y = acc + b ; y * sigmoid(y - 1)
+//   EPI_HR           h state write + residual (LSTM projection)
+//   EPI_RESID_SSQ    bias + residual + sum-of-squares partials (BasicNorm is applied by the consumer's A prologue)
+//   EPI_SLOT_STORE   bias + store into the session's slot row (encoder_proj, decoder_proj)
 // WT = 1 reads fp16 weights and rounds A to fp16 on load (v_mfma_f32_16x16x16_f16, fp32
 // accumulation, same lane<->k mapping and summation structure).  The K loop exists twice with
 // identical arithmetic: compiler-scheduled C++ (all shapes) and a generated hand-scheduled
@@ -38,12 +43,19 @@ using h4 = __attribute__((ext_vector_type(4))) _Float16;
 template <int WT> struct WQuad { using type = f32x4; };
 template <> struct WQuad<1> { using type = h4; };
 
-template <int MT, int NT, int EPI, int AOP, int WT>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
+// ASM = 1: the K loop is the hand-scheduled one (fixed operand registers v112..v175, accumulators in AGPRs); a separate
+// instantiation, so that neither loop's registers weigh on the other (both forms must stay within 256 registers: two
+// workgroups per CU).  The compiler-scheduled 64-row tiles are told so (second launch-bound = waves per SIMD).
+template <int MT, int NT, int EPI, int AOP, int WT, int MODE, int ASM>
+__global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kernel(GemmArgs g)
 {
     using Cfg = TileCfg<MT, NT>;
     using BQ = typename WQuad<WT>::type;       // one lane's four consecutive k values of a weight tile
     extern __shared__ __attribute__((aligned(16))) float red[];
+    constexpr bool FULLK = MODE == GM_FULLK;
+    constexpr bool ROW_EPI = EPI == EPI_HR || EPI == EPI_RESID_SSQ || EPI == EPI_SLOT_STORE;
+    // the slab tree (levels of pairwise sums) is only needed where a workgroup can own more than one slab
+    constexpr bool TREE = !FULLK && (EPI == EPI_PARTIAL || ROW_EPI);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -66,7 +78,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
     // M-blocks that share one weight column on the same XCD (same x mod 8).
     const int nt0 = blockIdx.x * NT;
     const int m0 = blockIdx.y * Cfg::BM;
-    const int zg = blockIdx.z;                 // this workgroup owns slabs [zg*zs, (zg+1)*zs)
+    const int zg = blockIdx.z;                 // GM_SLAB: this workgroup owns slabs [zg*zs, (zg+1)*zs)
     if (g.skew > 0) {
         // Two workgroups share a CU.  Dispatched together they run in lock-step: both stream MFMAs (halving each
         // other's rate), then both sit in their epilogues while the matrix pipe idles.  Delaying every second
@@ -84,7 +96,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
     // All operands are far below 4 GiB per array.
     // after the LDS meet every thread owns QPT groups of 4 consecutive columns ("quads") of the tile
     constexpr int QROW = Cfg::BN / 4, NQ = Cfg::BM * QROW, QPT = (NQ + 255) / 256;
+    // K blocks: KB = K/16 is a multiple of 4*kz (checked on the host): chunk = c blocks.
+    //   GM_SLAB : slab z, wave w -> blocks [(4z + w) c, (4z + w + 1) c); a workgroup walks zs consecutive slabs.
+    //   GM_FULLK: wave w -> blocks [w kz c, (w + 1) kz c), chunk after chunk.
+    const int c = g.debug == 1 ? 0 : KB / (4 * g.kz);
+    const int T = (FULLK ? g.kz : g.zs) * c;           // blocks this wave processes in total
+    const int first_kb = FULLK ? wave * g.kz * c : (4 * (zg * g.zs) + wave) * c;
+
     uint32_t aoff0[MT], aoff1[MT];
+    float sc[MT];                                      // AOP_SCALE: BasicNorm scale of this lane's rows (1 outside segment 0)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int row = m0 + mt * 16 + mrow;
@@ -93,21 +113,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
         aoff0[mt] = (uint32_t)(((size_t)r0 * g.lda0 + kq * 4) * sizeof(float));
         aoff1[mt] = 0;
         if (g.K1 > 0) { const int r1 = g.aidx1 ? g.aidx1[row] : row; aoff1[mt] = (uint32_t)(((size_t)r1 * g.lda1 + kq * 4) * sizeof(float)); }
+        sc[mt] = 1.0f;
+        // segment boundaries coincide with wave ranges (checked on the host), so "this wave reads segment 0" is uniform
+        if (AOP == AOP_SCALE) { if (first_kb * 16 < g.K0) sc[mt] = row_scale(g.a_scale, row); }
     }
     const uint32_t boff = (uint32_t)lane * sizeof(BQ);
     const bool stream_once = gridDim.y == 1;   // weights read by exactly one workgroup: bypass-friendly loads
 
-    // pairwise (balanced-tree) slab accumulation: level b holds the sum of 2^b consecutive slabs.  A workgroup that owns
-    // zs = 2^t slabs needs t levels; the 64x64 tile is capped at zs = 4 (2 levels, 32 registers) so that it stays
+    // pairwise (balanced-tree) slab accumulation (GM_SLAB): level b holds the sum of 2^b consecutive slabs.  A workgroup
+    // that owns zs = 2^t slabs needs t levels; the 64x64 tile is capped at zs = 4 (2 levels, 32 registers) so that it stays
     // within 256 registers and two workgroups share a CU (launch_gemm / gemm_partials apply the same cap)
-    constexpr int NLVL = (MT == 4 && NT == 4) ? 2 : 3;
+    constexpr int NLVL = !TREE ? 1 : ((MT == 4 && NT == 4) ? 2 : 3);
     f32x4 lvl[NLVL][QPT];
     int top = 0;
-    while ((1 << top) < g.zs) ++top;
+    if (TREE) while ((1 << top) < g.zs) ++top;
     constexpr int PLANE = Cfg::BM * Cfg::LDR;
-    auto summed4 = [&](int o) {                        // ((p0+p1)+p2)+p3 of four consecutive columns
+    auto summed4 = [&](int o) {                        // GM_SLAB: ((p0+p1)+p2)+p3 of four consecutive columns; GM_FULLK: (R0+R1)+(R2+R3)
         const f32x4 p0 = *reinterpret_cast<const f32x4 *>(red + o), p1 = *reinterpret_cast<const f32x4 *>(red + PLANE + o);
         const f32x4 p2 = *reinterpret_cast<const f32x4 *>(red + 2 * PLANE + o), p3 = *reinterpret_cast<const f32x4 *>(red + 3 * PLANE + o);
+        if (FULLK) return (p0 + p1) + (p2 + p3);
         return ((p0 + p1) + p2) + p3;
     };
 
@@ -133,15 +157,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
             b[nt] = stream_once ? __builtin_nontemporal_load(pw) : *pw;
         }
     };
-    // K blocks: KB = K/16 is a multiple of 4*kz (checked on the host), so every wave owns exactly c blocks of every
-    // slab: slab z, wave w -> blocks [(4z + w) c, (4z + w + 1) c).  A workgroup walks zs consecutive slabs.
-    const int c = g.debug == 1 ? 0 : KB / (4 * g.kz);
-    const int T = g.zs * c;                            // blocks this wave processes in total
 
     // Register-staged software pipeline: DEPTH k-blocks of loads are in flight per wave while the MFMAs of the
     // oldest stage issue.  Small batches (MT == 1) are HBM-bound weight streams and want many bytes in flight per
     // CU (6 x 4 waves x (1+NT) KiB); large tiles are MFMA-bound and need only enough depth to cover L2 latency.
-    // The prefetch stream runs ahead ACROSS slab boundaries, so the pipeline never restarts inside a workgroup;
+    // The prefetch stream runs ahead ACROSS chunk and slab boundaries, so the pipeline never restarts inside a workgroup;
     // loads in the main loop are unconditional (the fetch position parks on the last block) so the loop body is
     // straight-line code and the compiler keeps counted s_waitcnt vmcnt(N) instead of draining.
 #ifndef APRIL_DEPTH4
@@ -150,10 +170,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
     constexpr int DEPTH = (MT == 1) ? 6 : (MT == 2 ? 3 : APRIL_DEPTH4);
     f32x4 a_st[DEPTH][MT];
     BQ b_st[DEPTH][NT];
-    int ld_base = (4 * (zg * g.zs) + wave) * c, ld_off = 0, ld_cnt = 0;
+    int ld_base = first_kb, ld_off = 0, ld_cnt = 0;
     auto ld_next = [&]() {
         const int kb = g.debug == 3 ? 0 : ld_base + ld_off;     // debug 3 (measurement): every block re-reads block 0 (cache-resident operands)
-        if (ld_cnt + 1 < T) { ++ld_cnt; if (++ld_off == c) { ld_off = 0; ld_base += 4 * c; } }
+        if (ld_cnt + 1 < T) {
+            ++ld_cnt;
+            if (FULLK) ++ld_off;                                   // contiguous quarter
+            else if (++ld_off == c) { ld_off = 0; ld_base += 4 * c; }
+        }
         return kb;
     };
     f32x4 acc[MT][NT];
@@ -164,32 +188,65 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     auto compute = [&](const f32x4 (&a)[MT], const BQ (&b)[NT]) {
-        if constexpr (WT == 1) {
-            // the same 16 k values per lane as four fp32 k-steps, in one v_mfma_f32_16x16x16_f16 (fp32 accumulate)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const h4 ah = {(_Float16)a[mt].x, (_Float16)a[mt].y, (_Float16)a[mt].z, (_Float16)a[mt].w};
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 av = a[mt];
+            if (AOP == AOP_SCALE) av = av * sc[mt];           // x = y * scale: the value a normalisation kernel would have stored
+            if constexpr (WT == 1) {
+                // the same 16 k values per lane as four fp32 k-steps, in one v_mfma_f32_16x16x16_f16 (fp32 accumulate)
+                const h4 ah = {(_Float16)av.x, (_Float16)av.y, (_Float16)av.z, (_Float16)av.w};
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, b[nt], acc[mt][nt], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            } else {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b[nt].x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b[nt].y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b[nt].z, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b[nt].w, acc[mt][nt], 0, 0, 0);
                 }
+            }
         }
     };
-    int slab_done = 0;                                 // slabs finished so far by this workgroup
-    // quarter chains meet in LDS (red[wave][row][col]) and are added ((p0+p1)+p2)+p3; slab sums are combined
-    // pairwise in slab order (balanced tree), so owning 1, 2, 4 or 8 slabs per workgroup -- chosen from the batch
-    // size -- yields the same bits
-    auto meet = [&]() {
-        if (slab_done > 0) __syncthreads();            // previous slab's reads of red[] are done
+
+    // ---- chunk ends
+    // GM_FULLK: the chunk chain is closed in registers.  S = ((c0+c1)+c2)+c3 is a slab; with two slabs per wave (kz = 8)
+    // R = S_first + S_second is the first level of the slab tree; the wave's result (a partial tile) is in R.
+    f32x4 S[FULLK ? MT : 1][FULLK ? NT : 1], R[FULLK ? MT : 1][FULLK ? NT : 1];
+    int chunk_i = 0, slab_i = 0;
+    auto fold = [&]() {
+        if constexpr (FULLK) {
+            if (chunk_i == 0) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) S[mt][nt] = acc[mt][nt];
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) S[mt][nt] = S[mt][nt] + acc[mt][nt];
+            }
+            zero_acc();
+            if (++chunk_i == 4) {
+                chunk_i = 0;
+                if (slab_i == 0) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) R[mt][nt] = S[mt][nt];
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) R[mt][nt] = R[mt][nt] + S[mt][nt];
+                }
+                ++slab_i;
+            }
+        }
+    };
+    // partial tiles -> LDS (red[wave][row][col])
+    auto to_lds = [&](const f32x4 (&t)[MT][NT]) {
         float *mine = red + (size_t)wave * PLANE;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -197,14 +254,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    mine[(mt * 16 + kq * 4 + r) * Cfg::LDR + nt * 16 + mrow] = acc[mt][nt][r];
+                    mine[(mt * 16 + kq * 4 + r) * Cfg::LDR + nt * 16 + mrow] = t[mt][nt][r];
             // one m-tile (16 accumulator registers) at a time: left alone, the scheduler copies the whole accumulator
             // file out of the AGPRs first and the kernel no longer fits two workgroups per CU
             if (MT == 4) __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    int slab_done = 0;                                 // GM_SLAB: slabs finished so far by this workgroup
+    f32x4 v[QPT];                                      // this thread's quads of the workgroup's total (valid after the last meet)
+    // GM_SLAB: quarter chains meet in LDS and are added ((p0+p1)+p2)+p3; slab sums are combined pairwise in slab order
+    // (balanced tree), so owning 1, 2, 4 or 8 slabs per workgroup -- chosen from the batch size -- yields the same bits
+    auto meet = [&]() {
+        if (slab_done > 0) __syncthreads();            // previous slab's reads of red[] are done
+        to_lds(acc);
         __syncthreads();
-        if (EPI == EPI_PARTIAL) {
-            f32x4 v[QPT];
+        if (TREE) {
 #pragma unroll
             for (int i = 0; i < QPT; ++i) {
                 const int q = threadIdx.x + i * 256;
@@ -224,17 +288,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
                     }
                 }
             }
-            if (slab_done + 1 == g.zs) {               // the carry ran through every level: v is the total of the zs slabs
-#pragma unroll
-                for (int i = 0; i < QPT; ++i) {
-                    const int q = threadIdx.x + i * 256;
-                    const int m = m0 + q / QROW;
-                    if (q < NQ && m < g.M)
-                        *reinterpret_cast<f32x4 *>(g.out + ((size_t)zg * g.m_stride + m) * g.N + nt0 * 16 + (q % QROW) * 4) = v[i];
-                }
-            }
         }
         ++slab_done;
+    };
+    auto chunk_end = [&]() {
+        if constexpr (FULLK) fold();
+        else { meet(); if (slab_done < g.zs) zero_acc(); }
     };
 
     // EPI_LSTM: the thread's QPT (row, unit) pairs are known up front; their dependent global loads (row -> slot ->
@@ -264,13 +323,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
 
     zero_acc();
     stamp(1);
-    bool by_hand = false;
     // fused-epilogue GEMMs only (one slab, 5..16 blocks per wave): the split-K GEMMs walk several short slabs per
     // workgroup and rely on the cross-slab prefetch of the compiler-scheduled loop below (measured: no gain there)
-    if constexpr (MT == 4 && (NT == 4 || NT == 2) && WT == 0 && AOP == AOP_NONE && EPI != EPI_PARTIAL) {
-        if (g.asm_loop && c > 0) {
+    if constexpr (ASM) {
+        static_assert(!FULLK && MT == 4 && (NT == 4 || NT == 2) && WT == 0 && (AOP == AOP_NONE || AOP == AOP_SCALE) && (EPI == EPI_LSTM || EPI == EPI_BIAS_DSWISH), "no hand-scheduled loop for this form");
+        {
             // hand-scheduled K loop (tools/gen_gemm_asm.py): same blocks, same order, same accumulation chains
-            by_hand = true;
             uint32_t boffs[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) boffs[nt] = boff + (uint32_t)nt * (uint32_t)KB * 1024u;
@@ -286,31 +344,55 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
                     const char *bp = reinterpret_cast<const char *>(g.wp) + ((size_t)nt0 * KB + kb) * 1024;
                     const uint32_t o0 = seg0 ? aoff0[0] : aoff1[0], o1 = seg0 ? aoff0[1] : aoff1[1];
                     const uint32_t o2 = seg0 ? aoff0[2] : aoff1[2], o3 = seg0 ? aoff0[3] : aoff1[3];
+                    // ONE asm statement per kernel (two statements with tied accumulator operands make the register allocator keep
+                    // two accumulator sets): the AOP_SCALE form always runs the multiplying text; waves outside segment 0
+                    // hold sc = 1.0f, and x * 1.0f is x
+                    constexpr bool scaled = AOP == AOP_SCALE;
 #define APRIL_ASM_IN_A [aoff0] "v"(o0), [aoff1] "v"(o1), [aoff2] "v"(o2), [aoff3] "v"(o3), [ap] "s"(ap), [bp] "s"(bp), [nblk] "s"(n)
+#define APRIL_ASM_IN_S [sc0] "v"(sc[0]), [sc1] "v"(sc[1]), [sc2] "v"(sc[2]), [sc3] "v"(sc[3])
+#define APRIL_ASM_ACC16 [c0] "+a"(acc[0][0]), [c1] "+a"(acc[0][1]), [c2] "+a"(acc[0][2]), [c3] "+a"(acc[0][3]), \
+                        [c4] "+a"(acc[1][0]), [c5] "+a"(acc[1][1]), [c6] "+a"(acc[1][2]), [c7] "+a"(acc[1][3]), \
+                        [c8] "+a"(acc[2][0]), [c9] "+a"(acc[2][1]), [c10] "+a"(acc[2][2]), [c11] "+a"(acc[2][3]), \
+                        [c12] "+a"(acc[3][0]), [c13] "+a"(acc[3][1]), [c14] "+a"(acc[3][2]), [c15] "+a"(acc[3][3])
+#define APRIL_ASM_ACC8 [c0] "+a"(acc[0][0]), [c1] "+a"(acc[0][1]), [c2] "+a"(acc[1][0]), [c3] "+a"(acc[1][1]), \
+                       [c4] "+a"(acc[2][0]), [c5] "+a"(acc[2][1]), [c6] "+a"(acc[3][0]), [c7] "+a"(acc[3][1])
                     if constexpr (NT == 4) {
+                        if constexpr (scaled) {
+                            asm volatile(APRIL_MAINLOOP2_SC_TEXT
+                                : APRIL_ASM_ACC16
+                                : APRIL_ASM_IN_A, APRIL_ASM_IN_S, [boff0] "v"(boffs[0]), [boff1] "v"(boffs[1]), [boff2] "v"(boffs[NT - 2]), [boff3] "v"(boffs[NT - 1])
+                                : APRIL_MAINLOOP2_SC_CLOBBERS);
+                        } else {
 #if APRIL_ASM_NB == 3
-                        asm volatile(APRIL_MAINLOOP3_TEXT
+                            asm volatile(APRIL_MAINLOOP3_TEXT
 #else
-                        asm volatile(APRIL_MAINLOOP2_TEXT
+                            asm volatile(APRIL_MAINLOOP2_TEXT
 #endif
-                            : [c0] "+a"(acc[0][0]), [c1] "+a"(acc[0][1]), [c2] "+a"(acc[0][2]), [c3] "+a"(acc[0][3]),
-                              [c4] "+a"(acc[1][0]), [c5] "+a"(acc[1][1]), [c6] "+a"(acc[1][2]), [c7] "+a"(acc[1][3]),
-                              [c8] "+a"(acc[2][0]), [c9] "+a"(acc[2][1]), [c10] "+a"(acc[2][2]), [c11] "+a"(acc[2][3]),
-                              [c12] "+a"(acc[3][0]), [c13] "+a"(acc[3][1]), [c14] "+a"(acc[3][2]), [c15] "+a"(acc[3][3])
-                            : APRIL_ASM_IN_A, [boff0] "v"(boffs[0]), [boff1] "v"(boffs[1]), [boff2] "v"(boffs[NT - 2]), [boff3] "v"(boffs[NT - 1])
+                                : APRIL_ASM_ACC16
+                                : APRIL_ASM_IN_A, [boff0] "v"(boffs[0]), [boff1] "v"(boffs[1]), [boff2] "v"(boffs[NT - 2]), [boff3] "v"(boffs[NT - 1])
 #if APRIL_ASM_NB == 3
-                            : APRIL_MAINLOOP3_CLOBBERS);
+                                : APRIL_MAINLOOP3_CLOBBERS);
 #else
-                            : APRIL_MAINLOOP2_CLOBBERS);
+                                : APRIL_MAINLOOP2_CLOBBERS);
 #endif
+                        }
                     } else {
-                        asm volatile(APRIL_MAINLOOP2_NT2_TEXT
-                            : [c0] "+a"(acc[0][0]), [c1] "+a"(acc[0][1]), [c2] "+a"(acc[1][0]), [c3] "+a"(acc[1][1]),
-                              [c4] "+a"(acc[2][0]), [c5] "+a"(acc[2][1]), [c6] "+a"(acc[3][0]), [c7] "+a"(acc[3][1])
-                            : APRIL_ASM_IN_A, [boff0] "v"(boffs[0]), [boff1] "v"(boffs[1])
-                            : APRIL_MAINLOOP2_NT2_CLOBBERS);
+                        if constexpr (scaled) {
+                            asm volatile(APRIL_MAINLOOP2_NT2_SC_TEXT
+                                : APRIL_ASM_ACC8
+                                : APRIL_ASM_IN_A, APRIL_ASM_IN_S, [boff0] "v"(boffs[0]), [boff1] "v"(boffs[1])
+                                : APRIL_MAINLOOP2_NT2_SC_CLOBBERS);
+                        } else {
+                            asm volatile(APRIL_MAINLOOP2_NT2_TEXT
+                                : APRIL_ASM_ACC8
+                                : APRIL_ASM_IN_A, [boff0] "v"(boffs[0]), [boff1] "v"(boffs[1])
+                                : APRIL_MAINLOOP2_NT2_CLOBBERS);
+                        }
                     }
 #undef APRIL_ASM_IN_A
+#undef APRIL_ASM_IN_S
+#undef APRIL_ASM_ACC16
+#undef APRIL_ASM_ACC8
                     done += n;
                 }
                 stamp(2);
@@ -320,9 +402,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
             }
         }
     }
-    if (by_hand) {
-        // K loop done above
-    } else if (T > 0) {
+    else if (T > 0) {
         {
             int first[DEPTH];
 #pragma unroll
@@ -336,7 +416,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        int in_slab = 0, i = 0;
+        int in_chunk = 0, i = 0;
         for (; i + DEPTH <= T; i += DEPTH) {
 #pragma unroll
             for (int s = 0; s < DEPTH; ++s) {
@@ -347,21 +427,79 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
                 const int nk = ld_next();
                 load_b(nk, b_st[s]); load_a(nk, a_st[s]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (++in_slab == c) { in_slab = 0; meet(); if (slab_done < g.zs) zero_acc(); }
+                if (++in_chunk == c) { in_chunk = 0; chunk_end(); }
             }
         }
 #pragma unroll
         for (int s = 0; s < DEPTH - 1; ++s)
             if (i + s < T) {
                 compute(a_st[s], b_st[s]);
-                if (++in_slab == c) { in_slab = 0; meet(); if (slab_done < g.zs) zero_acc(); }
+                if (++in_chunk == c) { in_chunk = 0; chunk_end(); }
             }
     } else {
-        for (int z = 0; z < g.zs; ++z) meet();         // measurement mode without the main loop
+        if (FULLK) { for (int z = 0; z < 4 * g.kz; ++z) fold(); }
+        else for (int z = 0; z < g.zs; ++z) meet();    // measurement mode without the main loop
+    }
+
+    if constexpr (FULLK) {
+        // the ONE meet of the full-K schedule: (R0+R1)+(R2+R3) = the canonical slab tree
+        to_lds(R);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * 256;
+            v[i] = q < NQ ? summed4((q / QROW) * Cfg::LDR + (q % QROW) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
 
     if (EPI == EPI_PARTIAL) {
-        // stored by the last meet()
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * 256;
+            const int m = m0 + q / QROW;
+            if (q < NQ && m < g.M)
+                *reinterpret_cast<f32x4 *>(g.out + ((size_t)(FULLK ? 0 : zg) * g.m_stride + m) * g.N + nt0 * 16 + (q % QROW) * 4) = v[i];
+        }
+    } else if (EPI == EPI_HR) {
+        // LSTM projection: h' = acc goes to the session's state row, the layer continues with x + h' where
+        // x = y * scale(y) is the (never materialised) BasicNorm output of the previous layer
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * 256;
+            const int m = m0 + q / QROW, n = nt0 * 16 + (q % QROW) * 4;
+            if (q < NQ && m < g.M) {
+                const int slot = g.slot_idx[m];
+                const f32x4 y = *reinterpret_cast<const f32x4 *>(g.resid + (size_t)m * g.ldr + n);
+                const float rs = row_scale(g.r_scale, m);
+                *reinterpret_cast<f32x4 *>(g.state + (size_t)slot * g.ld_state + n) = v[i];
+                *reinterpret_cast<f32x4 *>(g.out + (size_t)m * g.ldo + n) = y * rs + v[i];
+            }
+        }
+    } else if (EPI == EPI_RESID_SSQ) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * 256;
+            const int m = m0 + q / QROW, n = nt0 * 16 + (q % QROW) * 4;
+            const bool ok = q < NQ && m < g.M;
+            f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                y = v[i] + *reinterpret_cast<const f32x4 *>(g.bias + n);
+                if (g.resid) y = *reinterpret_cast<const f32x4 *>(g.resid + (size_t)m * g.ldr + n) + y;
+                *reinterpret_cast<f32x4 *>(g.out + (size_t)m * g.ldo + n) = y;
+            }
+            const float ss = granule_ssq(y);           // all lanes take part in the shuffles
+            if (ok && (q & 7) == 0) g.ssq_out[(size_t)m * (g.N / SSQ_COLS) + n / SSQ_COLS] = ss;
+        }
+    } else if (EPI == EPI_SLOT_STORE) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * 256;
+            const int m = m0 + q / QROW, n = nt0 * 16 + (q % QROW) * 4;
+            if (q < NQ && m < g.M && (!g.row_mask || g.row_mask[m])) {
+                const int slot = g.slot_idx ? g.slot_idx[m] : m;
+                *reinterpret_cast<f32x4 *>(g.out + (size_t)slot * g.ldo + n) = v[i] + *reinterpret_cast<const f32x4 *>(g.bias + n);
+            }
+        }
     } else if (EPI == EPI_BIAS_DSWISH) {
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
@@ -388,22 +526,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g)
     stamp(4);
 }
 
-template <int MT, int NT>
-static void dispatch(const GemmArgs &g, hipStream_t s)
+// ---------------------------------------------------------------- host side
+struct TilePlan { int mt, nt, zs, mode; };
+
+static int env_int(const char *name, int def) { const char *v = getenv(name); return v && *v ? atoi(v) : def; }
+
+// The full-K schedule pays once output tiles alone occupy a good part of the chip.  Tiles: at most 64x32 (three
+// accumulator-sized register sets: chain, slab, tree level), at least 16x32 (a sum-of-squares granule is 32 columns).
+static bool plan_fullk(int M, int N, int kz, TilePlan &t)
 {
-    using Cfg = TileCfg<MT, NT>;
-    dim3 grid((unsigned)(g.N / Cfg::BN), (unsigned)((g.M + Cfg::BM - 1) / Cfg::BM), (unsigned)(g.kz / g.zs));
-    static const int ldspad = getenv("APRIL_GEMM_LDSPAD") ? atoi(getenv("APRIL_GEMM_LDSPAD")) : 0;   // measurement: KiB of LDS to request at least (> 80 forces one workgroup per CU)
-    const size_t lds = std::max((size_t)Cfg::LDS_FLOATS * sizeof(float), (size_t)ldspad * 1024);
-#define LAUNCH2(E, A) do { if (g.wt == 1) hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, E, A, 1>), grid, dim3(256), lds, s, g); \
-                           else hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, E, A, 0>), grid, dim3(256), lds, s, g); } while (0)
-    if (g.epi == EPI_PARTIAL) { if (g.a_op == AOP_TANH_ADD) LAUNCH2(EPI_PARTIAL, AOP_TANH_ADD); else LAUNCH2(EPI_PARTIAL, AOP_NONE); }
-    else if (g.epi == EPI_LSTM) LAUNCH2(EPI_LSTM, AOP_NONE);
-    else LAUNCH2(EPI_BIAS_DSWISH, AOP_NONE);
-#undef LAUNCH2
+    static const int enabled = env_int("APRIL_FULLK", 1);
+    static const int min_wgs = env_int("APRIL_FULLK_MIN_WGS", 96);
+    if (!enabled || N % 32 != 0) return false;
+    const int ncols = N / 32;
+    int mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+    while (mt > 1 && (long)ncols * ((M + 16 * mt - 1) / (16 * mt)) < 256) mt >>= 1;
+    const long wgs = (long)ncols * ((M + 16 * mt - 1) / (16 * mt));
+    if (wgs < min_wgs) return false;
+    t.mt = mt; t.nt = 2; t.zs = kz; t.mode = kz >= 4 ? GM_FULLK : GM_SLAB;    // kz 1 or 2: one workgroup walks the slabs (<= 2 meets)
+    return true;
 }
 
-struct TilePlan { int mt, nt, zs; };
+bool gemm_fullk(int M, int N, int kz) { TilePlan t; return plan_fullk(M, N, kz, t); }
 
 // Tile shape and slabs per workgroup.  Depends on M only through occupancy; numerics are tile-independent.
 static TilePlan plan_tiles(int M, int N, int kz, int epi)
@@ -411,9 +555,11 @@ static TilePlan plan_tiles(int M, int N, int kz, int epi)
     // measurement knobs (default 0): 1/2 = smaller tiles for the fused-epilogue GEMMs (measured slower on MI355X:
     // B=256 gates 27 -> 32..36 us, the kernel is limited by operand loads per MFMA, not by occupancy);
     // 5 = 64x32 tiles for split-K GEMMs at M > 32
-    static const int tune = getenv("APRIL_GEMM_TUNE") ? atoi(getenv("APRIL_GEMM_TUNE")) : 0;
-    const int ntiles = N / 16;
+    static const int tune = env_int("APRIL_GEMM_TUNE", 0);
     TilePlan t;
+    if (epi != EPI_LSTM && epi != EPI_BIAS_DSWISH && plan_fullk(M, N, kz, t)) return t;
+    const int ntiles = N / 16;
+    t.mode = GM_SLAB;
     t.mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
     int mblocks = (M + t.mt * 16 - 1) / (t.mt * 16);
     t.nt = 4;
@@ -434,27 +580,71 @@ static TilePlan plan_tiles(int M, int N, int kz, int epi)
     return t;
 }
 
-int gemm_partials(int M, int N, int kz) { return kz / plan_tiles(M, N, kz, EPI_PARTIAL).zs; }
+int gemm_partials(int M, int N, int kz)
+{
+    const TilePlan t = plan_tiles(M, N, kz, EPI_PARTIAL);
+    return t.mode == GM_FULLK ? 1 : kz / t.zs;
+}
+
+template <int MT, int NT, int EPI, int AOP, int MODE>
+static void launch_one(const GemmArgs &g, hipStream_t s)
+{
+    constexpr bool HAS_ASM = MODE == GM_SLAB && MT == 4 && (NT == 4 || NT == 2) && (AOP == AOP_NONE || AOP == AOP_SCALE) && (EPI == EPI_LSTM || EPI == EPI_BIAS_DSWISH);
+    using Cfg = TileCfg<MT, NT>;
+    dim3 grid((unsigned)(g.N / Cfg::BN), (unsigned)((g.M + Cfg::BM - 1) / Cfg::BM), (unsigned)(MODE == GM_FULLK ? 1 : g.kz / g.zs));
+    static const int ldspad = env_int("APRIL_GEMM_LDSPAD", 0);   // measurement: KiB of LDS to request at least (> 80 forces one workgroup per CU)
+    const size_t lds = std::max((size_t)Cfg::LDS_FLOATS * sizeof(float), (size_t)ldspad * 1024);
+    if (g.wt == 1) { hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, EPI, AOP, 1, MODE, 0>), grid, dim3(256), lds, s, g); return; }
+    if constexpr (HAS_ASM) {
+        if (g.asm_loop && g.debug != 1) { hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, EPI, AOP, 0, MODE, 1>), grid, dim3(256), lds, s, g); return; }
+    }
+    hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, EPI, AOP, 0, MODE, 0>), grid, dim3(256), lds, s, g);
+}
+
+// (epilogue, prologue, schedule) combinations that exist; everything else is a programming error
+template <int MT, int NT>
+static bool dispatch(const GemmArgs &g, hipStream_t s)
+{
+#define CASE(E, A, MD) if (g.epi == E && g.a_op == A && g.mode == MD) { launch_one<MT, NT, E, A, MD>(g, s); return true; }
+    if constexpr (NT == 2) {        // the full-K schedule uses 16/32/64 x 32 tiles only
+        CASE(EPI_PARTIAL, AOP_NONE, GM_FULLK) CASE(EPI_PARTIAL, AOP_TANH_ADD, GM_FULLK) CASE(EPI_PARTIAL, AOP_SCALE, GM_FULLK)
+        CASE(EPI_HR, AOP_NONE, GM_FULLK) CASE(EPI_RESID_SSQ, AOP_NONE, GM_FULLK)
+        CASE(EPI_SLOT_STORE, AOP_NONE, GM_FULLK) CASE(EPI_SLOT_STORE, AOP_SCALE, GM_FULLK)
+        CASE(EPI_HR, AOP_NONE, GM_SLAB) CASE(EPI_RESID_SSQ, AOP_NONE, GM_SLAB)
+        CASE(EPI_SLOT_STORE, AOP_NONE, GM_SLAB) CASE(EPI_SLOT_STORE, AOP_SCALE, GM_SLAB)
+    }
+    CASE(EPI_PARTIAL, AOP_NONE, GM_SLAB) CASE(EPI_PARTIAL, AOP_TANH_ADD, GM_SLAB) CASE(EPI_PARTIAL, AOP_SCALE, GM_SLAB)
+    CASE(EPI_LSTM, AOP_SCALE, GM_SLAB) CASE(EPI_LSTM, AOP_NONE, GM_SLAB)
+    CASE(EPI_BIAS_DSWISH, AOP_NONE, GM_SLAB)
+#undef CASE
+    return false;
+}
 
 void launch_gemm(const GemmArgs &g_in, hipStream_t s)
 {
     GemmArgs g = g_in;
-    static const int dbg = getenv("APRIL_GEMM_DEBUG") ? atoi(getenv("APRIL_GEMM_DEBUG")) : 0;
+    static const int dbg = env_int("APRIL_GEMM_DEBUG", 0);
     g.debug = dbg;
-    static const int skew = getenv("APRIL_GEMM_SKEW") ? atoi(getenv("APRIL_GEMM_SKEW")) : 2;
-    static const int asm_loop = getenv("APRIL_GEMM_ASM") ? atoi(getenv("APRIL_GEMM_ASM")) : 1;     // 0 = compiler-scheduled loop everywhere (A/B)
+    static const int skew = env_int("APRIL_GEMM_SKEW", 2);
+    static const int asm_loop = env_int("APRIL_GEMM_ASM", 1);     // 0 = compiler-scheduled loop everywhere (A/B)
     const TilePlan t = plan_tiles(g.M, g.N, g.kz, g.epi);
-    g.zs = t.zs;
+    const bool row_epi = g.epi == EPI_HR || g.epi == EPI_RESID_SSQ || g.epi == EPI_SLOT_STORE;
+    if (row_epi && t.zs != g.kz) { fprintf(stderr, "libapril(mi355x): launch_gemm: row epilogue %d needs the full-K plan (M=%d N=%d kz=%d)\n", g.epi, g.M, g.N, g.kz); abort(); }
+    g.zs = t.zs; g.mode = t.mode;
+    // AOP_SCALE multiplies the rows of A segment 0: a wave must not straddle the segment boundary
+    if (g.a_op == AOP_SCALE && g.K1 > 0 && ((g.K0 / 16) % std::max(1, (g.K / 16) / (4 * g.kz))) != 0) { fprintf(stderr, "libapril(mi355x): launch_gemm: AOP_SCALE segment boundary inside a chunk\n"); abort(); }
     // hand-scheduled K loop: measured gains with one workgroup per CU (gates at B <= 256: 24.8 -> 22.9 us) and for the
     // bias+DoubleSwish GEMMs at any size (FFN-up at B = 1024: 26.5 -> 23.3 us); the LSTM-cell GEMM with two
     // co-resident workgroups per CU is faster with the compiler-scheduled loop (B = 1024: 83 vs 91 us)
     const long wgs = (long)(g.N / 64) * ((g.M + 63) / 64);
     g.asm_loop = asm_loop == 1 ? !(g.epi == EPI_LSTM && wgs >= 512) : (asm_loop != 0);
-    g.skew = (long)(g.N / (16 * t.nt)) * ((g.M + 16 * t.mt - 1) / (16 * t.mt)) * (g.kz / g.zs) >= 512 ? skew : 0;   // two workgroups per CU
+    g.skew = (long)(g.N / (16 * t.nt)) * ((g.M + 16 * t.mt - 1) / (16 * t.mt)) * (t.mode == GM_FULLK ? 1 : g.kz / g.zs) >= 512 ? skew : 0;   // two workgroups per CU
     const int mt = t.mt, nt = t.nt;
-    if (mt == 1) { if (nt == 4) dispatch<1, 4>(g, s); else if (nt == 2) dispatch<1, 2>(g, s); else dispatch<1, 1>(g, s); }
-    else if (mt == 2) { if (nt == 4) dispatch<2, 4>(g, s); else if (nt == 2) dispatch<2, 2>(g, s); else dispatch<2, 1>(g, s); }
-    else { if (nt == 4) dispatch<4, 4>(g, s); else if (nt == 2) dispatch<4, 2>(g, s); else dispatch<4, 1>(g, s); }
+    bool ok = false;
+    if (mt == 1) { if (nt == 4) ok = dispatch<1, 4>(g, s); else if (nt == 2) ok = dispatch<1, 2>(g, s); else ok = dispatch<1, 1>(g, s); }
+    else if (mt == 2) { if (nt == 4) ok = dispatch<2, 4>(g, s); else if (nt == 2) ok = dispatch<2, 2>(g, s); else ok = dispatch<2, 1>(g, s); }
+    else { if (nt == 4) ok = dispatch<4, 4>(g, s); else if (nt == 2) ok = dispatch<4, 2>(g, s); else ok = dispatch<4, 1>(g, s); }
+    if (!ok) { fprintf(stderr, "libapril(mi355x): launch_gemm: no kernel for epi %d a_op %d mode %d tile %dx%d\n", g.epi, g.a_op, g.mode, mt, nt); abort(); }
 }
 
 }  // namespace aprilx

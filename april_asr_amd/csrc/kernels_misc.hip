@@ -12,89 +12,44 @@ namespace aprilx {
 __device__ __forceinline__ float sigmoid_dev(float x) { return fast_sigmoid(x); }
 __device__ __forceinline__ float dswish_dev(float y) { return y * sigmoid_dev(y - 1.0f); }
 
-// ---------------------------------------------------------------- row kernel
-// Finishes the split-K GEMMs: s[n] = ((ws[0]+ws[1])+...)+ws[kz-1] in slab order, then the
-// mode-specific tail.  Covers: LSTM projection + residual (ROW_HR), FFN-down / embed-linear +
-// bias + residual + BasicNorm (ROW_NORM), encoder_proj / decoder_proj (ROW_BIAS_STORE) and the
-// joiner's masked arg-max (ROW_ARGMAX, reference src/april_session.c:311-320,329).
+// ---------------------------------------------------------------- row kernels
+// Small-batch path: finish the split-K GEMMs.  s[n] = balanced tree over the partial planes, then the mode-specific
+// tail -- the same arithmetic, in the same order, as the GEMM's fused row epilogues (EPI_HR / EPI_RESID_SSQ /
+// EPI_SLOT_STORE), so a session computes the same bits whichever schedule its batch size selects.
+// Thread t owns the 4-column quad t, t + 256, ... of the row.
 template <int MODE>
 __global__ __launch_bounds__(256) void row_kernel(RowArgs r)
 {
-    __shared__ float scratch[4];
-    __shared__ float s_best[4];
-    __shared__ int s_idx[4];
     const int m = blockIdx.x;
     const int tid = threadIdx.x;
     const int slot = r.slot_idx ? r.slot_idx[m] : m;
-
-    // r.kz partial planes (1, 2, 4 or 8; each already a balanced-tree sum of consecutive K slabs): finish the tree
-    auto slab_sum = [&](int n) { return tree_sum(r.ws, r.kz, r.m_stride, r.N, m, n); };
-
-    if (MODE == ROW_HR) {
-        for (int n = tid; n < r.N; n += 256) {
-            const float s = slab_sum(n);
-            r.state[(size_t)slot * r.ld_state + n] = s;
-            r.out[(size_t)m * r.ldo + n] = r.resid[(size_t)m * r.ldr + n] + s;
-        }
-    } else if (MODE == ROW_NORM) {
-        // N <= 8 * 256 (checked on the host): keep the row in registers between the two passes
-        float y[8];
-        float sq = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int n = tid + i * 256;
-            y[i] = 0.0f;
-            if (n < r.N) {
-                float v = slab_sum(n) + r.bias[n];
-                if (r.resid) v = r.resid[(size_t)m * r.ldr + n] + v;
-                y[i] = v;
-                sq += v * v;
+    if (MODE == ROW_SLOT_STORE) { if (r.row_mask && !r.row_mask[m]) return; }
+    float rs = 0.0f;
+    if (MODE == ROW_HR) rs = row_scale(r.r_scale, m);
+    const int nq = r.N >> 2;                            // N is a multiple of 64
+    for (int q0 = 0; q0 < nq; q0 += 256) {
+        const int q = q0 + tid;
+        const bool ok = q < nq;
+        const int n = q * 4;
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok) s = tree_sum4(r.ws, r.parts, r.m_stride, r.N, m, n);
+        if (MODE == ROW_HR) {
+            if (ok) {
+                const f32x4 y = *reinterpret_cast<const f32x4 *>(r.resid + (size_t)m * r.ldr + n);
+                *reinterpret_cast<f32x4 *>(r.state + (size_t)slot * r.ld_state + n) = s;
+                *reinterpret_cast<f32x4 *>(r.out + (size_t)m * r.ldo + n) = y * rs + s;
             }
-        }
-        const float total = block_sum_256(sq, scratch);
-        const float scale = powf(total / (float)r.N + r.eps, -0.5f);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int n = tid + i * 256;
-            if (n < r.N) r.out[(size_t)m * r.ldo + n] = y[i] * scale;
-        }
-    } else if (MODE == ROW_BIAS_STORE) {
-        for (int n = tid; n < r.N; n += 256) r.out[(size_t)slot * r.ldo + n] = slab_sum(n) + r.bias[n];
-    } else {   // ROW_ARGMAX
-        float best = -9999999999.0f;
-        int best_i = -1;
-        float blank_v = 0.0f;
-        for (int n = tid; n < r.n_valid; n += 256) {
-            const float v = slab_sum(n) + r.bias[n];
-            if (r.logits_dump) r.logits_dump[(size_t)m * r.n_valid + n] = v;
-            if (n == r.blank) blank_v = v;
-            else if (v > best) { best = v; best_i = n; }
-        }
-        // lowest index wins on ties, as a sequential scan with '>' would
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(best, off);
-            const int oi = __shfl_xor(best_i, off);
-            const bool take = (oi >= 0) && (best_i < 0 || ov > best || (ov == best && oi < best_i));
-            if (take) { best = ov; best_i = oi; }
-            blank_v += __shfl_xor(blank_v, off);     // exactly one thread holds a non-zero term
-        }
-        const int wave = tid >> 6;
-        if ((tid & 63) == 0) { s_best[wave] = best; s_idx[wave] = best_i; scratch[wave] = blank_v; }
-        __syncthreads();
-        if (tid == 0) {
-            float b = s_best[0]; int bi = s_idx[0];
-            for (int w = 1; w < 4; ++w) {
-                const float ov = s_best[w]; const int oi = s_idx[w];
-                if (oi >= 0 && (bi < 0 || ov > b || (ov == b && oi < bi))) { b = ov; bi = oi; }
+        } else if (MODE == ROW_RESID_SSQ) {
+            f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                y = s + *reinterpret_cast<const f32x4 *>(r.bias + n);
+                if (r.resid) y = *reinterpret_cast<const f32x4 *>(r.resid + (size_t)m * r.ldr + n) + y;
+                *reinterpret_cast<f32x4 *>(r.out + (size_t)m * r.ldo + n) = y;
             }
-            // the blank logit sits in exactly one wave; the others contributed +0.0f
-            float bl = 0.0f;
-            const int bw = (r.blank & 255) >> 6;
-            bl = scratch[bw];
-            r.joint[m].idx = bi;
-            r.joint[m].max_val = b;
-            r.joint[m].blank_val = bl;
+            const float ss = granule_ssq(y);           // every lane takes part in the shuffles
+            if (ok && (q & 7) == 0) r.ssq_out[(size_t)m * (r.N / SSQ_COLS) + n / SSQ_COLS] = ss;
+        } else {   // ROW_SLOT_STORE
+            if (ok) *reinterpret_cast<f32x4 *>(r.out + (size_t)slot * r.ldo + n) = s + *reinterpret_cast<const f32x4 *>(r.bias + n);
         }
     }
 }
@@ -104,10 +59,194 @@ void launch_row(const RowArgs &r, hipStream_t s)
     dim3 grid((unsigned)r.M), block(256);
     switch (r.mode) {
     case ROW_HR: hipLaunchKernelGGL(row_kernel<ROW_HR>, grid, block, 0, s, r); break;
-    case ROW_NORM: hipLaunchKernelGGL(row_kernel<ROW_NORM>, grid, block, 0, s, r); break;
-    case ROW_BIAS_STORE: hipLaunchKernelGGL(row_kernel<ROW_BIAS_STORE>, grid, block, 0, s, r); break;
-    default: hipLaunchKernelGGL(row_kernel<ROW_ARGMAX>, grid, block, 0, s, r); break;
+    case ROW_RESID_SSQ: hipLaunchKernelGGL(row_kernel<ROW_RESID_SSQ>, grid, block, 0, s, r); break;
+    default: hipLaunchKernelGGL(row_kernel<ROW_SLOT_STORE>, grid, block, 0, s, r); break;
     }
+}
+
+// ---------------------------------------------------------------- decoder front end (device function)
+// Embedding gather of the `context` previous tokens, grouped Conv1d over the context axis
+// (kernel = context, so one output position), ReLU.  Pure function of the token context
+// (reference src/april_session.c:151-163,181-196).  Called by all 256 threads of a workgroup for one row.
+__device__ __forceinline__ void dec_embed_row(const DecEmbedParams &p, int tok0, int tok1, float *out)
+{
+    const int cg = p.d / p.groups;                 // input channels per group == output channels per group
+    for (int o = threadIdx.x; o < p.d; o += 256) {
+        const int g0 = (o / cg) * cg;
+        const float *w = p.conv_w + (size_t)o * cg * p.context;
+        float acc = 0.0f;
+        for (int ci = 0; ci < cg; ++ci) {
+            acc += p.emb[(size_t)tok0 * p.d + g0 + ci] * w[ci * p.context + 0];
+            acc += p.emb[(size_t)tok1 * p.d + g0 + ci] * w[ci * p.context + 1];
+        }
+        if (p.conv_b) acc += p.conv_b[o];
+        out[o] = acc > 0.0f ? acc : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------- joiner decision
+// logits = tree(ws) + bias; masked arg-max (reference src/april_session.c:311-320: first maximum wins, blank excluded);
+// then the part of aas_process_logits (:322-429) that the NEXT network call depends on: blank or not, context push,
+// the >= 2200 ms silence reset of the context, and the class of the last active token (digit-dot rule).  Everything the
+// callbacks need (token text, active list, de-duplication) stays on the host, which replays the same decisions from the
+// 16-byte record written here.
+__global__ __launch_bounds__(256) void decide_kernel(DecideArgs a)
+{
+    __shared__ float s_best[4], s_blank[4];
+    __shared__ int s_idx[4];
+    __shared__ int s_ctx[3];                        // [0..1] context for the decoder front end, [2] re-run flag
+    const int m = blockIdx.x;
+    const int tid = threadIdx.x;
+    StepRecord *rec = a.rec ? a.rec + m : a.rec_ring + (size_t)a.rec_off[0] + (size_t)a.round * a.M + m;
+    if (!a.active[m]) {                             // uniform per workgroup
+        if (tid == 0) { rec->idx = -1; rec->max_val = 0.0f; rec->blank_val = 0.0f; rec->flags = 0; a.dirty[m] = 0; }
+        return;
+    }
+    float best = -9999999999.0f;
+    int best_i = -1;
+    float blank_v = 0.0f;
+    for (int n = tid; n < a.n_valid; n += 256) {
+        const float v = tree_sum(a.ws, a.parts, a.m_stride, a.N, m, n) + a.bias[n];
+        if (a.logits_dump) a.logits_dump[(size_t)m * a.n_valid + n] = v;
+        if (n == a.blank) blank_v = v;
+        else if (v > best) { best = v; best_i = n; }
+    }
+    // lowest index wins on ties, as a sequential scan with '>' would
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off);
+        const int oi = __shfl_xor(best_i, off);
+        const bool take = (oi >= 0) && (best_i < 0 || ov > best || (ov == best && oi < best_i));
+        if (take) { best = ov; best_i = oi; }
+        blank_v += __shfl_xor(blank_v, off);     // exactly one thread holds a non-zero term
+    }
+    const int wave = tid >> 6;
+    if ((tid & 63) == 0) { s_best[wave] = best; s_idx[wave] = best_i; s_blank[wave] = blank_v; }
+    __syncthreads();
+    if (tid == 0) {
+        float b = s_best[0]; int bi = s_idx[0];
+        for (int w = 1; w < 4; ++w) {
+            const float ov = s_best[w]; const int oi = s_idx[w];
+            if (oi >= 0 && (bi < 0 || ov > b || (ov == b && oi < bi))) { b = ov; bi = oi; }
+        }
+        // the blank logit sits in exactly one wave; the others contributed +0.0f
+        const float bl = s_blank[(a.blank & 255) >> 6];
+        rec->idx = bi; rec->max_val = b; rec->blank_val = bl;
+
+        // ---- decision (Greedy::on_joint on the host replays exactly this from the record)
+        const int slot = a.slot_idx[m];
+        GreedyState st = a.state[slot];
+        int tok = bi; float tv = b;
+        if (tok < 0) { tok = a.blank == 0 ? 1 : 0; tv = -9999999999.0f; }        // no logit beat the initial value (NaNs)
+        const bool cleared = st.ctx1 == a.blank;                                  // :322
+        const bool same = st.ctx1 == tok;                                         // :326
+        const float ee = same ? 0.0f : a.early_emit;
+        bool is_blank = (bl - ee) > tv;                                           // :329-330
+        const unsigned tc = a.tok_class[tok];
+        bool punct = (tc & (TKC_SENT_END | TKC_COMMA)) != 0;
+        if (punct && st.last_tok >= 0 && (a.tok_class[st.last_tok] & TKC_DIGIT_START) && (tc & TKC_DOT)) punct = false;   // :345-351
+        if (!cleared && punct && !same && tv > (bl - 3.5f)) is_blank = false;     // :356-358
+        const unsigned now = (unsigned)a.now_ms[m];
+        unsigned flags = REC_VALID;
+        bool rerun = false;
+        if (!is_blank) {                                                          // :361-400
+            st.last_emit_ms = now;
+            st.ctx0 = st.ctx1; st.ctx1 = tok;
+            st.last_tok = tok;
+            rerun = true;
+        } else {                                                                  // :401-426
+            flags |= REC_BLANK;
+            if (now - st.last_emit_ms >= 2200u) {                                 // FINAL, clear context, SILENCE
+                st.last_tok = -1;
+                if (st.ctx0 != a.blank) { st.ctx0 = a.blank; st.ctx1 = a.blank; rerun = true; }   // :296-301
+            }
+            a.active[m] = 0;
+        }
+        if (rerun) flags |= REC_CTX;
+        rec->flags = flags;
+        a.state[slot] = st;
+        a.dirty[m] = rerun ? 1 : 0;
+        s_ctx[0] = st.ctx0; s_ctx[1] = st.ctx1; s_ctx[2] = rerun ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_ctx[2]) dec_embed_row(a.dec, s_ctx[0], s_ctx[1], a.de_out + (size_t)m * a.ld_de);
+}
+
+void launch_decide(const DecideArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(decide_kernel, dim3((unsigned)a.M), dim3(256), 0, s, a);
+}
+
+// decoder front end for listed slots with the context held on the device (first use of a session, end of a flush)
+__global__ __launch_bounds__(256) void dec_rows_kernel(DecRowsArgs a)
+{
+    __shared__ int s_ctx[2];
+    const int m = blockIdx.x;
+    if (threadIdx.x == 0) {
+        const int slot = a.slot_idx[m];
+        GreedyState st = a.state[slot];
+        if (a.op == 1) {                            // src/april_session.c:561-563 after the host's FINAL: forget, clear
+            st.last_tok = -1;
+            if (st.ctx0 != a.blank) { st.ctx0 = a.blank; st.ctx1 = a.blank; }
+            a.state[slot] = st;
+        }
+        s_ctx[0] = st.ctx0; s_ctx[1] = st.ctx1;
+    }
+    __syncthreads();
+    dec_embed_row(a.dec, s_ctx[0], s_ctx[1], a.de_out + (size_t)m * a.ld_de);
+}
+
+void launch_dec_rows(const DecRowsArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(dec_rows_kernel, dim3((unsigned)a.M), dim3(256), 0, s, a);
+}
+
+__global__ __launch_bounds__(256) void dec_embed_kernel(DecEmbedArgs a)
+{
+    const int m = blockIdx.x;
+    dec_embed_row(a.dec, a.ctx[m * a.dec.context + 0], a.ctx[m * a.dec.context + 1], a.out + (size_t)m * a.ldo);
+}
+
+void launch_dec_embed(const DecEmbedArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(dec_embed_kernel, dim3((unsigned)a.M), dim3(256), 0, s, a);
+}
+
+// ---------------------------------------------------------------- step bookkeeping
+__global__ __launch_bounds__(1024) void advance_kernel(AdvanceArgs a)
+{
+    __shared__ int s_k;
+    if (threadIdx.x == 0) s_k = a.counter[0];
+    __syncthreads();
+    const int k = s_k;
+    const int *src = a.host_ring + a.host_step_off[k];          // pinned host memory, read once per step
+    for (int i = threadIdx.x; i < 3 * a.m; i += 1024) a.dst[(i / a.m) * a.dst_stride + (i % a.m)] = src[i];
+    for (int i = threadIdx.x; i < a.m; i += 1024) a.active[i] = 1;
+    if (threadIdx.x == 0) { a.rec_off[0] = a.host_rec_off[k]; a.counter[0] = k + 1; }
+}
+
+void launch_advance(const AdvanceArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1024), 0, s, a);
+}
+
+__global__ __launch_bounds__(256) void zero_slot_kernel(ZeroSlotArgs a)
+{
+    const int l = blockIdx.x;                        // one workgroup per layer, the last one also resets the per-slot rows
+    const size_t s = (size_t)a.slot;
+    if (l < a.n_layers) {
+        float *h = a.h + ((size_t)l * a.slots + s) * a.d_model, *c = a.c + ((size_t)l * a.slots + s) * a.hidden;
+        for (int i = threadIdx.x; i < a.d_model; i += 256) h[i] = 0.0f;
+        for (int i = threadIdx.x; i < a.hidden; i += 256) c[i] = 0.0f;
+    } else {
+        for (int i = threadIdx.x; i < a.joiner; i += 256) { a.eout[s * a.joiner + i] = 0.0f; a.dout[s * a.joiner + i] = 0.0f; }
+        if (threadIdx.x == 0) { GreedyState st; st.ctx0 = a.blank; st.ctx1 = a.blank; st.last_tok = -1; st.last_emit_ms = 0; a.state[s] = st; }
+    }
+}
+
+void launch_zero_slot(const ZeroSlotArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(zero_slot_kernel, dim3((unsigned)a.n_layers + 1), dim3(256), 0, s, a);
 }
 
 // ---------------------------------------------------------------- conv front end
@@ -190,33 +329,6 @@ void launch_conv_embed(const ConvEmbedArgs &a, hipStream_t s)
     const int H2 = (H1 - 3) / a.stride[1] + 1, W2 = (W1 - 3) / a.stride[1] + 1;
     const size_t lds = sizeof(float) * ((size_t)a.seg * a.mel + (size_t)a.ch[0] * H1 * W1 + (size_t)a.ch1_per_group * H2 * W2);
     hipLaunchKernelGGL(conv12_kernel, dim3((unsigned)a.M, (unsigned)(a.ch[1] / a.ch1_per_group)), dim3(256), lds, s, a);
-}
-
-// ---------------------------------------------------------------- decoder front end
-// Embedding gather of the `context` previous tokens, grouped Conv1d over the context axis
-// (kernel = context, so one output position), ReLU.  Pure function of the token context
-// (reference src/april_session.c:151-163,181-196).
-__global__ __launch_bounds__(256) void dec_embed_kernel(DecEmbedArgs a)
-{
-    const int m = blockIdx.x;
-    const int cg = a.d / a.groups;                 // input channels per group == output channels per group
-    for (int o = threadIdx.x; o < a.d; o += 256) {
-        const int g0 = (o / cg) * cg;
-        const float *w = a.conv_w + (size_t)o * cg * a.context;
-        float acc = 0.0f;
-        for (int ci = 0; ci < cg; ++ci)
-            for (int t = 0; t < a.context; ++t) {
-                const int tok = a.ctx[m * a.context + t];
-                acc += a.emb[(size_t)tok * a.d + g0 + ci] * w[ci * a.context + t];
-            }
-        if (a.conv_b) acc += a.conv_b[o];
-        a.out[(size_t)m * a.ldo + o] = acc > 0.0f ? acc : 0.0f;
-    }
-}
-
-void launch_dec_embed(const DecEmbedArgs &a, hipStream_t s)
-{
-    hipLaunchKernelGGL(dec_embed_kernel, dim3((unsigned)a.M), dim3(256), 0, s, a);
 }
 
 // ---------------------------------------------------------------- fp16 weight copies

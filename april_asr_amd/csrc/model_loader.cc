@@ -55,25 +55,13 @@ struct Rd {
 bool parse_params(Rd &r, ModelParams &o, std::string &err)
 {
     static const char magic[8] = {'P', 'A', 'R', 'A', 'M', 'S', 0, 0};
-    if (r.pos + 8 > r.n || memcmp(r.p + r.pos, magic, 8) != 0) { err = "params: bad magic"; return false; }
+    if (r.pos > r.n || r.n - r.pos < 8 || memcmp(r.p + r.pos, magic, 8) != 0) { err = "params: bad magic"; return false; }
     r.pos += 8;
     o.batch_size = r.i32(); o.segment_size = r.i32(); o.segment_step = r.i32(); o.mel_features = r.i32();
     o.sample_rate = r.i32(); o.frame_shift_ms = r.i32(); o.frame_length_ms = r.i32(); o.round_pow2 = r.i32() != 0;
     o.mel_low = r.i32(); o.mel_high = r.i32(); o.snip_edges = r.i32() != 0; o.token_count = r.i32(); o.blank_id = r.i32();
     if (r.bad) { err = "params: truncated"; return false; }
-#define PCHECK(c) if (!(c)) { err = "params: check failed: " #c; return false; }
-    PCHECK(o.batch_size == 1);
-    PCHECK(o.segment_size > 0 && o.segment_size < 100);
-    PCHECK(o.segment_step > 0 && o.segment_step < 100 && o.segment_step <= o.segment_size);
-    PCHECK(o.mel_features > 0 && o.mel_features < 256);
-    PCHECK(o.sample_rate > 0 && o.sample_rate < 144000);
-    PCHECK(o.token_count > 0 && o.token_count < 16384);
-    PCHECK(o.blank_id >= 0 && o.blank_id < o.token_count);
-    PCHECK(o.frame_shift_ms > 0 && o.frame_shift_ms <= o.frame_length_ms);
-    PCHECK(o.frame_length_ms > 0 && o.frame_length_ms <= 5000);
-    PCHECK(o.mel_low > 0 && o.mel_low < o.sample_rate);
-    PCHECK(o.mel_high == 0 || o.mel_high > o.mel_low);
-#undef PCHECK
+    if (!validate_params(o, err)) return false;
     const size_t start = r.pos;
     size_t longest = 0;
     for (int i = 0; i < o.token_count; ++i) {
@@ -94,6 +82,28 @@ bool parse_params(Rd &r, ModelParams &o, std::string &err)
 }
 }  // namespace
 
+// Range checks of src/params.c:71-82, shared by the .april reader and the packed-blob reader (a blob is as untrusted
+// as a model file: these values size the feature ring, drive the chunk loop and index the token table).
+bool validate_params(const ModelParams &o, std::string &err)
+{
+#define PCHECK(c) if (!(c)) { err = "params: check failed: " #c; return false; }
+    PCHECK(o.batch_size == 1);
+    PCHECK(o.segment_size > 0 && o.segment_size < 100);
+    PCHECK(o.segment_step > 0 && o.segment_step < 100 && o.segment_step <= o.segment_size);
+    PCHECK(o.mel_features > 0 && o.mel_features < 256);
+    PCHECK(o.sample_rate > 0 && o.sample_rate < 144000);
+    PCHECK(o.token_count > 0 && o.token_count < 16384);
+    PCHECK(o.blank_id >= 0 && o.blank_id < o.token_count);
+    PCHECK(o.frame_shift_ms > 0 && o.frame_shift_ms <= o.frame_length_ms);
+    PCHECK(o.frame_length_ms > 0 && o.frame_length_ms <= 5000);
+    PCHECK(o.mel_low > 0 && o.mel_low < o.sample_rate);
+    PCHECK(o.mel_high == 0 || o.mel_high > o.mel_low);
+    // the frame shift in samples must be at least one (sample_rate * shift_ms / 1000), else framing never advances
+    PCHECK((long)o.sample_rate * o.frame_shift_ms >= 1000);
+#undef PCHECK
+    return true;
+}
+
 bool parse_container(const std::vector<uint8_t> &blob, ContainerInfo &info, std::string &err)
 {
     Rd r{blob.data(), blob.size()};
@@ -109,12 +119,12 @@ bool parse_container(const std::vector<uint8_t> &blob, ContainerInfo &info, std:
     info.model_type = (uint32_t)r.le(4);
     if (!(info.model_type > 0 && info.model_type < 2)) { err = "unexpected model type " + std::to_string(info.model_type); return false; }
     info.params_off = r.le(8); info.params_size = r.le(8);
-    if (r.bad || info.params_off + info.params_size > r.n) { err = "params out of bounds of file"; return false; }
+    if (r.bad || info.params_off > r.n || info.params_size > r.n - info.params_off) { err = "params out of bounds of file"; return false; }
     uint64_t nn = r.le(8);
     if (r.bad || nn > 8) { err = "too many networks"; return false; }
     for (uint64_t i = 0; i < nn; ++i) {
         uint64_t off = r.le(8), sz = r.le(8);
-        if (r.bad || off + sz > r.n) { err = "network " + std::to_string(i) + " out of bounds of file"; return false; }
+        if (r.bad || off > r.n || sz > r.n - off) { err = "network " + std::to_string(i) + " out of bounds of file"; return false; }
         info.net_off.push_back(off); info.net_size.push_back(sz);
     }
     Rd pr{blob.data(), blob.size(), (size_t)info.params_off};
@@ -136,6 +146,10 @@ struct View {
     const OGraph &g;
     std::string err;
     explicit View(const OGraph &g_) : g(g_) {}
+    // i-th input name of a node, or the empty string (no value is named "") when the node has fewer inputs:
+    // a malformed graph is rejected by the pattern checks instead of indexing past the input list
+    static const std::string &arg(const ONode &n, size_t i) { static const std::string none; return i < n.in.size() ? n.in[i] : none; }
+    static const std::string &res(const ONode &n, size_t i) { static const std::string none; return i < n.out.size() ? n.out[i] : none; }
 
     const ONode *producer(const std::string &v) const {
         auto it = g.producer.find(v);
@@ -172,9 +186,9 @@ struct View {
             return false;
         }
         if (p->op == "Identity" || p->op == "Cast" || p->op == "Unsqueeze" || p->op == "Squeeze" || p->op == "Reshape")
-            return const_floats(p->in[0], out, dims, depth + 1);
+            return const_floats(arg(*p, 0), out, dims, depth + 1);
         if (p->op == "Exp") {
-            if (!const_floats(p->in[0], out, dims, depth + 1)) return false;
+            if (!const_floats(arg(*p, 0), out, dims, depth + 1)) return false;
             for (auto &x : out) x = expf(x);
             return true;
         }
@@ -191,7 +205,7 @@ struct View {
             if (op == "Unsqueeze" || op == "Squeeze" || op == "Reshape" || op == "Transpose" || op == "Identity" ||
                 op == "Cast" || op == "Slice" || op == "Flatten" || (op == "Concat" && p->in.size() == 1) ||
                 (op == "Gather" && p->in.size() == 2 && is_const(p->in[1])) || (op == "Split" && p->out.size() == 1))
-                v = p->in[0];
+                v = arg(*p, 0);
             else return v;
         }
         return v;
@@ -207,6 +221,7 @@ struct View {
     bool linear_at(int idx, Linear &L) {
         const ONode &n = g.nodes[idx];
         L.node = idx;
+        if (n.in.size() < 2 || n.out.empty()) { err = "linear node without operands (" + n.name + ")"; return false; }
         L.in_value = n.in[0];
         const OTensor &w = g.inits.at(n.in[1]);
         if (w.dtype != 1 || w.dims.size() != 2) { err = "linear weight must be a 2-D float tensor (" + n.name + ")"; return false; }
@@ -249,15 +264,15 @@ struct View {
         for (const ONode *c : consumers(y)) {
             float shift = 0; bool ok = false;
             std::vector<float> k;
-            if (c->op == "Sub" && c->in[0] == y && const_floats(c->in[1], k) && k.size() == 1) { shift = k[0]; ok = true; }
+            if (c->op == "Sub" && c->in.size() == 2 && c->in[0] == y && const_floats(c->in[1], k) && k.size() == 1) { shift = k[0]; ok = true; }
             if (c->op == "Add" && c->in.size() == 2) {
                 const std::string &o = c->in[0] == y ? c->in[1] : c->in[0];
                 if (const_floats(o, k) && k.size() == 1) { shift = -k[0]; ok = true; }
             }
             if (!ok) continue;
             if (fabsf(shift - 1.0f) > 1e-6f) { err = "activation is x*sigmoid(x-c) with c != 1"; return false; }
-            for (const ONode *s : consumers(c->out[0])) if (s->op == "Sigmoid")
-                for (const ONode *m : consumers(s->out[0])) if (m->op == "Mul" && (m->in[0] == y || m->in[1] == y)) { out = m->out[0]; return true; }
+            for (const ONode *s : consumers(res(*c, 0))) if (s->op == "Sigmoid")
+                for (const ONode *m : consumers(res(*s, 0))) if (m->op == "Mul" && m->in.size() == 2 && !m->out.empty() && (m->in[0] == y || m->in[1] == y)) { out = m->out[0]; return true; }
         }
         err = "expected DoubleSwish (x * sigmoid(x - 1)) after '" + y + "'";
         return false;
@@ -268,18 +283,18 @@ struct View {
         for (const ONode *c : consumers(y)) {
             bool sq = false;
             std::vector<float> k;
-            if (c->op == "Pow" && c->in[0] == y && const_floats(c->in[1], k) && k.size() == 1 && k[0] == 2.0f) sq = true;
-            if (c->op == "Mul" && c->in[0] == y && c->in[1] == y) sq = true;
+            if (c->op == "Pow" && c->in.size() == 2 && c->in[0] == y && const_floats(c->in[1], k) && k.size() == 1 && k[0] == 2.0f) sq = true;
+            if (c->op == "Mul" && c->in.size() == 2 && c->in[0] == y && c->in[1] == y) sq = true;
             if (!sq) continue;
-            for (const ONode *rm : consumers(c->out[0])) if (rm->op == "ReduceMean")
-                for (const ONode *ad : consumers(rm->out[0])) if (ad->op == "Add") {
+            for (const ONode *rm : consumers(res(*c, 0))) if (rm->op == "ReduceMean")
+                for (const ONode *ad : consumers(res(*rm, 0))) if (ad->op == "Add" && ad->in.size() == 2 && !ad->out.empty()) {
                     const std::string &o = ad->in[0] == rm->out[0] ? ad->in[1] : ad->in[0];
                     std::vector<float> e;
                     if (!const_floats(o, e) || e.size() != 1) continue;
                     for (const ONode *pw : consumers(ad->out[0])) {
                         std::vector<float> ex;
-                        if (pw->op == "Pow" && const_floats(pw->in[1], ex) && ex.size() == 1 && ex[0] == -0.5f)
-                            for (const ONode *m : consumers(pw->out[0])) if (m->op == "Mul" && (m->in[0] == y || m->in[1] == y)) { eps = e[0]; out = m->out[0]; return true; }
+                        if (pw->op == "Pow" && const_floats(arg(*pw, 1), ex) && ex.size() == 1 && ex[0] == -0.5f)
+                            for (const ONode *m : consumers(res(*pw, 0))) if (m->op == "Mul" && m->in.size() == 2 && !m->out.empty() && (m->in[0] == y || m->in[1] == y)) { eps = e[0]; out = m->out[0]; return true; }
                     }
                 }
         }
@@ -318,7 +333,7 @@ bool extract_encoder(const OGraph &g, const ModelParams &P, HostModel &M, std::s
         const ONode &n = g.nodes[wn[i]];
         if (n.op != "Conv") return fail(err, "encoder: node " + std::to_string(i) + " of the embed stack is not Conv");
         const OTensor &w = g.inits.at(n.in[1]);
-        if (w.dims.size() != 4 || w.dims[2] != 3 || w.dims[3] != 3 || w.dims[1] != C) return fail(err, "embed conv must be 3x3 over " + std::to_string(C) + " channels");
+        if (w.dtype != 1 || w.dims.size() != 4 || w.dims[2] != 3 || w.dims[3] != 3 || w.dims[1] != C) return fail(err, "embed conv must be 3x3 over " + std::to_string(C) + " channels");
         if (n.attr_i("group", 1) != 1) return fail(err, "embed conv group != 1");
         int st = 1;
         if (auto a = n.attr("strides")) { if (a->ints.size() != 2 || a->ints[0] != a->ints[1]) return fail(err, "embed conv strides"); st = (int)a->ints[0]; }
@@ -408,22 +423,23 @@ bool extract_decoder(const OGraph &g, HostModel &M, std::string &err)
     const ONode *gather = nullptr, *conv = nullptr; bool relu = false; int mm = -1;
     for (size_t i = 0; i < g.nodes.size(); ++i) {
         const ONode &n = g.nodes[i];
-        if (n.op == "Gather" && g.inits.count(n.in[0]) && g.inits.at(n.in[0]).dims.size() == 2) gather = &n;
+        if (n.op == "Gather" && !n.in.empty() && g.inits.count(n.in[0]) && g.inits.at(n.in[0]).dims.size() == 2) gather = &n;
         else if (n.op == "Conv") conv = &n;
         else if (n.op == "Relu") relu = true;
         else if (v.weighted(n) && n.op != "Conv") mm = (int)i;
     }
     if (!gather || !conv || !relu || mm < 0) return fail(err, "decoder: expected Gather(embedding) -> Conv -> Relu -> Linear");
     const OTensor &emb = g.inits.at(gather->in[0]);
-    if ((int)emb.dims[1] != D.d_model && D.d_model) { /* decoder_dim may differ from encoder d_model; keep its own */ }
+    if (emb.dtype != 1 || emb.f.size() != emb.numel()) return fail(err, "decoder embedding table must be float32");
     M.emb = emb.f;
     const int V = (int)emb.dims[0], dd = (int)emb.dims[1];
+    if (conv->in.size() < 2 || !g.inits.count(conv->in[1])) return fail(err, "decoder conv weight must be an initializer");
     const OTensor &cw = g.inits.at(conv->in[1]);
-    if (cw.dims.size() != 3 || cw.dims[0] != dd || cw.dims[2] != D.context) return fail(err, "decoder conv weight shape");
+    if (cw.dtype != 1 || cw.dims.size() != 3 || cw.dims[0] != dd || cw.dims[2] != D.context) return fail(err, "decoder conv weight shape");
     D.dec_groups = (int)conv->attr_i("group", 1);
     if (cw.dims[1] * D.dec_groups != dd) return fail(err, "decoder conv groups do not divide channels");
     M.dec_conv = cw.f;
-    if (conv->in.size() > 2 && !conv->in[2].empty()) { if (!v.const_floats(conv->in[2], M.dec_conv_b)) return fail(err, "decoder conv bias"); }
+    if (conv->in.size() > 2 && !conv->in[2].empty()) { if (!v.const_floats(conv->in[2], M.dec_conv_b) || (int)M.dec_conv_b.size() != dd) return fail(err, "decoder conv bias must be a constant of length d_model"); }
     Linear p;
     if (!v.linear_at(mm, p)) return fail(err, "decoder_proj: " + v.err);
     if (p.K != dd) return fail(err, "decoder_proj input width");
@@ -460,6 +476,7 @@ bool extract_joiner(const OGraph &g, HostModel &M, std::string &err)
 
 bool load_april_file(const char *path, HostModel &out, std::string &err)
 {
+    if (!path) { err = "no model path given"; return false; }
     FILE *fd = fopen(path, "rb");
     if (!fd) { err = std::string("cannot open ") + path; return false; }
     fseek(fd, 0, SEEK_END);

@@ -67,5 +67,6 @@ struct ContainerInfo {
     ModelParams params;
 };
 bool parse_container(const std::vector<uint8_t> &blob, ContainerInfo &info, std::string &err);
+bool validate_params(const ModelParams &p, std::string &err);     // range checks of reference src/params.c:71-82 (+ frame shift >= 1 sample)
 
 }  // namespace aprilx

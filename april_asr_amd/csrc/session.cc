@@ -223,6 +223,12 @@ void Scheduler::attach(Session *s)
 void Scheduler::detach(Session *s)
 {
     std::unique_lock<std::mutex> lk(mu_);
+    if (on_loop_thread() && s->busy) {
+        // aas_free from inside this session's own asynchronous result handler: the stepping thread would wait for itself
+        // (the reference joins its own thread there, src/proc_thread.c:101-116).  Refuse loudly instead of hanging.
+        LOGE("aas_free called from inside the session's result handler: not supported, the session is left alive");
+        return;
+    }
     s->closing = true;
     cv_done_.wait(lk, [&] { return !s->busy; });
     sessions_.erase(std::remove(sessions_.begin(), sessions_.end(), s), sessions_.end());
@@ -244,7 +250,8 @@ void Scheduler::submit(int n, Session *const *ss, const short *const *pcm, const
             if (flush) s->flush_requested = true;
             else {
                 const size_t cnt = counts[i];
-                if (!s->sync_mode && s->inbox.size() + s->borrow_cnt + cnt > kAsyncRingSamples) { overflowed.push_back(s); continue; }   // april_session.c:482-492
+                // the reference's ring refuses a push that would make it hold MAX_AUDIO samples or more (src/audio_provider.c:61)
+                if (!s->sync_mode && s->inbox.size() + s->borrow_cnt + cnt >= kAsyncRingSamples) { overflowed.push_back(s); continue; }   // april_session.c:482-492
                 if (cnt) {
                     if (borrow && !s->borrow_cnt && s->inbox.empty()) { s->borrow_ptr = pcm[i]; s->borrow_cnt = cnt; }
                     else s->inbox.insert(s->inbox.end(), pcm[i], pcm[i] + cnt);
@@ -292,6 +299,7 @@ void Scheduler::deliver_sync_events(Session *s)
 void Scheduler::loop()
 {
     HIP_CHECK(hipSetDevice(eng_->device()));
+    { std::lock_guard<std::mutex> g(mu_); loop_tid_ = std::this_thread::get_id(); }
     std::vector<Session *> work;
     std::vector<uint64_t> taken;
     std::vector<std::tuple<Session *, const short *, size_t>> lent;
@@ -330,9 +338,20 @@ void Scheduler::loop()
         // buffer is only accepted when nothing is queued in front of it, so the order of samples is kept)
         pool_.run(lent.size(), 64, [&](size_t i) { auto &l = lent[i]; std::get<0>(l)->fb.fifo.insert(std::get<0>(l)->fb.fifo.end(), std::get<1>(l), std::get<1>(l) + std::get<2>(l)); });
         lent.clear();
-        stats_.host_ms[0] += lap();
+        tick_.host_ms[0] += lap();
+        for (Session *s : work) s->chunks_at_tick_start = s->chunks;
+        const auto t_tick = std::chrono::steady_clock::now();
         process(work);
         lap();
+        {   // reference src/april_session.c:456-462: EMA of (processing time x 1.1) / audio time per chunk.  All sessions of a
+            // tick are stepped together, so a chunk's processing time is the tick's wall time over the chunks the session advanced
+            const double tick_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tick).count();
+            const double stride_ms = (double)(model_->host.params.segment_step * model_->host.params.frame_shift_ms);
+            for (Session *s : work) {
+                const uint64_t n = s->chunks - s->chunks_at_tick_start;
+                for (uint64_t i = 0; i < n; ++i) s->speed_needed = (s->speed_needed * 9.0 + (tick_ms / (double)n) * 1.1 / stride_ms) / 10.0;
+            }
+        }
         // async sessions: deliver on this (library) thread, outside the lock
         for (Session *s : work) if (!s->sync_mode) {
             for (auto &e : s->events) s->handler(s->userdata, (AprilResultType)e.type, e.tokens.size(), e.tokens.empty() ? nullptr : e.tokens.data());
@@ -346,8 +365,10 @@ void Scheduler::loop()
                 s->completed = taken[i];
                 s->busy = false;
             }
-            stats_.ticks++;
-            stats_.host_ms[7] += lap();
+            tick_.ticks++;
+            tick_.host_ms[7] += lap();
+            stats_.add(tick_);
+            tick_ = SchedStats();
         }
         cv_done_.notify_all();
     }
@@ -358,7 +379,7 @@ void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
     Lap lap;
     desc_.clear(); pcm_parts_.clear();
     size_t staged = 0;
-    std::vector<Session *> need_decode;
+    std::vector<Session *> finishers;
     for (Session *s : work) {
         FrameBook &fb = s->fb;
         // new real frames: frame k covers stream samples [k*shift, k*shift + padded)  (fbank.c:195-236)
@@ -404,104 +425,141 @@ void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
             progressed = true;
             break;
         case 4:
-            s->greedy.finish_flush(s->events);
-            if (s->greedy.ctx_dirty) need_decode.push_back(s);
+            // FINAL, clear context, SILENCE (april_session.c:561-563): the host part is replayed in order with the chunk
+            // records of this flight; the device part (context reset + decoder refresh) is queued here
+            s->replay.push_back(Session::Replay{-1, 0, 0, (uint32_t)s->now_ms, 1});
+            finishers.push_back(s);
             s->flush_phase = 0;
             progressed = true;
             break;
         default: break;
         }
     }
-    stats_.host_ms[1] += lap();
+    tick_.host_ms[1] += lap();
     if (!desc_.empty()) {
         eng_->fbank((int)desc_.size(), desc_.data(), pcm_parts_.data(), pcm_parts_.size(), staged, &pool_);
         pool_.run(work.size(), 64, [&](size_t i) { Session *s = work[i]; if (s->compact_pending) { s->fb.compact(); s->compact_pending = false; } });
-        stats_.frames += desc_.size();
-        stats_.host_ms[2] += lap();
+        tick_.frames += desc_.size();
+        tick_.host_ms[2] += lap();
     }
-    if (!need_decode.empty()) {
-        slots_.clear(); ctx_.clear();
-        for (Session *s : need_decode) { slots_.push_back(s->slot); ctx_.push_back(s->greedy.ctx[0]); ctx_.push_back(s->greedy.ctx[1]); s->greedy.ctx_dirty = false; }
-        eng_->decode((int)slots_.size(), slots_.data(), ctx_.data());
+    if (!finishers.empty()) {
+        slots_.clear();
+        for (Session *s : finishers) slots_.push_back(s->slot);
+        eng_->decode_rows((int)slots_.size(), slots_.data(), 1);
+        tick_.host_ms[6] += lap();
     }
 }
 
-void Scheduler::step_chunks(std::vector<Session *> &ready)
+bool Scheduler::step_chunks(std::vector<Session *> &ready)
 {
     Lap lap;
     const int n = (int)ready.size();
     const NetDims &d = eng_->dims();
-    // first use of a session: context = [blank, blank], run the decoder (april_session.c:432-438)
-    slots_.clear(); ctx_.clear();
+    const int MB = eng_->max_batch();
+    if (!eng_->flight_has_room(n, (n + MB - 1) / MB)) return false;
+    // first use of a session: context = [blank, blank] (already in the slot's device state), run the decoder (april_session.c:432-438)
+    slots_.clear();
     for (Session *s : ready) if (!s->dout_ready) {
         s->greedy.reset_context_to_blank();
         s->greedy.ctx_dirty = false;
         s->dout_ready = true;
-        slots_.push_back(s->slot); ctx_.push_back(s->greedy.ctx[0]); ctx_.push_back(s->greedy.ctx[1]);
-    }
-    if (!slots_.empty()) eng_->decode((int)slots_.size(), slots_.data(), ctx_.data());
-
-    slots_.clear(); tails_.clear();
-    const int stride_ms = model_->host.params.segment_step * model_->host.params.frame_shift_ms;
-    for (Session *s : ready) {
-        FrameBook &fb = s->fb;
         slots_.push_back(s->slot);
-        tails_.push_back(fb.tail);                                  // fbank.c:327-349
-        fb.tail = (fb.tail + fb.seg_step) % fb.ring_frames;
-        fb.avail -= fb.seg_step;
-        fb.avail_shadow -= fb.seg_step;
-        s->now_ms += (size_t)stride_ms;                             // april_session.c:442-443
-        s->chunks++;
     }
-    eng_->encode(n, slots_.data(), tails_.data());
-    stats_.host_ms[3] += lap();
-    stats_.steps++; stats_.chunks += (uint64_t)n;
-    if ((uint64_t)n > stats_.max_batch_seen) stats_.max_batch_seen = (uint64_t)n;
+    if (!slots_.empty()) { eng_->decode_rows((int)slots_.size(), slots_.data(), 0); tick_.host_ms[6] += lap(); }
 
-    std::vector<Session *> rows(ready), next, dec;
-    for (int round = 0; round < 3 && !rows.empty(); ++round) {
-        const int m = (int)rows.size();
-        slots_.resize((size_t)m);
-        bool want_logits = false;
-        for (int i = 0; i < m; ++i) { slots_[(size_t)i] = rows[(size_t)i]->slot; if (rows[(size_t)i]->trace_buf) want_logits = true; }
-        jr_.resize((size_t)m);
-        if (want_logits) logit_stage_.resize((size_t)m * d.vocab);
-        lap();
-        eng_->joint(m, slots_.data(), jr_.data(), want_logits ? logit_stage_.data() : nullptr);
-        stats_.host_ms[4] += lap();
-        stats_.rounds++;
-        next.clear(); dec.clear();
+    const int stride_ms = model_->host.params.segment_step * model_->host.params.frame_shift_ms;
+    for (int o = 0; o < n; o += MB) {
+        const int m = std::min(MB, n - o);
+        slots_.clear(); tails_.clear(); now_.clear();
+        bool traced = false;
         for (int i = 0; i < m; ++i) {
-            Session *s = rows[(size_t)i];
-            if (s->trace_buf && *s->trace_used + (size_t)d.vocab <= s->trace_cap) {
-                memcpy(s->trace_buf + *s->trace_used, logit_stage_.data() + (size_t)i * d.vocab, (size_t)d.vocab * 4);
-                *s->trace_used += (size_t)d.vocab;
+            Session *s = ready[(size_t)(o + i)];
+            FrameBook &fb = s->fb;
+            slots_.push_back(s->slot);
+            tails_.push_back(fb.tail);                                  // fbank.c:327-349
+            fb.tail = (fb.tail + fb.seg_step) % fb.ring_frames;
+            fb.avail -= fb.seg_step;
+            fb.avail_shadow -= fb.seg_step;
+            s->now_ms += (size_t)stride_ms;                             // april_session.c:442-443
+            s->chunks++;
+            now_.push_back((int)s->now_ms);
+            if (s->trace_buf) traced = true;
+        }
+        if (traced) logit_stage_.resize((size_t)3 * m * d.vocab);
+        const int k = eng_->step(m, slots_.data(), tails_.data(), now_.data(), traced ? logit_stage_.data() : nullptr);
+        for (int i = 0; i < m; ++i) {
+            Session *s = ready[(size_t)(o + i)];
+            s->replay.push_back(Session::Replay{k, i, m, (uint32_t)s->now_ms, 0});
+            if (traced && s->trace_buf) {                               // tests: the logits of every round that ran, in order
+                const StepRecord *recs = eng_->records(k);
+                for (int r = 0; r < 3; ++r) {
+                    const StepRecord &rec = recs[(size_t)r * m + i];
+                    if (!(rec.flags & REC_VALID)) break;
+                    if (*s->trace_used + (size_t)d.vocab <= s->trace_cap) {
+                        memcpy(s->trace_buf + *s->trace_used, logit_stage_.data() + ((size_t)r * m + i) * d.vocab, (size_t)d.vocab * 4);
+                        *s->trace_used += (size_t)d.vocab;
+                    }
+                    if (rec.flags & REC_BLANK) break;
+                }
             }
-            const bool blank = s->greedy.on_joint(jr_[(size_t)i], round == 0 ? 1.0f : 0.0f, s->now_ms, s->events);   // :449-454
-            if (s->greedy.ctx_dirty) { dec.push_back(s); s->greedy.ctx_dirty = false; }
-            if (!blank) next.push_back(s);
         }
-        stats_.host_ms[5] += lap();
-        if (!dec.empty()) {
-            slots_.clear(); ctx_.clear();
-            for (Session *s : dec) { slots_.push_back(s->slot); ctx_.push_back(s->greedy.ctx[0]); ctx_.push_back(s->greedy.ctx[1]); }
-            eng_->decode((int)slots_.size(), slots_.data(), ctx_.data());
-            stats_.host_ms[6] += lap();
+        tick_.steps++; tick_.chunks += (uint64_t)m;
+        if ((uint64_t)m > tick_.max_batch_seen) tick_.max_batch_seen = (uint64_t)m;
+    }
+    tick_.host_ms[3] += lap();
+    return true;
+}
+
+// After the flight: per session, in the order things happened, feed the device's per-round records to the search state
+// machine (which builds the callbacks) and check that it takes the same decisions the device took.
+void Scheduler::replay(std::vector<Session *> &work)
+{
+    for (Session *s : work) {
+        for (const Session::Replay &it : s->replay) {
+            if (it.kind == 1) { s->greedy.finish_flush(s->events); s->greedy.ctx_dirty = false; continue; }
+            const StepRecord *recs = eng_->records(it.step);
+            for (int r = 0; r < 3; ++r) {                               // april_session.c:449-454
+                const StepRecord &rec = recs[(size_t)r * it.rows + it.row];
+                if (!(rec.flags & REC_VALID)) { tick_.replay_mismatch++; LOGE("replay: device skipped a round the host expected (slot %d)", s->slot); break; }
+                const JointResult jr{rec.idx, rec.max_val, rec.blank_val};
+                const bool blank = s->greedy.on_joint(jr, r == 0 ? 1.0f : 0.0f, (size_t)it.now_ms, s->events);
+                const bool ctx = s->greedy.ctx_dirty;
+                s->greedy.ctx_dirty = false;
+                tick_.rounds++;
+                if (blank != ((rec.flags & REC_BLANK) != 0) || ctx != ((rec.flags & REC_CTX) != 0)) {
+                    tick_.replay_mismatch++;
+                    LOGE("replay: host and device decisions differ (slot %d, round %d: host blank=%d ctx=%d, device flags=%u)", s->slot, r, (int)blank, (int)ctx, rec.flags);
+                }
+                if (blank) break;
+            }
         }
-        rows.swap(next);
+        s->replay.clear();
     }
 }
 
 void Scheduler::process(std::vector<Session *> &work)
 {
     std::vector<Session *> ready;
-    for (;;) {
-        bool progressed = false;
-        cut_frames(work, progressed);
-        ready.clear();
-        for (Session *s : work) if (s->fb.chunk_ready()) ready.push_back(s);
-        if (!ready.empty()) { step_chunks(ready); progressed = true; }
-        if (!progressed) break;
+    bool done = false;
+    while (!done) {
+        eng_->begin_flight();
+        for (;;) {
+            bool progressed = false;
+            cut_frames(work, progressed);
+            ready.clear();
+            for (Session *s : work) if (s->fb.chunk_ready()) ready.push_back(s);
+            if (!ready.empty()) {
+                if (!step_chunks(ready)) break;                       // rings full: land this flight, continue in the next
+                progressed = true;
+            }
+            if (!progressed) { done = true; break; }
+        }
+        Lap lap;
+        eng_->end_flight();
+        tick_.host_ms[4] += lap();
+        tick_.flights++;
+        replay(work);
+        tick_.host_ms[5] += lap();
     }
 }
 

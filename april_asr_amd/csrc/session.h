@@ -1,15 +1,20 @@
 // Host-side session runtime for the GPU engine.
 //
 //   Greedy      the per-session transducer search + partial/final/silence state machine
-//               (reference src/april_session.c:199-429), driven by 12-byte JointResults
-//               instead of 500-float logit rows.
+//               (reference src/april_session.c:199-429), driven by the 16-byte per-round records
+//               the device writes (arg-max, its logit, the blank logit) instead of 500-float logit
+//               rows.  The decisions that steer the NEXT network call (blank or not, context push,
+//               silence reset) are also taken on the device (kernels_misc.hip decide_kernel); the host
+//               replays them from the same numbers when it builds the callbacks.
 //   FrameBook   bookkeeping twin of the reference's OnlineFBank ring (src/fbank.c:98-127,
 //               174-349): which frames exist, where they live in the HBM ring, flush padding.
 //               The samples themselves only pass through (PCM16 FIFO -> pinned staging).
 //   Scheduler   one stepping thread per GPU: gathers every session that has work, cuts new
 //               frames (one fbank launch for all sessions), and advances all sessions with a
-//               ready chunk in lock-step: one batched encoder pass, then up to three masked
-//               joiner/decoder rounds (reference src/april_session.c:431-476, batched).
+//               ready chunk in lock-step: one batched encoder pass, then three masked
+//               joiner/decision/decoder rounds (reference src/april_session.c:431-476, batched),
+//               chunk after chunk without waiting for the GPU; ONE wait per flight, then the
+//               callbacks are replayed from the records.
 #pragma once
 #include <atomic>
 #include <condition_variable>
@@ -31,6 +36,8 @@ enum TokClass : uint8_t {
     TK_DIGIT_START = 16     // text[0] in '0'..'9'
 };
 std::vector<uint8_t> classify_tokens(const ModelParams &p);
+
+struct JointResult { int32_t idx; float max_val; float blank_val; };     // what one joiner round hands to the search
 
 struct Event {
     int type;                         // AprilResultType
@@ -107,6 +114,10 @@ struct Session {
     Greedy greedy;
     bool dout_ready = false;
     bool compact_pending = false;
+    struct Replay { int step; int row; int rows; uint32_t now_ms; int kind; };   // kind 0: chunk (3 rounds of records), 1: end of flush
+    std::vector<Replay> replay;               // what the flight in progress did for this session, in order
+    double speed_needed = 1.0;                // reference src/april_session.c:79,456-462 (EMA of processing time / audio time x 1.1)
+    uint64_t chunks_at_tick_start = 0;
     bool was_flushed = false;
     int flush_phase = 0;                      // 0 none, 1 pad-drain, 2 zeros, 3 pad-drain, 4 finish
     size_t now_ms = 0;
@@ -117,10 +128,15 @@ struct Session {
 };
 
 struct SchedStats {
-    uint64_t ticks = 0, steps = 0, chunks = 0, rounds = 0, frames = 0, max_batch_seen = 0;
-    // host wall time of the stepping thread by phase (ms): 0 collect, 1 cut frames (host), 2 fbank call, 3 encode launch,
-    // 4 joint (launch + wait for the GPU), 5 decisions, 6 decode launch, 7 deliver/complete
+    uint64_t ticks = 0, steps = 0, chunks = 0, rounds = 0, frames = 0, max_batch_seen = 0, flights = 0, replay_mismatch = 0;
+    // host wall time of the stepping thread by phase (ms): 0 collect, 1 cut frames (host), 2 fbank call, 3 step enqueue,
+    // 4 end of flight (wait for the GPU), 5 replay (decisions + events), 6 decoder refresh enqueue, 7 deliver/complete
     double host_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void add(const SchedStats &o) {
+        ticks += o.ticks; steps += o.steps; chunks += o.chunks; rounds += o.rounds; frames += o.frames; flights += o.flights; replay_mismatch += o.replay_mismatch;
+        if (o.max_batch_seen > max_batch_seen) max_batch_seen = o.max_batch_seen;
+        for (int i = 0; i < 8; ++i) host_ms[i] += o.host_ms[i];
+    }
 };
 
 class Scheduler {
@@ -138,12 +154,14 @@ public:
     void wait_idle_many(Session *const *ss, int n);
     SchedStats stats();
     Engine *engine() { return eng_; }
+    bool on_loop_thread() const { return std::this_thread::get_id() == loop_tid_; }
 
 private:
     void loop();
     void process(std::vector<Session *> &work);
     void cut_frames(std::vector<Session *> &work, bool &progressed);
-    void step_chunks(std::vector<Session *> &ready);
+    bool step_chunks(std::vector<Session *> &ready);     // false: the flight's rings are full, nothing was queued
+    void replay(std::vector<Session *> &work);
 
     Model *model_;
     Engine *eng_;
@@ -153,12 +171,13 @@ private:
     std::vector<Session *> sessions_;
     bool stop_ = false;
     std::thread thread_;
-    SchedStats stats_;
+    SchedStats stats_;                             // guarded by mu_
+    SchedStats tick_;                              // the stepping thread's own; merged into stats_ under mu_ at the end of a tick
+    std::thread::id loop_tid_;
     // scratch reused across ticks
     std::vector<FbankFrameDesc> desc_;
     std::vector<std::pair<const int16_t *, size_t>> pcm_parts_;   // windows to stage, in order
-    std::vector<int> slots_, tails_, ctx_;
-    std::vector<JointResult> jr_;
+    std::vector<int> slots_, tails_, now_;
     std::vector<float> logit_stage_;
 };
 

@@ -71,9 +71,15 @@ APRIL_EXPORT int aprilx_run_joiner(AprilASRModel model, int n, const float *eout
 APRIL_EXPORT int aprilx_run_fbank(AprilASRModel model, int n_frames, const int16_t *pcm_frames, float *out);
 
 /* ---- tracing / statistics ---------------------------------------------------------------*/
-/* every joiner evaluation of this session appends `vocab` floats to buf (tests only) */
+/* every joiner evaluation of this session appends `vocab` floats to buf (tests only; chunk steps of a traced session are
+   issued eagerly and waited for one by one) */
 APRIL_EXPORT void aprilx_session_trace_logits(AprilASRSession session, float *buf, size_t cap_floats, size_t *used_floats);
 APRIL_EXPORT uint64_t aprilx_session_chunks(AprilASRSession session);
+/* The token context as the host's result state machine holds it (host_ctx[2]) and the search state the device keeps for the
+   session's slot (device_state[4]: context[0], context[1], last active token or -1, time of the last emission in ms).  The two
+   contexts are derived independently from the same joiner results (reference context tensor, src/april_session.c:181-196)
+   and must agree; tests only. */
+APRIL_EXPORT void aprilx_session_context(AprilASRSession session, int32_t *host_ctx, int32_t *device_state);
 
 typedef struct AprilxStats {
     uint64_t ticks, steps, chunks, rounds, frames, max_batch_seen;
@@ -82,8 +88,12 @@ typedef struct AprilxStats {
     double kernel_ms[6];
     uint64_t kernel_launches[6];
     /* host wall time of the GPU's stepping thread by phase (ms): 0 collect work, 1 frame bookkeeping, 2 fbank call,
-       3 encoder launch, 4 joiner launch + wait for the GPU, 5 greedy decisions, 6 decoder launch, 7 completion */
+       3 chunk-step enqueue, 4 end of flight (the one wait for the GPU), 5 replay of the device's per-round records through
+       the result state machine, 6 decoder refresh enqueue, 7 completion */
     double host_ms[8];
+    uint64_t flights;            /* host waits for the GPU (one per flight = per batch of queued chunk steps) */
+    uint64_t replay_mismatch;    /* rounds where the host state machine and the device decision disagreed (must stay 0) */
+    uint64_t kernels_per_step;   /* launches of the last eagerly issued chunk chain (profiling / APRIL_NO_GRAPHS runs) */
 } AprilxStats;
 APRIL_EXPORT void aprilx_model_stats(AprilASRModel model, int device_index, AprilxStats *out);
 /* bracket every launch with hipEvents on the engine's stream (measurement runs only) */

@@ -114,3 +114,49 @@ def test_f16_session_against_both_oracles(f16_models, which, secs, request):
         err32 = float(np.abs(lg32 - lg1).max())
         print("fp16 mode vs fp32 oracle: max |dlogit| = %.4g (vs fp16-rounding oracle %.4g)" % (err32, err16))
         assert err32 < 5e-2, err32
+
+
+def test_config5_f16_larger_encoder_512_sessions(large_model):
+    """BASELINE configs[4] as stated: the larger encoder (16 x {768, 1536, 3072}), 512 concurrent sessions in 100 ms feeds,
+    fp16-operand MFMA path.  Session 0 against the fp16-rounding oracle (same callback sequence, logits of the session
+    stepped alone within 5e-3); sessions 1 and 511 against themselves stepped alone: identical callbacks, bit for bit."""
+    import april_asr_amd as A
+    from oracle import orc_py as O
+    os.environ["APRIL_PRECISION"] = "f16"
+    try:
+        gm = A.Model(large_model["path"])
+    finally:
+        del os.environ["APRIL_PRECISION"]
+    assert gm.dims.precision == 1 and (gm.dims.n_layers, gm.dims.d_model, gm.dims.hidden) == (16, 768, 1536)
+    n, secs = 512, 0.6
+    pcms = [speech_like_pcm(secs, seed=40)] + [O.lcg_pcm16_fast(int(16000 * secs), seed=300 + i) for i in range(1, n)]
+    watch = (0, 1, n - 1)
+    evs = {i: [] for i in watch}
+    counts = np.zeros(6, np.uint64)
+    sess = [A.Session(gm, (lambda k: (lambda t, toks: evs[k].append((t, toks))))(i), raw_events=True) if i in evs
+            else A.Session(gm, None, counters=counts) for i in range(n)]
+    grp = A.SessionGroup(sess)
+    for o in range(0, int(16000 * secs), 1600):
+        grp.feed([p[o:o + 1600] for p in pcms])
+    grp.flush()
+    st = gm.stats()
+    assert st.max_batch_seen == n and st.replay_mismatch == 0
+    O.set_f16_linear(True)
+    try:
+        om = O.Model(large_model["path"])
+        want, lg0, n0 = run_oracle(om, pcms[0], 1600)
+        om.close()
+    finally:
+        O.set_f16_linear(False)
+    assert sess[0].chunks() == n0
+    assert [t for t, _ in want] == [t for t, _ in evs[0]]
+    for (_, k0), (_, k1) in zip(want, evs[0]):
+        assert [a[0] for a in k0] == [b[0] for b in k1]
+    for i in watch:
+        ev1, lg1, _ = run_gpu(gm, pcms[i], 1600)
+        assert ev1 == evs[i], i
+        if i == 0:
+            assert lg1.shape == lg0.shape and np.abs(lg1 - lg0).max() < 5e-3, np.abs(lg1 - lg0).max()
+    for s in sess:
+        s.close()
+    gm.close()

@@ -246,6 +246,56 @@ def test_async_overflow_reports_cant_keep_up(gpu_tiny):
     s.close()
 
 
+def test_async_overflow_boundary(gpu_tiny):
+    """The reference's ring refuses a push that would make it hold MAX_AUDIO = 48000 samples or more
+    (src/audio_provider.c:31,61: `(available + count) >= MAX_AUDIO`): 47999 samples into an empty ring are accepted,
+    48000 are not."""
+    import april_asr_amd as A
+    for n, rejected in ((47999, False), (48000, True)):
+        seen = []
+        s = A.Session(gpu_tiny, lambda t, toks: seen.append(int(t)), asynchronous=True, no_rt=True, raw_events=True)
+        s.feed_pcm16(np.zeros(n, np.int16))
+        assert (3 in seen) == rejected, (n, seen)
+        s.drain()
+        frames = (n - 512) // 160 + 1                       # fbank.c:195-236: 512-sample frames every 160 samples
+        assert s.chunks() == (0 if rejected else (frames - 9) // 4 + 1)
+        s.close()
+
+
+def test_rt_speedup_is_reported(gpu_tiny):
+    """ASYNC_RT sessions report the reference's measure (EMA of processing time x 1.1 / audio time per chunk,
+    src/april_session.c:95-97,456-462): positive, and far below 1 on a GPU that keeps up; other sessions report 1.0."""
+    import april_asr_amd as A
+    from oracle import orc_py as O
+    s = A.Session(gpu_tiny, lambda t, toks: None, asynchronous=True, no_rt=False, raw_events=True)
+    pcm = O.lcg_pcm16_fast(16000 * 2, seed=77)
+    for o in range(0, pcm.size, 1600):
+        s.feed_pcm16(pcm[o:o + 1600]); s.drain()
+    v = s.get_rt_speedup()
+    assert 0.0 < v < 1.0, v
+    s.close()
+
+
+def test_device_and_host_contexts_agree(gpu_tiny):
+    """The device keeps the token context that steers the decoder; the host derives its own from the same records when it
+    builds the callbacks.  After audio that emits tokens and crosses the 2200 ms silence reset they are identical, and the
+    replay never disagreed with a device decision."""
+    import april_asr_amd as A
+    pcm = np.concatenate([speech_like_pcm(3.0, seed=1), np.zeros(16000 * 3, np.int16), speech_like_pcm(1.0, seed=2)])
+    ev = []
+    s = A.Session(gpu_tiny, lambda t, toks: ev.append((t, toks)), raw_events=True)
+    for o in range(0, pcm.size, 1600):
+        s.feed_pcm16(pcm[o:o + 1600])
+        h, d = s.contexts()
+        assert h[0] == d[0] and h[1] == d[1], (o, h, d)
+    s.flush()
+    h, d = s.contexts()
+    assert h[0] == d[0] == 0 and h[1] == d[1] == 0 and d[2] == -1        # flushed: [blank, blank], nothing active
+    assert any(t == 1 for t, _ in ev) and any(t == 2 for t, _ in ev)
+    assert gpu_tiny.stats().replay_mismatch == 0
+    s.close()
+
+
 def test_async_handler_runs_on_library_thread(gpu_tiny):
     import threading
     import april_asr_amd as A
@@ -324,6 +374,39 @@ def test_sessions_above_max_batch(tiny_model):
     assert outs[0] == outs[1] and any(len(e) for e in outs[0])
 
 
+def test_config3_256_sessions_aprilv0(gpu_v0, orc_v0):
+    """BASELINE configs[2]: 256 concurrent streaming sessions at aprilv0 dimensions in 100 ms feeds on one GPU (the workload
+    bench.py times).  The batch runs untraced, i.e. on the captured launch chains with the full-K GEMM schedule; session 0
+    against the CPU oracle (token-exact, log-probabilities within 1e-3, and every logit of the same session stepped alone
+    within 1e-3), sessions 1, 128 and 255 against themselves stepped alone: identical callbacks including the
+    log-probability bits (batch invariance across the two GEMM schedules)."""
+    import april_asr_amd as A
+    from oracle import orc_py as O
+    n, secs = 256, 4.0
+    pcms = [speech_like_pcm(secs, seed=50, silence=(1.2, 1.7))] + [O.lcg_pcm16_fast(int(16000 * secs), seed=900 + i) for i in range(1, n)]
+    watch = (0, 1, 128, 255)
+    evs = {i: [] for i in watch}
+    counts = np.zeros(6, np.uint64)
+    sess = [A.Session(gpu_v0, (lambda k: (lambda t, toks: evs[k].append((t, toks))))(i), raw_events=True) if i in evs
+            else A.Session(gpu_v0, None, counters=counts) for i in range(n)]
+    grp = A.SessionGroup(sess)
+    for o in range(0, int(16000 * secs), 1600):
+        grp.feed([p[o:o + 1600] for p in pcms])
+    grp.flush()
+    st = gpu_v0.stats()
+    assert st.max_batch_seen == n and st.replay_mismatch == 0
+    want, lg0, n0 = run_oracle(orc_v0, pcms[0], 1600)
+    assert sess[0].chunks() == n0
+    assert_same_transcript(want, evs[0])
+    for i in watch:
+        ev1, lg1, _ = run_gpu(gpu_v0, pcms[i], 1600)
+        assert ev1 == evs[i], i
+        if i == 0:
+            assert lg1.shape == lg0.shape and np.abs(lg1 - lg0).max() < 1e-3, np.abs(lg1 - lg0).max()
+    for s in sess:
+        s.close()
+
+
 def test_session_60s_aprilv0(gpu_v0, orc_v0):
     """BASELINE configs[1]: aprilv0 dimensions, one session, 60 s of synthetic 16 kHz PCM16 in 100 ms feeds + flush,
     token-exact against the CPU oracle, every logit within 1e-3."""
@@ -338,7 +421,7 @@ def test_session_60s_aprilv0(gpu_v0, orc_v0):
 
 
 def test_odd_dimensions_model(medium_model):
-    """3 layers, d=192, hidden=320, ffn=448, vocab=131 (padded to 144 on the device), 24 conv-2 channels
+    """3 layers, d=192, hidden=320, ffn=448, vocab=131 (padded to 160 on the device), 24 conv-2 channels
     (im2col K padded 216 -> 256): network calls and a full session against the oracle."""
     import april_asr_amd as A
     from oracle import orc_py as O

@@ -55,7 +55,7 @@ def layout_offsets(d):
     L["emb"] = take(d["vocab"] * d["d_model"])
     L["dec_conv"] = take(d["d_model"] * (d["d_model"] // d["dec_groups"]) * d["context"]); L["dec_conv_b"] = take(d["d_model"])
     L["w_decproj"] = take(d["d_model"] * d["joiner"]); L["b_decproj"] = take(d["joiner"])
-    vp = (d["vocab"] + 15) & ~15
+    vp = (d["vocab"] + 31) & ~31
     L["w_out"] = take(d["joiner"] * vp); L["b_out"] = take(vp)
     return L, ein, vp
 

@@ -1,7 +1,9 @@
 // Measurement aid: times launch_gemm (the product's GEMM kernel, linked from csrc/build/kernels_gemm.o) on one shape.
 //   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DAPRIL_GEMM_TRACE] -Iapril_asr_amd/csrc -c april_asr_amd/csrc/kernels_gemm.hip -o kg.o
 //          hipcc --offload-arch=gfx950 -O2 -Iapril_asr_amd/csrc -c tools/gemm_bench.hip -o gb.o && hipcc --offload-arch=gfx950 gb.o kg.o -o tools/gemm_bench
-//   usage: tools/gemm_bench M N K [epi=2 (bias+dswish) | 0 (partials, kz given)] [kz=1] [iters=200] [wcopies=1]
+//   usage: tools/gemm_bench M N K [epi=2 (bias+dswish) | 0 (partials, kz given) | 1 (gates + LSTM cell, A scaled on load) |
+//                                  3 (projection: state + residual) | 4 (bias + residual + sums of squares) | 5 (slot store)] [kz=1] [iters=200] [wcopies=1]
+//   epi 3..5 run on the full-K schedule when launch_gemm's planner allows it for the shape, otherwise this tool falls back to epi 0
 //   wcopies > 1 cycles through that many copies of W so the weights stream from HBM as in the product (12 layers x 28 MB)
 #include "kernels.h"
 #include <cstdio>
@@ -24,6 +26,18 @@ int main(int argc, char **argv)
     GemmArgs g;
     g.a0 = a; g.lda0 = K; g.K0 = K; g.wp = w; g.M = M; g.N = N; g.K = K; g.kz = kz; g.epi = epi;
     g.out = out; g.ldo = N; g.m_stride = M; g.bias = bias;
+    float *ssq; hipMalloc(&ssq, (size_t)M * (K / 32 + N / 32 + 2) * 4);
+    { std::vector<float> one((size_t)M * (K / 32 + N / 32 + 2), 1.0f); hipMemcpy(ssq, one.data(), one.size() * 4, hipMemcpyHostToDevice); }
+    int *slots; hipMalloc(&slots, (size_t)M * 4);
+    { std::vector<int> hi((size_t)M); for (int i = 0; i < M; ++i) hi[(size_t)i] = (int)(((unsigned)i * 2654435761u) % (unsigned)M); hipMemcpy(slots, hi.data(), (size_t)M * 4, hipMemcpyHostToDevice); }
+    if (epi >= 3) {
+        if (!gemm_fullk(M, N, kz)) { printf("(no full-K plan for M=%d N=%d kz=%d: timing the split-K partial GEMM instead)\n", M, N, kz); g.epi = 0; }
+        else {
+            float *st, *res; hipMalloc(&st, (size_t)M * N * 4); hipMalloc(&res, (size_t)M * N * 4); hipMemset(res, 0, (size_t)M * N * 4);
+            g.slot_idx = slots; g.state = st; g.ld_state = N; g.resid = res; g.ldr = N; g.ssq_out = ssq;
+            g.r_scale.ssq = ssq; g.r_scale.groups = N / 32; g.r_scale.inv_n = 1.0f / N; g.r_scale.eps = 0.25f;
+        }
+    }
     if (epi == 1) {   // the product's gates call: A = [x | h[slot]] in two K segments, fused LSTM cell (c in place, u out)
         int *idx; hipMalloc(&idx, (size_t)M * 4);
         std::vector<int> hi((size_t)M);
@@ -32,6 +46,7 @@ int main(int argc, char **argv)
         float *cst; hipMalloc(&cst, (size_t)M * (N / 4) * 4); hipMemset(cst, 0, (size_t)M * (N / 4) * 4);
         g.K0 = K / 2; g.lda0 = K / 2; g.a1 = a + (size_t)M * (K / 2); g.lda1 = K / 2; g.aidx1 = idx; g.K1 = K / 2;
         g.c_state = cst; g.slot_idx = idx; g.hidden = N / 4; g.ldo = N / 4;
+        g.a_op = AOP_SCALE; g.a_scale.ssq = ssq; g.a_scale.groups = (K / 2) / 32; g.a_scale.inv_n = 1.0f / (K / 2); g.a_scale.eps = 0.25f;
     }
     hipStream_t s; hipStreamCreate(&s);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

@@ -21,7 +21,7 @@ import sys
 BASE = 112
 
 
-def emit(nb, name, NT=4):
+def emit(nb, name, NT=4, scaled=False):
     out = []
     A = out.append
 
@@ -53,6 +53,17 @@ def emit(nb, name, NT=4):
         r = (b + nb - 1) % nb
         ld, adv = loads_and_advance(r)
         A("s_waitcnt vmcnt(%d)" % ((NT + 4) * (nb - 2)))
+        muls = []
+        if scaled:
+            # AOP_SCALE: the activation quads of this block are multiplied in place by the lane's row scales (x = y * scale)
+            # before the MFMAs that read them: the four k-step-0 components up front, the other twelve as fillers during
+            # the k-step-0 MFMAs (k-step s is first read by MFMA 4*NT*s)
+            for mt in range(4):
+                A("v_mul_f32 v%d, v%d, %%[sc%d]" % (aq(b, mt), aq(b, mt), mt))
+            A("s_nop 1")
+            for ks in range(1, 4):
+                for mt in range(4):
+                    muls.append("v_mul_f32 v%d, v%d, %%[sc%d]" % (aq(b, mt) + ks, aq(b, mt) + ks, mt))
         mfma = []
         for ks in range(4):                   # k-step major, then m-tile, then n-tile: every accumulator gets its k-steps in order
             for mt in range(4):
@@ -60,13 +71,19 @@ def emit(nb, name, NT=4):
                     mfma.append("v_mfma_f32_16x16x4_f32 %%[c%d], v%d, v%d, %%[c%d]" % (mt * NT + nt, aq(b, mt) + ks, bq(b, nt) + ks, mt * NT + nt))
         # fillers ride in the shadow of the matrix pipe (the loads, then the scalar bookkeeping): one after every third
         # MFMA of the 64 of a 64x64 tile, one after (almost) every MFMA of the 32 of a 64x32 tile
-        fill = ld + adv + ["s_sub_u32 s85, s85, 1", "s_cmp_eq_u32 s85, 0"]
-        every = 3 if NT == 4 else 1
+        fill = muls + ld + adv + ["s_sub_u32 s85, s85, 1", "s_cmp_eq_u32 s85, 0"]
+        every = (2 if scaled else 3) if NT == 4 else 1
         assert len(fill) * every + 1 <= len(mfma)
+        placed = 0
         for i, m in enumerate(mfma):
             A(m)
             if i % every == every - 1 and fill:
-                A(fill.pop(0))
+                f = fill.pop(0)
+                if f.startswith("v_mul_f32"):          # the multiply of k-step s must be issued before MFMA 4*NT*s
+                    ks = 1 + placed // 4
+                    assert i + 1 < 4 * NT * ks, (i, ks)
+                    placed += 1
+                A(f)
         assert not fill
         if b < nb - 1:
             A("s_cbranch_scc1 L_end_%=")
@@ -87,3 +104,5 @@ if __name__ == "__main__":
     print(emit(2, "APRIL_MAINLOOP2"))
     print(emit(3, "APRIL_MAINLOOP3"))
     print(emit(2, "APRIL_MAINLOOP2_NT2", NT=2))
+    print(emit(2, "APRIL_MAINLOOP2_SC", scaled=True))
+    print(emit(2, "APRIL_MAINLOOP2_NT2_SC", NT=2, scaled=True))
