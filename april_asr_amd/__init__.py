@@ -11,6 +11,7 @@ weight-blob export/import for the RCCL broadcast at load time.
 """
 import ctypes as C
 import struct
+import weakref
 from enum import IntEnum
 from typing import Callable, List, Sequence
 
@@ -71,6 +72,10 @@ class Model:
 
     def close(self):
         if getattr(self, "_handle", None):
+            # sessions must not outlive their model (reference april_api.h:72-73): close the ones still open first, so a
+            # session leaked by a failing caller cannot touch a freed model later (interpreter exit order is arbitrary)
+            for s in list(getattr(self, "_sessions", ())):
+                s.close()
             self._L.aam_free(self._handle)
             self._handle = None
 
@@ -215,6 +220,9 @@ class Session:
         self._handle = self._L.aas_create_session(model._handle, cfg)
         if not self._handle:
             raise Exception("Failed to create session")
+        if not hasattr(model, "_sessions"):
+            model._sessions = weakref.WeakSet()
+        model._sessions.add(self)
 
     def _on_result(self, result_type, count, tokens):
         if self._raw:

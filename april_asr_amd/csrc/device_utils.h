@@ -50,9 +50,18 @@ __device__ __forceinline__ f32x4 tree_sum4(const float *ws, int parts, int m_str
 // normalised row calls this one function, so they all see the same scale.
 __device__ __forceinline__ float row_scale(const RowScale &rs, int row)
 {
+    // partials are added in column order; the loads are issued eight at a time (a loop of dependent single loads costs a
+    // memory round trip per partial: measured +16 us on the gate GEMM); padding terms are +0.0f, which leaves a
+    // non-negative sum unchanged
     const float *p = rs.ssq + (size_t)row * rs.groups;
-    float t = p[0];
-    for (int j = 1; j < rs.groups; ++j) t += p[j];
+    float t = 0.0f;
+    for (int j0 = 0; j0 < rs.groups; j0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = j0 + k < rs.groups ? p[j0 + k] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += v[k];
+    }
     return __builtin_amdgcn_rsqf(t * rs.inv_n + rs.eps);
 }
 

@@ -192,10 +192,10 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     ring_cap_ = std::max<size_t>((size_t)1 << 20, 3 * MB * 8 + 2 * S); ring_h_ = hmalloc<int>(ring_cap_);
     step_cap_ = 1 << 14; step_off_h_ = hmalloc<int>((size_t)step_cap_); rec_off_h_ = hmalloc<int>((size_t)step_cap_);
     rec_cap_ = std::max<size_t>((size_t)1 << 20, 3 * MB * 8); rec_d_ = dmalloc<StepRecord>(rec_cap_); rec_h_ = hmalloc<StepRecord>(rec_cap_);
-    counter_d_ = dmalloc<int>(1); rec_off_d_ = dmalloc<int>(1); flags_d_ = dmalloc<int>(4);
+    counter_d_ = dmalloc<int>(1); rec_off_d_ = dmalloc<int>(1); flags_d_ = dmalloc<int>(8);
     step_d_ = dmalloc<int>(3 * MB); active_d_ = dmalloc<int>(MB); dirty_d_ = dmalloc<int>(MB);
     dec_slots_d_ = dmalloc<int>(S);
-    HIP_CHECK(hipMemset(counter_d_, 0, 4)); HIP_CHECK(hipMemset(rec_off_d_, 0, 4)); HIP_CHECK(hipMemset(flags_d_, 0, 16));
+    HIP_CHECK(hipMemset(counter_d_, 0, 4)); HIP_CHECK(hipMemset(rec_off_d_, 0, 4)); HIP_CHECK(hipMemset(flags_d_, 0, 32));
 
     upload_tables(ft);
     use_graphs_ = !(getenv("APRIL_NO_GRAPHS") && atoi(getenv("APRIL_NO_GRAPHS")));
@@ -360,7 +360,8 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
     ca.ring = ring_; ca.ring_frames = ring_frames_; ca.mel = d.mel; ca.seg = d.seg;
     ca.slot_idx = d_slots; ca.ring_tail = d_tails; ca.x_direct = x_direct;
     for (int i = 0; i < 3; ++i) { ca.w[i] = w_ + L_.conv_w[i]; ca.b[i] = w_ + L_.conv_b[i]; ca.ch[i] = d.conv_ch[i]; ca.stride[i] = d.conv_stride[i]; }
-    ca.ch1_per_group = (d.conv_ch[1] % 8 == 0) ? 8 : d.conv_ch[1];
+    ca.ch1_per_group = 1;                                 // largest divisor of the second conv's channel count that is <= 8
+    for (int k = 8; k > 1; --k) if (d.conv_ch[1] % k == 0) { ca.ch1_per_group = k; break; }
     ca.out = a3_; ca.ldo = L_.k3; ca.M = n;
     timed_begin(T_CONV); launch_conv_embed(ca, stream_); timed_end(T_CONV);
     {   // third conv: [n*f_out, k3] x [k3, c2] + bias, DoubleSwish -> xin[n][f_out*c2]
@@ -449,10 +450,9 @@ DecEmbedParams Engine::dec_params() const
 // dout[slot] = de x Wp + b for rows with row_mask != 0 (all rows when null)
 void Engine::run_decproj(int n, const int *d_slots, const int *row_mask, const int *run_flag)
 {
-    (void)run_flag;
     const NetDims &d = L_.dims;
     GemmArgs g; g.a0 = de_; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, L_.w_decproj);
-    g.M = n; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_;
+    g.M = n; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_; g.run_flag = run_flag;
     if (gemm_fullk(n, d.joiner, kz_proj_)) {
         g.epi = EPI_SLOT_STORE; g.bias = w_ + L_.b_decproj; g.out = dout_; g.ldo = d.joiner; g.slot_idx = d_slots; g.row_mask = row_mask;
         timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
@@ -461,7 +461,7 @@ void Engine::run_decproj(int n, const int *d_slots, const int *row_mask, const i
     g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
     timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
     RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_; r.parts = gemm_partials(n, d.joiner, kz_proj_); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = n;
-    r.bias = w_ + L_.b_decproj; r.out = dout_; r.ldo = d.joiner; r.slot_idx = d_slots; r.row_mask = row_mask;
+    r.bias = w_ + L_.b_decproj; r.out = dout_; r.ldo = d.joiner; r.slot_idx = d_slots; r.row_mask = row_mask; r.run_flag = run_flag;
     timed_begin(T_DEC); launch_row(r, stream_); timed_end(T_DEC);
 }
 
@@ -476,6 +476,7 @@ void Engine::run_greedy_rounds(int n, bool dump_logits)
         {   // logits = tanh(eout + dout) x Wout (+ bias in the decision kernel)
             GemmArgs g; g.a0 = eout_; g.a0b = dout_; g.lda0 = d.joiner; g.aidx0 = d_slots; g.K0 = d.joiner; g.a_op = AOP_TANH_ADD;
             lin(g, L_.w_out); g.M = n; g.N = L_.vocab_pad; g.K = d.joiner; g.kz = kz_out_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
+            g.run_flag = flags_d_ + round;
             timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
         }
         DecideArgs a;
@@ -485,8 +486,9 @@ void Engine::run_greedy_rounds(int n, bool dump_logits)
         a.rec_ring = rec_d_; a.rec_off = rec_off_d_; a.round = round;
         a.logits_dump = dump_logits ? logits_ + (size_t)round * MB * d.vocab : nullptr;
         a.dec = dec_params(); a.de_out = de_; a.ld_de = d.d_model;
+        a.run_flags = flags_d_; a.rerun_flags = flags_d_ + 4;
         timed_begin(T_DEC); launch_decide(a, stream_); timed_end(T_DEC);
-        run_decproj(n, d_slots, dirty_d_, nullptr);
+        run_decproj(n, d_slots, dirty_d_, flags_d_ + 4 + round);
     }
 }
 
@@ -496,6 +498,7 @@ void Engine::run_chain(int m, bool dump_logits)
     AdvanceArgs a;
     a.host_ring = ring_h_; a.host_step_off = step_off_h_; a.host_rec_off = rec_off_h_; a.counter = counter_d_;
     a.dst = step_d_; a.dst_stride = MB; a.active = active_d_; a.rec_off = rec_off_d_; a.m = m;
+    a.run_flags = flags_d_; a.rerun_flags = flags_d_ + 4;
     launch_advance(a, stream_);
     run_encoder_rows(m, step_d_, step_d_ + MB, nullptr);
     run_greedy_rounds(m, dump_logits);

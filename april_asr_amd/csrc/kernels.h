@@ -78,6 +78,7 @@ struct GemmArgs {
     RowScale r_scale;                      // EPI_HR: the residual is y * scale(y)
     float *ssq_out = nullptr;              // EPI_RESID_SSQ: [M][N / SSQ_COLS]
     const int *row_mask = nullptr;         // EPI_SLOT_STORE: optional
+    const int *run_flag = nullptr;         // optional device word: the kernel returns at once when it is 0
     int skew = 0;                          // start delay (x 4096 cycles) for every second generation of workgroups
     int asm_loop = 0;                      // != 0: hand-scheduled K loop (gemm_mainloop_asm.inc) in the fused-epilogue 64x64 fp32 tiles
     unsigned long long *trace = nullptr;   // measurement only: per-workgroup s_memtime stamps [wg][8] (wave 0, lane 0)
@@ -107,6 +108,7 @@ struct RowArgs {
     float *state = nullptr; int ld_state = 0;   // ROW_HR: h state of this layer
     float *ssq_out = nullptr;              // ROW_RESID_SSQ
     const int *row_mask = nullptr;         // ROW_SLOT_STORE
+    const int *run_flag = nullptr;         // optional device word: the kernel returns at once when it is 0
 };
 void launch_row(const RowArgs &r, hipStream_t s);
 
@@ -148,6 +150,10 @@ struct DecideArgs {
     float *logits_dump = nullptr;          // optional [M][n_valid]
     DecEmbedParams dec;
     float *de_out = nullptr; int ld_de = 0;   // relu(conv(emb[ctx])) rows for dirty rows
+    // round flags (device words, zeroed by the advance kernel except run[0]): run[r] = some row still searches in round r,
+    // rerun[r] = some row's context changed in round r.  A round nobody needs costs three empty launches.
+    int *run_flags = nullptr;              // [3]
+    int *rerun_flags = nullptr;            // [3]
 };
 void launch_decide(const DecideArgs &a, hipStream_t s);
 
@@ -182,6 +188,8 @@ struct AdvanceArgs {
     int *dst = nullptr; int dst_stride = 0;   // device: [3][dst_stride]
     int *active = nullptr;                 // device: [m] set to 1
     int *rec_off = nullptr;                // device: record offset of the current step
+    int *run_flags = nullptr;              // device: [3] -> 1, 0, 0
+    int *rerun_flags = nullptr;            // device: [3] -> 0, 0, 0
     int m = 0;
 };
 void launch_advance(const AdvanceArgs &a, hipStream_t s);

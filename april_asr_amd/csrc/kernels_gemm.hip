@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kerne
     // the slab tree (levels of pairwise sums) is only needed where a workgroup can own more than one slab
     constexpr bool TREE = !FULLK && (EPI == EPI_PARTIAL || ROW_EPI);
 
+    if (g.run_flag && *g.run_flag == 0) return;          // a joiner / decoder round nobody needs (all rows resolved earlier)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // measurement only (tools/gemm_bench built with -DAPRIL_GEMM_TRACE, run with GEMM_TRACE=1): wave 0 stamps s_memtime at
@@ -167,7 +168,9 @@ __global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kerne
 #ifndef APRIL_DEPTH4
 #define APRIL_DEPTH4 2
 #endif
-    constexpr int DEPTH = (MT == 1) ? 6 : (MT == 2 ? 3 : APRIL_DEPTH4);
+    // The full-K tiles are small (16..64 x 32) and read everything through L2: they are bound by bytes in flight per CU
+    // (measured 9 TB/s of L2 traffic at 6 stages x 3 KB per wave), so they run deeper.
+    constexpr int DEPTH = FULLK ? ((MT == 1) ? 12 : (MT == 2 ? 5 : 3)) : ((MT == 1) ? 6 : (MT == 2 ? 3 : APRIL_DEPTH4));
     f32x4 a_st[DEPTH][MT];
     BQ b_st[DEPTH][NT];
     int ld_base = first_kb, ld_off = 0, ld_cnt = 0;

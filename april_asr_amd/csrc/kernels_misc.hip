@@ -6,6 +6,8 @@
 #include "kernels.h"
 #include "device_utils.h"
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace aprilx {
 
@@ -20,6 +22,7 @@ __device__ __forceinline__ float dswish_dev(float y) { return y * sigmoid_dev(y 
 template <int MODE>
 __global__ __launch_bounds__(256) void row_kernel(RowArgs r)
 {
+    if (r.run_flag && *r.run_flag == 0) return;
     const int m = blockIdx.x;
     const int tid = threadIdx.x;
     const int slot = r.slot_idx ? r.slot_idx[m] : m;
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(256) void decide_kernel(DecideArgs a)
     __shared__ float s_best[4], s_blank[4];
     __shared__ int s_idx[4];
     __shared__ int s_ctx[3];                        // [0..1] context for the decoder front end, [2] re-run flag
+    if (a.run_flags && a.run_flags[a.round] == 0) return;      // every row resolved in an earlier round
     const int m = blockIdx.x;
     const int tid = threadIdx.x;
     StepRecord *rec = a.rec ? a.rec + m : a.rec_ring + (size_t)a.rec_off[0] + (size_t)a.round * a.M + m;
@@ -166,6 +170,10 @@ __global__ __launch_bounds__(256) void decide_kernel(DecideArgs a)
         rec->flags = flags;
         a.state[slot] = st;
         a.dirty[m] = rerun ? 1 : 0;
+        if (a.run_flags) {
+            if (!is_blank && a.round < 2) a.run_flags[a.round + 1] = 1;       // plain stores of the same value: no atomics needed
+            if (rerun) a.rerun_flags[a.round] = 1;
+        }
         s_ctx[0] = st.ctx0; s_ctx[1] = st.ctx1; s_ctx[2] = rerun ? 1 : 0;
     }
     __syncthreads();
@@ -223,6 +231,7 @@ __global__ __launch_bounds__(1024) void advance_kernel(AdvanceArgs a)
     for (int i = threadIdx.x; i < 3 * a.m; i += 1024) a.dst[(i / a.m) * a.dst_stride + (i % a.m)] = src[i];
     for (int i = threadIdx.x; i < a.m; i += 1024) a.active[i] = 1;
     if (threadIdx.x == 0) { a.rec_off[0] = a.host_rec_off[k]; a.counter[0] = k + 1; }
+    if (threadIdx.x < 3 && a.run_flags) { a.run_flags[threadIdx.x] = threadIdx.x == 0 ? 1 : 0; a.rerun_flags[threadIdx.x] = 0; }
 }
 
 void launch_advance(const AdvanceArgs &a, hipStream_t s)
@@ -286,32 +295,65 @@ __global__ __launch_bounds__(256) void conv12_kernel(ConvEmbedArgs a)
         }
     }
     __syncthreads();
-    for (int o = tid; o < c0 * H1 * W1; o += 256) {
-        const int c = o / (H1 * W1), oh = (o / W1) % H1, ow = o % W1;
-        const float *w = a.w[0] + c * 9;
-        float acc = 0.0f;
+    // Register blocking: a thread owns an output POSITION and computes several output channels there from one set of
+    // input-patch registers; the weights of a channel are wave-uniform addresses (scalar loads), so the only LDS traffic
+    // is the patch itself (the previous one-output-per-thread form was bound by LDS reads: 2 per multiply-add).
+    // Accumulation order per output: input channel, kernel row, kernel column; bias last.
+    for (int p = tid; p < H1 * W1; p += 256) {
+        const int oh = p / W1, ow = p % W1;
+        float patch[9];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc += x[(oh * s0 + i) * W0 + ow * s0 + j] * w[i * 3 + j];
-        acc += a.b[0][c];
-        a1[o] = dswish_dev(acc);
+            for (int j = 0; j < 3; ++j) patch[i * 3 + j] = x[(oh * s0 + i) * W0 + ow * s0 + j];
+        for (int c = 0; c < c0; ++c) {
+            const float *w = a.w[0] + c * 9;
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc += patch[k] * w[k];
+            acc += a.b[0][c];
+            a1[c * H1 * W1 + p] = dswish_dev(acc);
+        }
     }
     __syncthreads();
-    for (int o = tid; o < cg * H2 * W2; o += 256) {
-        const int cl = o / (H2 * W2), oh = (o / W2) % H2, ow = o % W2;
-        const int c = grp * cg + cl;
-        const float *w = a.w[1] + (size_t)c * c0 * 9;
-        float acc = 0.0f;
-        for (int ci = 0; ci < c0; ++ci) {
-            const float *src = a1 + ci * H1 * W1 + (oh * s1) * W1 + ow * s1;
+    {
+        const int NP = H2 * W2;
+        const int per = ((NP + 63) / 64) * 64;                     // positions rounded up to whole waves
+        int nsub = per <= 256 ? 256 / per : 1;                     // channel subsets handled side by side
+        while (nsub > 1 && (cg % nsub) != 0) --nsub;
+        const int cps = cg / nsub;                                 // channels per thread (<= 8 by construction of the launch)
+        const int stride = per <= 256 ? per : 256;
+        const int sub = per <= 256 ? __builtin_amdgcn_readfirstlane(tid / per) : 0;     // uniform: `per` is a multiple of the wave size
+        for (int base = 0; base < NP; base += stride) {
+            const int p = base + (per <= 256 ? tid % per : tid);
+            if (sub < nsub && p < NP) {
+                const int oh = p / W2, ow = p % W2;
+                float acc[8];
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+                for (int cc = 0; cc < 8; ++cc) acc[cc] = 0.0f;
+                for (int ci = 0; ci < c0; ++ci) {
+                    const float *src = a1 + ci * H1 * W1 + (oh * s1) * W1 + ow * s1;
+                    float patch[9];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc += src[i * W1 + j] * w[ci * 9 + i * 3 + j];
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) patch[i * 3 + j] = src[i * W1 + j];
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc)
+                        if (cc < cps) {
+                            const float *w = a.w[1] + ((size_t)(grp * cg + sub * cps + cc) * c0 + ci) * 9;
+#pragma unroll
+                            for (int k = 0; k < 9; ++k) acc[cc] += patch[k] * w[k];
+                        }
+                }
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc)
+                    if (cc < cps) {
+                        const int cl = sub * cps + cc;
+                        a2[cl * NP + p] = dswish_dev(acc[cc] + a.b[1][grp * cg + cl]);
+                    }
+            }
         }
-        acc += a.b[1][c];
-        a2[o] = dswish_dev(acc);
     }
     __syncthreads();
     // im2col slice of this channel group: consecutive threads write consecutive k (coalesced runs of cg*9 floats)
@@ -328,6 +370,7 @@ void launch_conv_embed(const ConvEmbedArgs &a, hipStream_t s)
     const int H1 = (a.seg - 3) / a.stride[0] + 1, W1 = (a.mel - 3) / a.stride[0] + 1;
     const int H2 = (H1 - 3) / a.stride[1] + 1, W2 = (W1 - 3) / a.stride[1] + 1;
     const size_t lds = sizeof(float) * ((size_t)a.seg * a.mel + (size_t)a.ch[0] * H1 * W1 + (size_t)a.ch1_per_group * H2 * W2);
+    if (a.ch1_per_group > 8 || a.ch[1] % a.ch1_per_group) { fprintf(stderr, "libapril(mi355x): conv front end: channels per workgroup must divide the second conv and be <= 8\n"); abort(); }
     hipLaunchKernelGGL(conv12_kernel, dim3((unsigned)a.M, (unsigned)(a.ch[1] / a.ch1_per_group)), dim3(256), lds, s, a);
 }
 
