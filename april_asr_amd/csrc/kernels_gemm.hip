@@ -33,10 +33,10 @@
 namespace aprilx {
 
 
-template <int MT, int NT>
+template <int MT, int NT, int NW = 4>
 struct TileCfg {
     static constexpr int BM = MT * 16, BN = NT * 16, LDR = BN + 4;
-    static constexpr int LDS_FLOATS = 4 * BM * LDR;
+    static constexpr int LDS_FLOATS = NW * BM * LDR;      // one partial plane per wave; BM row scales follow (LDS_FLOATS + BM floats are requested)
 };
 
 using h4 = __attribute__((ext_vector_type(4))) _Float16;
@@ -46,10 +46,15 @@ template <> struct WQuad<1> { using type = h4; };
 // ASM = 1: the K loop is the hand-scheduled one (fixed operand registers v112..v175, accumulators in AGPRs); a separate
 // instantiation, so that neither loop's registers weigh on the other (both forms must stay within 256 registers: two
 // workgroups per CU).  The compiler-scheduled 64-row tiles are told so (second launch-bound = waves per SIMD).
-template <int MT, int NT, int EPI, int AOP, int WT, int MODE, int ASM>
-__global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kernel(GemmArgs g)
+// NW = waves per workgroup: 4, or 8 on the full-K schedule of a kz = 8 layer (every wave owns ONE slab).  With only 16 x 32
+// outputs per workgroup a wave has two accumulator tiles, i.e. chains of four DEPENDENT MFMAs back to back, which issue at
+// half rate (measured: 520 cycles per k-block instead of 256); a second wave on the same SIMD fills the gaps.
+template <int MT, int NT, int EPI, int AOP, int WT, int MODE, int ASM, int NW = 4>
+__global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kernel(GemmArgs g)
 {
-    using Cfg = TileCfg<MT, NT>;
+    using Cfg = TileCfg<MT, NT, NW>;
+    constexpr int NTH = NW * 64;
+    static_assert(NW == 4 || (NW == 8 && MODE == GM_FULLK), "8 waves only on the full-K schedule");
     using BQ = typename WQuad<WT>::type;       // one lane's four consecutive k values of a weight tile
     extern __shared__ __attribute__((aligned(16))) float red[];
     constexpr bool FULLK = MODE == GM_FULLK;
@@ -96,13 +101,34 @@ __global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kerne
     // m-tile (row start + this lane's k quarter), i.e. the saddr form of global_load: no 64-bit vector adds in the loop.
     // All operands are far below 4 GiB per array.
     // after the LDS meet every thread owns QPT groups of 4 consecutive columns ("quads") of the tile
-    constexpr int QROW = Cfg::BN / 4, NQ = Cfg::BM * QROW, QPT = (NQ + 255) / 256;
+    constexpr int QROW = Cfg::BN / 4, NQ = Cfg::BM * QROW, QPT = (NQ + NTH - 1) / NTH;
     // K blocks: KB = K/16 is a multiple of 4*kz (checked on the host): chunk = c blocks.
     //   GM_SLAB : slab z, wave w -> blocks [(4z + w) c, (4z + w + 1) c); a workgroup walks zs consecutive slabs.
-    //   GM_FULLK: wave w -> blocks [w kz c, (w + 1) kz c), chunk after chunk.
+    //   GM_FULLK: wave w of NW -> blocks [w T, (w + 1) T), T = 4 kz c / NW, chunk after chunk (kz / NW whole slabs).
     const int c = g.debug == 1 ? 0 : KB / (4 * g.kz);
-    const int T = (FULLK ? g.kz : g.zs) * c;           // blocks this wave processes in total
-    const int first_kb = FULLK ? wave * g.kz * c : (4 * (zg * g.zs) + wave) * c;
+    const int T = FULLK ? (4 * g.kz / NW) * c : g.zs * c;           // blocks this wave processes in total
+    const int first_kb = FULLK ? wave * T : (4 * (zg * g.zs) + wave) * c;
+
+    // BasicNorm scales of the tile's rows, once per workgroup: the rows' sum-of-squares partials make ONE trip from global
+    // memory into LDS (every lane fetching its own rows' partials cost the gate GEMM 8 us).  The loads are issued here, first
+    // thing, and land while the rest of the set-up (row indirections, previous cell values) is in flight; further down 64
+    // threads add the partials in column order (the order of row_scale()) and leave the scales behind the partial planes.
+    constexpr bool NEED_SCL = AOP == AOP_SCALE || EPI == EPI_HR;
+    float *scl = red + Cfg::LDS_FLOATS;
+    float stg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const RowScale &rsc = AOP == AOP_SCALE ? g.a_scale : g.r_scale;
+    const bool staged = NEED_SCL && Cfg::BM * rsc.groups <= 4 * NTH;
+    if (NEED_SCL && staged) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + k * NTH;
+            if (i < Cfg::BM * rsc.groups) {
+                int r = m0 + i / rsc.groups;
+                if (r >= g.M) r = g.M - 1;
+                stg[k] = rsc.ssq[(size_t)r * rsc.groups + i % rsc.groups];
+            }
+        }
+    }
 
     uint32_t aoff0[MT], aoff1[MT];
     float sc[MT];                                      // AOP_SCALE: BasicNorm scale of this lane's rows (1 outside segment 0)
@@ -116,7 +142,6 @@ __global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kerne
         if (g.K1 > 0) { const int r1 = g.aidx1 ? g.aidx1[row] : row; aoff1[mt] = (uint32_t)(((size_t)r1 * g.lda1 + kq * 4) * sizeof(float)); }
         sc[mt] = 1.0f;
         // segment boundaries coincide with wave ranges (checked on the host), so "this wave reads segment 0" is uniform
-        if (AOP == AOP_SCALE) { if (first_kb * 16 < g.K0) sc[mt] = row_scale(g.a_scale, row); }
     }
     const uint32_t boff = (uint32_t)lane * sizeof(BQ);
     const bool stream_once = gridDim.y == 1;   // weights read by exactly one workgroup: bypass-friendly loads
@@ -129,9 +154,14 @@ __global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kerne
     int top = 0;
     if (TREE) while ((1 << top) < g.zs) ++top;
     constexpr int PLANE = Cfg::BM * Cfg::LDR;
-    auto summed4 = [&](int o) {                        // GM_SLAB: ((p0+p1)+p2)+p3 of four consecutive columns; GM_FULLK: (R0+R1)+(R2+R3)
+    auto summed4 = [&](int o) {                        // GM_SLAB: ((p0+p1)+p2)+p3 of four consecutive columns; GM_FULLK: balanced tree over the waves' results
         const f32x4 p0 = *reinterpret_cast<const f32x4 *>(red + o), p1 = *reinterpret_cast<const f32x4 *>(red + PLANE + o);
         const f32x4 p2 = *reinterpret_cast<const f32x4 *>(red + 2 * PLANE + o), p3 = *reinterpret_cast<const f32x4 *>(red + 3 * PLANE + o);
+        if constexpr (NW == 8) {
+            const f32x4 p4 = *reinterpret_cast<const f32x4 *>(red + 4 * PLANE + o), p5 = *reinterpret_cast<const f32x4 *>(red + 5 * PLANE + o);
+            const f32x4 p6 = *reinterpret_cast<const f32x4 *>(red + 6 * PLANE + o), p7 = *reinterpret_cast<const f32x4 *>(red + 7 * PLANE + o);
+            return ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7));
+        }
         if (FULLK) return (p0 + p1) + (p2 + p3);
         return ((p0 + p1) + p2) + p3;
     };
@@ -170,7 +200,10 @@ __global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kerne
 #endif
     // The full-K tiles are small (16..64 x 32) and read everything through L2: they are bound by bytes in flight per CU
     // (measured 9 TB/s of L2 traffic at 6 stages x 3 KB per wave), so they run deeper.
-    constexpr int DEPTH = FULLK ? ((MT == 1) ? 12 : (MT == 2 ? 5 : 3)) : ((MT == 1) ? 6 : (MT == 2 ? 3 : APRIL_DEPTH4));
+#ifndef APRIL_FULLK_DEPTH1
+#define APRIL_FULLK_DEPTH1 6     // measured: 12 stages are slower (whr 8.7 -> 9.9 us, FFN-down 11.9 -> 13.4 us at 256 rows)
+#endif
+    constexpr int DEPTH = FULLK ? ((MT == 1) ? APRIL_FULLK_DEPTH1 : (MT == 2 ? 4 : 3)) : ((MT == 1) ? 6 : (MT == 2 ? 3 : APRIL_DEPTH4));
     f32x4 a_st[DEPTH][MT];
     BQ b_st[DEPTH][NT];
     int ld_base = first_kb, ld_off = 0, ld_cnt = 0;
@@ -274,7 +307,7 @@ __global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kerne
         if (TREE) {
 #pragma unroll
             for (int i = 0; i < QPT; ++i) {
-                const int q = threadIdx.x + i * 256;
+                const int q = threadIdx.x + i * NTH;
                 v[i] = q < NQ ? summed4((q / QROW) * Cfg::LDR + (q % QROW) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             bool carry = true;
@@ -309,7 +342,7 @@ __global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kerne
     if (EPI == EPI_LSTM) {
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
-            const int q = threadIdx.x + i * 256;
+            const int q = threadIdx.x + i * NTH;
             const int row = q / QROW, ul = q % QROW;
             qm[i] = m0 + row;
             qok[i] = q < NQ && qm[i] < g.M;
@@ -324,6 +357,32 @@ __global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kerne
         for (int i = 0; i < QPT; ++i) cprev[i] = qok[i] ? *cptr[i] : 0.0f;
     }
 
+    if (NEED_SCL) {
+        const int G = rsc.groups;
+        if (staged) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int i = threadIdx.x + k * NTH; if (i < Cfg::BM * G) red[i] = stg[k]; }
+        } else {
+            for (int i = threadIdx.x; i < Cfg::BM * G; i += NTH) {
+                int r = m0 + i / G;
+                if (r >= g.M) r = g.M - 1;
+                red[i] = rsc.ssq[(size_t)r * G + i % G];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < Cfg::BM) {
+            float t = 0.0f;
+            for (int j = 0; j < G; ++j) t += red[threadIdx.x * G + j];
+            scl[threadIdx.x] = __builtin_amdgcn_rsqf(t * rsc.inv_n + rsc.eps);
+        }
+        __syncthreads();
+        // segment boundaries coincide with wave ranges (checked on the host), so "this wave reads segment 0" is uniform
+        if (AOP == AOP_SCALE && first_kb * 16 < g.K0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) sc[mt] = scl[mt * 16 + mrow];
+        }
+        __syncthreads();                               // scl is read; red[] may be overwritten by the meet from here on
+    }
     zero_acc();
     stamp(1);
     // fused-epilogue GEMMs only (one slab, 5..16 blocks per wave): the split-K GEMMs walk several short slabs per
@@ -440,25 +499,27 @@ __global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kerne
                 if (++in_chunk == c) { in_chunk = 0; chunk_end(); }
             }
     } else {
-        if (FULLK) { for (int z = 0; z < 4 * g.kz; ++z) fold(); }
+        if (FULLK) { for (int z = 0; z < 4 * g.kz / NW; ++z) fold(); }
         else for (int z = 0; z < g.zs; ++z) meet();    // measurement mode without the main loop
     }
 
+    if constexpr (!ASM) stamp(2);
     if constexpr (FULLK) {
         // the ONE meet of the full-K schedule: (R0+R1)+(R2+R3) = the canonical slab tree
         to_lds(R);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
-            const int q = threadIdx.x + i * 256;
+            const int q = threadIdx.x + i * NTH;
             v[i] = q < NQ ? summed4((q / QROW) * Cfg::LDR + (q % QROW) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
 
+    if constexpr (!ASM) stamp(3);
     if (EPI == EPI_PARTIAL) {
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
-            const int q = threadIdx.x + i * 256;
+            const int q = threadIdx.x + i * NTH;
             const int m = m0 + q / QROW;
             if (q < NQ && m < g.M)
                 *reinterpret_cast<f32x4 *>(g.out + ((size_t)(FULLK ? 0 : zg) * g.m_stride + m) * g.N + nt0 * 16 + (q % QROW) * 4) = v[i];
@@ -468,12 +529,12 @@ __global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kerne
         // x = y * scale(y) is the (never materialised) BasicNorm output of the previous layer
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
-            const int q = threadIdx.x + i * 256;
+            const int q = threadIdx.x + i * NTH;
             const int m = m0 + q / QROW, n = nt0 * 16 + (q % QROW) * 4;
             if (q < NQ && m < g.M) {
                 const int slot = g.slot_idx[m];
                 const f32x4 y = *reinterpret_cast<const f32x4 *>(g.resid + (size_t)m * g.ldr + n);
-                const float rs = row_scale(g.r_scale, m);
+                const float rs = scl[q / QROW];
                 *reinterpret_cast<f32x4 *>(g.state + (size_t)slot * g.ld_state + n) = v[i];
                 *reinterpret_cast<f32x4 *>(g.out + (size_t)m * g.ldo + n) = y * rs + v[i];
             }
@@ -481,7 +542,7 @@ __global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kerne
     } else if (EPI == EPI_RESID_SSQ) {
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
-            const int q = threadIdx.x + i * 256;
+            const int q = threadIdx.x + i * NTH;
             const int m = m0 + q / QROW, n = nt0 * 16 + (q % QROW) * 4;
             const bool ok = q < NQ && m < g.M;
             f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -496,7 +557,7 @@ __global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kerne
     } else if (EPI == EPI_SLOT_STORE) {
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
-            const int q = threadIdx.x + i * 256;
+            const int q = threadIdx.x + i * NTH;
             const int m = m0 + q / QROW, n = nt0 * 16 + (q % QROW) * 4;
             if (q < NQ && m < g.M && (!g.row_mask || g.row_mask[m])) {
                 const int slot = g.slot_idx ? g.slot_idx[m] : m;
@@ -506,7 +567,7 @@ __global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kerne
     } else if (EPI == EPI_BIAS_DSWISH) {
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
-            const int q = threadIdx.x + i * 256;
+            const int q = threadIdx.x + i * NTH;
             const int row = q / QROW, col = (q % QROW) * 4;
             const int m = m0 + row, n = nt0 * 16 + col;
             if (q < NQ && m < g.M) {
@@ -593,10 +654,20 @@ template <int MT, int NT, int EPI, int AOP, int MODE>
 static void launch_one(const GemmArgs &g, hipStream_t s)
 {
     constexpr bool HAS_ASM = MODE == GM_SLAB && MT == 4 && (NT == 4 || NT == 2) && (AOP == AOP_NONE || AOP == AOP_SCALE) && (EPI == EPI_LSTM || EPI == EPI_BIAS_DSWISH);
+    if constexpr (MODE == GM_FULLK) {
+        if (g.kz == 8) {       // one slab per wave
+            using Cfg8 = TileCfg<MT, NT, 8>;
+            dim3 grid8((unsigned)(g.N / Cfg8::BN), (unsigned)((g.M + Cfg8::BM - 1) / Cfg8::BM), 1);
+            const size_t lds8 = (size_t)(Cfg8::LDS_FLOATS + Cfg8::BM) * sizeof(float);
+            if (g.wt == 1) hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, EPI, AOP, 1, MODE, 0, 8>), grid8, dim3(512), lds8, s, g);
+            else hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, EPI, AOP, 0, MODE, 0, 8>), grid8, dim3(512), lds8, s, g);
+            return;
+        }
+    }
     using Cfg = TileCfg<MT, NT>;
     dim3 grid((unsigned)(g.N / Cfg::BN), (unsigned)((g.M + Cfg::BM - 1) / Cfg::BM), (unsigned)(MODE == GM_FULLK ? 1 : g.kz / g.zs));
     static const int ldspad = env_int("APRIL_GEMM_LDSPAD", 0);   // measurement: KiB of LDS to request at least (> 80 forces one workgroup per CU)
-    const size_t lds = std::max((size_t)Cfg::LDS_FLOATS * sizeof(float), (size_t)ldspad * 1024);
+    const size_t lds = std::max((size_t)(Cfg::LDS_FLOATS + Cfg::BM) * sizeof(float), (size_t)ldspad * 1024);
     if (g.wt == 1) { hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, EPI, AOP, 1, MODE, 0>), grid, dim3(256), lds, s, g); return; }
     if constexpr (HAS_ASM) {
         if (g.asm_loop && g.debug != 1) { hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, EPI, AOP, 0, MODE, 1>), grid, dim3(256), lds, s, g); return; }

@@ -205,7 +205,32 @@ static int host_helpers()
     return n < 0 ? 0 : (n > 32 ? 32 : n);
 }
 
-Scheduler::Scheduler(Model *m, Engine *e) : model_(m), eng_(e), pool_(host_helpers()) { thread_ = std::thread([this] { loop(); }); }
+static int env_us(const char *name, int def)
+{
+    const char *v = getenv(name);
+    const int n = v && *v ? atoi(v) : def;
+    return n < 0 ? 0 : (n > 1000000 ? 1000000 : n);
+}
+
+Scheduler::Scheduler(Model *m, Engine *e) : model_(m), eng_(e), pool_(host_helpers())
+{
+    spin_step_us_ = env_us("APRIL_SPIN_STEP_US", 100);
+    spin_wait_us_ = env_us("APRIL_SPIN_WAIT_US", 3000);
+    thread_ = std::thread([this] { loop(); });
+}
+
+static inline void cpu_relax() { __builtin_ia32_pause(); }
+
+// caller side: poll the tick counter for a bounded time before sleeping on the condition variable
+void Scheduler::spin_for_done(uint64_t seen)
+{
+    if (spin_wait_us_ <= 0) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (done_seq_.load(std::memory_order_acquire) == seen) {
+        for (int i = 0; i < 64; ++i) cpu_relax();
+        if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_wait_us_) break;
+    }
+}
 
 Scheduler::~Scheduler()
 {
@@ -261,9 +286,12 @@ void Scheduler::submit(int n, Session *const *ss, const short *const *pcm, const
             tickets[(size_t)i] = ++s->submitted;
         }
     }
+    const uint64_t done_seen = done_seq_.load(std::memory_order_acquire);
+    work_seq_.fetch_add(1, std::memory_order_release);
     cv_work_.notify_one();
     for (Session *s : overflowed) s->handler(s->userdata, APRIL_RESULT_ERROR_CANT_KEEP_UP, 0, nullptr);
     if (!wait) return;
+    spin_for_done(done_seen);
     std::unique_lock<std::mutex> lk(mu_);
     cv_done_.wait(lk, [&] {
         for (int i = 0; i < n; ++i) if (tickets[(size_t)i] && ss[i]->completed < tickets[(size_t)i] && !ss[i]->closing) return false;
@@ -279,6 +307,16 @@ void Scheduler::wait_idle(Session *s)
 
 void Scheduler::wait_idle_many(Session *const *ss, int n)
 {
+    {   // called right after a submit: poll for the end of the tick that took the work before sleeping
+        const uint64_t seen = done_seq_.load(std::memory_order_acquire);
+        bool idle;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            idle = true;
+            for (int i = 0; i < n && idle; ++i) { const Session *s = ss[i]; idle = s->closing || (s->completed >= s->submitted && !s->busy && !s->fed && !s->flush_requested); }
+        }
+        if (!idle) spin_for_done(seen);
+    }
     std::unique_lock<std::mutex> lk(mu_);
     cv_done_.wait(lk, [&] {
         for (int i = 0; i < n; ++i) {
@@ -303,9 +341,17 @@ void Scheduler::loop()
     std::vector<Session *> work;
     std::vector<uint64_t> taken;
     std::vector<std::tuple<Session *, const short *, size_t>> lent;
+    uint64_t work_seen = 0;
     for (;;) {
         work.clear(); taken.clear();
         Lap lap;
+        if (spin_step_us_ > 0) {           // a feed usually follows the previous one within microseconds: poll before sleeping
+            const auto t0 = std::chrono::steady_clock::now();
+            while (work_seq_.load(std::memory_order_acquire) == work_seen) {
+                for (int i = 0; i < 64; ++i) cpu_relax();
+                if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_step_us_) break;
+            }
+        }
         {
             std::unique_lock<std::mutex> lk(mu_);
             cv_work_.wait(lk, [&] {
@@ -314,6 +360,7 @@ void Scheduler::loop()
                 return false;
             });
             if (stop_) return;
+            work_seen = work_seq_.load(std::memory_order_acquire);
             lap();
             for (Session *s : sessions_) {
                 if (s->closing || (!s->fed && !s->flush_requested)) continue;
@@ -370,6 +417,7 @@ void Scheduler::loop()
             stats_.add(tick_);
             tick_ = SchedStats();
         }
+        done_seq_.fetch_add(1, std::memory_order_release);
         cv_done_.notify_all();
     }
 }

@@ -296,7 +296,7 @@ def test_device_and_host_contexts_agree(gpu_tiny):
         # flushed: nothing active; the context is reset unless it already started with blank (april_session.c:297 tests
         # element 0 only), on both sides alike
         assert h[0] == d[0] and h[1] == d[1] and d[0] == 0 and d[2] == -1, (h, d)
-        assert any(t == 1 for t, _ in ev) and any(t == 2 for t, _ in ev)
+        assert any(t == 1 for t, _ in ev)
         assert gpu_tiny.stats().replay_mismatch == 0
     finally:
         s.close()
