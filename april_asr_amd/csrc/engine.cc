@@ -348,7 +348,7 @@ void Engine::fbank(int n_frames, const FbankFrameDesc *desc, const std::pair<con
 // ---------------------------------------------------------------- encoder
 // Launch count per chunk at batch sizes where the full-K schedule applies: 2 (conv) + 1 (embed) + 4 per layer + 1.
 // BasicNorm never runs as a kernel: EPI_RESID_SSQ leaves y and its per-32-column sums of squares, and every consumer
-// of the normalised row (the next layer's gate GEMM, its residual, encoder_proj) multiplies by row_scale() on the way in.
+// of the normalised row (the next layer's gate GEMM, its residual, encoder_proj) folds the row scale in (kernels.h).
 void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, const float *x_direct)
 {
     const NetDims &d = L_.dims;
@@ -393,7 +393,7 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
         float *c_l = c_ + (size_t)l * S * d.hidden;
         const RowScale xs = scale_of(eps_in);
         {   // gates = [norm(y) | h_prev] x Wg ; fused LSTM cell
-            GemmArgs g; g.a0 = y_; g.lda0 = d.d_model; g.K0 = d.d_model; g.a_op = AOP_SCALE; g.a_scale = xs;
+            GemmArgs g; g.a0 = y_; g.lda0 = d.d_model; g.K0 = d.d_model; g.x_scale = xs;
             g.a1 = h_l; g.lda1 = d.d_model; g.aidx1 = d_slots; g.K1 = d.d_model;
             lin(g, o.wg); g.M = n; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_LSTM;
             g.out = u_; g.ldo = d.hidden; g.bias = w_ + o.bg; g.c_state = c_l; g.slot_idx = d_slots; g.hidden = d.hidden;
@@ -423,16 +423,17 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
         eps_in = L_.norm_eps[(size_t)l];
     }
     {   // encoder_proj(norm(y)) -> eout[slot]
-        GemmArgs g; g.a0 = y_; g.lda0 = d.d_model; g.K0 = d.d_model; g.a_op = AOP_SCALE; g.a_scale = scale_of(eps_in); lin(g, L_.w_encproj);
+        const RowScale ys = scale_of(eps_in);
+        GemmArgs g; g.a0 = y_; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, L_.w_encproj);
         g.M = n; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_;
         if (gemm_fullk(n, d.joiner, kz_proj_)) {
-            g.epi = EPI_SLOT_STORE; g.bias = w_ + L_.b_encproj; g.out = eout_; g.ldo = d.joiner; g.slot_idx = d_slots;
+            g.epi = EPI_SLOT_STORE; g.bias = w_ + L_.b_encproj; g.out = eout_; g.ldo = d.joiner; g.slot_idx = d_slots; g.x_scale = ys;
             timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
         } else {
             g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
             timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
             RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_; r.parts = gemm_partials(n, d.joiner, kz_proj_); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = n;
-            r.bias = w_ + L_.b_encproj; r.out = eout_; r.ldo = d.joiner; r.slot_idx = d_slots;
+            r.bias = w_ + L_.b_encproj; r.out = eout_; r.ldo = d.joiner; r.slot_idx = d_slots; r.r_scale = ys;
             timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
         }
     }

@@ -37,10 +37,13 @@ enum GemmEpilogue {
     EPI_RESID_SSQ = 4,    // y = resid + (acc + bias) (resid optional) ; out = y ; ssq[m][n/32] = sum of y^2 over 32 columns
     EPI_SLOT_STORE = 5    // out[slot] = acc + bias, rows with row_mask[m] == 0 skipped (mask optional)
 };
-// A-operand prologues.  AOP_SCALE: rows of segment 0 are multiplied by their BasicNorm scale
-// (sum of squares partials -> (mean + eps)^-1/2) as they are loaded, i.e. the GEMM consumes x = y * scale(y)
-// without a normalisation kernel in between; the product is the same fp32 value a separate kernel would store.
-enum GemmAOp { AOP_NONE = 0, AOP_TANH_ADD = 1, AOP_SCALE = 2 };
+// A-operand prologues
+enum GemmAOp { AOP_NONE = 0, AOP_TANH_ADD = 1 };
+// BasicNorm never runs as a kernel.  A layer leaves y and its per-32-column sums of squares (EPI_RESID_SSQ); the consumers
+// of x = y * scale(y), scale = (mean(y^2) + eps)^-1/2, fold the row scale in where it is cheapest:
+//   - a GEMM over x (LSTM gates' input half, encoder_proj) runs over y and multiplies the finished partial sum by the row's
+//     scale in its epilogue (`x_scale`): scale * sum_k(y_k w_k), one rounding away from sum_k((scale y_k) w_k);
+//   - the residual x + h' reads y and multiplies (`r_scale`).
 enum GemmMode { GM_SLAB = 0, GM_FULLK = 1 };
 
 constexpr int SSQ_COLS = 32;       // columns per sum-of-squares partial (one granule = 8 consecutive 4-column quads)
@@ -58,7 +61,8 @@ struct GemmArgs {
     const float *a1 = nullptr; int lda1 = 0; const int *aidx1 = nullptr; int K1 = 0;
     const float *a0b = nullptr;            // AOP_TANH_ADD second addend (same ld/idx as a0)
     int a_op = AOP_NONE;
-    RowScale a_scale;                      // AOP_SCALE: scale of segment-0 rows (indexed by batch row)
+    RowScale x_scale;                      // optional (ssq != null).  EPI_LSTM: the A-segment-0 half of the sum, ((p0+p1) * scale + p2) + p3;
+                                           // EPI_SLOT_STORE: the whole sum, out = acc * scale + bias
     const void *wp = nullptr;              // packed weights (fp32, or fp16 in the same element order when wt == 1)
     int wt = 0;                            // 0: fp32 operands, v_mfma_f32_16x16x4_f32; 1: fp16 weights, A rounded to fp16 on load,
                                            //    v_mfma_f32_16x16x16_f16 with fp32 accumulation (BASELINE configs[4])
@@ -95,14 +99,14 @@ bool gemm_fullk(int M, int N, int kz);
 enum RowMode {
     ROW_HR = 0,          // s = tree(ws); state[slot] = s; out = resid * rowscale(resid) + s
     ROW_RESID_SSQ = 1,   // y = resid + (s + bias) (resid optional); out = y; ssq partials of y
-    ROW_SLOT_STORE = 2   // out[slot] = s + bias (rows with row_mask == 0 skipped)
+    ROW_SLOT_STORE = 2   // out[slot] = s (* rowscale, optional) + bias (rows with row_mask == 0 skipped)
 };
 struct RowArgs {
     int mode = ROW_HR;
     const float *ws = nullptr; int parts = 1; int m_stride = 0; int N = 0; int M = 0;
     const float *bias = nullptr;
     const float *resid = nullptr; int ldr = 0;
-    RowScale r_scale;                      // ROW_HR
+    RowScale r_scale;                      // ROW_HR: scale of the residual; ROW_SLOT_STORE: optional scale of the sum
     float *out = nullptr; int ldo = 0;
     const int *slot_idx = nullptr;         // row -> slot for state / slot-indexed outputs
     float *state = nullptr; int ld_state = 0;   // ROW_HR: h state of this layer

@@ -113,10 +113,10 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
     // memory into LDS (every lane fetching its own rows' partials cost the gate GEMM 8 us).  The loads are issued here, first
     // thing, and land while the rest of the set-up (row indirections, previous cell values) is in flight; further down 64
     // threads add the partials in column order (the order of row_scale()) and leave the scales behind the partial planes.
-    constexpr bool NEED_SCL = AOP == AOP_SCALE || EPI == EPI_HR;
+    const RowScale &rsc = EPI == EPI_HR ? g.r_scale : g.x_scale;
+    const bool NEED_SCL = (EPI == EPI_HR || EPI == EPI_LSTM || EPI == EPI_SLOT_STORE) && rsc.ssq != nullptr;     // uniform
     float *scl = red + Cfg::LDS_FLOATS;
     float stg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    const RowScale &rsc = AOP == AOP_SCALE ? g.a_scale : g.r_scale;
     const bool staged = NEED_SCL && Cfg::BM * rsc.groups <= 4 * NTH;
     if (NEED_SCL && staged) {
 #pragma unroll
@@ -131,7 +131,6 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
     }
 
     uint32_t aoff0[MT], aoff1[MT];
-    float sc[MT];                                      // AOP_SCALE: BasicNorm scale of this lane's rows (1 outside segment 0)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int row = m0 + mt * 16 + mrow;
@@ -140,8 +139,6 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
         aoff0[mt] = (uint32_t)(((size_t)r0 * g.lda0 + kq * 4) * sizeof(float));
         aoff1[mt] = 0;
         if (g.K1 > 0) { const int r1 = g.aidx1 ? g.aidx1[row] : row; aoff1[mt] = (uint32_t)(((size_t)r1 * g.lda1 + kq * 4) * sizeof(float)); }
-        sc[mt] = 1.0f;
-        // segment boundaries coincide with wave ranges (checked on the host), so "this wave reads segment 0" is uniform
     }
     const uint32_t boff = (uint32_t)lane * sizeof(BQ);
     const bool stream_once = gridDim.y == 1;   // weights read by exactly one workgroup: bypass-friendly loads
@@ -226,8 +223,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
     auto compute = [&](const f32x4 (&a)[MT], const BQ (&b)[NT]) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            f32x4 av = a[mt];
-            if (AOP == AOP_SCALE) av = av * sc[mt];           // x = y * scale: the value a normalisation kernel would have stored
+            const f32x4 av = a[mt];
             if constexpr (WT == 1) {
                 // the same 16 k values per lane as four fp32 k-steps, in one v_mfma_f32_16x16x16_f16 (fp32 accumulate)
                 const h4 ah = {(_Float16)av.x, (_Float16)av.y, (_Float16)av.z, (_Float16)av.w};
@@ -375,20 +371,14 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
             for (int j = 0; j < G; ++j) t += red[threadIdx.x * G + j];
             scl[threadIdx.x] = __builtin_amdgcn_rsqf(t * rsc.inv_n + rsc.eps);
         }
-        __syncthreads();
-        // segment boundaries coincide with wave ranges (checked on the host), so "this wave reads segment 0" is uniform
-        if (AOP == AOP_SCALE && first_kb * 16 < g.K0) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) sc[mt] = scl[mt * 16 + mrow];
-        }
-        __syncthreads();                               // scl is read; red[] may be overwritten by the meet from here on
+        __syncthreads();                               // the scales are in scl[]; red[] may be overwritten by the meet from here on
     }
     zero_acc();
     stamp(1);
     // fused-epilogue GEMMs only (one slab, 5..16 blocks per wave): the split-K GEMMs walk several short slabs per
     // workgroup and rely on the cross-slab prefetch of the compiler-scheduled loop below (measured: no gain there)
     if constexpr (ASM) {
-        static_assert(!FULLK && MT == 4 && (NT == 4 || NT == 2) && WT == 0 && (AOP == AOP_NONE || AOP == AOP_SCALE) && (EPI == EPI_LSTM || EPI == EPI_BIAS_DSWISH), "no hand-scheduled loop for this form");
+        static_assert(!FULLK && MT == 4 && (NT == 4 || NT == 2) && WT == 0 && AOP == AOP_NONE && (EPI == EPI_LSTM || EPI == EPI_BIAS_DSWISH), "no hand-scheduled loop for this form");
         {
             // hand-scheduled K loop (tools/gen_gemm_asm.py): same blocks, same order, same accumulation chains
             uint32_t boffs[NT];
@@ -406,12 +396,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
                     const char *bp = reinterpret_cast<const char *>(g.wp) + ((size_t)nt0 * KB + kb) * 1024;
                     const uint32_t o0 = seg0 ? aoff0[0] : aoff1[0], o1 = seg0 ? aoff0[1] : aoff1[1];
                     const uint32_t o2 = seg0 ? aoff0[2] : aoff1[2], o3 = seg0 ? aoff0[3] : aoff1[3];
-                    // ONE asm statement per kernel (two statements with tied accumulator operands make the register allocator keep
-                    // two accumulator sets): the AOP_SCALE form always runs the multiplying text; waves outside segment 0
-                    // hold sc = 1.0f, and x * 1.0f is x
-                    constexpr bool scaled = AOP == AOP_SCALE;
 #define APRIL_ASM_IN_A [aoff0] "v"(o0), [aoff1] "v"(o1), [aoff2] "v"(o2), [aoff3] "v"(o3), [ap] "s"(ap), [bp] "s"(bp), [nblk] "s"(n)
-#define APRIL_ASM_IN_S [sc0] "v"(sc[0]), [sc1] "v"(sc[1]), [sc2] "v"(sc[2]), [sc3] "v"(sc[3])
 #define APRIL_ASM_ACC16 [c0] "+a"(acc[0][0]), [c1] "+a"(acc[0][1]), [c2] "+a"(acc[0][2]), [c3] "+a"(acc[0][3]), \
                         [c4] "+a"(acc[1][0]), [c5] "+a"(acc[1][1]), [c6] "+a"(acc[1][2]), [c7] "+a"(acc[1][3]), \
                         [c8] "+a"(acc[2][0]), [c9] "+a"(acc[2][1]), [c10] "+a"(acc[2][2]), [c11] "+a"(acc[2][3]), \
@@ -419,12 +404,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
 #define APRIL_ASM_ACC8 [c0] "+a"(acc[0][0]), [c1] "+a"(acc[0][1]), [c2] "+a"(acc[1][0]), [c3] "+a"(acc[1][1]), \
                        [c4] "+a"(acc[2][0]), [c5] "+a"(acc[2][1]), [c6] "+a"(acc[3][0]), [c7] "+a"(acc[3][1])
                     if constexpr (NT == 4) {
-                        if constexpr (scaled) {
-                            asm volatile(APRIL_MAINLOOP2_SC_TEXT
-                                : APRIL_ASM_ACC16
-                                : APRIL_ASM_IN_A, APRIL_ASM_IN_S, [boff0] "v"(boffs[0]), [boff1] "v"(boffs[1]), [boff2] "v"(boffs[NT - 2]), [boff3] "v"(boffs[NT - 1])
-                                : APRIL_MAINLOOP2_SC_CLOBBERS);
-                        } else {
+                        {
 #if APRIL_ASM_NB == 3
                             asm volatile(APRIL_MAINLOOP3_TEXT
 #else
@@ -439,12 +419,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
 #endif
                         }
                     } else {
-                        if constexpr (scaled) {
-                            asm volatile(APRIL_MAINLOOP2_NT2_SC_TEXT
-                                : APRIL_ASM_ACC8
-                                : APRIL_ASM_IN_A, APRIL_ASM_IN_S, [boff0] "v"(boffs[0]), [boff1] "v"(boffs[1])
-                                : APRIL_MAINLOOP2_NT2_SC_CLOBBERS);
-                        } else {
+                        {
                             asm volatile(APRIL_MAINLOOP2_NT2_TEXT
                                 : APRIL_ASM_ACC8
                                 : APRIL_ASM_IN_A, [boff0] "v"(boffs[0]), [boff1] "v"(boffs[1])
@@ -452,7 +427,6 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
                         }
                     }
 #undef APRIL_ASM_IN_A
-#undef APRIL_ASM_IN_S
 #undef APRIL_ASM_ACC16
 #undef APRIL_ASM_ACC8
                     done += n;
@@ -561,7 +535,8 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
             const int m = m0 + q / QROW, n = nt0 * 16 + (q % QROW) * 4;
             if (q < NQ && m < g.M && (!g.row_mask || g.row_mask[m])) {
                 const int slot = g.slot_idx ? g.slot_idx[m] : m;
-                *reinterpret_cast<f32x4 *>(g.out + (size_t)slot * g.ldo + n) = v[i] + *reinterpret_cast<const f32x4 *>(g.bias + n);
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(g.bias + n);
+                *reinterpret_cast<f32x4 *>(g.out + (size_t)slot * g.ldo + n) = NEED_SCL ? v[i] * scl[q / QROW] + b : v[i] + b;
             }
         }
     } else if (EPI == EPI_BIAS_DSWISH) {
@@ -581,7 +556,16 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
     } else {   // EPI_LSTM: each 4-column group = gates i,f,g,o of one hidden unit
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
-            const f32x4 gt = summed4(qo[i]) + qb[i];
+            // x = y * scale(y) entered the GEMM as y: waves 0 and 1 hold the input half of the sum, which takes the row's scale here
+            f32x4 gt;
+            if (NEED_SCL) {
+                const int o = qo[i];
+                const f32x4 p0 = *reinterpret_cast<const f32x4 *>(red + o), p1 = *reinterpret_cast<const f32x4 *>(red + PLANE + o);
+                const f32x4 p2 = *reinterpret_cast<const f32x4 *>(red + 2 * PLANE + o), p3 = *reinterpret_cast<const f32x4 *>(red + 3 * PLANE + o);
+                gt = (((p0 + p1) * scl[(threadIdx.x + i * NTH) / QROW] + p2) + p3) + qb[i];
+            } else {
+                gt = summed4(qo[i]) + qb[i];
+            }
             const float c_new = fast_sigmoid(gt.y) * cprev[i] + fast_sigmoid(gt.x) * fast_tanh(gt.z);
             const float u = g.debug == 2 ? gt.x + gt.y + gt.z + gt.w : fast_sigmoid(gt.w) * fast_tanh(c_new);
             if (qok[i]) { *cptr[i] = c_new; g.out[(size_t)qm[i] * g.ldo + qunit[i]] = u; }
@@ -653,9 +637,10 @@ int gemm_partials(int M, int N, int kz)
 template <int MT, int NT, int EPI, int AOP, int MODE>
 static void launch_one(const GemmArgs &g, hipStream_t s)
 {
-    constexpr bool HAS_ASM = MODE == GM_SLAB && MT == 4 && (NT == 4 || NT == 2) && (AOP == AOP_NONE || AOP == AOP_SCALE) && (EPI == EPI_LSTM || EPI == EPI_BIAS_DSWISH);
+    constexpr bool HAS_ASM = MODE == GM_SLAB && MT == 4 && (NT == 4 || NT == 2) && AOP == AOP_NONE && (EPI == EPI_LSTM || EPI == EPI_BIAS_DSWISH);
     if constexpr (MODE == GM_FULLK) {
-        if (g.kz == 8) {       // one slab per wave
+        static const int nw8 = env_int("APRIL_FULLK_NW8", 0);      // measured: no gain (the tiles are bound by L2 -> L1 bytes, ~24 B/clk/CU, not by MFMA issue)
+        if (g.kz == 8 && nw8) {       // one slab per wave
             using Cfg8 = TileCfg<MT, NT, 8>;
             dim3 grid8((unsigned)(g.N / Cfg8::BN), (unsigned)((g.M + Cfg8::BM - 1) / Cfg8::BM), 1);
             const size_t lds8 = (size_t)(Cfg8::LDS_FLOATS + Cfg8::BM) * sizeof(float);
@@ -681,14 +666,12 @@ static bool dispatch(const GemmArgs &g, hipStream_t s)
 {
 #define CASE(E, A, MD) if (g.epi == E && g.a_op == A && g.mode == MD) { launch_one<MT, NT, E, A, MD>(g, s); return true; }
     if constexpr (NT == 2) {        // the full-K schedule uses 16/32/64 x 32 tiles only
-        CASE(EPI_PARTIAL, AOP_NONE, GM_FULLK) CASE(EPI_PARTIAL, AOP_TANH_ADD, GM_FULLK) CASE(EPI_PARTIAL, AOP_SCALE, GM_FULLK)
-        CASE(EPI_HR, AOP_NONE, GM_FULLK) CASE(EPI_RESID_SSQ, AOP_NONE, GM_FULLK)
-        CASE(EPI_SLOT_STORE, AOP_NONE, GM_FULLK) CASE(EPI_SLOT_STORE, AOP_SCALE, GM_FULLK)
-        CASE(EPI_HR, AOP_NONE, GM_SLAB) CASE(EPI_RESID_SSQ, AOP_NONE, GM_SLAB)
-        CASE(EPI_SLOT_STORE, AOP_NONE, GM_SLAB) CASE(EPI_SLOT_STORE, AOP_SCALE, GM_SLAB)
+        CASE(EPI_PARTIAL, AOP_TANH_ADD, GM_FULLK)
+        CASE(EPI_HR, AOP_NONE, GM_FULLK) CASE(EPI_RESID_SSQ, AOP_NONE, GM_FULLK) CASE(EPI_SLOT_STORE, AOP_NONE, GM_FULLK)
+        CASE(EPI_HR, AOP_NONE, GM_SLAB) CASE(EPI_RESID_SSQ, AOP_NONE, GM_SLAB) CASE(EPI_SLOT_STORE, AOP_NONE, GM_SLAB)
     }
-    CASE(EPI_PARTIAL, AOP_NONE, GM_SLAB) CASE(EPI_PARTIAL, AOP_TANH_ADD, GM_SLAB) CASE(EPI_PARTIAL, AOP_SCALE, GM_SLAB)
-    CASE(EPI_LSTM, AOP_SCALE, GM_SLAB) CASE(EPI_LSTM, AOP_NONE, GM_SLAB)
+    CASE(EPI_PARTIAL, AOP_NONE, GM_SLAB) CASE(EPI_PARTIAL, AOP_TANH_ADD, GM_SLAB)
+    CASE(EPI_LSTM, AOP_NONE, GM_SLAB)
     CASE(EPI_BIAS_DSWISH, AOP_NONE, GM_SLAB)
 #undef CASE
     return false;
@@ -705,8 +688,8 @@ void launch_gemm(const GemmArgs &g_in, hipStream_t s)
     const bool row_epi = g.epi == EPI_HR || g.epi == EPI_RESID_SSQ || g.epi == EPI_SLOT_STORE;
     if (row_epi && t.zs != g.kz) { fprintf(stderr, "libapril(mi355x): launch_gemm: row epilogue %d needs the full-K plan (M=%d N=%d kz=%d)\n", g.epi, g.M, g.N, g.kz); abort(); }
     g.zs = t.zs; g.mode = t.mode;
-    // AOP_SCALE multiplies the rows of A segment 0: a wave must not straddle the segment boundary
-    if (g.a_op == AOP_SCALE && g.K1 > 0 && ((g.K0 / 16) % std::max(1, (g.K / 16) / (4 * g.kz))) != 0) { fprintf(stderr, "libapril(mi355x): launch_gemm: AOP_SCALE segment boundary inside a chunk\n"); abort(); }
+    // EPI_LSTM with x_scale scales the partial sums of waves 0 and 1: they must hold exactly A segment 0
+    if (g.epi == EPI_LSTM && g.x_scale.ssq && (g.kz != 1 || g.K0 * 2 != g.K)) { fprintf(stderr, "libapril(mi355x): launch_gemm: x_scale needs K0 == K / 2 and kz == 1\n"); abort(); }
     // hand-scheduled K loop: measured gains with one workgroup per CU (gates at B <= 256: 24.8 -> 22.9 us) and for the
     // bias+DoubleSwish GEMMs at any size (FFN-up at B = 1024: 26.5 -> 23.3 us); the LSTM-cell GEMM with two
     // co-resident workgroups per CU is faster with the compiler-scheduled loop (B = 1024: 83 vs 91 us)

@@ -27,8 +27,9 @@ __global__ __launch_bounds__(256) void row_kernel(RowArgs r)
     const int tid = threadIdx.x;
     const int slot = r.slot_idx ? r.slot_idx[m] : m;
     if (MODE == ROW_SLOT_STORE) { if (r.row_mask && !r.row_mask[m]) return; }
-    float rs = 0.0f;
-    if (MODE == ROW_HR) rs = row_scale(r.r_scale, m);
+    float rs = 1.0f;
+    const bool scaled = MODE == ROW_HR || (MODE == ROW_SLOT_STORE && r.r_scale.ssq != nullptr);
+    if (scaled) rs = row_scale(r.r_scale, m);
     const int nq = r.N >> 2;                            // N is a multiple of 64
     for (int q0 = 0; q0 < nq; q0 += 256) {
         const int q = q0 + tid;
@@ -52,7 +53,10 @@ __global__ __launch_bounds__(256) void row_kernel(RowArgs r)
             const float ss = granule_ssq(y);           // every lane takes part in the shuffles
             if (ok && (q & 7) == 0) r.ssq_out[(size_t)m * (r.N / SSQ_COLS) + n / SSQ_COLS] = ss;
         } else {   // ROW_SLOT_STORE
-            if (ok) *reinterpret_cast<f32x4 *>(r.out + (size_t)slot * r.ldo + n) = s + *reinterpret_cast<const f32x4 *>(r.bias + n);
+            if (ok) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(r.bias + n);
+                *reinterpret_cast<f32x4 *>(r.out + (size_t)slot * r.ldo + n) = scaled ? s * rs + b : s + b;
+            }
         }
     }
 }

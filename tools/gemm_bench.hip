@@ -46,7 +46,7 @@ int main(int argc, char **argv)
         float *cst; hipMalloc(&cst, (size_t)M * (N / 4) * 4); hipMemset(cst, 0, (size_t)M * (N / 4) * 4);
         g.K0 = K / 2; g.lda0 = K / 2; g.a1 = a + (size_t)M * (K / 2); g.lda1 = K / 2; g.aidx1 = idx; g.K1 = K / 2;
         g.c_state = cst; g.slot_idx = idx; g.hidden = N / 4; g.ldo = N / 4;
-        g.a_op = AOP_SCALE; g.a_scale.ssq = ssq; g.a_scale.groups = (K / 2) / 32; g.a_scale.inv_n = 1.0f / (K / 2); g.a_scale.eps = 0.25f;
+        g.x_scale.ssq = ssq; g.x_scale.groups = (K / 2) / 32; g.x_scale.inv_n = 1.0f / (K / 2); g.x_scale.eps = 0.25f;
     }
     hipStream_t s; hipStreamCreate(&s);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

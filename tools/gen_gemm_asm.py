@@ -104,5 +104,5 @@ if __name__ == "__main__":
     print(emit(2, "APRIL_MAINLOOP2"))
     print(emit(3, "APRIL_MAINLOOP3"))
     print(emit(2, "APRIL_MAINLOOP2_NT2", NT=2))
-    print(emit(2, "APRIL_MAINLOOP2_SC", scaled=True))
-    print(emit(2, "APRIL_MAINLOOP2_NT2_SC", NT=2, scaled=True))
+    # scaled=True variants (activation quads multiplied in place by a per-row scale, as fillers) were measured at +7 % loop
+    # time on the gate GEMM and are not emitted: the row scale is applied to the finished partial sums instead
