@@ -110,24 +110,23 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
     const int first_kb = FULLK ? wave * T : (4 * (zg * g.zs) + wave) * c;
 
     // BasicNorm scales of the tile's rows, once per workgroup: the rows' sum-of-squares partials make ONE trip from global
-    // memory into LDS (every lane fetching its own rows' partials cost the gate GEMM 8 us).  The loads are issued here, first
-    // thing, and land while the rest of the set-up (row indirections, previous cell values) is in flight; further down 64
-    // threads add the partials in column order (the order of row_scale()) and leave the scales behind the partial planes.
+    // memory (every lane fetching its own rows' partials cost the gate GEMM 8 us).  The loads are issued here, first thing,
+    // and stay in registers during the K loop; after the meet 64 threads add them up through LDS (see the epilogue).
     const RowScale &rsc = EPI == EPI_HR ? g.r_scale : g.x_scale;
     const bool NEED_SCL = (EPI == EPI_HR || EPI == EPI_LSTM || EPI == EPI_SLOT_STORE) && rsc.ssq != nullptr;     // uniform
     float *scl = red + Cfg::LDS_FLOATS;
     float stg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    const bool staged = NEED_SCL && Cfg::BM * rsc.groups <= 4 * NTH;
+    // TPR threads share a row, each holds up to 4 consecutive partials of it (no runtime divisions on the way in)
+    constexpr int TPR = NTH / Cfg::BM;
+    const int ppt = (rsc.groups + TPR - 1) / TPR;
+    const bool staged = NEED_SCL && ppt <= 4;
+    const int srow = threadIdx.x / TPR, sj0 = (threadIdx.x % TPR) * ppt;
     if (NEED_SCL && staged) {
+        int r = m0 + srow;
+        if (r >= g.M) r = g.M - 1;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = threadIdx.x + k * NTH;
-            if (i < Cfg::BM * rsc.groups) {
-                int r = m0 + i / rsc.groups;
-                if (r >= g.M) r = g.M - 1;
-                stg[k] = rsc.ssq[(size_t)r * rsc.groups + i % rsc.groups];
-            }
-        }
+        for (int k = 0; k < 4; ++k)
+            if (k < ppt && sj0 + k < rsc.groups) stg[k] = rsc.ssq[(size_t)r * rsc.groups + sj0 + k];
     }
 
     uint32_t aoff0[MT], aoff1[MT];
@@ -353,26 +352,6 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
         for (int i = 0; i < QPT; ++i) cprev[i] = qok[i] ? *cptr[i] : 0.0f;
     }
 
-    if (NEED_SCL) {
-        const int G = rsc.groups;
-        if (staged) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { const int i = threadIdx.x + k * NTH; if (i < Cfg::BM * G) red[i] = stg[k]; }
-        } else {
-            for (int i = threadIdx.x; i < Cfg::BM * G; i += NTH) {
-                int r = m0 + i / G;
-                if (r >= g.M) r = g.M - 1;
-                red[i] = rsc.ssq[(size_t)r * G + i % G];
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < Cfg::BM) {
-            float t = 0.0f;
-            for (int j = 0; j < G; ++j) t += red[threadIdx.x * G + j];
-            scl[threadIdx.x] = __builtin_amdgcn_rsqf(t * rsc.inv_n + rsc.eps);
-        }
-        __syncthreads();                               // the scales are in scl[]; red[] may be overwritten by the meet from here on
-    }
     zero_acc();
     stamp(1);
     // fused-epilogue GEMMs only (one slab, 5..16 blocks per wave): the split-K GEMMs walk several short slabs per
@@ -489,6 +468,29 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
         }
     }
 
+    if (NEED_SCL) {
+        // the rows' scales: partials (in registers since the first instruction of the kernel) -> LDS, 64 threads add them in
+        // column order (the order of row_scale()); rows are padded to G + 1 floats (conflict-free column walks)
+        const int G = rsc.groups;
+        float *part = scl + Cfg::BM;
+        if (staged) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k < ppt && sj0 + k < G) part[srow * (G + 1) + sj0 + k] = stg[k];
+        } else {
+            for (int i = threadIdx.x; i < Cfg::BM * G; i += NTH) {
+                int r = m0 + i / G;
+                if (r >= g.M) r = g.M - 1;
+                part[(i / G) * (G + 1) + i % G] = rsc.ssq[(size_t)r * G + i % G];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < Cfg::BM) {
+            float t = 0.0f;
+            for (int j = 0; j < G; ++j) t += part[threadIdx.x * (G + 1) + j];
+            scl[threadIdx.x] = __builtin_amdgcn_rsqf(t * rsc.inv_n + rsc.eps);
+        }
+        __syncthreads();
+    }
     if constexpr (!ASM) stamp(3);
     if (EPI == EPI_PARTIAL) {
 #pragma unroll
@@ -643,7 +645,8 @@ static void launch_one(const GemmArgs &g, hipStream_t s)
         if (g.kz == 8 && nw8) {       // one slab per wave
             using Cfg8 = TileCfg<MT, NT, 8>;
             dim3 grid8((unsigned)(g.N / Cfg8::BN), (unsigned)((g.M + Cfg8::BM - 1) / Cfg8::BM), 1);
-            const size_t lds8 = (size_t)(Cfg8::LDS_FLOATS + Cfg8::BM) * sizeof(float);
+            const int sg8 = EPI == EPI_HR ? g.r_scale.groups : (EPI == EPI_SLOT_STORE && g.x_scale.ssq ? g.x_scale.groups : 0);
+            const size_t lds8 = (size_t)(Cfg8::LDS_FLOATS + Cfg8::BM + (sg8 ? Cfg8::BM * (sg8 + 1) : 0)) * sizeof(float);
             if (g.wt == 1) hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, EPI, AOP, 1, MODE, 0, 8>), grid8, dim3(512), lds8, s, g);
             else hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, EPI, AOP, 0, MODE, 0, 8>), grid8, dim3(512), lds8, s, g);
             return;
@@ -652,7 +655,8 @@ static void launch_one(const GemmArgs &g, hipStream_t s)
     using Cfg = TileCfg<MT, NT>;
     dim3 grid((unsigned)(g.N / Cfg::BN), (unsigned)((g.M + Cfg::BM - 1) / Cfg::BM), (unsigned)(MODE == GM_FULLK ? 1 : g.kz / g.zs));
     static const int ldspad = env_int("APRIL_GEMM_LDSPAD", 0);   // measurement: KiB of LDS to request at least (> 80 forces one workgroup per CU)
-    const size_t lds = std::max((size_t)(Cfg::LDS_FLOATS + Cfg::BM) * sizeof(float), (size_t)ldspad * 1024);
+    const int sg = EPI == EPI_HR ? g.r_scale.groups : ((EPI == EPI_LSTM || EPI == EPI_SLOT_STORE) && g.x_scale.ssq ? g.x_scale.groups : 0);
+    const size_t lds = std::max((size_t)(Cfg::LDS_FLOATS + Cfg::BM + (sg ? Cfg::BM * (sg + 1) : 0)) * sizeof(float), (size_t)ldspad * 1024);
     if (g.wt == 1) { hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, EPI, AOP, 1, MODE, 0>), grid, dim3(256), lds, s, g); return; }
     if constexpr (HAS_ASM) {
         if (g.asm_loop && g.debug != 1) { hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, EPI, AOP, 0, MODE, 1>), grid, dim3(256), lds, s, g); return; }
