@@ -133,6 +133,38 @@ class Model:
         L.aprilx_model_dims(h, C.byref(m.dims))
         return m
 
+    # ---- one process per GPU: the model travels from rank 0 to the other ranks over RCCL inside the library
+    @staticmethod
+    def broadcast_id() -> bytes:
+        """RCCL unique id (rank 0 creates it; hand the bytes to the other ranks by any means)."""
+        L = _ffi.init()
+        buf = C.create_string_buffer(128)
+        n = L.aprilx_broadcast_get_id(buf, 128)
+        if n <= 0:
+            raise RuntimeError("aprilx_broadcast_get_id failed")
+        return buf.raw[:n]
+
+    @classmethod
+    def broadcast(cls, root_model, rank: int, world: int, id_bytes: bytes):
+        """Every rank calls this; rank 0 passes its model (and gets it back), the others pass None."""
+        L = _ffi.init()
+        idb = C.create_string_buffer(bytes(id_bytes), 128)
+        h = L.aprilx_model_broadcast(root_model._handle if root_model is not None else None, rank, world, idb)
+        if not h:
+            raise Exception("model broadcast failed")
+        if root_model is not None:
+            return root_model
+        m = cls.__new__(cls)
+        m._L = L; m._handle = h
+        m.dims = _ffi.AprilxDims()
+        L.aprilx_model_dims(h, C.byref(m.dims))
+        return m
+
+    def load_info(self):
+        info = _ffi.AprilxLoadInfo()
+        self._L.aprilx_model_load_info(self._handle, C.byref(info))
+        return info
+
     def save_blob(self, path: str):
         """Cache of the parsed + packed weights next to the model (aprilx_model_save_blob)."""
         if self._L.aprilx_model_save_blob(self._handle, path.encode("utf-8")) != 0:

@@ -41,6 +41,11 @@ class AprilxStats(C.Structure):
                 ("flights", C.c_uint64), ("replay_mismatch", C.c_uint64), ("kernels_per_step", C.c_uint64)]
 
 
+class AprilxLoadInfo(C.Structure):
+    _fields_ = [("broadcast_ms", C.c_double), ("comm_init_ms", C.c_double), ("broadcast_bytes", C.c_uint64),
+                ("ranks", C.c_int32), ("used_rccl", C.c_int32)]
+
+
 EXPORTED_REFERENCE_SYMBOLS = [
     "aam_api_init", "aam_create_model", "aam_get_name", "aam_get_description", "aam_get_language",
     "aam_get_sample_rate", "aam_free", "aas_create_session", "aas_feed_pcm16", "aas_flush",
@@ -48,7 +53,8 @@ EXPORTED_REFERENCE_SYMBOLS = [
 ]
 EXPORTED_ENGINE_SYMBOLS = [
     "aprilx_model_dims", "aprilx_model_token", "aprilx_model_blob_size", "aprilx_model_export_blob",
-    "aprilx_model_from_blob", "aprilx_model_save_blob", "aprilx_model_load_blob", "aprilx_feed_many", "aprilx_flush_many", "aprilx_session_drain",
+    "aprilx_model_from_blob", "aprilx_model_save_blob", "aprilx_model_load_blob",
+    "aprilx_broadcast_get_id", "aprilx_model_broadcast", "aprilx_model_load_info", "aprilx_feed_many", "aprilx_flush_many", "aprilx_session_drain",
     "aprilx_run_encoder", "aprilx_run_decoder", "aprilx_run_joiner", "aprilx_run_fbank",
     "aprilx_session_trace_logits", "aprilx_session_chunks", "aprilx_session_context", "aprilx_model_stats", "aprilx_model_profile",
     "aprilx_greedy_create", "aprilx_greedy_step", "aprilx_greedy_finish", "aprilx_greedy_free", "aprilx_probe_file", "aprilx_model_load_host", "aprilx_model_fbank_tables", "aprilx_counting_handler",
@@ -86,6 +92,9 @@ def lib():
     L.aprilx_model_from_blob.argtypes = [vp, sz, C.c_int]; L.aprilx_model_from_blob.restype = vp
     L.aprilx_model_save_blob.argtypes = [vp, C.c_char_p]; L.aprilx_model_save_blob.restype = C.c_int
     L.aprilx_model_load_blob.argtypes = [C.c_char_p]; L.aprilx_model_load_blob.restype = vp
+    L.aprilx_broadcast_get_id.argtypes = [vp, sz]; L.aprilx_broadcast_get_id.restype = C.c_int
+    L.aprilx_model_broadcast.argtypes = [vp, C.c_int, C.c_int, vp]; L.aprilx_model_broadcast.restype = vp
+    L.aprilx_model_load_info.argtypes = [vp, C.POINTER(AprilxLoadInfo)]; L.aprilx_model_load_info.restype = C.c_int
     L.aprilx_feed_many.argtypes = [sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz)]; L.aprilx_feed_many.restype = None
     L.aprilx_flush_many.argtypes = [sz, C.POINTER(vp)]; L.aprilx_flush_many.restype = None
     L.aprilx_session_drain.argtypes = [vp]; L.aprilx_session_drain.restype = None

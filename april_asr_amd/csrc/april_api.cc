@@ -2,6 +2,8 @@
 // (include/april_api.h, reference april_api.h:58-196) and the engine-level
 // aprilx_* entry points (include/aprilx_engine.h).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <chrono>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
@@ -30,7 +32,52 @@ int env_int(const char *name, int def)
     return v && *v ? atoi(v) : def;
 }
 
-bool build_runtime(Model &m, const float *blob_host, const float *blob_device)
+#define RCCL_TRY(expr)                                                                     \
+    do {                                                                                   \
+        ncclResult_t r_ = (expr);                                                          \
+        if (r_ != ncclSuccess) { LOGE("RCCL: %s failed: %s", #expr, ncclGetErrorString(r_)); return false; } \
+    } while (0)
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// One process, several GPUs (APRIL_GPU_DEVICES=0,1,...): the packed weights are uploaded ONCE, to the first device, and
+// broadcast from there to the other devices' engines with RCCL over xGMI (grouped ncclBroadcast on a communicator made by
+// ncclCommInitAll) -- the one collective of this system, at model load (reference load site src/april_model.c:57-61).
+bool broadcast_local(Model &m)
+{
+    std::vector<Engine *> peers;            // one engine per distinct device, root first
+    std::vector<int> devs;
+    for (Engine *e : m.engines) if (std::find(devs.begin(), devs.end(), e->device()) == devs.end()) { devs.push_back(e->device()); peers.push_back(e); }
+    const size_t count = m.layout.total;
+    if (devs.size() > 1) {
+        const double t0 = now_ms();
+        std::vector<ncclComm_t> comms(devs.size());
+        RCCL_TRY(ncclCommInitAll(comms.data(), (int)devs.size(), devs.data()));
+        const double t1 = now_ms();
+        RCCL_TRY(ncclGroupStart());
+        for (size_t i = 0; i < peers.size(); ++i) {
+            HIP_CHECK(hipSetDevice(devs[i]));
+            RCCL_TRY(ncclBroadcast(peers[0]->weights_device(), peers[i]->weights_mut(), count, ncclFloat, 0, comms[i], peers[i]->stream()));
+        }
+        RCCL_TRY(ncclGroupEnd());
+        for (size_t i = 0; i < peers.size(); ++i) { HIP_CHECK(hipSetDevice(devs[i])); HIP_CHECK(hipStreamSynchronize(peers[i]->stream())); }
+        m.load.broadcast_ms = now_ms() - t1; m.load.comm_init_ms = t1 - t0;
+        m.load.broadcast_bytes = count * 4; m.load.ranks = (int)devs.size(); m.load.used_rccl = 1;
+        for (ncclComm_t c : comms) (void)ncclCommDestroy(c);
+    }
+    // further engines on a device that already holds the weights ("lanes"): a device-to-device copy
+    for (Engine *e : m.engines) {
+        if (std::find(peers.begin(), peers.end(), e) != peers.end()) continue;
+        Engine *src = peers[(size_t)(std::find(devs.begin(), devs.end(), e->device()) - devs.begin())];
+        HIP_CHECK(hipSetDevice(e->device()));
+        HIP_CHECK(hipMemcpy(e->weights_mut(), src->weights_device(), count * 4, hipMemcpyDeviceToDevice));
+    }
+    return true;
+}
+
+// blob_host / blob_device (on g_devices[0]) may both be null: the caller fills engine 0's weights (RCCL receive) and then
+// calls distribute_weights() itself
+bool create_engines(Model &m, const float *blob_host, const float *blob_device)
 {
     const ModelParams &P = m.host.params;
     if (!build_fbank_tables(P.sample_rate, P.frame_shift_ms, P.frame_length_ms, P.mel_features, P.round_pow2 != 0, P.mel_low, P.mel_high, m.ftab)) {
@@ -41,7 +88,7 @@ bool build_runtime(Model &m, const float *blob_host, const float *blob_device)
         LOGE("aam: layer widths must be multiples of 64 for the MFMA kernels");
         return false;
     }
-    if (m.layout.dims.d_model > 2048) { LOGE("aam: d_model > 2048 unsupported by the row-norm kernel"); return false; }
+    if (m.layout.dims.d_model > 2048) { LOGE("aam: d_model > 2048 unsupported (row scales are staged for at most 64 column groups)"); return false; }
     m.tok_class = classify_tokens(P);
     EngineConfig cfg;
     cfg.max_slots = env_int("APRIL_MAX_SESSIONS", 4096);
@@ -51,14 +98,24 @@ bool build_runtime(Model &m, const float *blob_host, const float *blob_device)
         if (v == "f16" || v == "fp16" || v == "half") cfg.precision = 1;
         else if (!(v.empty() || v == "f32" || v == "fp32")) { LOGE("aam: APRIL_PRECISION must be f32 or f16 (got '%s')", pv); return false; }
     }
-    for (int dev : g_devices) {
-        cfg.device = dev;
-        const bool same_dev_blob = blob_device != nullptr;
-        Engine *e = new Engine(cfg, m.layout, blob_host, same_dev_blob ? blob_device : nullptr, P, m.ftab, m.tok_class);
+    for (size_t i = 0; i < g_devices.size(); ++i) {
+        cfg.device = g_devices[i];
+        Engine *e = new Engine(cfg, m.layout, i == 0 ? blob_host : nullptr, i == 0 ? blob_device : nullptr, P, m.ftab, m.tok_class);
         m.engines.push_back(e);
-        m.scheds.push_back(new Scheduler(&m, e));
     }
     return true;
+}
+
+bool distribute_weights(Model &m)
+{
+    if (!broadcast_local(m)) return false;
+    for (Engine *e : m.engines) { e->finish_weights(); m.scheds.push_back(new Scheduler(&m, e)); }
+    return true;
+}
+
+bool build_runtime(Model &m, const float *blob_host, const float *blob_device)
+{
+    return create_engines(m, blob_host, blob_device) && distribute_weights(m);
 }
 
 // ---- blob (de)serialisation: [magic][meta_bytes][weight_floats][meta][pad to 256][weights]
@@ -347,6 +404,7 @@ AprilASRModel aprilx_model_from_blob(const void *blob, size_t size, int blob_is_
     if (host_only && blob_is_device_ptr) { LOGE("aprilx: device blob without an initialised GPU runtime"); return nullptr; }
     BlobHeader hd;
     if (size < sizeof hd) return nullptr;
+    if (!host_only && g_devices.empty()) { LOGE("aprilx: no device selected"); return nullptr; }
     if (blob_is_device_ptr) { HIP_CHECK(hipSetDevice(g_devices[0])); HIP_CHECK(hipMemcpy(&hd, blob, sizeof hd, hipMemcpyDeviceToHost)); }
     else memcpy(&hd, blob, sizeof hd);
     if (memcmp(hd.magic, "APXBLOB1", 8) != 0 || hd.weights_offset > size || hd.weight_floats > (size - hd.weights_offset) / 4 ||
@@ -364,14 +422,82 @@ AprilASRModel aprilx_model_from_blob(const void *blob, size_t size, int blob_is_
         h->m.tok_class = classify_tokens(P);
         return h;
     }
-    std::vector<float> staged;
-    const float *host_w = nullptr, *dev_w = nullptr;
-    if (blob_is_device_ptr) {
-        if (g_devices.size() == 1) dev_w = w;
-        else { staged.resize((size_t)hd.weight_floats); HIP_CHECK(hipMemcpy(staged.data(), w, staged.size() * 4, hipMemcpyDeviceToHost)); host_w = staged.data(); }
-    } else host_w = w;
-    if (!build_runtime(h->m, host_w, dev_w)) { delete h; return nullptr; }
+    // a device blob lives on g_devices[0]: engine 0 copies it device-to-device, further devices receive it over RCCL
+    if (!build_runtime(h->m, blob_is_device_ptr ? nullptr : w, blob_is_device_ptr ? w : nullptr)) { delete h; return nullptr; }
     return h;
+}
+
+// ---- one process per GPU: the model travels from rank 0 to every other rank over RCCL (xGMI inside a node)
+int aprilx_broadcast_get_id(void *id_out, size_t cap)
+{
+    if (!id_out || cap < sizeof(ncclUniqueId)) return -1;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) { LOGE("RCCL: ncclGetUniqueId failed"); return -1; }
+    memcpy(id_out, &id, sizeof id);
+    return (int)sizeof id;
+}
+
+AprilASRModel aprilx_model_broadcast(AprilASRModel root_model, int rank, int world, const void *id_bytes)
+{
+    if (!g_inited || world < 1 || rank < 0 || rank >= world || !id_bytes) { LOGE("aprilx_model_broadcast: bad arguments or library not initialised"); return nullptr; }
+    if (rank == 0 && (!root_model || root_model->m.engines.empty())) { LOGE("aprilx_model_broadcast: rank 0 must pass a model that lives on a GPU"); return nullptr; }
+    auto fail = [&](const char *what, ncclResult_t r) { LOGE("RCCL: %s failed: %s", what, ncclGetErrorString(r)); return (AprilASRModel) nullptr; };
+    ncclUniqueId id; memcpy(&id, id_bytes, sizeof id);
+    const int dev = rank == 0 ? root_model->m.engines[0]->device() : g_devices[0];
+    HIP_CHECK(hipSetDevice(dev));
+    const double t0 = now_ms();
+    ncclComm_t comm;
+    ncclResult_t r = ncclCommInitRank(&comm, world, id, rank);
+    if (r != ncclSuccess) return fail("ncclCommInitRank", r);
+    const double t1 = now_ms();
+    hipStream_t st; HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    // 1. sizes, 2. metadata (names, PARAMS, token table, dimensions), 3. the packed weights straight into the engine
+    uint64_t *hdr_d; HIP_CHECK(hipMalloc((void **)&hdr_d, 16));
+    std::string meta;
+    uint64_t hdr[2] = {0, 0};
+    if (rank == 0) { meta = make_meta(root_model->m); hdr[0] = meta.size(); hdr[1] = root_model->m.layout.total; HIP_CHECK(hipMemcpy(hdr_d, hdr, 16, hipMemcpyHostToDevice)); }
+    if ((r = ncclBroadcast(hdr_d, hdr_d, 16, ncclUint8, 0, comm, st)) != ncclSuccess) return fail("ncclBroadcast(sizes)", r);
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipMemcpy(hdr, hdr_d, 16, hipMemcpyDeviceToHost));
+    if (hdr[0] == 0 || hdr[0] > ((uint64_t)1 << 30) || hdr[1] == 0) { LOGE("aprilx_model_broadcast: implausible sizes"); return nullptr; }
+    char *meta_d; HIP_CHECK(hipMalloc((void **)&meta_d, (size_t)hdr[0]));
+    if (rank == 0) HIP_CHECK(hipMemcpy(meta_d, meta.data(), meta.size(), hipMemcpyHostToDevice));
+    if ((r = ncclBroadcast(meta_d, meta_d, (size_t)hdr[0], ncclUint8, 0, comm, st)) != ncclSuccess) return fail("ncclBroadcast(metadata)", r);
+    HIP_CHECK(hipStreamSynchronize(st));
+    AprilASRModel_i *h = nullptr;
+    if (rank == 0) h = root_model;
+    else {
+        meta.resize((size_t)hdr[0]);
+        HIP_CHECK(hipMemcpy(&meta[0], meta_d, meta.size(), hipMemcpyDeviceToHost));
+        h = new AprilASRModel_i();
+        if (!parse_meta(meta.data(), meta.size(), h->m) || h->m.layout.total != hdr[1] || !create_engines(h->m, nullptr, nullptr)) {
+            LOGE("aprilx_model_broadcast: received metadata is invalid"); delete h; h = nullptr;
+        }
+    }
+    // every rank takes part in the weight broadcast even if its model could not be built (a missing rank would hang the others)
+    float *scratch = nullptr;
+    float *buf = h ? h->m.engines[0]->weights_mut() : nullptr;
+    if (!buf) { HIP_CHECK(hipMalloc((void **)&scratch, (size_t)hdr[1] * 4)); buf = scratch; }
+    const double t2 = now_ms();
+    r = ncclBroadcast(buf, buf, (size_t)hdr[1], ncclFloat, 0, comm, st);
+    if (r == ncclSuccess) HIP_CHECK(hipStreamSynchronize(st));
+    const double t3 = now_ms();
+    (void)hipFree(hdr_d); (void)hipFree(meta_d); if (scratch) (void)hipFree(scratch);
+    (void)ncclCommDestroy(comm);
+    (void)hipStreamDestroy(st);
+    if (r != ncclSuccess) { if (rank != 0 && h) delete h; return fail("ncclBroadcast(weights)", r); }
+    if (!h) return nullptr;
+    if (rank != 0 && !distribute_weights(h->m)) { delete h; return nullptr; }
+    h->m.load.broadcast_ms = t3 - t2; h->m.load.comm_init_ms = t1 - t0; h->m.load.broadcast_bytes = (size_t)hdr[1] * 4; h->m.load.ranks = world; h->m.load.used_rccl = 1;
+    return h;
+}
+
+int aprilx_model_load_info(AprilASRModel model, AprilxLoadInfo *out)
+{
+    if (!model || !out) return -1;
+    out->broadcast_ms = model->m.load.broadcast_ms; out->comm_init_ms = model->m.load.comm_init_ms;
+    out->broadcast_bytes = (uint64_t)model->m.load.broadcast_bytes; out->ranks = model->m.load.ranks; out->used_rccl = model->m.load.used_rccl;
+    return 0;
 }
 
 void aprilx_feed_many(size_t n, AprilASRSession *sessions, const short *const *pcm16, const size_t *short_counts)

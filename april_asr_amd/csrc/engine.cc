@@ -130,22 +130,8 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     const NetDims &d = L_.dims;
     w_ = dmalloc<float>(L_.total);
     if (blob_device) HIP_CHECK(hipMemcpy(w_, blob_device, L_.total * 4, hipMemcpyDeviceToDevice));
-    else HIP_CHECK(hipMemcpy(w_, blob_host, L_.total * 4, hipMemcpyHostToDevice));
-    if (cfg_.precision == 1) {
-        // fp16 operand mode (BASELINE configs[4]): every Linear / LSTM weight matrix gets an fp16 copy in the same
-        // packed element order (round-to-nearest-even, on the device); convolutions, biases, embeddings stay fp32
-        wh_ = dmalloc<uint16_t>(L_.total);
-        const NetDims &d0 = L_.dims;
-        auto cv = [&](size_t off, size_t n) { launch_cvt_f16(w_ + off, wh_ + off, n, nullptr); };
-        cv(L_.w_embed, (size_t)d0.embed_in * d0.d_model);
-        for (const PackedLayout::Layer &o : L_.layers) {
-            cv(o.wg, (size_t)2 * d0.d_model * 4 * d0.hidden); cv(o.whr, (size_t)d0.hidden * d0.d_model);
-            cv(o.wff1, (size_t)d0.d_model * d0.ffn); cv(o.wff2, (size_t)d0.ffn * d0.d_model);
-        }
-        cv(L_.w_encproj, (size_t)d0.d_model * d0.joiner); cv(L_.w_decproj, (size_t)d0.d_model * d0.joiner);
-        cv(L_.w_out, (size_t)d0.joiner * L_.vocab_pad);
-        HIP_CHECK(hipDeviceSynchronize());
-    }
+    else if (blob_host) HIP_CHECK(hipMemcpy(w_, blob_host, L_.total * 4, hipMemcpyHostToDevice));
+    // (neither: the caller fills weights_mut() -- peer copy or RCCL broadcast -- and then calls finish_weights())
 
     const size_t S = (size_t)cfg_.max_slots, MB = (size_t)cfg_.max_batch;
     ring_frames_ = P_.segment_size * 32;                   // reference src/fbank.c:147
@@ -203,6 +189,26 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     for (int i = cfg_.max_slots - 1; i >= 0; --i) free_.push_back(i);
     LOGI("engine: device %d, %d slots, max batch %d, weights %.1f MB, kz(embed,hr,ff2,proj,out)=%d,%d,%d,%d,%d",
          cfg_.device, cfg_.max_slots, cfg_.max_batch, L_.total * 4.0 / 1e6, kz_embed_, kz_hr_, kz_ff2_, kz_proj_, kz_out_);
+}
+
+void Engine::finish_weights()
+{
+    HIP_CHECK(hipSetDevice(cfg_.device));
+    if (cfg_.precision == 1 && !wh_) {
+        // fp16 operand mode (BASELINE configs[4]): every Linear / LSTM weight matrix gets an fp16 copy in the same
+        // packed element order (round-to-nearest-even, on the device); convolutions, biases, embeddings stay fp32
+        wh_ = dmalloc<uint16_t>(L_.total);
+        const NetDims &d0 = L_.dims;
+        auto cv = [&](size_t off, size_t n) { launch_cvt_f16(w_ + off, wh_ + off, n, nullptr); };
+        cv(L_.w_embed, (size_t)d0.embed_in * d0.d_model);
+        for (const PackedLayout::Layer &o : L_.layers) {
+            cv(o.wg, (size_t)2 * d0.d_model * 4 * d0.hidden); cv(o.whr, (size_t)d0.hidden * d0.d_model);
+            cv(o.wff1, (size_t)d0.d_model * d0.ffn); cv(o.wff2, (size_t)d0.ffn * d0.d_model);
+        }
+        cv(L_.w_encproj, (size_t)d0.d_model * d0.joiner); cv(L_.w_decproj, (size_t)d0.d_model * d0.joiner);
+        cv(L_.w_out, (size_t)d0.joiner * L_.vocab_pad);
+        HIP_CHECK(hipDeviceSynchronize());
+    }
 }
 
 Engine::~Engine()

@@ -69,6 +69,8 @@ public:
     const NetDims &dims() const { return L_.dims; }
     hipStream_t stream() const { return stream_; }
     const float *weights_device() const { return w_; }
+    float *weights_mut() { return w_; }        // load time only: the constructor leaves the weights unset when it is given no blob
+    void finish_weights();                     // after the weights are in place (upload, copy or RCCL broadcast): derived copies (fp16)
     int precision() const { return cfg_.precision; }
     const PackedLayout &layout() const { return L_; }
 

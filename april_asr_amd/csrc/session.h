@@ -186,7 +186,10 @@ private:
     std::vector<float> logit_stage_;
 };
 
+struct LoadInfo { double broadcast_ms = 0, comm_init_ms = 0; size_t broadcast_bytes = 0; int ranks = 1, used_rccl = 0; };
+
 struct Model {
+    LoadInfo load;                            // how the weights reached the engines
     HostModel host;                           // params, tokens, names (weights freed after upload)
     PackedLayout layout;
     FbankHostTables ftab;

@@ -91,23 +91,33 @@ def main():
             if not os.path.exists(path):
                 SM.write_model(path, SM.APRILV0_DIMS)
         model = A.Model(path)
-    if world > 1:
+    bcast_info = None
+    if world > 1 and args.backend == "nccl":
+        # the one collective of the job, inside the library: rank 0's packed weights -> every other rank's GPU over
+        # RCCL/xGMI (aprilx_model_broadcast).  torch.distributed only carries the 128-byte RCCL id.
+        ids = [A.Model.broadcast_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        model = A.Model.broadcast(model if rank == 0 else None, rank, world, ids[0])
+        li = model.load_info()
+        bcast_ms = li.broadcast_ms
+        bcast_info = {"where": "libaprilasr.so (RCCL ncclBroadcast)", "bytes": int(li.broadcast_bytes), "ranks": int(li.ranks),
+                      "comm_init_ms": round(li.comm_init_ms, 1)}
+    elif world > 1:
+        # gloo test mode (ranks may share a GPU, no RCCL communicator possible): the same content as a host blob
         if rank == 0:
-            blob = torch.from_numpy(model.export_blob()).to(cdev)
-            size = torch.tensor([blob.numel()], dtype=torch.int64, device=cdev)
+            blob = torch.from_numpy(model.export_blob())
+            size = torch.tensor([blob.numel()], dtype=torch.int64)
         else:
-            size = torch.zeros(1, dtype=torch.int64, device=cdev)
+            size = torch.zeros(1, dtype=torch.int64)
         dist.broadcast(size, 0)
         if rank != 0:
-            blob = torch.empty(int(size.item()), dtype=torch.uint8, device=cdev)
-        torch.cuda.synchronize(); t0 = time.time()
-        dist.broadcast(blob, 0)                      # the one collective: weights over xGMI
-        torch.cuda.synchronize(); bcast_ms = (time.time() - t0) * 1e3
+            blob = torch.empty(int(size.item()), dtype=torch.uint8)
+        t0 = time.time()
+        dist.broadcast(blob, 0)
+        bcast_ms = (time.time() - t0) * 1e3
+        bcast_info = {"where": "torch.distributed gloo (host blob, test mode)", "bytes": int(blob.numel()), "ranks": world}
         if rank != 0:
-            if args.backend == "nccl":
-                model = A.Model.from_blob(None, device_ptr=blob.data_ptr(), size=blob.numel())
-            else:
-                model = A.Model.from_blob(blob.numpy())
+            model = A.Model.from_blob(blob.numpy())
         del blob
     load_s = time.time() - t_load0
     d = model.dims
@@ -283,7 +293,7 @@ def main():
             "step_latency_ms": {"p50": round(float(np.percentile(step_wall, 50)) * 1e3, 3), "p99": round(float(np.percentile(step_wall, 99)) * 1e3, 3),
                                 "max": round(max(step_wall) * 1e3, 3), "what": "wall time of one aprilx_feed_many call (100 ms of audio for every session, callbacks delivered), rank 0"},
             "max_sessions_per_gpu_rtf_le_0.1_tested": max_ok, "rtf_by_sessions_per_gpu": sweep,
-            "callbacks": int(counts[0]), "tokens_in_callbacks": int(counts[5]), "model_load_s": round(load_s, 2), "weight_broadcast_ms": bcast_ms,
+            "callbacks": int(counts[0]), "tokens_in_callbacks": int(counts[5]), "model_load_s": round(load_s, 2), "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2), "weight_broadcast": bcast_info,
             "engine_steps": int(st.steps), "host_phase_ms_total": host_ms, "max_batch_seen": int(st.max_batch_seen),
             "roofline": roofline, "cpu_baseline": cpu,
         }

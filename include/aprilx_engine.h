@@ -30,12 +30,30 @@ APRIL_EXPORT int aprilx_model_dims(AprilASRModel model, AprilxDims *out);
 /* token text by id (reference src/params.c:31-33 get_token) */
 APRIL_EXPORT const char *aprilx_model_token(AprilASRModel model, int32_t id);
 
-/* ---- weight distribution (multi-GPU, one process per GPU) -------------------------------
- * Rank 0 parses the .april file (aam_create_model) and exports ONE self-describing blob
- * (header + params + packed weights).  The host broadcasts it (RCCL over xGMI) and every
- * other rank builds its model from the blob without touching the file.  Replaces nothing in
- * the reference (it has no multi-device path); placed next to aam_create_model
- * (reference april_api.h:61).                                                            */
+/* ---- weight distribution (multi-GPU) -------------------------------------------------------
+ * Sessions are independent, so a node's session pool is partitioned across its GPUs and the only
+ * collective is the broadcast of the packed weights at model load (reference load site
+ * src/april_model.c:57-61; the reference has no multi-device path).  The library does it with RCCL:
+ *   - one process, several GPUs: aam_create_model with APRIL_GPU_DEVICES=0,1,... uploads the weights
+ *     once and broadcasts them to the other devices (ncclCommInitAll + grouped ncclBroadcast);
+ *   - one process per GPU: rank 0 parses the .april file (aam_create_model), calls
+ *     aprilx_broadcast_get_id and hands the 128 bytes to the other ranks by any means (a launcher's
+ *     store, a file, torch.distributed); then EVERY rank calls aprilx_model_broadcast.  Rank 0 passes
+ *     its model and gets it back; the others pass NULL and receive a model built from the metadata and
+ *     the weights that arrive in their GPU's memory over xGMI -- no file access, no host staging.
+ * The blob functions below carry the same content through host memory (machines without RCCL peers,
+ * the gloo test path, the on-disk cache).                                                      */
+typedef struct AprilxLoadInfo {
+    double broadcast_ms;        /* wall time of the weight broadcast (0 if none happened) */
+    double comm_init_ms;        /* wall time of the RCCL communicator set-up */
+    uint64_t broadcast_bytes;
+    int32_t ranks;              /* devices / processes the weights were broadcast to, including the root */
+    int32_t used_rccl;
+} AprilxLoadInfo;
+/* writes an RCCL unique id (128 bytes) to id_out; returns its size, -1 on failure */
+APRIL_EXPORT int aprilx_broadcast_get_id(void *id_out, size_t cap);
+APRIL_EXPORT AprilASRModel aprilx_model_broadcast(AprilASRModel root_model, int rank, int world, const void *id_bytes);
+APRIL_EXPORT int aprilx_model_load_info(AprilASRModel model, AprilxLoadInfo *out);
 APRIL_EXPORT size_t aprilx_model_blob_size(AprilASRModel model);
 APRIL_EXPORT int aprilx_model_export_blob(AprilASRModel model, void *dst, size_t dst_size);
 /* `blob` may be a host pointer or a device pointer on the calling process's GPU */

@@ -351,6 +351,52 @@ def test_model_from_device_blob(gpu_tiny, tiny_model):
     m2.close()
 
 
+def test_model_broadcast_in_library(gpu_tiny, tiny_model):
+    """The weight broadcast is a library call (RCCL): with one rank it degenerates to a communicator of one, which still
+    exercises the linkage, the metadata / weight broadcasts and the bookkeeping; rank 0 gets its own model back."""
+    import april_asr_amd as A
+    with open("/proc/self/maps") as f:
+        assert "librccl" in f.read()
+    ident = A.Model.broadcast_id()
+    assert len(ident) == 128
+    m = A.Model.broadcast(gpu_tiny, 0, 1, ident)
+    assert m is gpu_tiny
+    li = m.load_info()
+    assert li.used_rccl == 1 and li.ranks == 1 and li.broadcast_bytes > 0 and li.broadcast_ms >= 0.0
+
+
+def test_two_engines_on_one_device(tiny_model):
+    """APRIL_GPU_DEVICES=0,0: two engines (stream + stepping thread + slot arrays each) on one GPU, the second one's
+    weights are a device-to-device copy of the first (the multi-device load path without a second GPU); sessions are
+    spread over both and every transcript equals the single-engine run."""
+    import os
+    import pickle
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import april_asr_amd as A\n"
+        "from april_asr_amd import synth_model as SM\n"
+        "m = A.Model(%r)\n"
+        "n = 6; pcms = [SM.lcg_pcm16(16000, seed=800 + i) for i in range(n)]\n"
+        "evs = [[] for _ in range(n)]\n"
+        "ss = [A.Session(m, (lambda k: (lambda t, toks: evs[k].append((t, toks))))(i), raw_events=True) for i in range(n)]\n"
+        "g = A.SessionGroup(ss)\n"
+        "for o in range(0, 16000, 1600): g.feed([p[o:o + 1600] for p in pcms])\n"
+        "g.flush()\n"
+        "import pickle; pickle.dump((evs, int(m.dims.n_devices), [int(m.stats(i).chunks) for i in range(int(m.dims.n_devices))]), open(sys.argv[1], 'wb'))\n"
+        "for s in ss: s.close()\n"
+        "m.close()\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), tiny_model["path"]))
+    outs = []
+    for devs in ("0", "0,0"):
+        out = os.path.join(os.path.dirname(tiny_model["path"]), "lanes_%d.pkl" % len(devs))
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, APRIL_GPU_DEVICES=devs))
+        outs.append(pickle.load(open(out, "rb")))
+    assert outs[0][1] == 1 and outs[1][1] == 2
+    assert all(c > 0 for c in outs[1][2])                      # both engines stepped sessions
+    assert outs[0][0] == outs[1][0] and any(len(e) for e in outs[0][0])
+
+
 def test_sessions_above_max_batch(tiny_model):
     """More ready sessions than APRIL_MAX_BATCH: the step is split into sub-batches, results unchanged."""
     import os
