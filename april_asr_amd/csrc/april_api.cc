@@ -587,7 +587,7 @@ void aprilx_model_stats(AprilASRModel model, int device_index, AprilxStats *out)
     const SchedStats st = model->m.scheds[(size_t)device_index]->stats();
     out->ticks = st.ticks; out->steps = st.steps; out->chunks = st.chunks; out->rounds = st.rounds; out->frames = st.frames; out->max_batch_seen = st.max_batch_seen;
     for (int i = 0; i < 8; ++i) out->host_ms[i] = st.host_ms[i];
-    out->flights = st.flights; out->replay_mismatch = st.replay_mismatch;
+    out->flights = st.flights; out->replay_mismatch = st.replay_mismatch; out->lm_steps = st.lm_steps; out->lm_chunks = st.lm_chunks;
     Engine *e = model->m.engines[(size_t)device_index];
     out->kernels_per_step = (uint64_t)e->kernels_per_step();
     for (int i = 0; i < 6; ++i) { out->kernel_ms[i] = e->timing(i).ms; out->kernel_launches[i] = (uint64_t)e->timing(i).launches; }

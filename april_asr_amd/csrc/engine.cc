@@ -179,7 +179,7 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     step_cap_ = 1 << 14; step_off_h_ = hmalloc<int>((size_t)step_cap_); rec_off_h_ = hmalloc<int>((size_t)step_cap_);
     rec_cap_ = std::max<size_t>((size_t)1 << 20, 3 * MB * 8); rec_d_ = dmalloc<StepRecord>(rec_cap_); rec_h_ = hmalloc<StepRecord>(rec_cap_);
     counter_d_ = dmalloc<int>(1); rec_off_d_ = dmalloc<int>(1); flags_d_ = dmalloc<int>(8);
-    step_d_ = dmalloc<int>(3 * MB); active_d_ = dmalloc<int>(MB); dirty_d_ = dmalloc<int>(MB);
+    step_d_ = dmalloc<int>(4 * MB); active_d_ = dmalloc<int>(MB); dirty_d_ = dmalloc<int>(MB);
     dec_slots_d_ = dmalloc<int>(S);
     HIP_CHECK(hipMemset(counter_d_, 0, 4)); HIP_CHECK(hipMemset(rec_off_d_, 0, 4)); HIP_CHECK(hipMemset(flags_d_, 0, 32));
 
@@ -217,6 +217,9 @@ Engine::~Engine()
     (void)hipStreamSynchronize(stream_);
     for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &g : step_graphs_) (void)hipGraphExecDestroy(g.second);
+    for (auto &g : lm_graphs_) (void)hipGraphExecDestroy(g.second);
+    if (p_lm_) (void)hipFree(p_lm_);
+    if (eout_lm_) (void)hipFree(eout_lm_);
     for (void *p : {(void *)w_, (void *)wh_, (void *)h_, (void *)c_, (void *)ring_, (void *)eout_, (void *)dout_, (void *)gstate_, (void *)cls_, (void *)ws_, (void *)xin_,
                     (void *)a3_, (void *)y_, (void *)ssq_, (void *)xb_, (void *)u_, (void *)ff_, (void *)de_, (void *)logits_, (void *)rec_d_, (void *)counter_d_,
                     (void *)rec_off_d_, (void *)flags_d_, (void *)step_d_, (void *)active_d_, (void *)dirty_d_, (void *)dec_slots_d_,
@@ -455,11 +458,11 @@ DecEmbedParams Engine::dec_params() const
 }
 
 // dout[slot] = de x Wp + b for rows with row_mask != 0 (all rows when null)
-void Engine::run_decproj(int n, const int *d_slots, const int *row_mask, const int *run_flag)
+void Engine::run_decproj(int n, const int *d_slots, const int *row_mask, const int *run_flag, int run_gen)
 {
     const NetDims &d = L_.dims;
     GemmArgs g; g.a0 = de_; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, L_.w_decproj);
-    g.M = n; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_; g.run_flag = run_flag;
+    g.M = n; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_; g.run_flag = run_flag; g.run_gen = run_gen;
     if (gemm_fullk(n, d.joiner, kz_proj_)) {
         g.epi = EPI_SLOT_STORE; g.bias = w_ + L_.b_decproj; g.out = dout_; g.ldo = d.joiner; g.slot_idx = d_slots; g.row_mask = row_mask;
         timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
@@ -468,34 +471,37 @@ void Engine::run_decproj(int n, const int *d_slots, const int *row_mask, const i
     g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
     timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
     RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_; r.parts = gemm_partials(n, d.joiner, kz_proj_); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = n;
-    r.bias = w_ + L_.b_decproj; r.out = dout_; r.ldo = d.joiner; r.slot_idx = d_slots; r.row_mask = row_mask; r.run_flag = run_flag;
+    r.bias = w_ + L_.b_decproj; r.out = dout_; r.ldo = d.joiner; r.slot_idx = d_slots; r.row_mask = row_mask; r.run_flag = run_flag; r.run_gen = run_gen;
     timed_begin(T_DEC); launch_row(r, stream_); timed_end(T_DEC);
 }
 
 // The reference's loop "joiner -> process_logits, up to three times, early-emit 1,0,0" (src/april_session.c:449-454)
 // for all rows of the step at once, decisions included: rows that resolved to blank are masked out of the later rounds.
-void Engine::run_greedy_rounds(int n, bool dump_logits)
+void Engine::run_greedy_rounds(int n, bool dump_logits, int chunk, const float *eout_rows)
 {
     const NetDims &d = L_.dims;
     const int MB = cfg_.max_batch;
-    const int *d_slots = step_d_, *d_now = step_d_ + 2 * MB;
+    const int gen = chunk + 1;
+    const int *d_slots = step_d_, *d_now = step_d_ + 2 * MB + (size_t)chunk * n;
     for (int round = 0; round < 3; ++round) {
         {   // logits = tanh(eout + dout) x Wout (+ bias in the decision kernel)
-            GemmArgs g; g.a0 = eout_; g.a0b = dout_; g.lda0 = d.joiner; g.aidx0 = d_slots; g.K0 = d.joiner; g.a_op = AOP_TANH_ADD;
+            GemmArgs g; g.a0b = dout_; g.lda0 = d.joiner; g.K0 = d.joiner; g.a_op = AOP_TANH_ADD;
+            if (eout_rows) { g.a0 = eout_rows; g.aidx0 = nullptr; g.same_idx_b = 0; g.aidx0b = d_slots; }     // layer-major: this chunk's rows of the batched encoder output
+            else { g.a0 = eout_; g.aidx0 = d_slots; }
             lin(g, L_.w_out); g.M = n; g.N = L_.vocab_pad; g.K = d.joiner; g.kz = kz_out_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
-            g.run_flag = flags_d_ + round;
+            if (round > 0) { g.run_flag = flags_d_ + round; g.run_gen = gen; }
             timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
         }
         DecideArgs a;
         a.ws = ws_; a.parts = gemm_partials(n, L_.vocab_pad, kz_out_); a.m_stride = ws_mstride_; a.N = L_.vocab_pad; a.M = n; a.n_valid = d.vocab;
         a.bias = w_ + L_.b_out; a.blank = P_.blank_id; a.early_emit = round == 0 ? 1.0f : 0.0f;
         a.slot_idx = d_slots; a.now_ms = d_now; a.active = active_d_; a.dirty = dirty_d_; a.tok_class = cls_; a.state = gstate_;
-        a.rec_ring = rec_d_; a.rec_off = rec_off_d_; a.round = round;
-        a.logits_dump = dump_logits ? logits_ + (size_t)round * MB * d.vocab : nullptr;
+        a.rec_ring = rec_d_; a.rec_off = rec_off_d_; a.round = round; a.gen = gen; a.rec_slot = chunk * 3 + round;
+        a.logits_dump = dump_logits ? logits_ + ((size_t)chunk * 3 + round) * n * d.vocab : nullptr;
         a.dec = dec_params(); a.de_out = de_; a.ld_de = d.d_model;
         a.run_flags = flags_d_; a.rerun_flags = flags_d_ + 4;
         timed_begin(T_DEC); launch_decide(a, stream_); timed_end(T_DEC);
-        run_decproj(n, d_slots, dirty_d_, flags_d_ + 4 + round);
+        run_decproj(n, d_slots, dirty_d_, flags_d_ + 4 + round, gen);
     }
 }
 
@@ -504,12 +510,185 @@ void Engine::run_chain(int m, bool dump_logits)
     const int MB = cfg_.max_batch;
     AdvanceArgs a;
     a.host_ring = ring_h_; a.host_step_off = step_off_h_; a.host_rec_off = rec_off_h_; a.counter = counter_d_;
-    a.dst = step_d_; a.dst_stride = MB; a.active = active_d_; a.rec_off = rec_off_d_; a.m = m;
-    a.run_flags = flags_d_; a.rerun_flags = flags_d_ + 4;
+    a.dst = step_d_; a.dst_stride = MB; a.n_arrays = 3; a.len[0] = a.len[1] = a.len[2] = m; a.rec_off = rec_off_d_;
+    a.flags = flags_d_; a.n_flags = 8;
     launch_advance(a, stream_);
     run_encoder_rows(m, step_d_, step_d_ + MB, nullptr);
     run_greedy_rounds(m, dump_logits);
 }
+
+// ---------------------------------------------------------------- layer-major step
+// Index arrays on the device (stride max_batch): [0] slots (m), [1] ring tails (T x m), [2] session times (T x m),
+// [3] slot of every row (T x m).  Row r = t * m + i.
+void Engine::run_encoder_lm(int m, int T)
+{
+    const NetDims &d = L_.dims;
+    const size_t S = (size_t)cfg_.max_slots;
+    const int MB = cfg_.max_batch;
+    const int rows = m * T;
+    const int *d_slots = step_d_, *d_tails = step_d_ + MB, *d_rowslot = step_d_ + 3 * MB;
+    const int G = d.d_model / SSQ_COLS;
+    auto scale_of = [&](float eps) { RowScale r; r.ssq = ssq_; r.groups = G; r.inv_n = 1.0f / (float)d.d_model; r.eps = eps; return r; };
+    ConvEmbedArgs ca;
+    ca.ring = ring_; ca.ring_frames = ring_frames_; ca.mel = d.mel; ca.seg = d.seg;
+    ca.slot_idx = d_rowslot; ca.ring_tail = d_tails;
+    for (int i = 0; i < 3; ++i) { ca.w[i] = w_ + L_.conv_w[i]; ca.b[i] = w_ + L_.conv_b[i]; ca.ch[i] = d.conv_ch[i]; ca.stride[i] = d.conv_stride[i]; }
+    ca.ch1_per_group = 1;
+    for (int k = 8; k > 1; --k) if (d.conv_ch[1] % k == 0) { ca.ch1_per_group = k; break; }
+    ca.out = a3_; ca.ldo = L_.k3; ca.M = rows;
+    timed_begin(T_CONV); launch_conv_embed(ca, stream_); timed_end(T_CONV);
+    {
+        GemmArgs g; g.a0 = a3_; g.lda0 = L_.k3; g.K0 = L_.k3; g.wp = w_ + L_.conv_w[2];
+        g.M = rows * d.f_out; g.N = d.conv_ch[2]; g.K = L_.k3; g.kz = 1; g.epi = EPI_BIAS_DSWISH; g.out = xin_; g.ldo = d.conv_ch[2]; g.bias = w_ + L_.conv_b[2];
+        timed_begin(T_CONV); launch_gemm(g, stream_); timed_end(T_CONV);
+    }
+    auto resid_ssq = [&](const float *a, int K, size_t w_off, int kz, const float *bias, const float *resid) {
+        GemmArgs g; g.a0 = a; g.lda0 = K; g.K0 = K; lin(g, w_off);
+        g.M = rows; g.N = d.d_model; g.K = K; g.kz = kz;
+        if (gemm_fullk(rows, d.d_model, kz)) {
+            g.epi = EPI_RESID_SSQ; g.bias = bias; g.resid = resid; g.ldr = d.d_model; g.out = y_; g.ldo = d.d_model; g.ssq_out = ssq_;
+            timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
+            return;
+        }
+        g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
+        timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
+        RowArgs r; r.mode = ROW_RESID_SSQ; r.ws = ws_; r.parts = gemm_partials(rows, d.d_model, kz); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = rows;
+        r.bias = bias; r.resid = resid; r.ldr = d.d_model; r.out = y_; r.ldo = d.d_model; r.ssq_out = ssq_;
+        timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
+    };
+    resid_ssq(xin_, d.embed_in, L_.w_embed, kz_embed_, w_ + L_.b_embed, nullptr);
+    float eps_in = L_.embed_eps;
+    for (int l = 0; l < d.n_layers; ++l) {
+        const PackedLayout::Layer &o = L_.layers[(size_t)l];
+        float *h_l = h_ + (size_t)l * S * d.d_model;
+        float *c_l = c_ + (size_t)l * S * d.hidden;
+        const RowScale xs = scale_of(eps_in);
+        {   // input half of the gates for all rows: P = (p0 + p1) * scale   (waves 0,1; the recurrent half sits this launch out)
+            GemmArgs g; g.a0 = y_; g.lda0 = d.d_model; g.K0 = d.d_model; g.x_scale = xs;
+            g.a1 = y_; g.lda1 = d.d_model; g.K1 = d.d_model;          // never read (wave_mask)
+            lin(g, o.wg); g.M = rows; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_XPART; g.wave_mask = 0x3;
+            g.out = p_lm_; g.ldo = 4 * d.hidden;
+            timed_begin(T_GATES); launch_gemm(g, stream_); timed_end(T_GATES);
+        }
+        for (int t = 0; t < T; ++t) {
+            const size_t r0 = (size_t)t * m;
+            {   // recurrent half + LSTM cell: ((P + p2) + p3) + bias
+                GemmArgs g; g.a0 = y_ + r0 * d.d_model; g.lda0 = d.d_model; g.K0 = d.d_model;      // never read (wave_mask)
+                g.a1 = h_l; g.lda1 = d.d_model; g.aidx1 = d_slots; g.K1 = d.d_model;
+                lin(g, o.wg); g.M = m; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_LSTM; g.wave_mask = 0xC;
+                g.p_add = p_lm_ + r0 * 4 * d.hidden; g.ldp = 4 * d.hidden;
+                g.out = u_ + r0 * d.hidden; g.ldo = d.hidden; g.bias = w_ + o.bg; g.c_state = c_l; g.slot_idx = d_slots; g.hidden = d.hidden;
+                timed_begin(T_GATES); launch_gemm(g, stream_); timed_end(T_GATES);
+            }
+            {   // h' = u x Whr ; state write + residual
+                GemmArgs g; g.a0 = u_ + r0 * d.hidden; g.lda0 = d.hidden; g.K0 = d.hidden; lin(g, o.whr);
+                g.M = m; g.N = d.d_model; g.K = d.hidden; g.kz = kz_hr_;
+                RowScale rs = xs; rs.ssq = ssq_ + r0 * G;
+                if (gemm_fullk(m, d.d_model, kz_hr_)) {
+                    g.epi = EPI_HR; g.state = h_l; g.ld_state = d.d_model; g.slot_idx = d_slots; g.resid = y_ + r0 * d.d_model; g.ldr = d.d_model; g.r_scale = rs;
+                    g.out = xb_ + r0 * d.d_model; g.ldo = d.d_model;
+                    timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
+                } else {
+                    g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
+                    timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
+                    RowArgs r; r.mode = ROW_HR; r.ws = ws_; r.parts = gemm_partials(m, d.d_model, kz_hr_); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = m;
+                    r.resid = y_ + r0 * d.d_model; r.ldr = d.d_model; r.r_scale = rs; r.out = xb_ + r0 * d.d_model; r.ldo = d.d_model;
+                    r.slot_idx = d_slots; r.state = h_l; r.ld_state = d.d_model;
+                    timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
+                }
+            }
+        }
+        {   // FFN up + DoubleSwish, all rows
+            GemmArgs g; g.a0 = xb_; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, o.wff1);
+            g.M = rows; g.N = d.ffn; g.K = d.d_model; g.kz = 1; g.epi = EPI_BIAS_DSWISH; g.out = ff_; g.ldo = d.ffn; g.bias = w_ + o.bff1;
+            timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
+        }
+        resid_ssq(ff_, d.ffn, o.wff2, kz_ff2_, w_ + o.bff2, xb_);
+        eps_in = L_.norm_eps[(size_t)l];
+    }
+    {   // encoder_proj over all rows -> eout_lm[row]
+        const RowScale ys = scale_of(eps_in);
+        GemmArgs g; g.a0 = y_; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, L_.w_encproj);
+        g.M = rows; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_;
+        if (gemm_fullk(rows, d.joiner, kz_proj_)) {
+            g.epi = EPI_SLOT_STORE; g.bias = w_ + L_.b_encproj; g.out = eout_lm_; g.ldo = d.joiner; g.x_scale = ys;
+            timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
+        } else {
+            g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
+            timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
+            RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_; r.parts = gemm_partials(rows, d.joiner, kz_proj_); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = rows;
+            r.bias = w_ + L_.b_encproj; r.out = eout_lm_; r.ldo = d.joiner; r.r_scale = ys;
+            timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
+        }
+    }
+}
+
+void Engine::run_lm_chain(int m, int T, bool dump_logits)
+{
+    const NetDims &d = L_.dims;
+    const int MB = cfg_.max_batch;
+    AdvanceArgs a;
+    a.host_ring = ring_h_; a.host_step_off = step_off_h_; a.host_rec_off = rec_off_h_; a.counter = counter_d_;
+    a.dst = step_d_; a.dst_stride = MB; a.n_arrays = 4; a.len[0] = m; a.len[1] = a.len[2] = a.len[3] = m * T; a.rec_off = rec_off_d_;
+    a.flags = flags_d_; a.n_flags = 8;
+    launch_advance(a, stream_);
+    run_encoder_lm(m, T);
+    // the search stays sequential in time (the decoder input of chunk t + 1 depends on the tokens of chunk t)
+    for (int t = 0; t < T; ++t) run_greedy_rounds(m, dump_logits, t, eout_lm_ + (size_t)t * m * d.joiner);
+}
+
+int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const int *now_ms, float *logits_out)
+{
+    const int rows = m * T;
+    if (m <= 0 || T <= 0 || rows > cfg_.max_batch || !flight_has_room(rows + m, 1)) { LOGE("engine: layer-major step %d x %d does not fit (max batch %d)", m, T, cfg_.max_batch); abort(); }
+    HIP_CHECK(hipSetDevice(cfg_.device));
+    const NetDims &d = L_.dims;
+    if (!p_lm_) {
+        p_lm_ = dmalloc<float>((size_t)cfg_.max_batch * 4 * d.hidden);
+        eout_lm_ = dmalloc<float>((size_t)cfg_.max_batch * d.joiner);
+    }
+    const int k = steps_++;
+    int *blk = ring_h_ + ring_pos_;
+    memcpy(blk, slots, (size_t)m * 4);
+    memcpy(blk + m, ring_tails, (size_t)rows * 4);
+    memcpy(blk + m + rows, now_ms, (size_t)rows * 4);
+    for (int t = 0; t < T; ++t) memcpy(blk + m + 2 * rows + (size_t)t * m, slots, (size_t)m * 4);
+    step_off_h_[k] = (int)ring_pos_; rec_off_h_[k] = (int)rec_pos_;
+    ring_pos_ += (size_t)m + 3 * (size_t)rows; rec_pos_ += (size_t)3 * rows;
+    if (use_graphs_ && !profiling_ && !logits_out) {
+        const std::pair<int, int> key(m, T);
+        auto it = lm_graphs_.find(key);
+        if (it == lm_graphs_.end()) {
+            if (lm_graphs_.size() >= 16) { for (auto &g : lm_graphs_) (void)hipGraphExecDestroy(g.second); lm_graphs_.clear(); }
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            std::lock_guard<std::mutex> cg(capture_mu_);
+            HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+            run_lm_chain(m, T, false);
+            HIP_CHECK(hipStreamEndCapture(stream_, &graph));
+            HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            HIP_CHECK(hipGraphDestroy(graph));
+            it = lm_graphs_.emplace(key, exec).first;
+        }
+        std::lock_guard<std::mutex> cg(capture_mu_);
+        HIP_CHECK(hipGraphLaunch(it->second, stream_));
+        return k;
+    }
+    {
+        std::lock_guard<std::mutex> cg(capture_mu_);
+        launch_count_ = 0;
+        run_lm_chain(m, T, logits_out != nullptr);
+        kernels_per_step_ = launch_count_ + 1;
+    }
+    if (logits_out) {
+        HIP_CHECK(hipMemcpyAsync(logits_h_, logits_, (size_t)3 * rows * d.vocab * 4, hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipMemcpyAsync(rec_h_ + rec_off_h_[k], rec_d_ + rec_off_h_[k], (size_t)3 * rows * sizeof(StepRecord), hipMemcpyDeviceToHost, stream_));
+        sync();
+        memcpy(logits_out, logits_h_, (size_t)3 * rows * d.vocab * 4);
+    }
+    return k;
+}
+
 
 void Engine::begin_flight()
 {
@@ -562,9 +741,7 @@ int Engine::step(int m, const int *slots, const int *ring_tails, const int *now_
     }
     if (logits_out) {
         const NetDims &d = L_.dims;
-        const size_t MB = (size_t)cfg_.max_batch;
-        for (int r = 0; r < 3; ++r)
-            HIP_CHECK(hipMemcpyAsync(logits_h_ + (size_t)r * m * d.vocab, logits_ + (size_t)r * MB * d.vocab, (size_t)m * d.vocab * 4, hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipMemcpyAsync(logits_h_, logits_, (size_t)3 * m * d.vocab * 4, hipMemcpyDeviceToHost, stream_));
         HIP_CHECK(hipMemcpyAsync(rec_h_ + rec_off_h_[k], rec_d_ + rec_off_h_[k], (size_t)3 * m * sizeof(StepRecord), hipMemcpyDeviceToHost, stream_));
         sync();
         memcpy(logits_out, logits_h_, (size_t)3 * m * d.vocab * 4);
@@ -588,7 +765,7 @@ void Engine::decode_rows(int n, const int *slots, int op)
         HIP_CHECK(hipMemcpyAsync(dec_slots_d_, blk, (size_t)m * 4, hipMemcpyHostToDevice, stream_));
         DecRowsArgs a; a.slot_idx = dec_slots_d_; a.M = m; a.op = op; a.blank = P_.blank_id; a.state = gstate_; a.dec = dec_params(); a.de_out = de_; a.ld_de = d.d_model;
         timed_begin(T_DEC); launch_dec_rows(a, stream_); timed_end(T_DEC);
-        run_decproj(m, dec_slots_d_, nullptr, nullptr);
+        run_decproj(m, dec_slots_d_, nullptr, nullptr, 1);
     }
 }
 
@@ -655,7 +832,7 @@ void Engine::debug_decoder(int n, const int64_t *ctx, float *dout)
     HIP_CHECK(hipMemcpy(dec_slots_d_, slots.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     DecEmbedArgs a; a.dec = dec_params(); a.ctx = ctx_d; a.M = n; a.out = de_; a.ldo = d.d_model;
     launch_dec_embed(a, stream_);
-    run_decproj(n, dec_slots_d_, nullptr, nullptr);
+    run_decproj(n, dec_slots_d_, nullptr, nullptr, 1);
     sync();
     HIP_CHECK(hipMemcpy(dout, dout_, (size_t)n * d.joiner * 4, hipMemcpyDeviceToHost));
     (void)hipFree(ctx_d);

@@ -89,6 +89,13 @@ public:
     // one chunk for m sessions (m <= max_batch): returns the step's index inside the flight.  logits_out (tests): when
     // non-null the step runs eagerly, waits, and returns the logits of the three rounds [3][m][vocab]
     int step(int m, const int *slots, const int *ring_tails, const int *now_ms, float *logits_out = nullptr);
+    // Layer-major step: T consecutive chunks of each of m sessions (T * m <= max_batch rows) in one
+    // go.  Everything that does not depend on the recurrence -- conv front end, the INPUT half of every layer's gate GEMM, the
+    // feed-forward blocks, encoder_proj -- runs once over all T * m rows; only the recurrent half of the gates and the
+    // projection run per time step.  Same chains, same order: logits and state are bit-identical to T one-chunk steps.
+    // ring_tails / now_ms are [T][m].  Records: [T][3][m]; logits_out (tests) [T][3][m][vocab].
+    int lm_step(int m, int T, const int *slots, const int *ring_tails, const int *now_ms, float *logits_out = nullptr);
+    int lm_max_rows() const { return cfg_.max_batch; }
     // decoder output refresh for listed slots from the context held on the device; op 1 = end-of-flush reset first
     void decode_rows(int n, const int *slots, int op);
     void end_flight();                          // records -> host, wait
@@ -114,8 +121,10 @@ private:
     void upload_tables(const FbankHostTables &ft);
     void zero_slots(int n);
     void run_encoder_rows(int n, const int *d_slots, const int *d_tails, const float *x_direct);
-    void run_greedy_rounds(int n, bool dump_logits);
-    void run_decproj(int n, const int *d_slots, const int *row_mask, const int *run_flag);
+    void run_encoder_lm(int m, int T);
+    void run_greedy_rounds(int n, bool dump_logits, int chunk = 0, const float *eout_rows = nullptr);
+    void run_lm_chain(int m, int T, bool dump_logits);
+    void run_decproj(int n, const int *d_slots, const int *row_mask, const int *run_flag, int run_gen);
     void run_chain(int m, bool dump_logits);     // advance + encoder + greedy rounds with arguments that depend on m only
     void timed_begin(int cls);
     void timed_end(int cls);
@@ -136,6 +145,7 @@ private:
     // work buffers
     float *xin_ = nullptr, *a3_ = nullptr, *y_ = nullptr, *ssq_ = nullptr, *xb_ = nullptr, *u_ = nullptr, *ff_ = nullptr, *ws_ = nullptr, *de_ = nullptr;
     float *logits_ = nullptr;                  // [3][max_batch][vocab] (traced steps, debug_joiner)
+    float *p_lm_ = nullptr, *eout_lm_ = nullptr;   // layer-major: input half of the gates [rows][4 hidden], encoder outputs [rows][joiner] (allocated on first use)
     // step bookkeeping: pinned host rings (read by the advance kernel) + device mirrors
     int *ring_h_ = nullptr; size_t ring_cap_ = 0, ring_pos_ = 0;      // index blocks
     int *step_off_h_ = nullptr, *rec_off_h_ = nullptr; int step_cap_ = 0, steps_ = 0;
@@ -164,6 +174,7 @@ private:
     // chunk-step launch chains captured per batch size
     bool use_graphs_ = true;
     std::map<int, hipGraphExec_t> step_graphs_;
+    std::map<std::pair<int, int>, hipGraphExec_t> lm_graphs_;      // (m, T)
     long kernels_per_step_ = 0, launch_count_ = 0;
     // profiling
     bool profiling_ = false;

@@ -35,7 +35,8 @@ enum GemmEpilogue {
     EPI_BIAS_DSWISH = 2,  // out = y * sigmoid(y - 1), y = acc + bias
     EPI_HR = 3,           // LSTM projection: state[slot] = acc ; out = resid * rowscale(resid) + acc
     EPI_RESID_SSQ = 4,    // y = resid + (acc + bias) (resid optional) ; out = y ; ssq[m][n/32] = sum of y^2 over 32 columns
-    EPI_SLOT_STORE = 5    // out[slot] = acc + bias, rows with row_mask[m] == 0 skipped (mask optional)
+    EPI_SLOT_STORE = 5,   // out[slot] = acc + bias, rows with row_mask[m] == 0 skipped (mask optional)
+    EPI_XPART = 6         // layer-major schedule: out = (p0 + p1) (* x_scale) = the input half of the gate pre-activations
 };
 // A-operand prologues
 enum GemmAOp { AOP_NONE = 0, AOP_TANH_ADD = 1 };
@@ -59,7 +60,8 @@ struct GemmArgs {
     // A operand as up to two K segments with optional row indirection (slot ids)
     const float *a0 = nullptr; int lda0 = 0; const int *aidx0 = nullptr; int K0 = 0;
     const float *a1 = nullptr; int lda1 = 0; const int *aidx1 = nullptr; int K1 = 0;
-    const float *a0b = nullptr;            // AOP_TANH_ADD second addend (same ld/idx as a0)
+    const float *a0b = nullptr;            // AOP_TANH_ADD second addend (same ld as a0; row index aidx0b, or aidx0 when same_idx_b)
+    const int *aidx0b = nullptr; int same_idx_b = 1;
     int a_op = AOP_NONE;
     RowScale x_scale;                      // optional (ssq != null).  EPI_LSTM: the A-segment-0 half of the sum, ((p0+p1) * scale + p2) + p3;
                                            // EPI_SLOT_STORE: the whole sum, out = acc * scale + bias
@@ -82,7 +84,14 @@ struct GemmArgs {
     RowScale r_scale;                      // EPI_HR: the residual is y * scale(y)
     float *ssq_out = nullptr;              // EPI_RESID_SSQ: [M][N / SSQ_COLS]
     const int *row_mask = nullptr;         // EPI_SLOT_STORE: optional
-    const int *run_flag = nullptr;         // optional device word: the kernel returns at once when it is 0
+    const int *run_flag = nullptr;         // optional device word: the kernel returns at once unless it holds run_gen
+    int run_gen = 1;
+    // layer-major schedule (the encoder input of T chunks is known up front): the gate GEMM is split in two launches with the
+    // SAME chains -- waves 0,1 own the input half of K, waves 2,3 the recurrent half (kz = 1, K0 = K1):
+    //   wave_mask 0b0011 + EPI_XPART : P = (p0 + p1) * scale for all T x sessions rows at once
+    //   wave_mask 0b1100 + EPI_LSTM + p_add : ((P + p2) + p3) + bias per time step -- bit-identical to the one-launch form
+    int wave_mask = 0xF;
+    const float *p_add = nullptr; int ldp = 0;
     int skew = 0;                          // start delay (x 4096 cycles) for every second generation of workgroups
     int asm_loop = 0;                      // != 0: hand-scheduled K loop (gemm_mainloop_asm.inc) in the fused-epilogue 64x64 fp32 tiles
     unsigned long long *trace = nullptr;   // measurement only: per-workgroup s_memtime stamps [wg][8] (wave 0, lane 0)
@@ -112,7 +121,8 @@ struct RowArgs {
     float *state = nullptr; int ld_state = 0;   // ROW_HR: h state of this layer
     float *ssq_out = nullptr;              // ROW_RESID_SSQ
     const int *row_mask = nullptr;         // ROW_SLOT_STORE
-    const int *run_flag = nullptr;         // optional device word: the kernel returns at once when it is 0
+    const int *run_flag = nullptr;         // optional device word: the kernel returns at once unless it holds run_gen
+    int run_gen = 1;
 };
 void launch_row(const RowArgs &r, hipStream_t s);
 
@@ -144,7 +154,9 @@ struct DecideArgs {
     float early_emit = 0.0f;               // 1.0 in the first round of a chunk, 0.0 afterwards (:449-454)
     const int *slot_idx = nullptr;         // row -> slot
     const int *now_ms = nullptr;           // row -> session time of this chunk
-    int *active = nullptr;                 // row -> still searching in this chunk (in/out)
+    int *active = nullptr;                 // row -> `gen` while the row is still searching in this chunk (in/out; round 0 treats every row as active)
+    int gen = 1;                           // generation of this chunk inside the step (1 for a one-chunk step, t + 1 in a layer-major step)
+    int rec_slot = 0;                      // record index of this round inside the step's record block (chunk * 3 + round)
     int *dirty = nullptr;                  // row -> context changed in this round (out; the decoder projection's row mask)
     const uint8_t *tok_class = nullptr;    // [vocab] TokClassBits
     GreedyState *state = nullptr;          // [slots]
@@ -154,8 +166,8 @@ struct DecideArgs {
     float *logits_dump = nullptr;          // optional [M][n_valid]
     DecEmbedParams dec;
     float *de_out = nullptr; int ld_de = 0;   // relu(conv(emb[ctx])) rows for dirty rows
-    // round flags (device words, zeroed by the advance kernel except run[0]): run[r] = some row still searches in round r,
-    // rerun[r] = some row's context changed in round r.  A round nobody needs costs three empty launches.
+    // round flags (device words, zeroed by the advance kernel): run[r] == gen: some row still searches in round r (r > 0),
+    // rerun[r] == gen: some row's context changed in round r.  A round nobody needs costs three empty launches.
     int *run_flags = nullptr;              // [3]
     int *rerun_flags = nullptr;            // [3]
 };
@@ -182,19 +194,18 @@ struct DecEmbedArgs {
 };
 void launch_dec_embed(const DecEmbedArgs &a, hipStream_t s);
 
-// start of a chunk step inside a launch chain whose arguments are fixed (hipGraph): fetches the step's index block
-// (slots | ring tails | session times, m ints each) from the pinned host ring through the device step counter
+// start of a step inside a launch chain whose arguments are fixed (hipGraph): fetches the step's index block
+// (n_arrays arrays of `len[a]` ints: slots | ring tails | session times | row slots) from the pinned host ring through the
+// device step counter
 struct AdvanceArgs {
     const int *host_ring = nullptr;        // pinned, device-readable
     const int *host_step_off = nullptr;    // pinned: [step] -> offset of the step's block in host_ring
     const int *host_rec_off = nullptr;     // pinned: [step] -> offset of the step's records in the record ring
     int *counter = nullptr;                // device: next step
-    int *dst = nullptr; int dst_stride = 0;   // device: [3][dst_stride]
-    int *active = nullptr;                 // device: [m] set to 1
+    int *dst = nullptr; int dst_stride = 0;   // device: [n_arrays][dst_stride]
+    int n_arrays = 3; int len[4] = {0, 0, 0, 0};
     int *rec_off = nullptr;                // device: record offset of the current step
-    int *run_flags = nullptr;              // device: [3] -> 1, 0, 0
-    int *rerun_flags = nullptr;            // device: [3] -> 0, 0, 0
-    int m = 0;
+    int *flags = nullptr; int n_flags = 0; // device: zeroed
 };
 void launch_advance(const AdvanceArgs &a, hipStream_t s);
 

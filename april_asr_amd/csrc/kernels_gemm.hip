@@ -60,9 +60,9 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
     constexpr bool FULLK = MODE == GM_FULLK;
     constexpr bool ROW_EPI = EPI == EPI_HR || EPI == EPI_RESID_SSQ || EPI == EPI_SLOT_STORE;
     // the slab tree (levels of pairwise sums) is only needed where a workgroup can own more than one slab
-    constexpr bool TREE = !FULLK && (EPI == EPI_PARTIAL || ROW_EPI);
+    constexpr bool TREE = !FULLK && (EPI == EPI_PARTIAL || ROW_EPI);       // (EPI_LSTM, EPI_BIAS_DSWISH, EPI_XPART: kz = 1)
 
-    if (g.run_flag && *g.run_flag == 0) return;          // a joiner / decoder round nobody needs (all rows resolved earlier)
+    if (g.run_flag && *g.run_flag != g.run_gen) return;  // a joiner / decoder round nobody needs (all rows resolved earlier)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // measurement only (tools/gemm_bench built with -DAPRIL_GEMM_TRACE, run with GEMM_TRACE=1): wave 0 stamps s_memtime at
@@ -106,14 +106,15 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
     //   GM_SLAB : slab z, wave w -> blocks [(4z + w) c, (4z + w + 1) c); a workgroup walks zs consecutive slabs.
     //   GM_FULLK: wave w of NW -> blocks [w T, (w + 1) T), T = 4 kz c / NW, chunk after chunk (kz / NW whole slabs).
     const int c = g.debug == 1 ? 0 : KB / (4 * g.kz);
-    const int T = FULLK ? (4 * g.kz / NW) * c : g.zs * c;           // blocks this wave processes in total
+    const bool wave_on = ((g.wave_mask >> wave) & 1) != 0;          // layer-major split of the gate GEMM: half of the waves sit a launch out
+    const int T = !wave_on ? 0 : (FULLK ? (4 * g.kz / NW) * c : g.zs * c);   // blocks this wave processes in total
     const int first_kb = FULLK ? wave * T : (4 * (zg * g.zs) + wave) * c;
 
     // BasicNorm scales of the tile's rows, once per workgroup: the rows' sum-of-squares partials make ONE trip from global
     // memory (every lane fetching its own rows' partials cost the gate GEMM 8 us).  The loads are issued here, first thing,
     // and stay in registers during the K loop; after the meet 64 threads add them up through LDS (see the epilogue).
     const RowScale &rsc = EPI == EPI_HR ? g.r_scale : g.x_scale;
-    const bool NEED_SCL = (EPI == EPI_HR || EPI == EPI_LSTM || EPI == EPI_SLOT_STORE) && rsc.ssq != nullptr;     // uniform
+    const bool NEED_SCL = (EPI == EPI_HR || EPI == EPI_LSTM || EPI == EPI_SLOT_STORE || EPI == EPI_XPART) && rsc.ssq != nullptr;     // uniform
     float *scl = red + Cfg::LDS_FLOATS;
     float stg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     // TPR threads share a row, each holds up to 4 consecutive partials of it (no runtime divisions on the way in)
@@ -129,13 +130,17 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
             if (k < ppt && sj0 + k < rsc.groups) stg[k] = rsc.ssq[(size_t)r * rsc.groups + sj0 + k];
     }
 
-    uint32_t aoff0[MT], aoff1[MT];
+    uint32_t aoff0[MT], aoff1[MT], aoffb[AOP == AOP_TANH_ADD ? MT : 1];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int row = m0 + mt * 16 + mrow;
         if (row >= g.M) row = g.M - 1;                        // padding rows recompute the last row; never stored
         const int r0 = g.aidx0 ? g.aidx0[row] : row;
         aoff0[mt] = (uint32_t)(((size_t)r0 * g.lda0 + kq * 4) * sizeof(float));
+        if (AOP == AOP_TANH_ADD) {
+            const int rb = g.same_idx_b ? r0 : (g.aidx0b ? g.aidx0b[row] : row);
+            aoffb[mt] = (uint32_t)(((size_t)rb * g.lda0 + kq * 4) * sizeof(float));
+        }
         aoff1[mt] = 0;
         if (g.K1 > 0) { const int r1 = g.aidx1 ? g.aidx1[row] : row; aoff1[mt] = (uint32_t)(((size_t)r1 * g.lda1 + kq * 4) * sizeof(float)); }
     }
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
             const uint32_t off = seg0 ? aoff0[mt] : aoff1[mt];
             f32x4 v = *reinterpret_cast<const f32x4 *>(sb + off);
             if (AOP == AOP_TANH_ADD) {
-                const f32x4 w = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(g.a0b) + (ptrdiff_t)kb * 64 + off);
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(g.a0b) + (ptrdiff_t)kb * 64 + aoffb[mt]);
                 v.x = fast_tanh(v.x + w.x); v.y = fast_tanh(v.y + w.y); v.z = fast_tanh(v.z + w.z); v.w = fast_tanh(v.w + w.w);
             }
             a[mt] = v;
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
             for (int nt = 0; nt < NT; ++nt) boffs[nt] = boff + (uint32_t)nt * (uint32_t)KB * 1024u;
             for (int z = 0; z < g.zs; ++z) {
                 const int kb0 = (4 * (zg * g.zs + z) + wave) * c;
-                int done = 0;
+                int done = wave_on ? 0 : c;
                 while (done < c) {
                     const int kb = kb0 + done;
                     const bool seg0 = kb * 16 < g.K0;
@@ -541,6 +546,18 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
                 *reinterpret_cast<f32x4 *>(g.out + (size_t)slot * g.ldo + n) = NEED_SCL ? v[i] * scl[q / QROW] + b : v[i] + b;
             }
         }
+    } else if (EPI == EPI_XPART) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * NTH;
+            const int row = q / QROW, col = (q % QROW) * 4;
+            const int m = m0 + row, n = nt0 * 16 + col;
+            if (q < NQ && m < g.M) {
+                const int o = row * Cfg::LDR + col;
+                const f32x4 p0 = *reinterpret_cast<const f32x4 *>(red + o), p1 = *reinterpret_cast<const f32x4 *>(red + PLANE + o);
+                *reinterpret_cast<f32x4 *>(g.out + (size_t)m * g.ldo + n) = NEED_SCL ? (p0 + p1) * scl[row] : (p0 + p1);
+            }
+        }
     } else if (EPI == EPI_BIAS_DSWISH) {
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
@@ -560,11 +577,17 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
         for (int i = 0; i < QPT; ++i) {
             // x = y * scale(y) entered the GEMM as y: waves 0 and 1 hold the input half of the sum, which takes the row's scale here
             f32x4 gt;
-            if (NEED_SCL) {
+            if (g.p_add || NEED_SCL) {
                 const int o = qo[i];
-                const f32x4 p0 = *reinterpret_cast<const f32x4 *>(red + o), p1 = *reinterpret_cast<const f32x4 *>(red + PLANE + o);
                 const f32x4 p2 = *reinterpret_cast<const f32x4 *>(red + 2 * PLANE + o), p3 = *reinterpret_cast<const f32x4 *>(red + 3 * PLANE + o);
-                gt = (((p0 + p1) * scl[(threadIdx.x + i * NTH) / QROW] + p2) + p3) + qb[i];
+                f32x4 xin;
+                if (g.p_add) {           // layer-major: the input half was computed for all time steps at once (EPI_XPART)
+                    xin = qok[i] ? *reinterpret_cast<const f32x4 *>(g.p_add + (size_t)qm[i] * g.ldp + qunit[i] * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {
+                    const f32x4 p0 = *reinterpret_cast<const f32x4 *>(red + o), p1 = *reinterpret_cast<const f32x4 *>(red + PLANE + o);
+                    xin = (p0 + p1) * scl[(threadIdx.x + i * NTH) / QROW];
+                }
+                gt = ((xin + p2) + p3) + qb[i];
             } else {
                 gt = summed4(qo[i]) + qb[i];
             }
@@ -607,7 +630,7 @@ static TilePlan plan_tiles(int M, int N, int kz, int epi)
     // 5 = 64x32 tiles for split-K GEMMs at M > 32
     static const int tune = env_int("APRIL_GEMM_TUNE", 0);
     TilePlan t;
-    if (epi != EPI_LSTM && epi != EPI_BIAS_DSWISH && plan_fullk(M, N, kz, t)) return t;
+    if (epi != EPI_LSTM && epi != EPI_BIAS_DSWISH && epi != EPI_XPART && plan_fullk(M, N, kz, t)) return t;
     const int ntiles = N / 16;
     t.mode = GM_SLAB;
     t.mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
@@ -655,7 +678,7 @@ static void launch_one(const GemmArgs &g, hipStream_t s)
     using Cfg = TileCfg<MT, NT>;
     dim3 grid((unsigned)(g.N / Cfg::BN), (unsigned)((g.M + Cfg::BM - 1) / Cfg::BM), (unsigned)(MODE == GM_FULLK ? 1 : g.kz / g.zs));
     static const int ldspad = env_int("APRIL_GEMM_LDSPAD", 0);   // measurement: KiB of LDS to request at least (> 80 forces one workgroup per CU)
-    const int sg = EPI == EPI_HR ? g.r_scale.groups : ((EPI == EPI_LSTM || EPI == EPI_SLOT_STORE) && g.x_scale.ssq ? g.x_scale.groups : 0);
+    const int sg = EPI == EPI_HR ? g.r_scale.groups : ((EPI == EPI_LSTM || EPI == EPI_SLOT_STORE || EPI == EPI_XPART) && g.x_scale.ssq ? g.x_scale.groups : 0);
     const size_t lds = std::max((size_t)(Cfg::LDS_FLOATS + Cfg::BM + (sg ? Cfg::BM * (sg + 1) : 0)) * sizeof(float), (size_t)ldspad * 1024);
     if (g.wt == 1) { hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, EPI, AOP, 1, MODE, 0>), grid, dim3(256), lds, s, g); return; }
     if constexpr (HAS_ASM) {
@@ -675,7 +698,7 @@ static bool dispatch(const GemmArgs &g, hipStream_t s)
         CASE(EPI_HR, AOP_NONE, GM_SLAB) CASE(EPI_RESID_SSQ, AOP_NONE, GM_SLAB) CASE(EPI_SLOT_STORE, AOP_NONE, GM_SLAB)
     }
     CASE(EPI_PARTIAL, AOP_NONE, GM_SLAB) CASE(EPI_PARTIAL, AOP_TANH_ADD, GM_SLAB)
-    CASE(EPI_LSTM, AOP_NONE, GM_SLAB)
+    CASE(EPI_LSTM, AOP_NONE, GM_SLAB) CASE(EPI_XPART, AOP_NONE, GM_SLAB)
     CASE(EPI_BIAS_DSWISH, AOP_NONE, GM_SLAB)
 #undef CASE
     return false;
@@ -693,7 +716,7 @@ void launch_gemm(const GemmArgs &g_in, hipStream_t s)
     if (row_epi && t.zs != g.kz) { fprintf(stderr, "libapril(mi355x): launch_gemm: row epilogue %d needs the full-K plan (M=%d N=%d kz=%d)\n", g.epi, g.M, g.N, g.kz); abort(); }
     g.zs = t.zs; g.mode = t.mode;
     // EPI_LSTM with x_scale scales the partial sums of waves 0 and 1: they must hold exactly A segment 0
-    if (g.epi == EPI_LSTM && g.x_scale.ssq && (g.kz != 1 || g.K0 * 2 != g.K)) { fprintf(stderr, "libapril(mi355x): launch_gemm: x_scale needs K0 == K / 2 and kz == 1\n"); abort(); }
+    if ((g.epi == EPI_LSTM || g.epi == EPI_XPART) && (g.x_scale.ssq || g.p_add || g.wave_mask != 0xF) && (g.kz != 1 || g.K0 * 2 != g.K)) { fprintf(stderr, "libapril(mi355x): launch_gemm: x_scale needs K0 == K / 2 and kz == 1\n"); abort(); }
     // hand-scheduled K loop: measured gains with one workgroup per CU (gates at B <= 256: 24.8 -> 22.9 us) and for the
     // bias+DoubleSwish GEMMs at any size (FFN-up at B = 1024: 26.5 -> 23.3 us); the LSTM-cell GEMM with two
     // co-resident workgroups per CU is faster with the compiler-scheduled loop (B = 1024: 83 vs 91 us)

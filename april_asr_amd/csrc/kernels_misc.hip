@@ -22,7 +22,7 @@ __device__ __forceinline__ float dswish_dev(float y) { return y * sigmoid_dev(y 
 template <int MODE>
 __global__ __launch_bounds__(256) void row_kernel(RowArgs r)
 {
-    if (r.run_flag && *r.run_flag == 0) return;
+    if (r.run_flag && *r.run_flag != r.run_gen) return;
     const int m = blockIdx.x;
     const int tid = threadIdx.x;
     const int slot = r.slot_idx ? r.slot_idx[m] : m;
@@ -102,11 +102,11 @@ __global__ __launch_bounds__(256) void decide_kernel(DecideArgs a)
     __shared__ float s_best[4], s_blank[4];
     __shared__ int s_idx[4];
     __shared__ int s_ctx[3];                        // [0..1] context for the decoder front end, [2] re-run flag
-    if (a.run_flags && a.run_flags[a.round] == 0) return;      // every row resolved in an earlier round
+    if (a.round > 0 && a.run_flags && a.run_flags[a.round] != a.gen) return;      // every row resolved in an earlier round
     const int m = blockIdx.x;
     const int tid = threadIdx.x;
-    StepRecord *rec = a.rec ? a.rec + m : a.rec_ring + (size_t)a.rec_off[0] + (size_t)a.round * a.M + m;
-    if (!a.active[m]) {                             // uniform per workgroup
+    StepRecord *rec = a.rec ? a.rec + m : a.rec_ring + (size_t)a.rec_off[0] + (size_t)a.rec_slot * a.M + m;
+    if (a.round > 0 && a.active[m] != a.gen) {      // uniform per workgroup
         if (tid == 0) { rec->idx = -1; rec->max_val = 0.0f; rec->blank_val = 0.0f; rec->flags = 0; a.dirty[m] = 0; }
         return;
     }
@@ -168,15 +168,15 @@ __global__ __launch_bounds__(256) void decide_kernel(DecideArgs a)
                 st.last_tok = -1;
                 if (st.ctx0 != a.blank) { st.ctx0 = a.blank; st.ctx1 = a.blank; rerun = true; }   // :296-301
             }
-            a.active[m] = 0;
         }
+        a.active[m] = is_blank ? 0 : a.gen;
         if (rerun) flags |= REC_CTX;
         rec->flags = flags;
         a.state[slot] = st;
         a.dirty[m] = rerun ? 1 : 0;
         if (a.run_flags) {
-            if (!is_blank && a.round < 2) a.run_flags[a.round + 1] = 1;       // plain stores of the same value: no atomics needed
-            if (rerun) a.rerun_flags[a.round] = 1;
+            if (!is_blank && a.round < 2) a.run_flags[a.round + 1] = a.gen;   // plain stores of the same value: no atomics needed
+            if (rerun) a.rerun_flags[a.round] = a.gen;
         }
         s_ctx[0] = st.ctx0; s_ctx[1] = st.ctx1; s_ctx[2] = rerun ? 1 : 0;
     }
@@ -232,10 +232,12 @@ __global__ __launch_bounds__(1024) void advance_kernel(AdvanceArgs a)
     __syncthreads();
     const int k = s_k;
     const int *src = a.host_ring + a.host_step_off[k];          // pinned host memory, read once per step
-    for (int i = threadIdx.x; i < 3 * a.m; i += 1024) a.dst[(i / a.m) * a.dst_stride + (i % a.m)] = src[i];
-    for (int i = threadIdx.x; i < a.m; i += 1024) a.active[i] = 1;
+    for (int arr = 0; arr < a.n_arrays; ++arr) {
+        for (int i = threadIdx.x; i < a.len[arr]; i += 1024) a.dst[arr * a.dst_stride + i] = src[i];
+        src += a.len[arr];
+    }
+    if (threadIdx.x < a.n_flags) a.flags[threadIdx.x] = 0;
     if (threadIdx.x == 0) { a.rec_off[0] = a.host_rec_off[k]; a.counter[0] = k + 1; }
-    if (threadIdx.x < 3 && a.run_flags) { a.run_flags[threadIdx.x] = threadIdx.x == 0 ? 1 : 0; a.rerun_flags[threadIdx.x] = 0; }
 }
 
 void launch_advance(const AdvanceArgs &a, hipStream_t s)

@@ -216,6 +216,7 @@ Scheduler::Scheduler(Model *m, Engine *e) : model_(m), eng_(e), pool_(host_helpe
 {
     spin_step_us_ = env_us("APRIL_SPIN_STEP_US", 100);
     spin_wait_us_ = env_us("APRIL_SPIN_WAIT_US", 3000);
+    lm_min_chunks_ = env_us("APRIL_LM_MIN_CHUNKS", 8);
     thread_ = std::thread([this] { loop(); });
 }
 
@@ -435,7 +436,8 @@ void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
             const size_t base = staged;
             const size_t first = fb.fifo_pos;
             int cut = 0;
-            while (fb.can_cut() && cut < 96) {
+            // (up to a ring's worth per pass: a long feed then yields ~70 chunks per session at once for the layer-major step)
+            while (fb.can_cut() && cut < fb.ring_frames) {
                 FbankFrameDesc d; d.slot = s->slot; d.ring_row = fb.head; d.pcm_off = (int)(base + (size_t)cut * fb.shift);
                 desc_.push_back(d);
                 fb.head = (fb.head + 1) % fb.ring_frames;
@@ -475,7 +477,7 @@ void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
         case 4:
             // FINAL, clear context, SILENCE (april_session.c:561-563): the host part is replayed in order with the chunk
             // records of this flight; the device part (context reset + decoder refresh) is queued here
-            s->replay.push_back(Session::Replay{-1, 0, 0, (uint32_t)s->now_ms, 1});
+            s->replay.push_back(Session::Replay{-1, 0, 0, (uint32_t)s->now_ms, 1, 0});
             finishers.push_back(s);
             s->flush_phase = 0;
             progressed = true;
@@ -498,13 +500,64 @@ void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
     }
 }
 
+// Layer-major step for a group of sessions that all have at least T chunks waiting (a long feed: "whole file at once",
+// reference use case example.cpp:157-216 -> src/april_session.c:431-476).  The encoder does not depend on emitted tokens, so
+// the T chunks of a session go through each layer together; see Engine::lm_step.
+bool Scheduler::step_layer_major(std::vector<Session *> &group, int T)
+{
+    const int m = (int)group.size();
+    const int rows = m * T;
+    const NetDims &d = eng_->dims();
+    if (!eng_->flight_has_room(rows + m, 1)) return false;
+    const int stride_ms = model_->host.params.segment_step * model_->host.params.frame_shift_ms;
+    slots_.clear(); tails_.assign((size_t)rows, 0); now_.assign((size_t)rows, 0);
+    bool traced = false;
+    for (int i = 0; i < m; ++i) {
+        Session *s = group[(size_t)i];
+        FrameBook &fb = s->fb;
+        slots_.push_back(s->slot);
+        for (int t = 0; t < T; ++t) {
+            tails_[(size_t)t * m + i] = (fb.tail + t * fb.seg_step) % fb.ring_frames;          // fbank.c:327-349, T pulls
+            now_[(size_t)t * m + i] = (int)(s->now_ms + (size_t)(t + 1) * stride_ms);         // april_session.c:442-443
+        }
+        fb.tail = (fb.tail + T * fb.seg_step) % fb.ring_frames;
+        fb.avail -= (long)T * fb.seg_step;
+        fb.avail_shadow -= (long)T * fb.seg_step;
+        if (s->trace_buf) traced = true;
+    }
+    if (traced) logit_stage_.resize((size_t)3 * rows * d.vocab);
+    const int k = eng_->lm_step(m, T, slots_.data(), tails_.data(), now_.data(), traced ? logit_stage_.data() : nullptr);
+    for (int i = 0; i < m; ++i) {
+        Session *s = group[(size_t)i];
+        for (int t = 0; t < T; ++t) {
+            s->now_ms += (size_t)stride_ms;
+            s->chunks++;
+            s->replay.push_back(Session::Replay{k, i, m, (uint32_t)s->now_ms, 0, t});
+            if (traced && s->trace_buf) {
+                const StepRecord *recs = eng_->records(k);
+                for (int r = 0; r < 3; ++r) {
+                    const size_t at = ((size_t)t * 3 + r) * m + i;
+                    const StepRecord &rec = recs[at];
+                    if (!(rec.flags & REC_VALID)) break;
+                    if (*s->trace_used + (size_t)d.vocab <= s->trace_cap) {
+                        memcpy(s->trace_buf + *s->trace_used, logit_stage_.data() + at * d.vocab, (size_t)d.vocab * 4);
+                        *s->trace_used += (size_t)d.vocab;
+                    }
+                    if (rec.flags & REC_BLANK) break;
+                }
+            }
+        }
+    }
+    tick_.steps++; tick_.lm_steps++; tick_.chunks += (uint64_t)rows; tick_.lm_chunks += (uint64_t)rows;
+    if ((uint64_t)m > tick_.max_batch_seen) tick_.max_batch_seen = (uint64_t)m;
+    return true;
+}
+
 bool Scheduler::step_chunks(std::vector<Session *> &ready)
 {
     Lap lap;
-    const int n = (int)ready.size();
     const NetDims &d = eng_->dims();
     const int MB = eng_->max_batch();
-    if (!eng_->flight_has_room(n, (n + MB - 1) / MB)) return false;
     // first use of a session: context = [blank, blank] (already in the slot's device state), run the decoder (april_session.c:432-438)
     slots_.clear();
     for (Session *s : ready) if (!s->dout_ready) {
@@ -515,13 +568,30 @@ bool Scheduler::step_chunks(std::vector<Session *> &ready)
     }
     if (!slots_.empty()) { eng_->decode_rows((int)slots_.size(), slots_.data(), 0); tick_.host_ms[6] += lap(); }
 
+    // sessions with a long backlog (a whole file fed at once) go layer-major, in groups that fit the work buffers
+    std::vector<Session *> one, lm;
+    auto waiting = [](const Session *s) { return (int)((s->fb.avail - s->fb.seg_count) / s->fb.seg_step + 1); };
+    for (Session *s : ready) ((lm_min_chunks_ > 0 && waiting(s) >= lm_min_chunks_ && lm_min_chunks_ <= MB) ? lm : one).push_back(s);
+    if (!lm.empty()) {
+        const int per = std::max(1, MB / lm_min_chunks_);
+        std::vector<Session *> group;
+        for (size_t o = 0; o < lm.size(); o += (size_t)per) {
+            group.assign(lm.begin() + (long)o, lm.begin() + (long)std::min(lm.size(), o + (size_t)per));
+            int T = MB / (int)group.size();
+            for (Session *s : group) T = std::min(T, waiting(s));
+            if (!step_layer_major(group, T)) { tick_.host_ms[3] += lap(); return false; }
+        }
+    }
+
+    const int n = (int)one.size();
+    if (n > 0 && !eng_->flight_has_room(n, (n + MB - 1) / MB)) { tick_.host_ms[3] += lap(); return false; }
     const int stride_ms = model_->host.params.segment_step * model_->host.params.frame_shift_ms;
     for (int o = 0; o < n; o += MB) {
         const int m = std::min(MB, n - o);
         slots_.clear(); tails_.clear(); now_.clear();
         bool traced = false;
         for (int i = 0; i < m; ++i) {
-            Session *s = ready[(size_t)(o + i)];
+            Session *s = one[(size_t)(o + i)];
             FrameBook &fb = s->fb;
             slots_.push_back(s->slot);
             tails_.push_back(fb.tail);                                  // fbank.c:327-349
@@ -536,8 +606,8 @@ bool Scheduler::step_chunks(std::vector<Session *> &ready)
         if (traced) logit_stage_.resize((size_t)3 * m * d.vocab);
         const int k = eng_->step(m, slots_.data(), tails_.data(), now_.data(), traced ? logit_stage_.data() : nullptr);
         for (int i = 0; i < m; ++i) {
-            Session *s = ready[(size_t)(o + i)];
-            s->replay.push_back(Session::Replay{k, i, m, (uint32_t)s->now_ms, 0});
+            Session *s = one[(size_t)(o + i)];
+            s->replay.push_back(Session::Replay{k, i, m, (uint32_t)s->now_ms, 0, 0});
             if (traced && s->trace_buf) {                               // tests: the logits of every round that ran, in order
                 const StepRecord *recs = eng_->records(k);
                 for (int r = 0; r < 3; ++r) {
@@ -567,7 +637,7 @@ void Scheduler::replay(std::vector<Session *> &work)
             if (it.kind == 1) { s->greedy.finish_flush(s->events); s->greedy.ctx_dirty = false; continue; }
             const StepRecord *recs = eng_->records(it.step);
             for (int r = 0; r < 3; ++r) {                               // april_session.c:449-454
-                const StepRecord &rec = recs[(size_t)r * it.rows + it.row];
+                const StepRecord &rec = recs[((size_t)it.chunk * 3 + r) * it.rows + it.row];
                 if (!(rec.flags & REC_VALID)) { tick_.replay_mismatch++; LOGE("replay: device skipped a round the host expected (slot %d)", s->slot); break; }
                 const JointResult jr{rec.idx, rec.max_val, rec.blank_val};
                 const bool blank = s->greedy.on_joint(jr, r == 0 ? 1.0f : 0.0f, (size_t)it.now_ms, s->events);

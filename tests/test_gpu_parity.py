@@ -186,6 +186,48 @@ def test_session_transcript_v0(gpu_v0, orc_v0):
     assert_same_transcript(want, got)
 
 
+@pytest.mark.parametrize("which,secs", [("tiny", 6.0), ("v0", 3.0)])
+def test_layer_major_equals_streaming(which, secs, request):
+    """a long feed (the whole input at once) takes the layer-major schedule -- conv front end,
+    the input half of every gate GEMM, feed-forward blocks and encoder_proj once over all chunks, only the recurrent half
+    per time step.  Same chains in the same order: every logit and every callback equals the 100 ms-feed run BIT FOR BIT."""
+    gm = request.getfixturevalue("gpu_" + which)
+    pcm = np.concatenate([speech_like_pcm(secs / 2, seed=11), np.zeros(16000, np.int16), speech_like_pcm(secs / 2, seed=12)])
+    before = gm.stats().lm_chunks
+    ev_s, lg_s, n_s = run_gpu(gm, pcm, 1600)
+    assert gm.stats().lm_chunks == before                      # 100 ms feeds never reach the layer-major threshold
+    ev_o, lg_o, n_o = run_gpu(gm, pcm, pcm.size)
+    st = gm.stats()
+    assert st.lm_chunks - before >= n_o - 40 and st.replay_mismatch == 0     # all but the flush tail went layer-major
+    assert n_s == n_o
+    assert np.array_equal(lg_s, lg_o)
+    assert ev_s == ev_o
+
+
+def test_layer_major_ragged_group(gpu_tiny):
+    """Several sessions fed whole inputs of different lengths in one call: grouped layer-major steps (T = the shortest
+    backlog of the group), the rest in further steps; each session equals itself streamed alone, bit for bit."""
+    import april_asr_amd as A
+    from oracle import orc_py as O
+    lens = [16000 * 3, 16000 * 2 + 777, 16000 * 4, 9000, 16000 * 3]
+    pcms = [O.lcg_pcm16_fast(n, seed=600 + i) for i, n in enumerate(lens)]
+    evs = [[] for _ in lens]
+    sess = [A.Session(gpu_tiny, (lambda k: (lambda t, toks: evs[k].append((t, toks))))(i), raw_events=True) for i in range(len(lens))]
+    for s in sess:
+        s.trace_logits(1200)
+    grp = A.SessionGroup(sess)
+    before = gpu_tiny.stats().lm_chunks
+    grp.feed(pcms)
+    grp.flush()
+    assert gpu_tiny.stats().lm_chunks > before
+    for i, s in enumerate(sess):
+        ev1, lg1, _ = run_gpu(gpu_tiny, pcms[i], 1600)
+        assert np.array_equal(lg1, s.traced_logits()), i
+        assert ev1 == evs[i], i
+    for s in sess:
+        s.close()
+
+
 def test_many_sessions_equal_single(gpu_tiny):
     """64 sessions fed together (different inputs) == each one alone, bit for bit (logits and callbacks)."""
     import april_asr_amd as A
