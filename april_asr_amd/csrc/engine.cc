@@ -162,6 +162,7 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     ws_mstride_ = cfg_.max_batch;
     const size_t ws_n = (size_t)std::max({kz_embed_ * d.d_model, kz_hr_ * d.d_model, kz_ff2_ * d.d_model, kz_proj_ * d.joiner, kz_out_ * L_.vocab_pad});
     ws_ = dmalloc<float>(ws_n * MB);
+    ws_g_ = dmalloc<float>((size_t)std::max(kz_proj_ * d.joiner, kz_out_ * L_.vocab_pad) * MB);    // the search's own workspace: it runs beside encoder stages
     xin_ = dmalloc<float>(MB * d.embed_in);
     a3_ = dmalloc<float>(MB * d.f_out * L_.k3);
     HIP_CHECK(hipMemset(a3_, 0, MB * d.f_out * L_.k3 * 4));      // padded k columns (if any) stay zero
@@ -218,6 +219,9 @@ Engine::~Engine()
     for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &g : step_graphs_) (void)hipGraphExecDestroy(g.second);
     for (auto &g : lm_graphs_) (void)hipGraphExecDestroy(g.second);
+    for (hipStream_t st : lm_streams_) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : lm_events_) (void)hipEventDestroy(e);
+    if (ws_g_) (void)hipFree(ws_g_);
     if (p_lm_) (void)hipFree(p_lm_);
     if (eout_lm_) (void)hipFree(eout_lm_);
     for (void *p : {(void *)w_, (void *)wh_, (void *)h_, (void *)c_, (void *)ring_, (void *)eout_, (void *)dout_, (void *)gstate_, (void *)cls_, (void *)ws_, (void *)xin_,
@@ -468,9 +472,9 @@ void Engine::run_decproj(int n, const int *d_slots, const int *row_mask, const i
         timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
         return;
     }
-    g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
+    g.epi = EPI_PARTIAL; g.out = ws_g_; g.m_stride = ws_mstride_;
     timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
-    RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_; r.parts = gemm_partials(n, d.joiner, kz_proj_); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = n;
+    RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_g_; r.parts = gemm_partials(n, d.joiner, kz_proj_); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = n;
     r.bias = w_ + L_.b_decproj; r.out = dout_; r.ldo = d.joiner; r.slot_idx = d_slots; r.row_mask = row_mask; r.run_flag = run_flag; r.run_gen = run_gen;
     timed_begin(T_DEC); launch_row(r, stream_); timed_end(T_DEC);
 }
@@ -488,12 +492,12 @@ void Engine::run_greedy_rounds(int n, bool dump_logits, int chunk, const float *
             GemmArgs g; g.a0b = dout_; g.lda0 = d.joiner; g.K0 = d.joiner; g.a_op = AOP_TANH_ADD;
             if (eout_rows) { g.a0 = eout_rows; g.aidx0 = nullptr; g.same_idx_b = 0; g.aidx0b = d_slots; }     // layer-major: this chunk's rows of the batched encoder output
             else { g.a0 = eout_; g.aidx0 = d_slots; }
-            lin(g, L_.w_out); g.M = n; g.N = L_.vocab_pad; g.K = d.joiner; g.kz = kz_out_; g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
+            lin(g, L_.w_out); g.M = n; g.N = L_.vocab_pad; g.K = d.joiner; g.kz = kz_out_; g.epi = EPI_PARTIAL; g.out = ws_g_; g.m_stride = ws_mstride_;
             if (round > 0) { g.run_flag = flags_d_ + round; g.run_gen = gen; }
             timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
         }
         DecideArgs a;
-        a.ws = ws_; a.parts = gemm_partials(n, L_.vocab_pad, kz_out_); a.m_stride = ws_mstride_; a.N = L_.vocab_pad; a.M = n; a.n_valid = d.vocab;
+        a.ws = ws_g_; a.parts = gemm_partials(n, L_.vocab_pad, kz_out_); a.m_stride = ws_mstride_; a.N = L_.vocab_pad; a.M = n; a.n_valid = d.vocab;
         a.bias = w_ + L_.b_out; a.blank = P_.blank_id; a.early_emit = round == 0 ? 1.0f : 0.0f;
         a.slot_idx = d_slots; a.now_ms = d_now; a.active = active_d_; a.dirty = dirty_d_; a.tok_class = cls_; a.state = gstate_;
         a.rec_ring = rec_d_; a.rec_off = rec_off_d_; a.round = round; a.gen = gen; a.rec_slot = chunk * 3 + round;
@@ -519,107 +523,133 @@ void Engine::run_chain(int m, bool dump_logits)
 
 // ---------------------------------------------------------------- layer-major step
 // Index arrays on the device (stride max_batch): [0] slots (m), [1] ring tails (T x m), [2] session times (T x m),
-// [3] slot of every row (T x m).  Row r = t * m + i.
-void Engine::run_encoder_lm(int m, int T)
+// [3] slot of every row (T x m).  Row r = t * m + i.  The work is cut into STAGES over a block of time steps [t0, t1):
+//   embed(block)      conv front end + embed linear                 -> y, ssq rows of the block
+//   layer(l, block)   input half of the gates for the block's rows at once; per time step recurrent half + cell and the
+//                     projection; feed-forward over the block's rows   -> y, ssq rows of the block
+//   proj(block)       encoder_proj                                   -> eout_lm rows of the block
+// layer(l, b) needs layer(l - 1, b) (its input rows) and layer(l, b - 1) (the recurrent state): stages of different layers
+// on different blocks are independent and run on different streams (see run_lm_chain).  Work buffers are row-partitioned,
+// so concurrent stages never share a byte.
+void Engine::lm_stage_embed(int m, int t0, int t1, hipStream_t st)
 {
     const NetDims &d = L_.dims;
-    const size_t S = (size_t)cfg_.max_slots;
     const int MB = cfg_.max_batch;
-    const int rows = m * T;
-    const int *d_slots = step_d_, *d_tails = step_d_ + MB, *d_rowslot = step_d_ + 3 * MB;
-    const int G = d.d_model / SSQ_COLS;
-    auto scale_of = [&](float eps) { RowScale r; r.ssq = ssq_; r.groups = G; r.inv_n = 1.0f / (float)d.d_model; r.eps = eps; return r; };
+    const size_t r0 = (size_t)t0 * m;
+    const int rows = (t1 - t0) * m;
+    const int *d_tails = step_d_ + MB, *d_rowslot = step_d_ + 3 * MB;
     ConvEmbedArgs ca;
     ca.ring = ring_; ca.ring_frames = ring_frames_; ca.mel = d.mel; ca.seg = d.seg;
-    ca.slot_idx = d_rowslot; ca.ring_tail = d_tails;
+    ca.slot_idx = d_rowslot + r0; ca.ring_tail = d_tails + r0;
     for (int i = 0; i < 3; ++i) { ca.w[i] = w_ + L_.conv_w[i]; ca.b[i] = w_ + L_.conv_b[i]; ca.ch[i] = d.conv_ch[i]; ca.stride[i] = d.conv_stride[i]; }
     ca.ch1_per_group = 1;
     for (int k = 8; k > 1; --k) if (d.conv_ch[1] % k == 0) { ca.ch1_per_group = k; break; }
-    ca.out = a3_; ca.ldo = L_.k3; ca.M = rows;
-    timed_begin(T_CONV); launch_conv_embed(ca, stream_); timed_end(T_CONV);
+    ca.out = a3_ + r0 * d.f_out * L_.k3; ca.ldo = L_.k3; ca.M = rows;
+    timed_begin(T_CONV); launch_conv_embed(ca, st); timed_end(T_CONV);
     {
-        GemmArgs g; g.a0 = a3_; g.lda0 = L_.k3; g.K0 = L_.k3; g.wp = w_ + L_.conv_w[2];
-        g.M = rows * d.f_out; g.N = d.conv_ch[2]; g.K = L_.k3; g.kz = 1; g.epi = EPI_BIAS_DSWISH; g.out = xin_; g.ldo = d.conv_ch[2]; g.bias = w_ + L_.conv_b[2];
-        timed_begin(T_CONV); launch_gemm(g, stream_); timed_end(T_CONV);
+        GemmArgs g; g.a0 = a3_ + r0 * d.f_out * L_.k3; g.lda0 = L_.k3; g.K0 = L_.k3; g.wp = w_ + L_.conv_w[2];
+        g.M = rows * d.f_out; g.N = d.conv_ch[2]; g.K = L_.k3; g.kz = 1; g.epi = EPI_BIAS_DSWISH; g.out = xin_ + r0 * d.embed_in; g.ldo = d.conv_ch[2]; g.bias = w_ + L_.conv_b[2];
+        timed_begin(T_CONV); launch_gemm(g, st); timed_end(T_CONV);
     }
-    auto resid_ssq = [&](const float *a, int K, size_t w_off, int kz, const float *bias, const float *resid) {
-        GemmArgs g; g.a0 = a; g.lda0 = K; g.K0 = K; lin(g, w_off);
-        g.M = rows; g.N = d.d_model; g.K = K; g.kz = kz;
-        if (gemm_fullk(rows, d.d_model, kz)) {
-            g.epi = EPI_RESID_SSQ; g.bias = bias; g.resid = resid; g.ldr = d.d_model; g.out = y_; g.ldo = d.d_model; g.ssq_out = ssq_;
-            timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
-            return;
-        }
-        g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
-        timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
-        RowArgs r; r.mode = ROW_RESID_SSQ; r.ws = ws_; r.parts = gemm_partials(rows, d.d_model, kz); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = rows;
-        r.bias = bias; r.resid = resid; r.ldr = d.d_model; r.out = y_; r.ldo = d.d_model; r.ssq_out = ssq_;
-        timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
-    };
-    resid_ssq(xin_, d.embed_in, L_.w_embed, kz_embed_, w_ + L_.b_embed, nullptr);
-    float eps_in = L_.embed_eps;
-    for (int l = 0; l < d.n_layers; ++l) {
-        const PackedLayout::Layer &o = L_.layers[(size_t)l];
-        float *h_l = h_ + (size_t)l * S * d.d_model;
-        float *c_l = c_ + (size_t)l * S * d.hidden;
-        const RowScale xs = scale_of(eps_in);
-        {   // input half of the gates for all rows: P = (p0 + p1) * scale   (waves 0,1; the recurrent half sits this launch out)
-            GemmArgs g; g.a0 = y_; g.lda0 = d.d_model; g.K0 = d.d_model; g.x_scale = xs;
-            g.a1 = y_; g.lda1 = d.d_model; g.K1 = d.d_model;          // never read (wave_mask)
-            lin(g, o.wg); g.M = rows; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_XPART; g.wave_mask = 0x3;
-            g.out = p_lm_; g.ldo = 4 * d.hidden;
-            timed_begin(T_GATES); launch_gemm(g, stream_); timed_end(T_GATES);
-        }
-        for (int t = 0; t < T; ++t) {
-            const size_t r0 = (size_t)t * m;
-            {   // recurrent half + LSTM cell: ((P + p2) + p3) + bias
-                GemmArgs g; g.a0 = y_ + r0 * d.d_model; g.lda0 = d.d_model; g.K0 = d.d_model;      // never read (wave_mask)
-                g.a1 = h_l; g.lda1 = d.d_model; g.aidx1 = d_slots; g.K1 = d.d_model;
-                lin(g, o.wg); g.M = m; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_LSTM; g.wave_mask = 0xC;
-                g.p_add = p_lm_ + r0 * 4 * d.hidden; g.ldp = 4 * d.hidden;
-                g.out = u_ + r0 * d.hidden; g.ldo = d.hidden; g.bias = w_ + o.bg; g.c_state = c_l; g.slot_idx = d_slots; g.hidden = d.hidden;
-                timed_begin(T_GATES); launch_gemm(g, stream_); timed_end(T_GATES);
-            }
-            {   // h' = u x Whr ; state write + residual
-                GemmArgs g; g.a0 = u_ + r0 * d.hidden; g.lda0 = d.hidden; g.K0 = d.hidden; lin(g, o.whr);
-                g.M = m; g.N = d.d_model; g.K = d.hidden; g.kz = kz_hr_;
-                RowScale rs = xs; rs.ssq = ssq_ + r0 * G;
-                if (gemm_fullk(m, d.d_model, kz_hr_)) {
-                    g.epi = EPI_HR; g.state = h_l; g.ld_state = d.d_model; g.slot_idx = d_slots; g.resid = y_ + r0 * d.d_model; g.ldr = d.d_model; g.r_scale = rs;
-                    g.out = xb_ + r0 * d.d_model; g.ldo = d.d_model;
-                    timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
-                } else {
-                    g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
-                    timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
-                    RowArgs r; r.mode = ROW_HR; r.ws = ws_; r.parts = gemm_partials(m, d.d_model, kz_hr_); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = m;
-                    r.resid = y_ + r0 * d.d_model; r.ldr = d.d_model; r.r_scale = rs; r.out = xb_ + r0 * d.d_model; r.ldo = d.d_model;
-                    r.slot_idx = d_slots; r.state = h_l; r.ld_state = d.d_model;
-                    timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
-                }
-            }
-        }
-        {   // FFN up + DoubleSwish, all rows
-            GemmArgs g; g.a0 = xb_; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, o.wff1);
-            g.M = rows; g.N = d.ffn; g.K = d.d_model; g.kz = 1; g.epi = EPI_BIAS_DSWISH; g.out = ff_; g.ldo = d.ffn; g.bias = w_ + o.bff1;
-            timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
-        }
-        resid_ssq(ff_, d.ffn, o.wff2, kz_ff2_, w_ + o.bff2, xb_);
-        eps_in = L_.norm_eps[(size_t)l];
+    lm_resid_ssq(xin_ + r0 * d.embed_in, d.embed_in, L_.w_embed, kz_embed_, w_ + L_.b_embed, nullptr, r0, rows, st);
+}
+
+// y[r0 .. r0 + rows) = A x W + bias (+ residual) with sums of squares; fused where the tiles own all of K
+void Engine::lm_resid_ssq(const float *a, int K, size_t w_off, int kz, const float *bias, const float *resid, size_t r0, int rows, hipStream_t st)
+{
+    const NetDims &d = L_.dims;
+    const int G = d.d_model / SSQ_COLS;
+    GemmArgs g; g.a0 = a; g.lda0 = K; g.K0 = K; lin(g, w_off);
+    g.M = rows; g.N = d.d_model; g.K = K; g.kz = kz;
+    float *yo = y_ + r0 * d.d_model, *so = ssq_ + r0 * G;
+    if (gemm_fullk(rows, d.d_model, kz)) {
+        g.epi = EPI_RESID_SSQ; g.bias = bias; g.resid = resid; g.ldr = d.d_model; g.out = yo; g.ldo = d.d_model; g.ssq_out = so;
+        timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
+        return;
     }
-    {   // encoder_proj over all rows -> eout_lm[row]
-        const RowScale ys = scale_of(eps_in);
-        GemmArgs g; g.a0 = y_; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, L_.w_encproj);
-        g.M = rows; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_;
-        if (gemm_fullk(rows, d.joiner, kz_proj_)) {
-            g.epi = EPI_SLOT_STORE; g.bias = w_ + L_.b_encproj; g.out = eout_lm_; g.ldo = d.joiner; g.x_scale = ys;
-            timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
-        } else {
-            g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
-            timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
-            RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_; r.parts = gemm_partials(rows, d.joiner, kz_proj_); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = rows;
-            r.bias = w_ + L_.b_encproj; r.out = eout_lm_; r.ldo = d.joiner; r.r_scale = ys;
-            timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
+    g.epi = EPI_PARTIAL; g.out = ws_ + r0 * d.d_model; g.m_stride = ws_mstride_;
+    timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
+    RowArgs r; r.mode = ROW_RESID_SSQ; r.ws = ws_ + r0 * d.d_model; r.parts = gemm_partials(rows, d.d_model, kz); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = rows;
+    r.bias = bias; r.resid = resid; r.ldr = d.d_model; r.out = yo; r.ldo = d.d_model; r.ssq_out = so;
+    timed_begin(T_ROW); launch_row(r, st); timed_end(T_ROW);
+}
+
+void Engine::lm_stage_layer(int l, int m, int t0, int t1, hipStream_t st)
+{
+    const NetDims &d = L_.dims;
+    const size_t S = (size_t)cfg_.max_slots;
+    const int G = d.d_model / SSQ_COLS;
+    const int *d_slots = step_d_;
+    const PackedLayout::Layer &o = L_.layers[(size_t)l];
+    float *h_l = h_ + (size_t)l * S * d.d_model;
+    float *c_l = c_ + (size_t)l * S * d.hidden;
+    const size_t b0 = (size_t)t0 * m;
+    const int brows = (t1 - t0) * m;
+    RowScale xs; xs.groups = G; xs.inv_n = 1.0f / (float)d.d_model; xs.eps = l == 0 ? L_.embed_eps : L_.norm_eps[(size_t)l - 1];
+    {   // input half of the gates for the block's rows: P = (p0 + p1) * scale   (waves 0,1; the recurrent half sits this launch out)
+        GemmArgs g; g.a0 = y_ + b0 * d.d_model; g.lda0 = d.d_model; g.K0 = d.d_model; g.x_scale = xs; g.x_scale.ssq = ssq_ + b0 * G;
+        g.a1 = g.a0; g.lda1 = d.d_model; g.K1 = d.d_model;          // never read (wave_mask)
+        lin(g, o.wg); g.M = brows; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_XPART; g.wave_mask = 0x3;
+        g.out = p_lm_ + b0 * 4 * d.hidden; g.ldo = 4 * d.hidden;
+        timed_begin(T_GATES); launch_gemm(g, st); timed_end(T_GATES);
+    }
+    for (int t = t0; t < t1; ++t) {
+        const size_t r0 = (size_t)t * m;
+        {   // recurrent half + LSTM cell: ((P + p2) + p3) + bias
+            GemmArgs g; g.a0 = y_ + r0 * d.d_model; g.lda0 = d.d_model; g.K0 = d.d_model;      // never read (wave_mask)
+            g.a1 = h_l; g.lda1 = d.d_model; g.aidx1 = d_slots; g.K1 = d.d_model;
+            lin(g, o.wg); g.M = m; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_LSTM; g.wave_mask = 0xC;
+            g.p_add = p_lm_ + r0 * 4 * d.hidden; g.ldp = 4 * d.hidden;
+            g.out = u_ + r0 * d.hidden; g.ldo = d.hidden; g.bias = w_ + o.bg; g.c_state = c_l; g.slot_idx = d_slots; g.hidden = d.hidden;
+            timed_begin(T_GATES); launch_gemm(g, st); timed_end(T_GATES);
         }
+        {   // h' = u x Whr ; state write + residual
+            GemmArgs g; g.a0 = u_ + r0 * d.hidden; g.lda0 = d.hidden; g.K0 = d.hidden; lin(g, o.whr);
+            g.M = m; g.N = d.d_model; g.K = d.hidden; g.kz = kz_hr_;
+            RowScale rs = xs; rs.ssq = ssq_ + r0 * G;
+            if (gemm_fullk(m, d.d_model, kz_hr_, true)) {       // sequential step: one launch, however few workgroups
+                g.force_fullk = 1;
+                g.epi = EPI_HR; g.state = h_l; g.ld_state = d.d_model; g.slot_idx = d_slots; g.resid = y_ + r0 * d.d_model; g.ldr = d.d_model; g.r_scale = rs;
+                g.out = xb_ + r0 * d.d_model; g.ldo = d.d_model;
+                timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
+            } else {
+                g.epi = EPI_PARTIAL; g.out = ws_ + r0 * d.d_model; g.m_stride = ws_mstride_;
+                timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
+                RowArgs r; r.mode = ROW_HR; r.ws = ws_ + r0 * d.d_model; r.parts = gemm_partials(m, d.d_model, kz_hr_); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = m;
+                r.resid = y_ + r0 * d.d_model; r.ldr = d.d_model; r.r_scale = rs; r.out = xb_ + r0 * d.d_model; r.ldo = d.d_model;
+                r.slot_idx = d_slots; r.state = h_l; r.ld_state = d.d_model;
+                timed_begin(T_ROW); launch_row(r, st); timed_end(T_ROW);
+            }
+        }
+    }
+    {   // FFN up + DoubleSwish, the block's rows
+        GemmArgs g; g.a0 = xb_ + b0 * d.d_model; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, o.wff1);
+        g.M = brows; g.N = d.ffn; g.K = d.d_model; g.kz = 1; g.epi = EPI_BIAS_DSWISH; g.out = ff_ + b0 * d.ffn; g.ldo = d.ffn; g.bias = w_ + o.bff1;
+        timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
+    }
+    lm_resid_ssq(ff_ + b0 * d.ffn, d.ffn, o.wff2, kz_ff2_, w_ + o.bff2, xb_ + b0 * d.d_model, b0, brows, st);
+}
+
+void Engine::lm_stage_proj(int m, int t0, int t1, hipStream_t st)
+{
+    const NetDims &d = L_.dims;
+    const int G = d.d_model / SSQ_COLS;
+    const size_t b0 = (size_t)t0 * m;
+    const int brows = (t1 - t0) * m;
+    RowScale ys; ys.ssq = ssq_ + b0 * G; ys.groups = G; ys.inv_n = 1.0f / (float)d.d_model; ys.eps = L_.norm_eps[(size_t)d.n_layers - 1];
+    GemmArgs g; g.a0 = y_ + b0 * d.d_model; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, L_.w_encproj);
+    g.M = brows; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_;
+    float *eo = eout_lm_ + b0 * d.joiner;
+    if (gemm_fullk(brows, d.joiner, kz_proj_, true)) {
+        g.force_fullk = 1;
+        g.epi = EPI_SLOT_STORE; g.bias = w_ + L_.b_encproj; g.out = eo; g.ldo = d.joiner; g.x_scale = ys;
+        timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
+    } else {
+        g.epi = EPI_PARTIAL; g.out = ws_ + b0 * d.d_model; g.m_stride = ws_mstride_;     // (joiner width == a d_model-wide slice or less: see the constructor's workspace size)
+        timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
+        RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_ + b0 * d.d_model; r.parts = gemm_partials(brows, d.joiner, kz_proj_); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = brows;
+        r.bias = w_ + L_.b_encproj; r.out = eo; r.ldo = d.joiner; r.r_scale = ys;
+        timed_begin(T_ROW); launch_row(r, st); timed_end(T_ROW);
     }
 }
 
@@ -627,14 +657,63 @@ void Engine::run_lm_chain(int m, int T, bool dump_logits)
 {
     const NetDims &d = L_.dims;
     const int MB = cfg_.max_batch;
+    const int L = d.n_layers;
     AdvanceArgs a;
     a.host_ring = ring_h_; a.host_step_off = step_off_h_; a.host_rec_off = rec_off_h_; a.counter = counter_d_;
     a.dst = step_d_; a.dst_stride = MB; a.n_arrays = 4; a.len[0] = m; a.len[1] = a.len[2] = a.len[3] = m * T; a.rec_off = rec_off_d_;
     a.flags = flags_d_; a.n_flags = 8;
     launch_advance(a, stream_);
-    run_encoder_lm(m, T);
-    // the search stays sequential in time (the decoder input of chunk t + 1 depends on the tokens of chunk t)
-    for (int t = 0; t < T; ++t) run_greedy_rounds(m, dump_logits, t, eout_lm_ + (size_t)t * m * d.joiner);
+    static const int lm_block = std::max(1, getenv("APRIL_LM_BLOCK") ? atoi(getenv("APRIL_LM_BLOCK")) : 7);
+    static const int lm_streams = getenv("APRIL_LM_STREAMS") ? atoi(getenv("APRIL_LM_STREAMS")) : 1;
+    const bool pipelined = lm_streams != 0 && !profiling_ && !dump_logits && T > lm_block;
+    if (!pipelined) {
+        lm_stage_embed(m, 0, T, stream_);
+        for (int l = 0; l < L; ++l) lm_stage_layer(l, m, 0, T, stream_);
+        lm_stage_proj(m, 0, T, stream_);
+        // the search stays sequential in time (the decoder input of chunk t + 1 depends on the tokens of chunk t)
+        for (int t = 0; t < T; ++t) run_greedy_rounds(m, dump_logits, t, eout_lm_ + (size_t)t * m * d.joiner);
+        return;
+    }
+    // Software pipeline over blocks of `lm_block` time steps: layer l works on block b while layer l + 1 works on block
+    // b - 1, ..., and the search on an earlier block still.  One stream per layer (its blocks in order = the recurrence),
+    // one for embed + proj, the engine's stream for the search; events carry "block b left stage s".  At one session every
+    // recurrent kernel is a latency-bound launch: this turns 12 serial chains into 12 concurrent ones.
+    const int NB = (T + lm_block - 1) / lm_block;
+    if ((int)lm_streams_.size() < L + 1) {
+        while ((int)lm_streams_.size() < L + 1) { hipStream_t s; HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); lm_streams_.push_back(s); }
+    }
+    const size_t need_ev = (size_t)(L + 2) * NB + 1;
+    while (lm_events_.size() < need_ev) { hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); lm_events_.push_back(e); }
+    auto ev = [&](int stage, int b) { return lm_events_[1 + (size_t)stage * NB + b]; };   // stage 0 embed, 1..L layers, L + 1 proj
+    hipStream_t s_io = lm_streams_[(size_t)L];
+    HIP_CHECK(hipEventRecord(lm_events_[0], stream_));                 // the index block is on the device
+    for (int i = 0; i <= L; ++i) HIP_CHECK(hipStreamWaitEvent(lm_streams_[(size_t)i], lm_events_[0], 0));
+    // enqueue in wavefront order, so that every stream's queue is in the order its stages become ready
+    for (int wave = 0; wave < NB + L + 2; ++wave) {
+        for (int stage = 0; stage <= L + 1; ++stage) {
+            const int b = wave - stage;
+            if (b < 0 || b >= NB) continue;
+            const int t0 = b * lm_block, t1 = std::min(T, t0 + lm_block);
+            if (stage == 0) {
+                lm_stage_embed(m, t0, t1, s_io);
+                HIP_CHECK(hipEventRecord(ev(0, b), s_io));
+            } else if (stage <= L) {
+                hipStream_t st = lm_streams_[(size_t)stage - 1];
+                HIP_CHECK(hipStreamWaitEvent(st, ev(stage - 1, b), 0));
+                lm_stage_layer(stage - 1, m, t0, t1, st);
+                HIP_CHECK(hipEventRecord(ev(stage, b), st));
+            } else {
+                HIP_CHECK(hipStreamWaitEvent(s_io, ev(L, b), 0));
+                lm_stage_proj(m, t0, t1, s_io);
+                HIP_CHECK(hipEventRecord(ev(L + 1, b), s_io));
+            }
+        }
+        const int bg = wave - (L + 2);                                  // the search follows proj by one wave
+        if (bg >= 0 && bg < NB) {
+            HIP_CHECK(hipStreamWaitEvent(stream_, ev(L + 1, bg), 0));
+            for (int t = bg * lm_block; t < std::min(T, (bg + 1) * lm_block); ++t) run_greedy_rounds(m, false, t, eout_lm_ + (size_t)t * m * d.joiner);
+        }
+    }
 }
 
 int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const int *now_ms, float *logits_out)

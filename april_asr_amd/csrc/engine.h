@@ -121,7 +121,10 @@ private:
     void upload_tables(const FbankHostTables &ft);
     void zero_slots(int n);
     void run_encoder_rows(int n, const int *d_slots, const int *d_tails, const float *x_direct);
-    void run_encoder_lm(int m, int T);
+    void lm_stage_embed(int m, int t0, int t1, hipStream_t st);
+    void lm_stage_layer(int l, int m, int t0, int t1, hipStream_t st);
+    void lm_stage_proj(int m, int t0, int t1, hipStream_t st);
+    void lm_resid_ssq(const float *a, int K, size_t w_off, int kz, const float *bias, const float *resid, size_t r0, int rows, hipStream_t st);
     void run_greedy_rounds(int n, bool dump_logits, int chunk = 0, const float *eout_rows = nullptr);
     void run_lm_chain(int m, int T, bool dump_logits);
     void run_decproj(int n, const int *d_slots, const int *row_mask, const int *run_flag, int run_gen);
@@ -143,7 +146,7 @@ private:
     uint8_t *cls_ = nullptr;                   // [vocab] token classes
     int ring_frames_ = 0;
     // work buffers
-    float *xin_ = nullptr, *a3_ = nullptr, *y_ = nullptr, *ssq_ = nullptr, *xb_ = nullptr, *u_ = nullptr, *ff_ = nullptr, *ws_ = nullptr, *de_ = nullptr;
+    float *xin_ = nullptr, *a3_ = nullptr, *y_ = nullptr, *ssq_ = nullptr, *xb_ = nullptr, *u_ = nullptr, *ff_ = nullptr, *ws_ = nullptr, *ws_g_ = nullptr, *de_ = nullptr;
     float *logits_ = nullptr;                  // [3][max_batch][vocab] (traced steps, debug_joiner)
     float *p_lm_ = nullptr, *eout_lm_ = nullptr;   // layer-major: input half of the gates [rows][4 hidden], encoder outputs [rows][joiner] (allocated on first use)
     // step bookkeeping: pinned host rings (read by the advance kernel) + device mirrors
@@ -175,6 +178,8 @@ private:
     bool use_graphs_ = true;
     std::map<int, hipGraphExec_t> step_graphs_;
     std::map<std::pair<int, int>, hipGraphExec_t> lm_graphs_;      // (m, T)
+    std::vector<hipStream_t> lm_streams_;                           // one per layer + one for embed / proj (layer-major pipeline)
+    std::vector<hipEvent_t> lm_events_;
     long kernels_per_step_ = 0, launch_count_ = 0;
     // profiling
     bool profiling_ = false;

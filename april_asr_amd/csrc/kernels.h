@@ -92,6 +92,8 @@ struct GemmArgs {
     //   wave_mask 0b1100 + EPI_LSTM + p_add : ((P + p2) + p3) + bias per time step -- bit-identical to the one-launch form
     int wave_mask = 0xF;
     const float *p_add = nullptr; int ldp = 0;
+    int force_fullk = 0;                   // take the full-K plan even when it yields few workgroups (latency-bound sequential steps: one launch
+                                           // instead of split-K + row kernel matters more than filling the chip)
     int skew = 0;                          // start delay (x 4096 cycles) for every second generation of workgroups
     int asm_loop = 0;                      // != 0: hand-scheduled K loop (gemm_mainloop_asm.inc) in the fused-epilogue 64x64 fp32 tiles
     unsigned long long *trace = nullptr;   // measurement only: per-workgroup s_memtime stamps [wg][8] (wave 0, lane 0)
@@ -102,7 +104,7 @@ void launch_gemm(const GemmArgs &g, hipStream_t s);
 int gemm_partials(int M, int N, int kz);
 // true when launch_gemm runs a GEMM of this shape on the full-K schedule, i.e. the caller may (must, for the row
 // epilogues EPI_HR / EPI_RESID_SSQ / EPI_SLOT_STORE) fuse the row work; false: EPI_PARTIAL + row kernel
-bool gemm_fullk(int M, int N, int kz);
+bool gemm_fullk(int M, int N, int kz, bool force = false);
 
 // ---------------------------------------------------------------- row kernels (one workgroup per row; small-batch path)
 enum RowMode {

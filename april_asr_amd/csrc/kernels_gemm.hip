@@ -606,7 +606,7 @@ static int env_int(const char *name, int def) { const char *v = getenv(name); re
 
 // The full-K schedule pays once output tiles alone occupy a good part of the chip.  Tiles: at most 64x32 (three
 // accumulator-sized register sets: chain, slab, tree level), at least 16x32 (a sum-of-squares granule is 32 columns).
-static bool plan_fullk(int M, int N, int kz, TilePlan &t)
+static bool plan_fullk(int M, int N, int kz, TilePlan &t, bool force = false)
 {
     static const int enabled = env_int("APRIL_FULLK", 1);
     static const int min_wgs = env_int("APRIL_FULLK_MIN_WGS", 96);
@@ -615,22 +615,22 @@ static bool plan_fullk(int M, int N, int kz, TilePlan &t)
     int mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
     while (mt > 1 && (long)ncols * ((M + 16 * mt - 1) / (16 * mt)) < 256) mt >>= 1;
     const long wgs = (long)ncols * ((M + 16 * mt - 1) / (16 * mt));
-    if (wgs < min_wgs) return false;
+    if (wgs < min_wgs && !force) return false;
     t.mt = mt; t.nt = 2; t.zs = kz; t.mode = kz >= 4 ? GM_FULLK : GM_SLAB;    // kz 1 or 2: one workgroup walks the slabs (<= 2 meets)
     return true;
 }
 
-bool gemm_fullk(int M, int N, int kz) { TilePlan t; return plan_fullk(M, N, kz, t); }
+bool gemm_fullk(int M, int N, int kz, bool force) { TilePlan t; return plan_fullk(M, N, kz, t, force); }
 
 // Tile shape and slabs per workgroup.  Depends on M only through occupancy; numerics are tile-independent.
-static TilePlan plan_tiles(int M, int N, int kz, int epi)
+static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = false)
 {
     // measurement knobs (default 0): 1/2 = smaller tiles for the fused-epilogue GEMMs (measured slower on MI355X:
     // B=256 gates 27 -> 32..36 us, the kernel is limited by operand loads per MFMA, not by occupancy);
     // 5 = 64x32 tiles for split-K GEMMs at M > 32
     static const int tune = env_int("APRIL_GEMM_TUNE", 0);
     TilePlan t;
-    if (epi != EPI_LSTM && epi != EPI_BIAS_DSWISH && epi != EPI_XPART && plan_fullk(M, N, kz, t)) return t;
+    if (epi != EPI_LSTM && epi != EPI_BIAS_DSWISH && epi != EPI_XPART && plan_fullk(M, N, kz, t, force_fullk)) return t;
     const int ntiles = N / 16;
     t.mode = GM_SLAB;
     t.mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
@@ -711,7 +711,7 @@ void launch_gemm(const GemmArgs &g_in, hipStream_t s)
     g.debug = dbg;
     static const int skew = env_int("APRIL_GEMM_SKEW", 2);
     static const int asm_loop = env_int("APRIL_GEMM_ASM", 1);     // 0 = compiler-scheduled loop everywhere (A/B)
-    const TilePlan t = plan_tiles(g.M, g.N, g.kz, g.epi);
+    const TilePlan t = plan_tiles(g.M, g.N, g.kz, g.epi, g.force_fullk != 0);
     const bool row_epi = g.epi == EPI_HR || g.epi == EPI_RESID_SSQ || g.epi == EPI_SLOT_STORE;
     if (row_epi && t.zs != g.kz) { fprintf(stderr, "libapril(mi355x): launch_gemm: row epilogue %d needs the full-K plan (M=%d N=%d kz=%d)\n", g.epi, g.M, g.N, g.kz); abort(); }
     g.zs = t.zs; g.mode = t.mode;

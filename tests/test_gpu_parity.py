@@ -195,13 +195,24 @@ def test_layer_major_equals_streaming(which, secs, request):
     pcm = np.concatenate([speech_like_pcm(secs / 2, seed=11), np.zeros(16000, np.int16), speech_like_pcm(secs / 2, seed=12)])
     before = gm.stats().lm_chunks
     ev_s, lg_s, n_s = run_gpu(gm, pcm, 1600)
-    assert gm.stats().lm_chunks == before                      # 100 ms feeds never reach the layer-major threshold
+    assert gm.stats().lm_chunks - before <= 28                 # 100 ms feeds stay below the layer-major threshold (the flush tail may not)
+    mid = gm.stats().lm_chunks
     ev_o, lg_o, n_o = run_gpu(gm, pcm, pcm.size)
     st = gm.stats()
-    assert st.lm_chunks - before >= n_o - 40 and st.replay_mismatch == 0     # all but the flush tail went layer-major
+    assert st.lm_chunks - mid >= n_o - 8 and st.replay_mismatch == 0         # (nearly) everything went layer-major
     assert n_s == n_o
     assert np.array_equal(lg_s, lg_o)
     assert ev_s == ev_o
+    # untraced: the captured, multi-stream pipelined form of the same step (layers overlap across blocks of time steps);
+    # the callbacks carry the emitted tokens' logits bit for bit
+    import april_asr_amd as A
+    ev_p = []
+    s = A.Session(gm, lambda t, toks: ev_p.append((t, toks)), raw_events=True)
+    s.feed_pcm16(pcm); s.flush()
+    n_p = s.chunks()
+    s.close()
+    assert n_p == n_o and ev_p == ev_o
+    assert gm.stats().replay_mismatch == 0
 
 
 def test_layer_major_ragged_group(gpu_tiny):
