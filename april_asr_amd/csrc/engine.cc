@@ -219,6 +219,7 @@ Engine::~Engine()
     for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &g : step_graphs_) (void)hipGraphExecDestroy(g.second);
     for (auto &g : lm_graphs_) (void)hipGraphExecDestroy(g.second);
+    for (auto &g : lm_stage_graphs_) (void)hipGraphExecDestroy(g.second);
     for (hipStream_t st : lm_streams_) (void)hipStreamDestroy(st);
     for (hipEvent_t e : lm_events_) (void)hipEventDestroy(e);
     if (ws_g_) (void)hipFree(ws_g_);
@@ -653,6 +654,28 @@ void Engine::lm_stage_proj(int m, int t0, int t1, hipStream_t st)
     }
 }
 
+// A stage of the pipelined form as a captured single-stream launch chain, replayed on the stage's stream (capturing the
+// whole multi-stream pipeline as ONE graph crashes inside the HIP runtime's capture of ROCm 7.2; stage graphs + runtime
+// events between them cost ~2 graph launches per chunk on the host instead).
+void Engine::lm_run_stage(int kind, int l, int m, int t0, int t1, hipStream_t st, const std::function<void(hipStream_t)> &fn)
+{
+    if (!use_graphs_) { fn(st); return; }
+    const std::array<int, 5> key{{kind, l, m, t0, t1}};
+    auto it = lm_stage_graphs_.find(key);
+    if (it == lm_stage_graphs_.end()) {
+        if (lm_stage_graphs_.size() >= 4096) { for (auto &g : lm_stage_graphs_) (void)hipGraphExecDestroy(g.second); lm_stage_graphs_.clear(); }
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        fn(st);
+        HIP_CHECK(hipStreamEndCapture(st, &graph));
+        HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        HIP_CHECK(hipGraphDestroy(graph));
+        it = lm_stage_graphs_.emplace(key, exec).first;
+    }
+    HIP_CHECK(hipGraphLaunch(it->second, st));
+}
+
 void Engine::run_lm_chain(int m, int T, bool dump_logits)
 {
     const NetDims &d = L_.dims;
@@ -679,15 +702,18 @@ void Engine::run_lm_chain(int m, int T, bool dump_logits)
     // one for embed + proj, the engine's stream for the search; events carry "block b left stage s".  At one session every
     // recurrent kernel is a latency-bound launch: this turns 12 serial chains into 12 concurrent ones.
     const int NB = (T + lm_block - 1) / lm_block;
-    if ((int)lm_streams_.size() < L + 1) {
-        while ((int)lm_streams_.size() < L + 1) { hipStream_t s; HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); lm_streams_.push_back(s); }
-    }
-    const size_t need_ev = (size_t)(L + 2) * NB + 1;
-    while (lm_events_.size() < need_ev) { hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); lm_events_.push_back(e); }
+    // (streams and events exist already: lm_step() creates them before any capture starts)
+    if ((int)lm_streams_.size() < L + 1 || lm_events_.size() < (size_t)(L + 2) * NB + 1) { LOGE("engine: layer-major streams not prepared"); abort(); }
     auto ev = [&](int stage, int b) { return lm_events_[1 + (size_t)stage * NB + b]; };   // stage 0 embed, 1..L layers, L + 1 proj
+    // Measured on ROCm 7.2 (1 session, aprilv0 dims, 60 s in one feed): one stream per layer + one for embed / proj
+    // 131..145 us per chunk (sequential chain: 184); 2, 3, 4 or 6 layer streams with embed / proj on the engine's stream
+    // 147..214; more hardware queues (GPU_MAX_HW_QUEUES = 8, 16) 435..712.  Cross-stream events are expensive here and the
+    // runtime multiplexes streams onto 4 hardware queues, so the overlap stays far below the 12 the dependency graph allows.
+    static const int lm_nstreams = std::max(1, std::min(L, getenv("APRIL_LM_NSTREAMS") ? atoi(getenv("APRIL_LM_NSTREAMS")) : L));
     hipStream_t s_io = lm_streams_[(size_t)L];
     HIP_CHECK(hipEventRecord(lm_events_[0], stream_));                 // the index block is on the device
-    for (int i = 0; i <= L; ++i) HIP_CHECK(hipStreamWaitEvent(lm_streams_[(size_t)i], lm_events_[0], 0));
+    for (int i = 0; i < lm_nstreams; ++i) HIP_CHECK(hipStreamWaitEvent(lm_streams_[(size_t)i], lm_events_[0], 0));
+    HIP_CHECK(hipStreamWaitEvent(s_io, lm_events_[0], 0));
     // enqueue in wavefront order, so that every stream's queue is in the order its stages become ready
     for (int wave = 0; wave < NB + L + 2; ++wave) {
         for (int stage = 0; stage <= L + 1; ++stage) {
@@ -695,23 +721,24 @@ void Engine::run_lm_chain(int m, int T, bool dump_logits)
             if (b < 0 || b >= NB) continue;
             const int t0 = b * lm_block, t1 = std::min(T, t0 + lm_block);
             if (stage == 0) {
-                lm_stage_embed(m, t0, t1, s_io);
+                lm_run_stage(0, 0, m, t0, t1, s_io, [&](hipStream_t st) { lm_stage_embed(m, t0, t1, st); });
                 HIP_CHECK(hipEventRecord(ev(0, b), s_io));
             } else if (stage <= L) {
-                hipStream_t st = lm_streams_[(size_t)stage - 1];
+                hipStream_t st = lm_streams_[(size_t)((stage - 1) % lm_nstreams)];
                 HIP_CHECK(hipStreamWaitEvent(st, ev(stage - 1, b), 0));
-                lm_stage_layer(stage - 1, m, t0, t1, st);
+                lm_run_stage(1, stage - 1, m, t0, t1, st, [&](hipStream_t s2) { lm_stage_layer(stage - 1, m, t0, t1, s2); });
                 HIP_CHECK(hipEventRecord(ev(stage, b), st));
             } else {
                 HIP_CHECK(hipStreamWaitEvent(s_io, ev(L, b), 0));
-                lm_stage_proj(m, t0, t1, s_io);
+                lm_run_stage(2, 0, m, t0, t1, s_io, [&](hipStream_t st) { lm_stage_proj(m, t0, t1, st); });
                 HIP_CHECK(hipEventRecord(ev(L + 1, b), s_io));
             }
         }
         const int bg = wave - (L + 2);                                  // the search follows proj by one wave
         if (bg >= 0 && bg < NB) {
             HIP_CHECK(hipStreamWaitEvent(stream_, ev(L + 1, bg), 0));
-            for (int t = bg * lm_block; t < std::min(T, (bg + 1) * lm_block); ++t) run_greedy_rounds(m, false, t, eout_lm_ + (size_t)t * m * d.joiner);
+            const int g0 = bg * lm_block, g1 = std::min(T, (bg + 1) * lm_block);
+            lm_run_stage(3, 0, m, g0, g1, stream_, [&](hipStream_t) { for (int t = g0; t < g1; ++t) run_greedy_rounds(m, false, t, eout_lm_ + (size_t)t * m * d.joiner); });
         }
     }
 }
@@ -726,6 +753,11 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
         p_lm_ = dmalloc<float>((size_t)cfg_.max_batch * 4 * d.hidden);
         eout_lm_ = dmalloc<float>((size_t)cfg_.max_batch * d.joiner);
     }
+    {   // streams / events of the pipelined form, created outside any stream capture (one event per stage and time step covers every block size)
+        while ((int)lm_streams_.size() < d.n_layers + 1) { hipStream_t st; HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); lm_streams_.push_back(st); }
+        const size_t need_ev = (size_t)(d.n_layers + 2) * T + 1;
+        while (lm_events_.size() < need_ev) { hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); lm_events_.push_back(e); }
+    }
     const int k = steps_++;
     int *blk = ring_h_ + ring_pos_;
     memcpy(blk, slots, (size_t)m * 4);
@@ -734,6 +766,14 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
     for (int t = 0; t < T; ++t) memcpy(blk + m + 2 * rows + (size_t)t * m, slots, (size_t)m * 4);
     step_off_h_[k] = (int)ring_pos_; rec_off_h_[k] = (int)rec_pos_;
     ring_pos_ += (size_t)m + 3 * (size_t)rows; rec_pos_ += (size_t)3 * rows;
+    static const int lm_block_ = std::max(1, getenv("APRIL_LM_BLOCK") ? atoi(getenv("APRIL_LM_BLOCK")) : 7);
+    static const int lm_streams_on = getenv("APRIL_LM_STREAMS") ? atoi(getenv("APRIL_LM_STREAMS")) : 1;
+    const bool pipelined = lm_streams_on != 0 && !profiling_ && !logits_out && T > lm_block_;
+    if (pipelined) {                 // stage graphs on per-layer streams (run_lm_chain)
+        std::lock_guard<std::mutex> cg(capture_mu_);
+        run_lm_chain(m, T, false);
+        return k;
+    }
     if (use_graphs_ && !profiling_ && !logits_out) {
         const std::pair<int, int> key(m, T);
         auto it = lm_graphs_.find(key);

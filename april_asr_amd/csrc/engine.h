@@ -15,6 +15,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <array>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -121,6 +123,7 @@ private:
     void upload_tables(const FbankHostTables &ft);
     void zero_slots(int n);
     void run_encoder_rows(int n, const int *d_slots, const int *d_tails, const float *x_direct);
+    void lm_run_stage(int kind, int l, int m, int t0, int t1, hipStream_t st, const std::function<void(hipStream_t)> &fn);
     void lm_stage_embed(int m, int t0, int t1, hipStream_t st);
     void lm_stage_layer(int l, int m, int t0, int t1, hipStream_t st);
     void lm_stage_proj(int m, int t0, int t1, hipStream_t st);
@@ -178,6 +181,7 @@ private:
     bool use_graphs_ = true;
     std::map<int, hipGraphExec_t> step_graphs_;
     std::map<std::pair<int, int>, hipGraphExec_t> lm_graphs_;      // (m, T)
+    std::map<std::array<int, 5>, hipGraphExec_t> lm_stage_graphs_;   // (kind, layer, m, t0, t1)
     std::vector<hipStream_t> lm_streams_;                           // one per layer + one for embed / proj (layer-major pipeline)
     std::vector<hipEvent_t> lm_events_;
     long kernels_per_step_ = 0, launch_count_ = 0;
