@@ -3,6 +3,9 @@
 // aprilx_* entry points (include/aprilx_engine.h).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include <chrono>
 #include <cstdlib>
 #include <cstdio>
@@ -196,11 +199,25 @@ void free_host_weights(HostModel &h)
 }
 }  // namespace
 
+namespace {
+void crash_backtrace(int sig)
+{
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "libapril(mi355x): fatal signal, native backtrace:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+}  // namespace
+
 extern "C" {
 
 // ------------------------------------------------------------------ reference ABI
 void aam_api_init(int version)
 {
+    if (env_int("APRIL_BACKTRACE", 0)) { signal(SIGSEGV, crash_backtrace); signal(SIGABRT, crash_backtrace); }   // debugging aid
     g_client_version = version;                       // stored, never checked (reference src/init.c:34)
     if (const char *lv = getenv("APRIL_LOG_LEVEL")) {
         static const char *names[5] = {"DEBUG", "INFO", "WARNING", "ERROR", "NONE"};

@@ -709,7 +709,8 @@ void Engine::run_lm_chain(int m, int T, bool dump_logits)
     // 131..145 us per chunk (sequential chain: 184); 2, 3, 4 or 6 layer streams with embed / proj on the engine's stream
     // 147..214; more hardware queues (GPU_MAX_HW_QUEUES = 8, 16) 435..712.  Cross-stream events are expensive here and the
     // runtime multiplexes streams onto 4 hardware queues, so the overlap stays far below the 12 the dependency graph allows.
-    static const int lm_nstreams = std::max(1, std::min(L, getenv("APRIL_LM_NSTREAMS") ? atoi(getenv("APRIL_LM_NSTREAMS")) : L));
+    static const int lm_nstreams_env = getenv("APRIL_LM_NSTREAMS") ? atoi(getenv("APRIL_LM_NSTREAMS")) : 0;
+    const int lm_nstreams = std::max(1, std::min(L, lm_nstreams_env > 0 ? lm_nstreams_env : L));      // per engine: models differ in depth
     hipStream_t s_io = lm_streams_[(size_t)L];
     HIP_CHECK(hipEventRecord(lm_events_[0], stream_));                 // the index block is on the device
     for (int i = 0; i < lm_nstreams; ++i) HIP_CHECK(hipStreamWaitEvent(lm_streams_[(size_t)i], lm_events_[0], 0));

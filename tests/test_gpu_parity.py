@@ -199,7 +199,7 @@ def test_layer_major_equals_streaming(which, secs, request):
     mid = gm.stats().lm_chunks
     ev_o, lg_o, n_o = run_gpu(gm, pcm, pcm.size)
     st = gm.stats()
-    assert st.lm_chunks - mid >= n_o - 8 and st.replay_mismatch == 0         # (nearly) everything went layer-major
+    assert st.lm_chunks - mid >= n_o - 28 - 8 and st.replay_mismatch == 0    # everything but (parts of) the flush tail went layer-major
     assert n_s == n_o
     assert np.array_equal(lg_s, lg_o)
     assert ev_s == ev_o
