@@ -9,8 +9,14 @@
 // "onnx::MatMul_###", so nothing is looked up by name.  The walker lists the
 // weight-bearing nodes (Conv / MatMul / Gemm with a constant operand) in graph
 // order and checks the surrounding operators (DoubleSwish constant, BasicNorm
-// epsilon, gate split order i,f,g,o, state lineage of the recurrent matmul)
-// against what the HIP kernels implement; anything else is rejected with a message.
+// epsilon, the ROLE of every gate -- which product meets the previous cell state --,
+// state lineage of the recurrent matmul) against what the HIP kernels implement;
+// anything else is rejected with a message that names the node it stopped at.
+// Spellings an exporter / constant folder may choose freely are accepted alike and give the
+// same packed weights (tests/test_loader.py): Gemm(transB) or MatMul(+Add), biases on either
+// or both gate products or added after their sum, Split or four Slices (any gate order),
+// constants as initializers / Constant nodes / behind Identity, Cast, Transpose, and
+// Identity / Cast / Dropout nodes anywhere on the activation path.
 #include "model_loader.h"
 #include <cmath>
 #include <cstdio>
@@ -155,11 +161,61 @@ struct View {
         auto it = g.producer.find(v);
         return it == g.producer.end() ? nullptr : &g.nodes[it->second];
     }
-    std::vector<const ONode *> consumers(const std::string &v) const {
+    static bool pass_through(const ONode &n) {      // value-preserving at inference time
+        return (n.op == "Identity" || n.op == "Dropout" || n.op == "Cast") && !n.in.empty() && !n.out.empty();
+    }
+    // consumers of a value, looking through Identity / Dropout / Cast nodes
+    std::vector<const ONode *> consumers(const std::string &v, int depth = 0) const {
         std::vector<const ONode *> r;
         auto range = g.consumers.equal_range(v);
-        for (auto it = range.first; it != range.second; ++it) r.push_back(&g.nodes[it->second]);
+        for (auto it = range.first; it != range.second; ++it) {
+            const ONode *n = &g.nodes[it->second];
+            if (pass_through(*n) && depth < 8) { for (const ONode *c : consumers(n->out[0], depth + 1)) r.push_back(c); }
+            else r.push_back(n);
+        }
         return r;
+    }
+    // the value a node input really carries (producer chain of Identity / Dropout / Cast skipped)
+    std::string source(std::string v) const {
+        for (int guard = 0; guard < 16; ++guard) {
+            const ONode *p = producer(v);
+            if (!p || !pass_through(*p)) return v;
+            v = p->in[0];
+        }
+        return v;
+    }
+    bool same(const std::string &a, const std::string &b) const { return !a.empty() && source(a) == source(b); }
+    static std::string describe(const ONode &n) {
+        std::string s = n.op + " '" + n.name + "' (inputs:";
+        for (auto &i : n.in) s += " " + i;
+        s += "; outputs:";
+        for (auto &o : n.out) s += " " + o;
+        return s + ")";
+    }
+    // a constant float tensor WITH its shape: initializer, Constant node, or one of those behind Identity / Cast /
+    // a 2-D Transpose (constant folding may or may not have removed the transpose of a Linear weight)
+    bool const_tensor(const std::string &v, OTensor &out, int depth = 0) const {
+        if (depth > 8 || v.empty()) return false;
+        auto it = g.inits.find(v);
+        if (it != g.inits.end()) { if (it->second.dtype != 1) return false; out = it->second; return true; }
+        const ONode *p = producer(v);
+        if (!p) return false;
+        if (p->op == "Constant") {
+            const OAttr *a = p->attr("value");
+            if (a && a->has_t && a->t.dtype == 1) { out = a->t; return true; }
+            return false;
+        }
+        if (pass_through(*p)) return const_tensor(p->in[0], out, depth + 1);
+        if (p->op == "Transpose" && !p->in.empty()) {
+            OTensor t;
+            if (!const_tensor(p->in[0], t, depth + 1) || t.dims.size() != 2) return false;
+            const OAttr *pa = p->attr("perm");
+            if (pa && !(pa->ints.size() == 2 && pa->ints[0] == 1 && pa->ints[1] == 0)) return false;
+            out.dtype = 1; out.dims = {t.dims[1], t.dims[0]}; out.f.resize(t.f.size());
+            for (int64_t r = 0; r < t.dims[0]; ++r) for (int64_t c = 0; c < t.dims[1]; ++c) out.f[(size_t)(c * t.dims[0] + r)] = t.f[(size_t)(r * t.dims[1] + c)];
+            return true;
+        }
+        return false;
     }
     // constant tensor behind a value name (initializer, Constant node, or a constant pushed
     // through Identity/Cast/Unsqueeze/Squeeze/Reshape/Exp)
@@ -185,7 +241,7 @@ struct View {
             if ((a = p->attr("value_float"))) { out = {a->f}; if (dims) dims->clear(); return true; }
             return false;
         }
-        if (p->op == "Identity" || p->op == "Cast" || p->op == "Unsqueeze" || p->op == "Squeeze" || p->op == "Reshape")
+        if (p->op == "Identity" || p->op == "Cast" || p->op == "Dropout" || p->op == "Unsqueeze" || p->op == "Squeeze" || p->op == "Reshape")
             return const_floats(arg(*p, 0), out, dims, depth + 1);
         if (p->op == "Exp") {
             if (!const_floats(arg(*p, 0), out, dims, depth + 1)) return false;
@@ -202,7 +258,7 @@ struct View {
             const ONode *p = producer(v);
             if (!p) return v;
             const std::string &op = p->op;
-            if (op == "Unsqueeze" || op == "Squeeze" || op == "Reshape" || op == "Transpose" || op == "Identity" ||
+            if (op == "Unsqueeze" || op == "Squeeze" || op == "Reshape" || op == "Transpose" || op == "Identity" || op == "Dropout" ||
                 op == "Cast" || op == "Slice" || op == "Flatten" || (op == "Concat" && p->in.size() == 1) ||
                 (op == "Gather" && p->in.size() == 2 && is_const(p->in[1])) || (op == "Split" && p->out.size() == 1))
                 v = arg(*p, 0);
@@ -212,9 +268,10 @@ struct View {
     }
 
     bool weighted(const ONode &n) const {
-        if (n.op == "Conv") return n.in.size() >= 2 && g.inits.count(n.in[1]);
-        if (n.op == "MatMul") return n.in.size() == 2 && g.inits.count(n.in[1]) && g.inits.at(n.in[1]).dims.size() == 2;
-        if (n.op == "Gemm") return n.in.size() >= 2 && g.inits.count(n.in[1]);
+        OTensor t;
+        if (n.op == "Conv") return n.in.size() >= 2 && const_tensor(n.in[1], t);
+        if (n.op == "MatMul") return n.in.size() == 2 && const_tensor(n.in[1], t) && t.dims.size() == 2;
+        if (n.op == "Gemm") return n.in.size() >= 2 && const_tensor(n.in[1], t) && t.dims.size() == 2;
         return false;
     }
 
@@ -223,15 +280,15 @@ struct View {
         L.node = idx;
         if (n.in.size() < 2 || n.out.empty()) { err = "linear node without operands (" + n.name + ")"; return false; }
         L.in_value = n.in[0];
-        const OTensor &w = g.inits.at(n.in[1]);
-        if (w.dtype != 1 || w.dims.size() != 2) { err = "linear weight must be a 2-D float tensor (" + n.name + ")"; return false; }
+        OTensor w;
+        if (!const_tensor(n.in[1], w) || w.dims.size() != 2) { err = "linear weight must be a constant 2-D float tensor: " + describe(n); return false; }
         if (n.op == "MatMul") {
             L.K = (int)w.dims[0]; L.N = (int)w.dims[1];
             L.W = w.f;
             L.out_value = n.out[0];
             for (const ONode *c : consumers(n.out[0])) {
                 if (c->op != "Add" || c->in.size() != 2) continue;
-                const std::string &other = c->in[0] == n.out[0] ? c->in[1] : c->in[0];
+                const std::string &other = same(c->in[0], n.out[0]) ? c->in[1] : c->in[0];
                 std::vector<float> b;
                 if (const_floats(other, b) && (int)b.size() == L.N) { L.b = b; L.out_value = c->out[0]; break; }
             }
@@ -239,9 +296,9 @@ struct View {
         }
         if (n.op == "Gemm") {
             const bool tB = n.attr_i("transB", 0) != 0;
-            if (n.attr_i("transA", 0) != 0) { err = "Gemm transA unsupported"; return false; }
+            if (n.attr_i("transA", 0) != 0) { err = "Gemm transA unsupported: " + describe(n); return false; }
             const OAttr *al = n.attr("alpha"), *be = n.attr("beta");
-            if ((al && al->f != 1.0f) || (be && be->f != 1.0f)) { err = "Gemm alpha/beta != 1 unsupported"; return false; }
+            if ((al && al->f != 1.0f) || (be && be->f != 1.0f)) { err = "Gemm alpha/beta != 1 unsupported: " + describe(n); return false; }
             L.K = (int)(tB ? w.dims[1] : w.dims[0]);
             L.N = (int)(tB ? w.dims[0] : w.dims[1]);
             L.W.resize((size_t)L.K * L.N);
@@ -249,10 +306,18 @@ struct View {
             else L.W = w.f;
             if (n.in.size() > 2 && !n.in[2].empty()) {
                 std::vector<float> b;
-                if (!const_floats(n.in[2], b) || (int)b.size() != L.N) { err = "Gemm bias must be a constant of length N"; return false; }
+                if (!const_floats(n.in[2], b) || (int)b.size() != L.N) { err = "Gemm bias must be a constant of length N: " + describe(n); return false; }
                 L.b = b;
             }
             L.out_value = n.out[0];
+            if (L.b.empty()) {            // Gemm without C, bias added by a separate node
+                for (const ONode *c : consumers(n.out[0])) {
+                    if (c->op != "Add" || c->in.size() != 2) continue;
+                    const std::string &other = same(c->in[0], n.out[0]) ? c->in[1] : c->in[0];
+                    std::vector<float> b;
+                    if (const_floats(other, b) && (int)b.size() == L.N) { L.b = b; L.out_value = c->out[0]; break; }
+                }
+            }
             return true;
         }
         err = "not a linear node";
@@ -264,41 +329,57 @@ struct View {
         for (const ONode *c : consumers(y)) {
             float shift = 0; bool ok = false;
             std::vector<float> k;
-            if (c->op == "Sub" && c->in.size() == 2 && c->in[0] == y && const_floats(c->in[1], k) && k.size() == 1) { shift = k[0]; ok = true; }
+            if (c->op == "Sub" && c->in.size() == 2 && same(c->in[0], y) && const_floats(c->in[1], k) && k.size() == 1) { shift = k[0]; ok = true; }
             if (c->op == "Add" && c->in.size() == 2) {
-                const std::string &o = c->in[0] == y ? c->in[1] : c->in[0];
+                const std::string &o = same(c->in[0], y) ? c->in[1] : c->in[0];
                 if (const_floats(o, k) && k.size() == 1) { shift = -k[0]; ok = true; }
             }
             if (!ok) continue;
-            if (fabsf(shift - 1.0f) > 1e-6f) { err = "activation is x*sigmoid(x-c) with c != 1"; return false; }
+            if (fabsf(shift - 1.0f) > 1e-6f) { err = "activation is x*sigmoid(x-c) with c != 1 at " + describe(*c); return false; }
             for (const ONode *s : consumers(res(*c, 0))) if (s->op == "Sigmoid")
-                for (const ONode *m : consumers(res(*s, 0))) if (m->op == "Mul" && m->in.size() == 2 && !m->out.empty() && (m->in[0] == y || m->in[1] == y)) { out = m->out[0]; return true; }
+                for (const ONode *m : consumers(res(*s, 0))) if (m->op == "Mul" && m->in.size() == 2 && !m->out.empty() && (same(m->in[0], y) || same(m->in[1], y))) { out = m->out[0]; return true; }
         }
         err = "expected DoubleSwish (x * sigmoid(x - 1)) after '" + y + "'";
+        for (const ONode *c : consumers(y)) { err += "; found " + describe(*c); break; }
         return false;
     }
 
-    // y -> y * (mean(y^2) + eps)^-0.5 ; returns eps and the output value
+    // y -> y * (mean(y^2) + eps)^-0.5 ; returns eps and the output value.  Spellings of the square: Pow(y, 2) or Mul(y, y);
+    // of the scale: Pow(v, -0.5), Reciprocal(Sqrt(v)), Div(1, Sqrt(v)) followed by Mul(y, .), or Div(y, Sqrt(v)).
     bool basic_norm(const std::string &y, float &eps, std::string &out) {
         for (const ONode *c : consumers(y)) {
             bool sq = false;
             std::vector<float> k;
-            if (c->op == "Pow" && c->in.size() == 2 && c->in[0] == y && const_floats(c->in[1], k) && k.size() == 1 && k[0] == 2.0f) sq = true;
-            if (c->op == "Mul" && c->in.size() == 2 && c->in[0] == y && c->in[1] == y) sq = true;
+            if (c->op == "Pow" && c->in.size() == 2 && same(c->in[0], y) && const_floats(c->in[1], k) && k.size() == 1 && k[0] == 2.0f) sq = true;
+            if (c->op == "Mul" && c->in.size() == 2 && same(c->in[0], y) && same(c->in[1], y)) sq = true;
             if (!sq) continue;
             for (const ONode *rm : consumers(res(*c, 0))) if (rm->op == "ReduceMean")
                 for (const ONode *ad : consumers(res(*rm, 0))) if (ad->op == "Add" && ad->in.size() == 2 && !ad->out.empty()) {
-                    const std::string &o = ad->in[0] == rm->out[0] ? ad->in[1] : ad->in[0];
+                    const std::string &o = same(ad->in[0], rm->out[0]) ? ad->in[1] : ad->in[0];
                     std::vector<float> e;
                     if (!const_floats(o, e) || e.size() != 1) continue;
+                    auto mul_with_y = [&](const std::string &scale) {
+                        for (const ONode *m : consumers(scale)) if (m->op == "Mul" && m->in.size() == 2 && !m->out.empty() && (same(m->in[0], y) || same(m->in[1], y))) { eps = e[0]; out = m->out[0]; return true; }
+                        return false;
+                    };
                     for (const ONode *pw : consumers(ad->out[0])) {
                         std::vector<float> ex;
-                        if (pw->op == "Pow" && const_floats(arg(*pw, 1), ex) && ex.size() == 1 && ex[0] == -0.5f)
-                            for (const ONode *m : consumers(res(*pw, 0))) if (m->op == "Mul" && m->in.size() == 2 && !m->out.empty() && (m->in[0] == y || m->in[1] == y)) { eps = e[0]; out = m->out[0]; return true; }
+                        if (pw->op == "Pow" && const_floats(arg(*pw, 1), ex) && ex.size() == 1 && ex[0] == -0.5f && mul_with_y(res(*pw, 0))) return true;
+                        if (pw->op == "Sqrt") {
+                            for (const ONode *r : consumers(res(*pw, 0))) {
+                                if (r->op == "Reciprocal" && mul_with_y(res(*r, 0))) return true;
+                                if (r->op == "Div" && r->in.size() == 2 && !r->out.empty() && same(r->in[1], pw->out[0])) {
+                                    if (same(r->in[0], y)) { eps = e[0]; out = r->out[0]; return true; }
+                                    std::vector<float> one;
+                                    if (const_floats(r->in[0], one) && one.size() == 1 && one[0] == 1.0f && mul_with_y(r->out[0])) return true;
+                                }
+                            }
+                        }
                     }
                 }
         }
         err = "expected BasicNorm (x * (mean(x^2)+eps)^-0.5) after '" + y + "'";
+        for (const ONode *c : consumers(y)) { err += "; found " + describe(*c); break; }
         return false;
     }
 };
@@ -331,9 +412,10 @@ bool extract_encoder(const OGraph &g, const ModelParams &P, HostModel &M, std::s
     std::string cur;
     for (int i = 0; i < 3; ++i) {
         const ONode &n = g.nodes[wn[i]];
-        if (n.op != "Conv") return fail(err, "encoder: node " + std::to_string(i) + " of the embed stack is not Conv");
-        const OTensor &w = g.inits.at(n.in[1]);
-        if (w.dtype != 1 || w.dims.size() != 4 || w.dims[2] != 3 || w.dims[3] != 3 || w.dims[1] != C) return fail(err, "embed conv must be 3x3 over " + std::to_string(C) + " channels");
+        if (n.op != "Conv") return fail(err, "encoder: node " + std::to_string(i) + " of the embed stack is not Conv but " + View::describe(n));
+        OTensor w;
+        if (!v.const_tensor(n.in[1], w)) return fail(err, "embed conv weight is not a constant: " + View::describe(n));
+        if (w.dims.size() != 4 || w.dims[2] != 3 || w.dims[3] != 3 || w.dims[1] != C) return fail(err, "embed conv must be 3x3 over " + std::to_string(C) + " channels");
         if (n.attr_i("group", 1) != 1) return fail(err, "embed conv group != 1");
         int st = 1;
         if (auto a = n.attr("strides")) { if (a->ints.size() != 2 || a->ints[0] != a->ints[1]) return fail(err, "embed conv strides"); st = (int)a->ints[0]; }
@@ -369,25 +451,95 @@ bool extract_encoder(const OGraph &g, const ModelParams &P, HostModel &M, std::s
         if (a_is_h == b_is_h) return fail(err, "encoder layer " + std::to_string(l) + ": cannot tell input and recurrent gate matmuls apart");
         const Linear &ih = a_is_h ? b : a, &hh = a_is_h ? a : b;
         if (ih.K != d || hh.K != d || ih.N != 4 * Hh || hh.N != 4 * Hh) return fail(err, "encoder layer " + std::to_string(l) + ": gate matmul shapes");
-        // gates = ih + hh -> Split(4) -> sigmoid, sigmoid, tanh, sigmoid
+        // gates = ih + hh (+ bias) -> four equal parts (Split, or four Slices) -> activations.  WHICH part is which gate is
+        // read off the cell update c' = sigma(f) * c_prev + sigma(i) * tanh(g), h = sigma(o) * tanh(c'): the sigmoid whose
+        // product meets the previous cell state is f, the one multiplied with the tanh part is i, the remaining sigmoid
+        // (multiplied with tanh of the new cell) is o.  torch.nn.LSTM order is i,f,g,o, but nothing here depends on it.
+        const std::string lay = "encoder layer " + std::to_string(l) + ": ";
+        std::vector<float> extra_bias;
+        int part_of_gate[4] = {-1, -1, -1, -1};            // gate i,f,g,o -> index of the quarter of the 4H columns
         {
             const ONode *sum = nullptr;
-            for (const ONode *c : v.consumers(ih.out_value)) if (c->op == "Add" && (c->in[0] == hh.out_value || c->in[1] == hh.out_value)) sum = c;
-            if (!sum) return fail(err, "encoder layer " + std::to_string(l) + ": gate pre-activations are not summed by one Add");
+            for (const ONode *c : v.consumers(ih.out_value)) if (c->op == "Add" && c->in.size() == 2 && (v.same(c->in[0], hh.out_value) || v.same(c->in[1], hh.out_value))) sum = c;
+            if (!sum) {
+                std::string found;
+                for (const ONode *c : v.consumers(ih.out_value)) { found = "; the input product feeds " + View::describe(*c); break; }
+                return fail(err, lay + "gate pre-activations are not summed by one Add" + found);
+            }
+            std::string gates = sum->out[0];
+            for (const ONode *c : v.consumers(gates)) {        // bias added after the sum
+                if (c->op != "Add" || c->in.size() != 2) continue;
+                const std::string &o = v.same(c->in[0], gates) ? c->in[1] : c->in[0];
+                std::vector<float> b;
+                if (v.const_floats(o, b) && (int)b.size() == 4 * Hh) { extra_bias = b; gates = c->out[0]; break; }
+            }
+            std::string part[4];
             const ONode *split = nullptr;
-            for (const ONode *c : v.consumers(sum->out[0])) if (c->op == "Split") split = c;
-            if (!split || split->out.size() != 4) return fail(err, "encoder layer " + std::to_string(l) + ": expected Split into 4 gates");
-            static const char *want[4] = {"Sigmoid", "Sigmoid", "Tanh", "Sigmoid"};
+            for (const ONode *c : v.consumers(gates)) if (c->op == "Split") split = c;
+            if (split) {
+                if (split->out.size() != 4) return fail(err, lay + "expected 4 gate parts: " + View::describe(*split));
+                if (const OAttr *sp = split->attr("split")) for (auto x : sp->ints) if (x != Hh) return fail(err, lay + "unequal gate parts: " + View::describe(*split));
+                for (int k = 0; k < 4; ++k) part[k] = split->out[k];
+            } else {
+                int seen = 0;
+                for (const ONode *c : v.consumers(gates)) {
+                    if (c->op != "Slice" || c->out.empty()) continue;
+                    std::vector<float> st, en;
+                    if (c->in.size() >= 3) { if (!v.const_floats(c->in[1], st) || !v.const_floats(c->in[2], en)) continue; }
+                    else { const OAttr *a = c->attr("starts"), *b = c->attr("ends"); if (!a || !b) continue; for (auto x : a->ints) st.push_back((float)x); for (auto x : b->ints) en.push_back((float)x); }
+                    if (st.size() != 1 || en.size() != 1) continue;
+                    const long s0 = (long)st[0], e0 = (long)en[0];
+                    if (s0 % Hh != 0 || s0 < 0 || s0 >= 4L * Hh || !(e0 == s0 + Hh || (s0 == 3L * Hh && e0 >= 4L * Hh))) return fail(err, lay + "gate Slice bounds: " + View::describe(*c));
+                    part[s0 / Hh] = c->out[0]; ++seen;
+                }
+                if (seen != 4) {
+                    std::string found;
+                    for (const ONode *c : v.consumers(gates)) { found = "; the sum feeds " + View::describe(*c); break; }
+                    return fail(err, lay + "expected Split (or four Slices) of the gate pre-activations" + found);
+                }
+            }
+            std::string act_out[4], act_op[4];
             for (int k = 0; k < 4; ++k) {
-                auto cs = v.consumers(split->out[k]);
-                if (cs.size() != 1 || cs[0]->op != want[k]) return fail(err, "encoder layer " + std::to_string(l) + ": gate order is not i,f,g,o");
+                auto cs = v.consumers(part[k]);
+                if (cs.size() != 1 || (cs[0]->op != "Sigmoid" && cs[0]->op != "Tanh") || cs[0]->out.empty())
+                    return fail(err, lay + "gate part " + std::to_string(k) + " must feed exactly one Sigmoid or Tanh" + (cs.empty() ? std::string() : ", found " + View::describe(*cs[0])));
+                act_op[k] = cs[0]->op; act_out[k] = cs[0]->out[0];
+            }
+            int tanh_part = -1, n_tanh = 0;
+            for (int k = 0; k < 4; ++k) if (act_op[k] == "Tanh") { tanh_part = k; ++n_tanh; }
+            if (n_tanh != 1) return fail(err, lay + "expected three sigmoid gates and one tanh gate");
+            part_of_gate[2] = tanh_part;
+            for (int k = 0; k < 4; ++k) {
+                if (k == tanh_part) continue;
+                int role = -1;
+                for (const ONode *m : v.consumers(act_out[k])) {
+                    if (m->op != "Mul" || m->in.size() != 2) continue;
+                    const std::string &other = v.same(m->in[0], act_out[k]) ? m->in[1] : m->in[0];
+                    if (v.lineage(other) == ci.name) role = 1;                                  // * c_prev  -> forget gate
+                    else if (v.same(other, act_out[tanh_part])) role = 0;                       // * tanh(g) -> input gate
+                    else { const ONode *pp = v.producer(v.source(other)); if (pp && pp->op == "Tanh") role = 3; }   // * tanh(c') -> output gate
+                }
+                if (role < 0 || part_of_gate[role] >= 0) return fail(err, lay + "cannot tell the role of gate part " + std::to_string(k) + " from the cell update");
+                part_of_gate[role] = k;
             }
         }
-        lw.w_gates.resize((size_t)2 * d * 4 * Hh);
-        memcpy(lw.w_gates.data(), ih.W.data(), ih.W.size() * 4);
-        memcpy(lw.w_gates.data() + ih.W.size(), hh.W.data(), hh.W.size() * 4);
+        // canonical column order i,f,g,o
+        lw.w_gates.assign((size_t)2 * d * 4 * Hh, 0.0f);
         lw.b_gates.assign((size_t)4 * Hh, 0.0f);
-        for (int k = 0; k < 4 * Hh; ++k) lw.b_gates[(size_t)k] = (ih.b.empty() ? 0.0f : ih.b[(size_t)k]) + (hh.b.empty() ? 0.0f : hh.b[(size_t)k]);
+        for (int gate = 0; gate < 4; ++gate) {
+            const int src = part_of_gate[gate];
+            for (int k = 0; k < d; ++k) {
+                memcpy(&lw.w_gates[((size_t)k) * 4 * Hh + (size_t)gate * Hh], &ih.W[(size_t)k * 4 * Hh + (size_t)src * Hh], (size_t)Hh * 4);
+                memcpy(&lw.w_gates[((size_t)(d + k)) * 4 * Hh + (size_t)gate * Hh], &hh.W[(size_t)k * 4 * Hh + (size_t)src * Hh], (size_t)Hh * 4);
+            }
+            for (int u = 0; u < Hh; ++u) {
+                const size_t sidx = (size_t)src * Hh + u;
+                // (b_ih + b_hh) first, a bias added after the sum last: any spelling of the same three terms gives these bits
+                float b = (ih.b.empty() ? 0.0f : ih.b[sidx]) + (hh.b.empty() ? 0.0f : hh.b[sidx]);
+                if (!extra_bias.empty()) b += extra_bias[sidx];
+                lw.b_gates[(size_t)gate * Hh + u] = b;
+            }
+        }
         if (hr.K != Hh || hr.N != d || !hr.b.empty()) return fail(err, "encoder layer " + std::to_string(l) + ": projection matmul shape");
         lw.w_hr = hr.W;
         if (f1.K != d || f2.N != d || f1.N != f2.K) return fail(err, "encoder layer " + std::to_string(l) + ": feed-forward shapes");
@@ -398,7 +550,7 @@ bool extract_encoder(const OGraph &g, const ModelParams &P, HostModel &M, std::s
         if (!v.double_swish(f1.out_value, act)) return fail(err, "encoder layer " + std::to_string(l) + ": " + v.err);
         // residual add after ff2, then BasicNorm
         bool normed = false;
-        for (const ONode *c : v.consumers(f2.out_value)) if (c->op == "Add") {
+        for (const ONode *c : v.consumers(f2.out_value)) if (c->op == "Add" && !c->out.empty()) {
             std::string o;
             if (v.basic_norm(c->out[0], lw.norm_eps, o)) { normed = true; break; }
         }
@@ -407,7 +559,7 @@ bool extract_encoder(const OGraph &g, const ModelParams &P, HostModel &M, std::s
     Linear ep;
     if (!v.linear_at(wn.back(), ep)) return fail(err, "encoder_proj: " + v.err);
     if (ep.K != d || ep.N != D.joiner) return fail(err, "encoder_proj shape");
-    if (ep.out_value != g.outputs[0].name) return fail(err, "encoder_proj does not produce the first graph output");
+    if (!v.same(ep.out_value, g.outputs[0].name)) return fail(err, "encoder_proj does not produce the first graph output");
     M.w_encproj = ep.W; M.b_encproj = ep.b.empty() ? std::vector<float>((size_t)ep.N, 0.0f) : ep.b;
     return true;
 }
@@ -423,19 +575,20 @@ bool extract_decoder(const OGraph &g, HostModel &M, std::string &err)
     const ONode *gather = nullptr, *conv = nullptr; bool relu = false; int mm = -1;
     for (size_t i = 0; i < g.nodes.size(); ++i) {
         const ONode &n = g.nodes[i];
-        if (n.op == "Gather" && !n.in.empty() && g.inits.count(n.in[0]) && g.inits.at(n.in[0]).dims.size() == 2) gather = &n;
+        OTensor tt;
+        if (n.op == "Gather" && !n.in.empty() && v.const_tensor(n.in[0], tt) && tt.dims.size() == 2) gather = &n;
         else if (n.op == "Conv") conv = &n;
         else if (n.op == "Relu") relu = true;
         else if (v.weighted(n) && n.op != "Conv") mm = (int)i;
     }
     if (!gather || !conv || !relu || mm < 0) return fail(err, "decoder: expected Gather(embedding) -> Conv -> Relu -> Linear");
-    const OTensor &emb = g.inits.at(gather->in[0]);
-    if (emb.dtype != 1 || emb.f.size() != emb.numel()) return fail(err, "decoder embedding table must be float32");
+    OTensor emb;
+    if (!v.const_tensor(gather->in[0], emb) || emb.f.size() != emb.numel()) return fail(err, "decoder embedding table must be float32");
     M.emb = emb.f;
     const int V = (int)emb.dims[0], dd = (int)emb.dims[1];
-    if (conv->in.size() < 2 || !g.inits.count(conv->in[1])) return fail(err, "decoder conv weight must be an initializer");
-    const OTensor &cw = g.inits.at(conv->in[1]);
-    if (cw.dtype != 1 || cw.dims.size() != 3 || cw.dims[0] != dd || cw.dims[2] != D.context) return fail(err, "decoder conv weight shape");
+    OTensor cw;
+    if (conv->in.size() < 2 || !v.const_tensor(conv->in[1], cw)) return fail(err, "decoder conv weight must be a constant: " + View::describe(*conv));
+    if (cw.dims.size() != 3 || cw.dims[0] != dd || cw.dims[2] != D.context) return fail(err, "decoder conv weight shape");
     D.dec_groups = (int)conv->attr_i("group", 1);
     if (cw.dims[1] * D.dec_groups != dd) return fail(err, "decoder conv groups do not divide channels");
     M.dec_conv = cw.f;
@@ -443,7 +596,7 @@ bool extract_decoder(const OGraph &g, HostModel &M, std::string &err)
     Linear p;
     if (!v.linear_at(mm, p)) return fail(err, "decoder_proj: " + v.err);
     if (p.K != dd) return fail(err, "decoder_proj input width");
-    if (p.out_value != g.outputs[0].name) return fail(err, "decoder_proj does not produce the graph output");
+    if (!v.same(p.out_value, g.outputs[0].name)) return fail(err, "decoder_proj does not produce the graph output");
     M.w_decproj = p.W; M.b_decproj = p.b.empty() ? std::vector<float>((size_t)p.N, 0.0f) : p.b;
     if (dd != D.d_model) return fail(err, "decoder embedding width must equal encoder d_model in this engine");
     if (p.N != D.joiner) return fail(err, "decoder_out width differs from encoder_out width");
@@ -466,7 +619,7 @@ bool extract_joiner(const OGraph &g, HostModel &M, std::string &err)
     if (!v.linear_at(mm, o)) return fail(err, "joiner output linear: " + v.err);
     if (o.K != D.joiner) return fail(err, "joiner input width");
     if (o.N != D.vocab) return fail(err, "joiner vocabulary differs from the decoder embedding table");
-    if (o.out_value != g.outputs[0].name) return fail(err, "joiner linear does not produce the graph output");
+    if (!v.same(o.out_value, g.outputs[0].name)) return fail(err, "joiner linear does not produce the graph output");
     if (g.outputs[0].dims.size() != 3) return fail(err, "logits must be rank 3");
     M.w_out = o.W; M.b_out = o.b.empty() ? std::vector<float>((size_t)o.N, 0.0f) : o.b;
     return true;

@@ -198,29 +198,88 @@ def make_weights(dims, seed=2023, joiner_gain=6.0, blank_bias=4.7, blank_id=0):
     return w
 
 
+# Spelling knobs (the `variant` dict of write_model / build_*; every combination describes the SAME network and must load
+# to the SAME packed weights, tests/test_loader.py):
+#   lstm_gemm   True: gate products as Gemm(transB=1) | False: MatMul (+ Add)
+#   gemm_bias   "both" | "separate" (bias added by an Add node after each product) | "single" (b_ih + b_hh folded onto the
+#               input product) | "after_sum" (b_ih + b_hh added after the two products were summed)
+#   gate_split  "split" | "slice" (four Slice nodes with constant inputs, opset >= 10) | "slice_attr" (opset < 10 attributes)
+#   gate_order  a permutation of "ifgo": order of the gate blocks in the weight rows (torch.nn.LSTM: "ifgo")
+#   fold_eps    BasicNorm epsilon as a folded constant | Exp(initializer)
+#   norm        "pow" | "mulself" (x * x) | "sqrt_recip" (Reciprocal(Sqrt)) | "div_sqrt" (x / Sqrt)
+#   swish       "sub" (x - 1) | "add_neg" (x + (-1))
+#   passthrough Identity / Cast / Dropout nodes on the activation path and in front of constants
+#   const_nodes small tensors and the conv weights as Constant nodes instead of initializers
+#   w_transpose Linear weights stored [out, in] behind a Transpose node (constant folding switched off)
+#   state_index "slice" | "gather" (per-layer state through Gather + Unsqueeze)
+_V = {}
+
+
+def _variant(variant):
+    _V.clear()
+    _V.update(variant or {})
+
+
+def _pt(g, x, kind="Identity"):
+    """optional value-preserving node"""
+    if not _V.get("passthrough"):
+        return x
+    if kind == "Cast":
+        return g.node("Cast", [x], to=1)
+    if kind == "Dropout":
+        return g.node("Dropout", [x], ratio=0.1)
+    return g.node("Identity", [x])
+
+
+def _small(g, name, arr):
+    """bias-sized constants: initializer, or Constant node"""
+    if _V.get("const_nodes"):
+        return g.const(np.asarray(arr))
+    c = g.init(name, np.asarray(arr))
+    return g.node("Identity", [c]) if _V.get("passthrough") else c
+
+
 def _double_swish(g, x):
-    one = g.const(np.array(1.0, np.float32))
-    return g.node("Mul", [x, g.node("Sigmoid", [g.node("Sub", [x, one])])])
+    if _V.get("swish", "sub") == "add_neg":
+        shifted = g.node("Add", [x, g.const(np.array(-1.0, np.float32))])
+    else:
+        shifted = g.node("Sub", [x, g.const(np.array(1.0, np.float32))])
+    return g.node("Mul", [x, g.node("Sigmoid", [shifted])])
 
 
 def _basic_norm(g, x, eps_log, name, fold):
-    sq = g.node("Pow", [x, g.const(np.array(2.0, np.float32))])
+    how = _V.get("norm", "pow")
+    sq = g.node("Mul", [x, x]) if how == "mulself" else g.node("Pow", [x, g.const(np.array(2.0, np.float32))])
     mean = g.node("ReduceMean", [sq], axes=[-1], keepdims=1)
     if fold:
         e = g.const(np.array(np.exp(np.float32(eps_log)), np.float32))
     else:
         e = g.node("Exp", [g.init(name + ".eps", np.array(eps_log, np.float32))])
-    scale = g.node("Pow", [g.node("Add", [mean, e]), g.const(np.array(-0.5, np.float32))])
+    v = g.node("Add", [mean, e])
+    if how == "sqrt_recip":
+        return g.node("Mul", [x, g.node("Reciprocal", [g.node("Sqrt", [v])])])
+    if how == "div_sqrt":
+        return g.node("Div", [x, g.node("Sqrt", [v])])
+    scale = g.node("Pow", [v, g.const(np.array(-0.5, np.float32))])
     return g.node("Mul", [x, scale])
+
+
+def _wconst(g, name, w_out_in):
+    """a Linear weight given [out, in] as the [in, out] operand of a MatMul"""
+    if _V.get("w_transpose"):
+        return g.node("Transpose", [g.init(name, np.ascontiguousarray(w_out_in))], perm=[1, 0])
+    c = g.init("onnx::MatMul_" + name, np.ascontiguousarray(w_out_in.T))
+    return g.node("Identity", [c]) if _V.get("passthrough") else c
 
 
 def _linear3d(g, x, w, b, name):
     """nn.Linear on a 3-D input: MatMul with the transposed weight as initializer, then Add(bias)."""
-    y = g.node("MatMul", [x, g.init("onnx::MatMul_" + name, np.ascontiguousarray(w.T))])
-    return g.node("Add", [g.init(name + ".bias", b), y]) if b is not None else y
+    y = g.node("MatMul", [x, _wconst(g, name, w)])
+    return g.node("Add", [_small(g, name + ".bias", b), y]) if b is not None else y
 
 
 def build_encoder(dims, w, variant):
+    _variant(variant)
     g = GraphBuilder("torch_jit")
     L, d, H = dims["n_layers"], dims["d_model"], dims["hidden"]
     T, mel = dims["seg"], dims["mel"]
@@ -231,9 +290,9 @@ def build_encoder(dims, w, variant):
     t = g.node("Unsqueeze", ["x"], axes=[1])
     for i, stride in enumerate((1, 2, 2)):
         attrs = dict(dilations=[1, 1], group=1, kernel_shape=[3, 3], pads=[0, 0, 0, 0], strides=[stride, stride])
-        t = g.node("Conv", [t, g.init("encoder.encoder_embed.conv.%d.weight" % (3 * i), w["conv%d.w" % i]),
-                            g.init("encoder.encoder_embed.conv.%d.bias" % (3 * i), w["conv%d.b" % i])], **attrs)
-        t = _double_swish(g, t)
+        cw = g.const(w["conv%d.w" % i]) if _V.get("const_nodes") else g.init("encoder.encoder_embed.conv.%d.weight" % (3 * i), w["conv%d.w" % i])
+        t = g.node("Conv", [t, cw, _small(g, "encoder.encoder_embed.conv.%d.bias" % (3 * i), w["conv%d.b" % i])], **attrs)
+        t = _double_swish(g, _pt(g, t))
     c3 = dims["conv_ch"][2]
     f_out = ((mel - 3) // 2 - 1) // 2
     t_out = ((T - 3) // 2 - 1) // 2
@@ -247,46 +306,75 @@ def build_encoder(dims, w, variant):
         p = "l%d." % l
         nm = "encoder.encoder.layers.%d" % l
         def sl(inp):
+            if _V.get("state_index", "slice") == "gather":
+                return g.node("Unsqueeze", [g.node("Gather", [inp, g.const(np.array(l, np.int64))], axis=0)], axes=[0])
             return g.node("Slice", [inp, g.const(np.array([l], np.int64)), g.const(np.array([l + 1], np.int64)),
                                     g.const(np.array([0], np.int64)), g.const(np.array([1], np.int64))])
         h_l, c_l = sl("h"), sl("c")
         x_t = g.node("Gather", [src, g.const(np.array(0, np.int64))], axis=0)
         h0 = g.node("Squeeze", [h_l], axes=[0])
-        c0 = g.node("Squeeze", [c_l], axes=[0])
-        if variant.get("lstm_gemm", True):
-            g1 = g.node("Gemm", [x_t, g.init(nm + ".lstm.w_ih", w[p + "w_ih"]), g.init(nm + ".lstm.b_ih", w[p + "b_ih"])],
-                        alpha=1.0, beta=1.0, transB=1)
-            g2 = g.node("Gemm", [h0, g.init(nm + ".lstm.w_hh", w[p + "w_hh"]), g.init(nm + ".lstm.b_hh", w[p + "b_hh"])],
-                        alpha=1.0, beta=1.0, transB=1)
-        else:
-            g1 = g.node("Add", [g.node("MatMul", [x_t, g.init(nm + ".lstm.w_ih_t", np.ascontiguousarray(w[p + "w_ih"].T))]),
-                                g.init(nm + ".lstm.b_ih", w[p + "b_ih"])])
-            g2 = g.node("Add", [g.node("MatMul", [h0, g.init(nm + ".lstm.w_hh_t", np.ascontiguousarray(w[p + "w_hh"].T))]),
-                                g.init(nm + ".lstm.b_hh", w[p + "b_hh"])])
+        c0 = _pt(g, g.node("Squeeze", [c_l], axes=[0]))
+        # gate blocks in the order the variant asks for (rows of the [4H, d] weights)
+        order = _V.get("gate_order", "ifgo")
+        blk = ["ifgo".index(ch) for ch in order]
+        def perm_rows(a):
+            return np.ascontiguousarray(np.concatenate([a[k * H:(k + 1) * H] for k in blk], 0))
+        w_ih, w_hh, b_ih, b_hh = perm_rows(w[p + "w_ih"]), perm_rows(w[p + "w_hh"]), perm_rows(w[p + "b_ih"]), perm_rows(w[p + "b_hh"])
+        bias_mode = _V.get("gemm_bias", "both")
+        b_sum = (b_ih + b_hh).astype(np.float32)
+        def product(x_in, wt, b, tag):
+            bb = {"both": b, "separate": None, "single": (b_sum if tag == "ih" else None), "after_sum": None}[bias_mode]
+            if _V.get("lstm_gemm", True):
+                ins = [x_in, g.init(nm + ".lstm.w_" + tag, wt)] + ([_small(g, nm + ".lstm.b_" + tag, bb)] if bb is not None else [])
+                y = g.node("Gemm", ins, alpha=1.0, beta=1.0, transB=1)
+            else:
+                y = g.node("MatMul", [x_in, g.init(nm + ".lstm.w_" + tag + "_t", np.ascontiguousarray(wt.T))])
+                if bb is not None:
+                    y = g.node("Add", [y, _small(g, nm + ".lstm.b_" + tag, bb)])
+            if bias_mode == "separate":
+                y = g.node("Add", [y, _small(g, nm + ".lstm.b_" + tag, b)])
+            return y
+        g1 = product(x_t, w_ih, b_ih, "ih")
+        g2 = product(h0, w_hh, b_hh, "hh")
         gates = g.node("Add", [g1, g2])
-        gi, gf, gg, go = g.node("Split", [gates], n_out=4, axis=1, split=[H] * 4)
-        si, sf, tg, so = g.node("Sigmoid", [gi]), g.node("Sigmoid", [gf]), g.node("Tanh", [gg]), g.node("Sigmoid", [go])
+        if bias_mode == "after_sum":
+            gates = g.node("Add", [gates, _small(g, nm + ".lstm.b_sum", b_sum)])
+        gates = _pt(g, gates)
+        how = _V.get("gate_split", "split")
+        if how == "split":
+            parts = g.node("Split", [gates], n_out=4, axis=1, split=[H] * 4)
+        elif how == "slice":
+            parts = [g.node("Slice", [gates, g.const(np.array([k * H], np.int64)), g.const(np.array([(k + 1) * H], np.int64)),
+                                      g.const(np.array([1], np.int64)), g.const(np.array([1], np.int64))]) for k in range(4)]
+        else:
+            parts = [g.node("Slice", [gates], axes=[1], starts=[k * H], ends=[(k + 1) * H]) for k in range(4)]
+        byname = {ch: parts[k] for k, ch in enumerate(order)}
+        si, sf, tg, so = g.node("Sigmoid", [byname["i"]]), g.node("Sigmoid", [byname["f"]]), g.node("Tanh", [byname["g"]]), g.node("Sigmoid", [byname["o"]])
         c1 = g.node("Add", [g.node("Mul", [sf, c0]), g.node("Mul", [si, tg])])
         hh = g.node("Mul", [so, g.node("Tanh", [c1])])
-        h1 = g.node("MatMul", [hh, g.init("onnx::MatMul_" + nm + ".lstm.w_hr", np.ascontiguousarray(w[p + "w_hr"].T))])
+        h1 = g.node("MatMul", [hh, _wconst(g, nm + ".lstm.w_hr", w[p + "w_hr"])])
         ys = g.node("Concat", [g.node("Unsqueeze", [h1], axes=[0])], axis=0)
         new_h.append(g.node("Unsqueeze", [h1], axes=[0]))
         new_c.append(g.node("Unsqueeze", [c1], axes=[0]))
-        src1 = g.node("Add", [ys, src])
+        src1 = _pt(g, g.node("Add", [ys, src]), "Cast")
         ff = _linear3d(g, src1, w[p + "ff1.w"], w[p + "ff1.b"], nm + ".feed_forward.0")
-        ff = _double_swish(g, ff)
+        ff = _pt(g, _double_swish(g, ff), "Dropout")
         ff = _linear3d(g, ff, w[p + "ff2.w"], w[p + "ff2.b"], nm + ".feed_forward.4")
-        src2 = g.node("Add", [src1, ff])
+        src2 = g.node("Add", [src1, _pt(g, ff, "Dropout")])
         src = _basic_norm(g, src2, w[p + "eps"], nm + ".norm_final", fold)
     g.node_named("Concat", new_h, ["next_h"], axis=0)
     g.node_named("Concat", new_c, ["next_c"], axis=0)
     t = g.node("Transpose", [src], perm=[1, 0, 2])
-    y = g.node("MatMul", [t, g.init("onnx::MatMul_encoder_proj", np.ascontiguousarray(w["enc_proj.w"].T))])
-    g.node_named("Add", [g.init("encoder_proj.bias", w["enc_proj.b"]), y], ["encoder_out"])
+    y = g.node("MatMul", [t, _wconst(g, "encoder_proj", w["enc_proj.w"])])
+    if _V.get("passthrough"):
+        g.node_named("Identity", [g.node("Add", [_small(g, "encoder_proj.bias", w["enc_proj.b"]), y])], ["encoder_out"])
+    else:
+        g.node_named("Add", [_small(g, "encoder_proj.bias", w["enc_proj.b"]), y], ["encoder_out"])
     return g.model_bytes()
 
 
 def build_decoder(dims, w, variant):
+    _variant(variant)
     g = GraphBuilder("torch_jit")
     d, J, ctx = dims["d_model"], dims["joiner"], dims["context"]
     g.inputs = [value_info("context", INT64, (1, ctx))]
@@ -297,19 +385,20 @@ def build_decoder(dims, w, variant):
                kernel_shape=[ctx], pads=[0, 0], strides=[1])
     e = g.node("Transpose", [e], perm=[0, 2, 1])
     e = g.node("Relu", [e])
-    y = g.node("MatMul", [e, g.init("onnx::MatMul_decoder_proj", np.ascontiguousarray(w["dec_proj.w"].T))])
-    g.node_named("Add", [g.init("decoder_proj.bias", w["dec_proj.b"]), y], ["decoder_out"])
+    y = g.node("MatMul", [_pt(g, e), _wconst(g, "decoder_proj", w["dec_proj.w"])])
+    g.node_named("Add", [_small(g, "decoder_proj.bias", w["dec_proj.b"]), y], ["decoder_out"])
     return g.model_bytes()
 
 
 def build_joiner(dims, w, variant):
+    _variant(variant)
     g = GraphBuilder("torch_jit")
     J, V = dims["joiner"], dims["vocab"]
     g.inputs = [value_info("encoder_out", FLOAT, (1, 1, J)), value_info("decoder_out", FLOAT, (1, 1, J))]
     g.outputs = [value_info("logits", FLOAT, (1, 1, V))]
     t = g.node("Tanh", [g.node("Add", ["encoder_out", "decoder_out"])])
-    y = g.node("MatMul", [t, g.init("onnx::MatMul_output_linear", np.ascontiguousarray(w["out.w"].T))])
-    g.node_named("Add", [g.init("output_linear.bias", w["out.b"]), y], ["logits"])
+    y = g.node("MatMul", [_pt(g, t), _wconst(g, "output_linear", w["out.w"])])
+    g.node_named("Add", [_small(g, "output_linear.bias", w["out.b"]), y], ["logits"])
     return g.model_bytes()
 
 

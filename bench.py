@@ -276,6 +276,23 @@ def main():
                          "%d chunks, no flush; ONNXRuntime (the reference's backend) is not installed here" % (sample_s, osess.chunks()),
                "rtf": round((b - a) / sample_s, 4), "host_cpus": os.cpu_count()}
         osess.close(); om.close()
+        # the reference's own backend, when the host has it: ONNXRuntime CPU, intra = inter = 1, through
+        # the same session driver; only meaningful with a model whose graphs ORT can run (APRIL_MODEL = a real export)
+        from oracle import ort_leg as OL
+        if OL.available():
+            try:
+                rs = OL.OrtSession(path)
+                a = time.perf_counter()
+                for o in range(0, p.size, step_samples):
+                    rs.feed(p[o:o + step_samples])
+                b = time.perf_counter()
+                cpu["onnxruntime_cpu"] = {"value": round(sample_s / (b - a), 4), "unit": "audio_seconds_per_second", "cores": 1, "rtf": round((b - a) / sample_s, 4),
+                                          "sample": "onnxruntime CPUExecutionProvider, 1 thread, 1 session, the same %.0f s of audio, %d chunks" % (sample_s, rs.chunks())}
+                rs.close()
+            except Exception as e:
+                cpu["onnxruntime_cpu"] = {"error": repr(e)}
+        else:
+            cpu["onnxruntime_cpu"] = None       # not installed on this host: CPU baseline = the in-repo restatement only
         # the same port on many cores at once (one process, one session, one thread each -- how the reference would be
         # scaled on a CPU host: its ORT sessions run intra=inter=1, april_model.c:54-55)
         import subprocess

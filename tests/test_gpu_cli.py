@@ -51,3 +51,45 @@ def test_main_cli_matches_oracle(tiny_model, tmp_path, container):
     want = render(s.events, om.token)
     assert got == want and len(got) > 3 and all(l == "" or l[:2] in ("- ", "@ ") for l in got)
     s.close(); om.close()
+
+
+def _stamp(ms):
+    """hh:mm:ss,mmm as the reference's example_srt.cpp computes it (units peeled off while the remainder EXCEEDS a unit)."""
+    out = []
+    for unit in (3600 * 1000, 60 * 1000, 1000):
+        n = (ms - 1) // unit if ms > unit else 0
+        ms -= n * unit
+        out.append(n)
+    return "%02d:%02d:%02d,%03d" % (out[0], out[1], out[2], ms)
+
+
+def test_srt_cli_matches_oracle(tiny_model, tmp_path):
+    """the ./srt-style client (examples/srt.cpp, reference example_srt.cpp:57-129): one cue per
+    token of every FINAL result, timed by AprilToken.time_ms; the whole file goes in ONE feed (layer-major schedule).  Expected
+    cues are rendered from the oracle's transcript."""
+    from oracle import orc_py as O
+    exe = str(tmp_path / "srt")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "examples", "srt.cpp"), "-I", os.path.join(ROOT, "include"),
+                           "-L", os.path.join(ROOT, "april_asr_amd"), "-laprilasr", "-Wl,-rpath," + os.path.join(ROOT, "april_asr_amd"), "-o", exe])
+    pcm = np.concatenate([speech_like_pcm(3.0, seed=12), np.zeros(16000 * 3, np.int16), speech_like_pcm(2.0, seed=13), np.zeros(16000 * 3, np.int16)])
+    path = str(tmp_path / "audio.raw")
+    pcm.tofile(path)
+    out = subprocess.run([exe, path, tiny_model["path"]], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert out.returncode == 0, out.stderr.decode()
+    om = O.Model(tiny_model["path"])
+    s = O.Session(om)
+    for o in range(0, pcm.size, 1600):
+        s.feed(pcm[o:o + 1600])
+    s.flush()
+    want, cue = [], 0
+    for typ, toks in s.events:
+        if typ != 2:
+            continue
+        text = ""
+        for t, (tid, _lp, _fl, ms) in enumerate(toks):
+            end = toks[t + 1][3] if t + 1 < len(toks) else ms + 2000
+            cue += 1
+            text += om.token(tid)
+            want += [str(cue), "%s --> %s" % (_stamp(ms), _stamp(end)), text, ""]
+    got = out.stdout.decode().split("\n")[:-1]
+    assert got == want and cue > 0

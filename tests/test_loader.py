@@ -113,6 +113,54 @@ def test_alternative_onnx_spelling_gives_identical_blob(built, tiny_model, tiny_
     a.close(); b.close()
 
 
+EXPORTER_SPELLINGS = [
+    dict(gemm_bias="separate"),
+    dict(gemm_bias="single"),
+    dict(gemm_bias="after_sum"),
+    dict(lstm_gemm=False, gemm_bias="separate"),
+    dict(lstm_gemm=False, gemm_bias="after_sum", gate_split="slice"),
+    dict(gate_split="slice"),
+    dict(gate_split="slice_attr"),
+    dict(gate_order="fiog"),
+    dict(gate_order="gofi", gate_split="slice", gemm_bias="single"),
+    dict(passthrough=True),
+    dict(passthrough=True, const_nodes=True, fold_eps=False),
+    dict(const_nodes=True),
+    dict(w_transpose=True),
+    dict(norm="mulself"),
+    dict(norm="sqrt_recip", swish="add_neg"),
+    dict(norm="div_sqrt", state_index="gather"),
+    dict(state_index="gather", passthrough=True, w_transpose=True, gate_split="slice", gate_order="oifg", gemm_bias="after_sum", lstm_gemm=False),
+]
+
+
+@pytest.mark.parametrize("variant", EXPORTER_SPELLINGS, ids=lambda v: ",".join("%s=%s" % kv for kv in sorted(v.items())))
+def test_exporter_spellings_give_identical_blob(built, tiny_model, tmp_path, variant):
+    """What an ONNX exporter / constant folder may spell freely (Gemm vs MatMul+Add, where the LSTM biases sit, Split vs
+    Slice, the ORDER of the gate blocks -- the loader reads each gate's role off the cell update --, constants as
+    initializers / Constant nodes / behind Identity, Cast or Transpose, Identity / Cast / Dropout on the activation path,
+    the spelling of BasicNorm and DoubleSwish, per-layer state through Slice or Gather) loads to the SAME packed weights."""
+    p = str(tmp_path / "variant.april")
+    SM.write_model(p, SM.TINY_DIMS, variant=variant)
+    a = A.Model.load_host_only(tiny_model["path"]); b = A.Model.load_host_only(p)
+    assert np.array_equal(split_blob(a.export_blob()), split_blob(b.export_blob()))
+    a.close(); b.close()
+
+
+def test_rejection_names_the_offending_node(built, tmp_path, capfd):
+    """An unsupported graph is refused with a message that says which node the loader stopped at (op, name, inputs)."""
+    import april_asr_amd.synth_model as S
+    dims = dict(S.TINY_DIMS)
+    w = S.make_weights(dims); toks = S.make_tokens(dims["vocab"])
+    enc = S.build_encoder(dims, w, {}).replace(b"\x22\x05Split", b"\x22\x05Spliz", 1)      # op_type of the first layer's Split
+    blob = S.container_bytes([enc, S.build_decoder(dims, w, {}), S.build_joiner(dims, w, {})], S.params_block(dims, toks))
+    p = tmp_path / "bad.april"; p.write_bytes(blob)
+    with pytest.raises(Exception):
+        A.Model.load_host_only(str(p))
+    msg = capfd.readouterr().err
+    assert "encoder layer 0" in msg and "Spliz" in msg and "inputs:" in msg
+
+
 def test_blob_roundtrip_host(built, tiny_model):
     a = A.Model.load_host_only(tiny_model["path"])
     blob = a.export_blob()
