@@ -165,9 +165,11 @@ class Model:
         self._L.aprilx_model_load_info(self._handle, C.byref(info))
         return info
 
-    def save_blob(self, path: str):
-        """Cache of the parsed + packed weights next to the model (aprilx_model_save_blob)."""
-        if self._L.aprilx_model_save_blob(self._handle, path.encode("utf-8")) != 0:
+    def save_blob(self, path: str, f16: bool = False):
+        """Cache of the parsed + packed weights next to the model (aprilx_model_save_blob); f16: the half-size variant for
+        fp16-operand mode (aprilx_model_save_blob_f16)."""
+        fn = self._L.aprilx_model_save_blob_f16 if f16 else self._L.aprilx_model_save_blob
+        if fn(self._handle, path.encode("utf-8")) != 0:
             raise RuntimeError("blob save failed")
 
     @classmethod

@@ -54,7 +54,7 @@ EXPORTED_REFERENCE_SYMBOLS = [
 ]
 EXPORTED_ENGINE_SYMBOLS = [
     "aprilx_model_dims", "aprilx_model_token", "aprilx_model_blob_size", "aprilx_model_export_blob",
-    "aprilx_model_from_blob", "aprilx_model_save_blob", "aprilx_model_load_blob",
+    "aprilx_model_from_blob", "aprilx_model_save_blob", "aprilx_model_save_blob_f16", "aprilx_model_load_blob",
     "aprilx_broadcast_get_id", "aprilx_model_broadcast", "aprilx_model_load_info", "aprilx_feed_many", "aprilx_flush_many", "aprilx_session_drain",
     "aprilx_run_encoder", "aprilx_run_decoder", "aprilx_run_joiner", "aprilx_run_fbank",
     "aprilx_session_trace_logits", "aprilx_session_chunks", "aprilx_session_context", "aprilx_model_stats", "aprilx_model_profile",
@@ -92,6 +92,7 @@ def lib():
     L.aprilx_model_export_blob.argtypes = [vp, vp, sz]; L.aprilx_model_export_blob.restype = C.c_int
     L.aprilx_model_from_blob.argtypes = [vp, sz, C.c_int]; L.aprilx_model_from_blob.restype = vp
     L.aprilx_model_save_blob.argtypes = [vp, C.c_char_p]; L.aprilx_model_save_blob.restype = C.c_int
+    L.aprilx_model_save_blob_f16.argtypes = [vp, C.c_char_p]; L.aprilx_model_save_blob_f16.restype = C.c_int
     L.aprilx_model_load_blob.argtypes = [C.c_char_p]; L.aprilx_model_load_blob.restype = vp
     L.aprilx_broadcast_get_id.argtypes = [vp, sz]; L.aprilx_broadcast_get_id.restype = C.c_int
     L.aprilx_model_broadcast.argtypes = [vp, C.c_int, C.c_int, vp]; L.aprilx_model_broadcast.restype = vp

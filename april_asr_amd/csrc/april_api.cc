@@ -402,6 +402,35 @@ int aprilx_model_save_blob(AprilASRModel model, const char *path)
     return (fclose(f) == 0 && ok) ? 0 : -1;
 }
 
+// The fp16 cache file (BASELINE configs[4]): same header and metadata, magic "APXBLB16"; the payload walks the blob's float
+// index space in order -- MFMA-packed Linear / LSTM matrices as binary16 (round to nearest even, what the engine's fp16
+// copies hold), everything else (convolutions, biases, embeddings) as fp32.  Half the size of the fp32 file; loading expands
+// it to the fp32 blob whose fp16 copies are bit-identical to those of the original model, so it serves fp16-operand mode only.
+int aprilx_model_save_blob_f16(AprilASRModel model, const char *path)
+{
+    if (!model || !path) return -1;
+    std::vector<char> full(aprilx_model_blob_size(model));
+    if (aprilx_model_export_blob(model, full.data(), full.size()) != 0) return -1;
+    BlobHeader hd; memcpy(&hd, full.data(), sizeof hd);
+    const float *w = (const float *)(full.data() + hd.weights_offset);
+    std::string out(full.data(), (size_t)hd.weights_offset);
+    memcpy(&out[0], "APXBLB16", 8);
+    size_t pos = 0;
+    auto raw = [&](size_t upto) { if (upto > pos) out.append((const char *)(w + pos), (upto - pos) * 4); pos = upto; };
+    for (const auto &sec : gemm_sections(model->m.layout)) {
+        raw(sec.first);
+        std::vector<_Float16> h(sec.second);
+        for (size_t i = 0; i < sec.second; ++i) h[i] = (_Float16)w[sec.first + i];
+        out.append((const char *)h.data(), h.size() * 2);
+        pos = sec.first + sec.second;
+    }
+    raw((size_t)hd.weight_floats);
+    FILE *f = fopen(path, "wb");
+    if (!f) { LOGE("aprilx: cannot write '%s'", path); return -1; }
+    const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    return (fclose(f) == 0 && ok) ? 0 : -1;
+}
+
 AprilASRModel aprilx_model_load_blob(const char *path)
 {
     FILE *f = path ? fopen(path, "rb") : nullptr;
@@ -409,6 +438,35 @@ AprilASRModel aprilx_model_load_blob(const char *path)
     std::vector<char> buf;
     if (fseek(f, 0, SEEK_END) == 0) { const long n = ftell(f); if (n > 0) { buf.resize((size_t)n); rewind(f); if (fread(buf.data(), 1, buf.size(), f) != buf.size()) buf.clear(); } }
     fclose(f);
+    if (buf.size() >= sizeof(BlobHeader) && memcmp(buf.data(), "APXBLB16", 8) == 0) {
+        // expand to the fp32 blob; only the fp16-operand engine may use the rounded matrices
+        if (g_inited) {
+            const char *pv = getenv("APRIL_PRECISION");
+            if (!pv || !(std::string(pv) == "f16" || std::string(pv) == "fp16" || std::string(pv) == "half")) { LOGE("aprilx: '%s' is an fp16 cache file: set APRIL_PRECISION=f16 (the fp32 engine needs the fp32 file)", path); return nullptr; }
+        }
+        BlobHeader hd; memcpy(&hd, buf.data(), sizeof hd);
+        if (hd.weights_offset > buf.size() || hd.meta_bytes > buf.size() || sizeof hd + hd.meta_bytes > hd.weights_offset || hd.weight_floats > ((uint64_t)1 << 34)) { LOGE("aprilx: bad blob"); return nullptr; }
+        AprilASRModel_i probe;
+        if (!parse_meta(buf.data() + sizeof hd, (size_t)hd.meta_bytes, probe.m) || probe.m.layout.total != hd.weight_floats) { LOGE("aprilx: blob metadata invalid"); return nullptr; }
+        std::vector<char> full((size_t)hd.weights_offset + (size_t)hd.weight_floats * 4);
+        memcpy(full.data(), buf.data(), (size_t)hd.weights_offset);
+        memcpy(full.data(), "APXBLOB1", 8);
+        float *w = (float *)(full.data() + hd.weights_offset);
+        const char *src = buf.data() + hd.weights_offset, *end = buf.data() + buf.size();
+        size_t pos = 0;
+        bool ok = true;
+        auto raw = [&](size_t upto) { if (upto > pos) { const size_t n = (upto - pos) * 4; if ((size_t)(end - src) < n) { ok = false; return; } memcpy(w + pos, src, n); src += n; } pos = upto; };
+        for (const auto &sec : gemm_sections(probe.m.layout)) {
+            raw(sec.first);
+            if (!ok || (size_t)(end - src) < sec.second * 2) { ok = false; break; }
+            const _Float16 *h = (const _Float16 *)src;
+            for (size_t i = 0; i < sec.second; ++i) w[sec.first + i] = (float)h[i];
+            src += sec.second * 2; pos = sec.first + sec.second;
+        }
+        if (ok) raw((size_t)hd.weight_floats);
+        if (!ok || src != end) { LOGE("aprilx: fp16 blob payload size mismatch"); return nullptr; }
+        return aprilx_model_from_blob(full.data(), full.size(), 0);
+    }
     return buf.empty() ? nullptr : aprilx_model_from_blob(buf.data(), buf.size(), 0);
 }
 

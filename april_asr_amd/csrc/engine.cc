@@ -39,6 +39,20 @@ void plan_layout(const NetDims &d, bool has_dec_conv_b, PackedLayout &L)
     L.total = off;
 }
 
+std::vector<std::pair<size_t, size_t>> gemm_sections(const PackedLayout &L)
+{
+    const NetDims &d = L.dims;
+    std::vector<std::pair<size_t, size_t>> v;
+    v.emplace_back(L.w_embed, (size_t)d.embed_in * d.d_model);
+    for (const PackedLayout::Layer &o : L.layers) {
+        v.emplace_back(o.wg, (size_t)2 * d.d_model * 4 * d.hidden); v.emplace_back(o.whr, (size_t)d.hidden * d.d_model);
+        v.emplace_back(o.wff1, (size_t)d.d_model * d.ffn); v.emplace_back(o.wff2, (size_t)d.ffn * d.d_model);
+    }
+    v.emplace_back(L.w_encproj, (size_t)d.d_model * d.joiner); v.emplace_back(L.w_decproj, (size_t)d.d_model * d.joiner);
+    v.emplace_back(L.w_out, (size_t)d.joiner * L.vocab_pad);
+    return v;
+}
+
 // W is K x N row-major; see kernels.h for the packed order.  colmap (optional) gives, for each
 // packed column, the source column.
 static void pack_mfma(const float *W, int K, int N, int Npad, const std::vector<int> *colmap, float *dst)
@@ -199,15 +213,7 @@ void Engine::finish_weights()
         // fp16 operand mode (BASELINE configs[4]): every Linear / LSTM weight matrix gets an fp16 copy in the same
         // packed element order (round-to-nearest-even, on the device); convolutions, biases, embeddings stay fp32
         wh_ = dmalloc<uint16_t>(L_.total);
-        const NetDims &d0 = L_.dims;
-        auto cv = [&](size_t off, size_t n) { launch_cvt_f16(w_ + off, wh_ + off, n, nullptr); };
-        cv(L_.w_embed, (size_t)d0.embed_in * d0.d_model);
-        for (const PackedLayout::Layer &o : L_.layers) {
-            cv(o.wg, (size_t)2 * d0.d_model * 4 * d0.hidden); cv(o.whr, (size_t)d0.hidden * d0.d_model);
-            cv(o.wff1, (size_t)d0.d_model * d0.ffn); cv(o.wff2, (size_t)d0.ffn * d0.d_model);
-        }
-        cv(L_.w_encproj, (size_t)d0.d_model * d0.joiner); cv(L_.w_decproj, (size_t)d0.d_model * d0.joiner);
-        cv(L_.w_out, (size_t)d0.joiner * L_.vocab_pad);
+        for (const auto &sec : gemm_sections(L_)) launch_cvt_f16(w_ + sec.first, wh_ + sec.first, sec.second, nullptr);
         HIP_CHECK(hipDeviceSynchronize());
     }
 }

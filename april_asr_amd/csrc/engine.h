@@ -46,6 +46,9 @@ struct PackedLayout {
     float embed_eps = 0;
 };
 void plan_layout(const NetDims &d, bool has_dec_conv_b, PackedLayout &L);
+// (offset, count) of every MFMA-packed Linear / LSTM weight matrix inside the blob, in blob order: the sections that get
+// binary16 copies in fp16-operand mode and are stored as binary16 in the fp16 cache file
+std::vector<std::pair<size_t, size_t>> gemm_sections(const PackedLayout &L);
 // fills `blob` (L.total floats) from the neutral host weights
 void pack_weights(const HostModel &m, PackedLayout &L, std::vector<float> &blob);
 

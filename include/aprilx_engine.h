@@ -62,6 +62,9 @@ APRIL_EXPORT AprilASRModel aprilx_model_from_blob(const void *blob, size_t size,
  * ONNX parse and the packing (the reference re-parses the .april file at every
  * aam_create_model, april_model.c:24-107).  save returns 0 on success; load returns NULL on any failure. */
 APRIL_EXPORT int aprilx_model_save_blob(AprilASRModel model, const char *path);
+/* fp16 variant of the cache file for fp16-operand mode (BASELINE configs[4]): the MFMA-packed matrices as binary16, half the
+ * size; aprilx_model_load_blob recognises it and requires APRIL_PRECISION=f16 on a GPU runtime */
+APRIL_EXPORT int aprilx_model_save_blob_f16(AprilASRModel model, const char *path);
 APRIL_EXPORT AprilASRModel aprilx_model_load_blob(const char *path);
 
 /* ---- batched session driving ------------------------------------------------------------

@@ -160,3 +160,25 @@ def test_config5_f16_larger_encoder_512_sessions(large_model):
     for s in sess:
         s.close()
     gm.close()
+
+
+def test_f16_cache_file_gives_the_same_model(tiny_model, tmp_path):
+    """A model loaded from the fp16 cache file behaves bit for bit like the model it was saved from, in fp16-operand mode;
+    without APRIL_PRECISION=f16 the file is refused."""
+    import april_asr_amd as A
+    os.environ["APRIL_PRECISION"] = "f16"
+    try:
+        m0 = A.Model(tiny_model["path"])
+        p16 = str(tmp_path / "tiny.apxblob16")
+        m0.save_blob(p16, f16=True)
+        m1 = A.Model.load_blob(p16)
+    finally:
+        del os.environ["APRIL_PRECISION"]
+    with pytest.raises(Exception):
+        A.Model.load_blob(p16)
+    assert m1.dims.precision == 1
+    pcm = speech_like_pcm(2.0, seed=9)
+    e0, l0, _ = run_gpu(m0, pcm, 1600)
+    e1, l1, _ = run_gpu(m1, pcm, 1600)
+    assert e0 == e1 and np.array_equal(l0, l1)
+    m0.close(); m1.close()

@@ -188,6 +188,33 @@ def test_blob_file_cache(built, tiny_model, tmp_path):
     a.close(); b.close()
 
 
+def test_blob_file_cache_f16(built, tiny_model, tmp_path):
+    """The fp16 cache file (BASELINE configs[4]): MFMA-packed matrices as binary16, the rest fp32; about
+    half the size; it expands to the fp32 blob with exactly the binary16-rounded matrices (so the engine's fp16 copies are the
+    same bits as those derived from the original model) and everything else untouched."""
+    import os
+    a = A.Model.load_host_only(tiny_model["path"])
+    p32, p16 = str(tmp_path / "tiny.apxblob"), str(tmp_path / "tiny.apxblob16")
+    a.save_blob(p32); a.save_blob(p16, f16=True)
+    assert os.path.getsize(p16) < 0.62 * os.path.getsize(p32)
+    b = A.Model.load_blob(p16, init_gpu=False)
+    wa, wb = split_blob(a.export_blob()), split_blob(b.export_blob())
+    assert wa.shape == wb.shape
+    L, ein, vp = layout_offsets(tiny_model["dims"])
+    d = tiny_model["dims"]
+    D, H, F, J = d["d_model"], d["hidden"], d["ffn"], d["joiner"]
+    gemm = np.zeros(wa.size, bool)
+    secs = [(L["w_embed"], ein * D), (L["w_encproj"], D * J), (L["w_decproj"], D * J), (L["w_out"], J * vp)]
+    for l in range(d["n_layers"]):
+        secs += [(L["wg%d" % l], 2 * D * 4 * H), (L["whr%d" % l], H * D), (L["wff1%d" % l], D * F), (L["wff2%d" % l], F * D)]
+    for off, n in secs:
+        gemm[off:off + n] = True
+    assert np.array_equal(wb[gemm], wa[gemm].astype(np.float16).astype(np.float32))       # round to nearest even, like the device conversion
+    assert np.array_equal(wb[~gemm], wa[~gemm])
+    assert [b.token(i) for i in range(b.dims.vocab)] == tiny_model["tokens"]
+    a.close(); b.close()
+
+
 def test_param_count_aprilv0_dims():
     """84.18 M parameters at aprilv0 dimensions (SURVEY.md Appendix C cross-check), from shapes alone."""
     d = SM.APRILV0_DIMS
