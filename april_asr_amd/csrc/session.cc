@@ -182,10 +182,33 @@ void Greedy::finish_flush(std::vector<Event> &out)
 
 void FrameBook::compact()
 {
+    if (ext) return;                                   // positions may point into the lent buffer: settle() does it
     if (fifo_pos > 0 && (fifo_pos >= 8192 || fifo_pos == fifo.size())) {
         fifo.erase(fifo.begin(), fifo.begin() + (long)fifo_pos);
         fifo_pos = 0;
     }
+}
+
+void FrameBook::absorb_ext()
+{
+    if (!ext) return;
+    fifo.insert(fifo.end(), ext, ext + ext_cnt);
+    ext = nullptr; ext_cnt = 0;
+}
+
+void FrameBook::settle()
+{
+    if (ext) {
+        if (fifo_pos >= fifo.size()) {                 // everything older is consumed: the fifo becomes the lent buffer's tail
+            const size_t skip = fifo_pos - fifo.size();
+            fifo.assign(ext + skip, ext + ext_cnt);
+            fifo_pos = 0;
+            ext = nullptr; ext_cnt = 0;
+        } else {
+            absorb_ext();
+        }
+    }
+    compact();
 }
 
 // ---------------------------------------------------------------- model
@@ -341,7 +364,6 @@ void Scheduler::loop()
     { std::lock_guard<std::mutex> g(mu_); loop_tid_ = std::this_thread::get_id(); }
     std::vector<Session *> work;
     std::vector<uint64_t> taken;
-    std::vector<std::tuple<Session *, const short *, size_t>> lent;
     uint64_t work_seen = 0;
     for (;;) {
         work.clear(); taken.clear();
@@ -367,11 +389,11 @@ void Scheduler::loop()
                 if (s->closing || (!s->fed && !s->flush_requested)) continue;
                 s->busy = true;
                 if (s->borrow_cnt) {
-                    if (s->inbox.empty()) lent.emplace_back(s, s->borrow_ptr, s->borrow_cnt);
-                    else s->fb.fifo.insert(s->fb.fifo.end(), s->borrow_ptr, s->borrow_ptr + s->borrow_cnt);   // something queued behind it: keep the order
+                    if (s->inbox.empty() && !s->fb.ext) { s->fb.ext = s->borrow_ptr; s->fb.ext_cnt = s->borrow_cnt; }   // read in place during this tick
+                    else { s->fb.absorb_ext(); s->fb.fifo.insert(s->fb.fifo.end(), s->borrow_ptr, s->borrow_ptr + s->borrow_cnt); }   // something queued behind it: keep the order
                     s->borrow_ptr = nullptr; s->borrow_cnt = 0;
                 }
-                if (!s->inbox.empty()) { s->fb.fifo.insert(s->fb.fifo.end(), s->inbox.begin(), s->inbox.end()); s->inbox.clear(); }
+                if (!s->inbox.empty()) { s->fb.absorb_ext(); s->fb.fifo.insert(s->fb.fifo.end(), s->inbox.begin(), s->inbox.end()); s->inbox.clear(); }
                 if (s->fed) s->was_flushed = false;                               // april_session.c:510
                 s->fed = false;
                 if (s->flush_requested) {                                           // :547-552
@@ -382,10 +404,8 @@ void Scheduler::loop()
                 taken.push_back(s->submitted);
             }
         }
-        // lent PCM: the caller is blocked until `completed` moves, so its buffer is read here, outside the lock (a lent
+        // lent PCM: the caller is blocked until `completed` moves, so its buffer is read in place during this tick (a lent
         // buffer is only accepted when nothing is queued in front of it, so the order of samples is kept)
-        pool_.run(lent.size(), 64, [&](size_t i) { auto &l = lent[i]; std::get<0>(l)->fb.fifo.insert(std::get<0>(l)->fb.fifo.end(), std::get<1>(l), std::get<1>(l) + std::get<2>(l)); });
-        lent.clear();
         tick_.host_ms[0] += lap();
         for (Session *s : work) s->chunks_at_tick_start = s->chunks;
         const auto t_tick = std::chrono::steady_clock::now();
@@ -447,7 +467,9 @@ void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
                 ++cut;
             }
             const size_t last_end = first + (size_t)(cut - 1) * fb.shift + (size_t)fb.padded;
-            pcm_parts_.emplace_back(fb.fifo.data() + first, last_end - first);
+            const size_t fsz = fb.fifo.size();
+            if (first < fsz) pcm_parts_.emplace_back(fb.fifo.data() + first, std::min(last_end, fsz) - first);          // (contiguous in staging)
+            if (last_end > fsz) pcm_parts_.emplace_back(fb.ext + (std::max(first, fsz) - fsz), last_end - std::max(first, fsz));
             staged += last_end - first;
             s->compact_pending = true;                 // the fifo must not move until the window has been staged
             progressed = true;
@@ -470,6 +492,7 @@ void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
             progressed = true;
             break;
         case 2:
+            fb.absorb_ext();
             fb.fifo.insert(fb.fifo.end(), (size_t)2 * 3200, (int16_t)0);      // april_session.c:555-556
             s->flush_phase = 3;
             progressed = true;
@@ -679,6 +702,8 @@ void Scheduler::process(std::vector<Session *> &work)
         replay(work);
         tick_.host_ms[5] += lap();
     }
+    // lent buffers go back to their callers when this tick completes: keep what framing has not consumed yet
+    pool_.run(work.size(), 64, [&](size_t i) { work[i]->fb.settle(); });
 }
 
 }  // namespace aprilx

@@ -79,9 +79,16 @@ struct FrameBook {
     int head = 0, tail = 0;
     long avail = 0, avail_shadow = 0;
     std::vector<int16_t> fifo;      // samples not yet fully consumed by framing
-    size_t fifo_pos = 0;            // start of the next frame inside fifo
+    size_t fifo_pos = 0;            // start of the next frame inside the stream  fifo ++ ext  (may point into ext)
+    // A caller that blocks until its feed is processed LENDS its buffer: the samples are staged for the GPU straight from
+    // there (one copy: caller -> pinned staging); only the unconsumed tail (less than a frame, normally) moves into the
+    // fifo when the tick ends (settle()).
+    const int16_t *ext = nullptr; size_t ext_cnt = 0;
+    size_t stream_end() const { return fifo.size() + ext_cnt; }
     bool chunk_ready() const { return avail >= seg_count; }
-    bool can_cut() const { return fifo.size() - fifo_pos >= (size_t)padded && avail + 1 <= ring_frames; }
+    bool can_cut() const { return stream_end() - fifo_pos >= (size_t)padded && avail + 1 <= ring_frames; }
+    void absorb_ext();              // ext -> fifo (keeps stream positions valid)
+    void settle();                  // end of tick: drop consumed samples, keep the tail, forget the lent buffer
     bool flush_allowed() const { return avail_shadow >= -(long)(seg_count * 3); }
     void compact();
 };

@@ -63,7 +63,7 @@ def _stamp(ms):
     return "%02d:%02d:%02d,%03d" % (out[0], out[1], out[2], ms)
 
 
-def test_srt_cli_matches_oracle(tiny_model, tmp_path):
+def test_srt_cli_matches_oracle(v0_model, tmp_path):
     """the ./srt-style client (examples/srt.cpp, reference example_srt.cpp:57-129): one cue per
     token of every FINAL result, timed by AprilToken.time_ms; the whole file goes in ONE feed (layer-major schedule).  Expected
     cues are rendered from the oracle's transcript."""
@@ -71,7 +71,8 @@ def test_srt_cli_matches_oracle(tiny_model, tmp_path):
     exe = str(tmp_path / "srt")
     subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "examples", "srt.cpp"), "-I", os.path.join(ROOT, "include"),
                            "-L", os.path.join(ROOT, "april_asr_amd"), "-laprilasr", "-Wl,-rpath," + os.path.join(ROOT, "april_asr_amd"), "-o", exe])
-    pcm = np.concatenate([speech_like_pcm(3.0, seed=12), np.zeros(16000 * 3, np.int16), speech_like_pcm(2.0, seed=13), np.zeros(16000 * 3, np.int16)])
+    tiny_model = v0_model          # aprilv0 dimensions: this audio yields FINAL results with several tokens there
+    pcm = np.concatenate([speech_like_pcm(4.0, seed=12), np.zeros(16000 * 3, np.int16)])
     path = str(tmp_path / "audio.raw")
     pcm.tofile(path)
     out = subprocess.run([exe, path, tiny_model["path"]], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
@@ -92,4 +93,4 @@ def test_srt_cli_matches_oracle(tiny_model, tmp_path):
             text += om.token(tid)
             want += [str(cue), "%s --> %s" % (_stamp(ms), _stamp(end)), text, ""]
     got = out.stdout.decode().split("\n")[:-1]
-    assert got == want and cue > 0
+    assert got == want and cue >= 3
