@@ -709,7 +709,7 @@ void launch_gemm(const GemmArgs &g_in, hipStream_t s)
     GemmArgs g = g_in;
     static const int dbg = env_int("APRIL_GEMM_DEBUG", 0);
     g.debug = dbg;
-    static const int skew = env_int("APRIL_GEMM_SKEW", 2);
+    static const int skew = env_int("APRIL_GEMM_SKEW", 0);        // round 2: no start skew (measured below)
     static const int asm_loop = env_int("APRIL_GEMM_ASM", 1);     // 0 = compiler-scheduled loop everywhere (A/B)
     const TilePlan t = plan_tiles(g.M, g.N, g.kz, g.epi, g.force_fullk != 0);
     const bool row_epi = g.epi == EPI_HR || g.epi == EPI_RESID_SSQ || g.epi == EPI_SLOT_STORE;
@@ -717,11 +717,11 @@ void launch_gemm(const GemmArgs &g_in, hipStream_t s)
     g.zs = t.zs; g.mode = t.mode;
     // EPI_LSTM with x_scale scales the partial sums of waves 0 and 1: they must hold exactly A segment 0
     if ((g.epi == EPI_LSTM || g.epi == EPI_XPART) && (g.x_scale.ssq || g.p_add || g.wave_mask != 0xF) && (g.kz != 1 || g.K0 * 2 != g.K)) { fprintf(stderr, "libapril(mi355x): launch_gemm: x_scale needs K0 == K / 2 and kz == 1\n"); abort(); }
-    // hand-scheduled K loop: measured gains with one workgroup per CU (gates at B <= 256: 24.8 -> 22.9 us) and for the
-    // bias+DoubleSwish GEMMs at any size (FFN-up at B = 1024: 26.5 -> 23.3 us); the LSTM-cell GEMM with two
-    // co-resident workgroups per CU is faster with the compiler-scheduled loop (B = 1024: 83 vs 91 us)
-    const long wgs = (long)(g.N / 64) * ((g.M + 63) / 64);
-    g.asm_loop = asm_loop == 1 ? !(g.epi == EPI_LSTM && wgs >= 512) : (asm_loop != 0);
+    // hand-scheduled K loop wherever it exists (fused-epilogue 64x64 / 64x32 fp32 tiles).  Round-2 measurements
+    // (tools/gemm_bench, gates [M,1024]x[1024,4096] + LSTM cell, us per launch at M = 512 / 1024 / 2048):
+    //   hand loop, no skew 42.2 / 85.6 / 159.2   hand loop, skew 2: 85.5 / 174.3   compiler loop, skew 2 (round-1 choice at two
+    //   workgroups per CU): 91.3 / 170.4   compiler loop, no skew: 56.5 / 100.7 / 180.2;  FFN-up [2048,512]x[512,2048]: 42.3 vs 45.7
+    g.asm_loop = asm_loop != 0;
     g.skew = (long)(g.N / (16 * t.nt)) * ((g.M + 16 * t.mt - 1) / (16 * t.mt)) * (t.mode == GM_FULLK ? 1 : g.kz / g.zs) >= 512 ? skew : 0;   // two workgroups per CU
     const int mt = t.mt, nt = t.nt;
     bool ok = false;

@@ -224,7 +224,9 @@ static constexpr size_t kAsyncRingSamples = 48000;     // reference src/audio_pr
 static int host_helpers()
 {
     const char *v = getenv("APRIL_HOST_THREADS");
-    const int n = v && *v ? atoi(v) : 3;
+    // default: one helper per 16 hardware threads, 3..8 (measured at 2048 sessions: 8 helpers 10.07 ms per step, 3 helpers 10.59)
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int n = v && *v ? atoi(v) : std::max(3, std::min(8, hw / 16));
     return n < 0 ? 0 : (n > 32 ? 32 : n);
 }
 

@@ -202,14 +202,14 @@ def main():
                             "frac": round(frac_hbm, 4), "traffic": None}
             # HBM traffic per launch from the committed PMC pass of the same workload (bench.py cannot collect PMC itself)
             try:
-                tr = json.load(open(os.path.join(ROOT, "profiles", "r01_gates_traffic.json")))
+                tr = json.load(open(os.path.join(ROOT, "profiles", "r02_gates_traffic.json")))
                 if int(tr["sessions_per_gpu"]) == B and d.precision == 0:
                     roofline["traffic"] = int(tr["traffic_bytes_per_launch"])
-                    roofline["traffic_source"] = "profiles/r01_gates_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950 x2 read correction)"
+                    roofline["traffic_source"] = "profiles/r02_gates_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950 x2 read correction)"
             except Exception:
                 pass
             roofline["algorithmic_bytes_per_launch"] = int(wbytes + sbytes)
-            roofline.update({"kernel": "gemm_f32_kernel<EPI_LSTM> (LSTM gates [B,1024]x[1024,4096] + cell)",
+            roofline.update({"kernel": "gemm_f32_kernel<4,4,EPI_LSTM,...> (LSTM gates [B,1024]x[1024,4096] + BasicNorm row scale + cell)",
                              "avg_launch_us": round(avg_ms * 1e3, 2), "rows_per_launch": round(rows_per_launch, 1),
                              "launches": int(launches), "alt_frac_hbm": round(frac_hbm, 4), "alt_frac_mfma": round(frac_mfma, 4),
                              "class_ms": {k: round(sp.kernel_ms[i], 3) for i, k in enumerate(
@@ -337,6 +337,7 @@ def main():
             "max_sessions_per_gpu_rtf_le_0.1_tested": max_ok, "rtf_by_sessions_per_gpu": sweep,
             "callbacks": int(counts[0]), "tokens_in_callbacks": int(counts[5]), "model_load_s": round(load_s, 2), "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2), "weight_broadcast": bcast_info,
             "engine_steps": int(st.steps), "host_phase_ms_total": host_ms, "max_batch_seen": int(st.max_batch_seen),
+            "kernels_per_chunk_step": int(sp.kernels_per_step) if roofline else None,
             "offline_single_session_60s": offline, "flights": int(st.flights), "replay_mismatch": int(st.replay_mismatch),
             "roofline": roofline, "cpu_baseline": cpu,
         }
