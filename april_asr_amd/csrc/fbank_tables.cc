@@ -1,4 +1,10 @@
 // See fbank_tables.h.
+//
+// Third-party notice.  The radix-4 / radix-2 real-FFT pass structure and the twiddle-factor polynomial
+// coefficients restated here follow pocketfft (the FFT the reference links, src/fft/pocketfft.c):
+//   Copyright (C) 2010-2019 Max-Planck-Society.  All rights reserved.  BSD 3-Clause License
+//   (https://gitlab.mpcdf.mpg.de/mtr/pocketfft/-/blob/81d171a6/LICENSE.md); the full text, including the
+//   disclaimer, is in THIRD_PARTY_NOTICES.md at the repository root.
 #include "fbank_tables.h"
 #include <cmath>
 

@@ -17,6 +17,12 @@
 // exact multiple of 2^-15 below 2^9 and the float sum is exact; it equals the integer
 // sum of the PCM samples / 32768, which is what the wave reduction computes.  For
 // larger frames lane 0 replays the sequential float chain.
+//
+// Third-party notice.  The radix-4 / radix-2 real-FFT pass structure and the twiddle-factor polynomial
+// coefficients restated here follow pocketfft (the FFT the reference links, src/fft/pocketfft.c):
+//   Copyright (C) 2010-2019 Max-Planck-Society.  All rights reserved.  BSD 3-Clause License
+//   (https://gitlab.mpcdf.mpg.de/mtr/pocketfft/-/blob/81d171a6/LICENSE.md); the full text, including the
+//   disclaimer, is in THIRD_PARTY_NOTICES.md at the repository root.
 #include "kernels.h"
 
 namespace aprilx {

@@ -642,6 +642,7 @@ static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = fal
         else if (tune == 2 && t.nt == 4) t.nt = 2;
     }
     if (tune == 5 && epi == EPI_PARTIAL && t.mt == 4 && t.nt == 4) t.nt = 2;
+    if (tune == 3 && epi != EPI_PARTIAL && t.mt == 4 && t.nt == 4) t.nt = 2;      // measurement: 64x32 fused tiles at every size (three workgroups per CU with the compiler loop)
     t.zs = 1;
     if (epi == EPI_PARTIAL) {
         // slabs per workgroup grow once the output tiles alone fill the chip; the 64x64 tile has registers for two

@@ -28,6 +28,10 @@
  *
  * Build with -ffp-contract=off: the reference is built for baseline x86-64
  * (no FMA contraction) and bit-exactness depends on it.
+  *
+ * Third-party notice: the FFT pass structure and twiddle polynomial coefficients
+ * restated below follow pocketfft, Copyright (C) 2010-2019 Max-Planck-Society,
+ * BSD 3-Clause License (full text in THIRD_PARTY_NOTICES.md).
  */
 #include <math.h>
 #include <stdint.h>

@@ -14,7 +14,7 @@
  *
  * The reference's own april_session.c cannot be compiled in this image (it
  * includes onnxruntime_c_api.h) so this part is PARITY UNPINNED; it is checked
- * by hand-derived expectations in tests/test_oracle_session.py.
+ * by hand-derived expectations in tests/test_state_machine.py.
  *
  * Tokens are carried as vocabulary indices; the reference carries char*
  * into the model's token table (src/params.c:31-33) -- same identity.

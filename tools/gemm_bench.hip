@@ -31,7 +31,7 @@ int main(int argc, char **argv)
     int *slots; hipMalloc(&slots, (size_t)M * 4);
     { std::vector<int> hi((size_t)M); for (int i = 0; i < M; ++i) hi[(size_t)i] = (int)(((unsigned)i * 2654435761u) % (unsigned)M); hipMemcpy(slots, hi.data(), (size_t)M * 4, hipMemcpyHostToDevice); }
     if (epi >= 3) {
-        if (!gemm_fullk(M, N, kz)) { printf("(no full-K plan for M=%d N=%d kz=%d: timing the split-K partial GEMM instead)\n", M, N, kz); g.epi = 0; }
+        if (!gemm_fullk(M, N, kz, false)) { printf("(no full-K plan for M=%d N=%d kz=%d: timing the split-K partial GEMM instead)\n", M, N, kz); g.epi = 0; }
         else {
             float *st, *res; hipMalloc(&st, (size_t)M * N * 4); hipMalloc(&res, (size_t)M * N * 4); hipMemset(res, 0, (size_t)M * N * 4);
             g.slot_idx = slots; g.state = st; g.ld_state = N; g.resid = res; g.ldr = N; g.ssq_out = ssq;

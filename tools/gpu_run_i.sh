@@ -1,7 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-for v in "APRIL_GEMM_ASM=2 APRIL_GEMM_SKEW=0" "APRIL_GEMM_ASM=0 APRIL_GEMM_TUNE=2 APRIL_GEMM_SKEW=0" "APRIL_GEMM_ASM=0 APRIL_GEMM_TUNE=2 APRIL_GEMM_SKEW=2" "APRIL_GEMM_ASM=0 APRIL_GEMM_TUNE=1 APRIL_GEMM_SKEW=0" "APRIL_GEMM_ASM=0 APRIL_GEMM_SKEW=0"; do
-  echo "== $v"
-  for shape in "2048 4096 1024 1 1" "1024 4096 1024 1 1" "512 4096 1024 1 1" "2048 2048 512 2 1" "512 2048 512 2 1"; do env $v timeout 60 tools/gemm_bench $shape 100 12; done
-done > gpurun_out/i_gates2.txt 2>&1
-cat gpurun_out/i_gates2.txt
+for shape in "256 512 2048 4 4" "256 512 1024 3 4" "256 2048 512 2 1" "256 512 2048 4 8" "256 512 1024 3 8"; do GEMM_TRACE=1 GEMM_TRACE_CU=1 timeout 60 tools/gemm_bench_trace $shape 200 12; done > gpurun_out/i_trace.txt 2>&1
+cat gpurun_out/i_trace.txt
