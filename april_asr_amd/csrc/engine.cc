@@ -1,6 +1,7 @@
 // See engine.h.
 #include "engine.h"
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include "common.h"
@@ -148,7 +149,14 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     // (neither: the caller fills weights_mut() -- peer copy or RCCL broadcast -- and then calls finish_weights())
 
     const size_t S = (size_t)cfg_.max_slots, MB = (size_t)cfg_.max_batch;
-    ring_frames_ = P_.segment_size * 32;                   // reference src/fbank.c:147
+    // Feature ring per session.  The reference keeps segment_size * 32 frames (src/fbank.c:147); a session that is fed faster
+    // than real time (a whole file in one call) is processed a ring's worth of chunks at a time, and the offline wavefront
+    // (run_lm_wavefront) needs many more blocks of time steps than layers to fill: 2048 frames = ~20 s of audio per pass,
+    // 640 KB per slot (2.7 GB at 4096 slots, 1 % of this GPU's memory).  Results do not depend on the ring size.
+    {
+        const char *e = getenv("APRIL_RING_FRAMES");
+        ring_frames_ = std::max(P_.segment_size * 32, e && *e ? atoi(e) : 2048);
+    }
     h_ = dmalloc<float>((size_t)d.n_layers * S * d.d_model);
     c_ = dmalloc<float>((size_t)d.n_layers * S * d.hidden);
     ring_ = dmalloc<float>(S * ring_frames_ * d.mel);
@@ -216,6 +224,41 @@ void Engine::finish_weights()
         for (const auto &sec : gemm_sections(L_)) launch_cvt_f16(w_ + sec.first, wh_ + sec.first, sec.second, nullptr);
         HIP_CHECK(hipDeviceSynchronize());
     }
+    build_dec_table();
+}
+
+// The decoder network is a pure function of the two context tokens (embedding, grouped conv over the context, ReLU, projection:
+// reference src/april_session.c:151-163), so its output for EVERY context is computed once at load -- vocab^2 rows of `joiner`
+// floats (500^2 x 512 x 4 B = 512 MB of this GPU's 288 GB) by the same kernels that would run per emitted token -- and the
+// joiner reads the row of a session's current context.  A context change then costs nothing: no decoder launches in the chunk
+// chain (2..3 per search round), none at session start or after a flush.  Not built for context != 2 or when the table would
+// exceed APRIL_DEC_TABLE_MB (default 2048; 0 disables): those models run the decoder per context change as before.
+void Engine::build_dec_table()
+{
+    if (dec_table_) return;
+    const NetDims &d = L_.dims;
+    const char *e = getenv("APRIL_DEC_TABLE_MB");
+    const size_t limit_mb = e && *e ? (size_t)std::max(0, atoi(e)) : 2048;
+    const size_t rows = (size_t)d.vocab * (size_t)d.vocab;
+    if (d.context != 2 || rows * (size_t)d.joiner * 4 > limit_mb * 1024 * 1024 || rows * (size_t)d.joiner * 4 >= ((size_t)1 << 32)) return;   // (32-bit byte offsets in the GEMM's A addressing)
+    const int MB = cfg_.max_batch;
+    float *table = dmalloc<float>(rows * (size_t)d.joiner);
+    std::vector<int> iota((size_t)MB), ctx((size_t)MB * 2);
+    for (int i = 0; i < MB; ++i) iota[(size_t)i] = i;
+    int *ctx_d = dmalloc<int>((size_t)MB * 2);
+    HIP_CHECK(hipMemcpy(dec_slots_d_, iota.data(), (size_t)MB * 4, hipMemcpyHostToDevice));
+    for (size_t base = 0; base < rows; base += (size_t)MB) {
+        const int n = (int)std::min<size_t>((size_t)MB, rows - base);
+        for (int i = 0; i < n; ++i) { const size_t r = base + (size_t)i; ctx[(size_t)2 * i] = (int)(r / (size_t)d.vocab); ctx[(size_t)2 * i + 1] = (int)(r % (size_t)d.vocab); }
+        HIP_CHECK(hipMemcpy(ctx_d, ctx.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+        DecEmbedArgs a; a.dec = dec_params(); a.ctx = ctx_d; a.M = n; a.out = de_; a.ldo = d.d_model;
+        launch_dec_embed(a, stream_);
+        run_decproj(n, dec_slots_d_, nullptr, nullptr, 1, table + base * (size_t)d.joiner);
+        HIP_CHECK(hipStreamSynchronize(stream_));
+    }
+    (void)hipFree(ctx_d);
+    dec_table_ = table;
+    LOGI("engine: decoder table %zu rows x %d (%.0f MB)", rows, d.joiner, rows * (double)d.joiner * 4 / 1e6);
 }
 
 Engine::~Engine()
@@ -225,10 +268,14 @@ Engine::~Engine()
     for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &g : step_graphs_) (void)hipGraphExecDestroy(g.second);
     for (auto &g : lm_graphs_) (void)hipGraphExecDestroy(g.second);
-    for (auto &g : lm_stage_graphs_) (void)hipGraphExecDestroy(g.second);
-    for (hipStream_t st : lm_streams_) (void)hipStreamDestroy(st);
+    for (auto &g : lm_search_graphs_) (void)hipGraphExecDestroy(g.second);
+    if (lm_stream_) { (void)hipStreamSynchronize(lm_stream_); (void)hipStreamDestroy(lm_stream_); }
     for (hipEvent_t e : lm_events_) (void)hipEventDestroy(e);
+    if (zargs_h_) { (void)hipHostFree(zargs_h_); (void)hipFree(zargs_d_); }
+    for (int i = 0; i < 3; ++i) if (zargs_done_[i]) (void)hipEventDestroy(zargs_done_[i]);
+    for (void *p : {(void *)lm_now_d_, (void *)lm_rows_d_, (void *)lm_rec_off_d_}) if (p) (void)hipFree(p);
     if (ws_g_) (void)hipFree(ws_g_);
+    if (dec_table_) (void)hipFree(dec_table_);
     if (p_lm_) (void)hipFree(p_lm_);
     if (eout_lm_) (void)hipFree(eout_lm_);
     for (void *p : {(void *)w_, (void *)wh_, (void *)h_, (void *)c_, (void *)ring_, (void *)eout_, (void *)dout_, (void *)gstate_, (void *)cls_, (void *)ws_, (void *)xin_,
@@ -469,20 +516,21 @@ DecEmbedParams Engine::dec_params() const
 }
 
 // dout[slot] = de x Wp + b for rows with row_mask != 0 (all rows when null)
-void Engine::run_decproj(int n, const int *d_slots, const int *row_mask, const int *run_flag, int run_gen)
+void Engine::run_decproj(int n, const int *d_slots, const int *row_mask, const int *run_flag, int run_gen, float *out)
 {
     const NetDims &d = L_.dims;
+    if (!out) out = dout_;
     GemmArgs g; g.a0 = de_; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, L_.w_decproj);
     g.M = n; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_; g.run_flag = run_flag; g.run_gen = run_gen;
     if (gemm_fullk(n, d.joiner, kz_proj_)) {
-        g.epi = EPI_SLOT_STORE; g.bias = w_ + L_.b_decproj; g.out = dout_; g.ldo = d.joiner; g.slot_idx = d_slots; g.row_mask = row_mask;
+        g.epi = EPI_SLOT_STORE; g.bias = w_ + L_.b_decproj; g.out = out; g.ldo = d.joiner; g.slot_idx = d_slots; g.row_mask = row_mask;
         timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
         return;
     }
     g.epi = EPI_PARTIAL; g.out = ws_g_; g.m_stride = ws_mstride_;
     timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
     RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_g_; r.parts = gemm_partials(n, d.joiner, kz_proj_); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = n;
-    r.bias = w_ + L_.b_decproj; r.out = dout_; r.ldo = d.joiner; r.slot_idx = d_slots; r.row_mask = row_mask; r.run_flag = run_flag; r.run_gen = run_gen;
+    r.bias = w_ + L_.b_decproj; r.out = out; r.ldo = d.joiner; r.slot_idx = d_slots; r.row_mask = row_mask; r.run_flag = run_flag; r.run_gen = run_gen;
     timed_begin(T_DEC); launch_row(r, stream_); timed_end(T_DEC);
 }
 
@@ -490,14 +538,23 @@ void Engine::run_decproj(int n, const int *d_slots, const int *row_mask, const i
 // for all rows of the step at once, decisions included: rows that resolved to blank are masked out of the later rounds.
 void Engine::run_greedy_rounds(int n, bool dump_logits, int chunk, const float *eout_rows)
 {
-    const NetDims &d = L_.dims;
     const int MB = cfg_.max_batch;
-    const int gen = chunk + 1;
-    const int *d_slots = step_d_, *d_now = step_d_ + 2 * MB + (size_t)chunk * n;
+    GreedyIo io;
+    io.gen = chunk + 1; io.now = step_d_ + 2 * MB + (size_t)chunk * n; io.eout = eout_rows; io.rec_off = rec_off_d_; io.rec_slot0 = chunk * 3;
+    io.dump = dump_logits ? logits_ + (size_t)chunk * 3 * n * L_.dims.vocab : nullptr;
+    run_greedy_rounds(n, io);
+}
+
+void Engine::run_greedy_rounds(int n, const GreedyIo &io)
+{
+    const NetDims &d = L_.dims;
+    const int gen = io.gen;
+    const int *d_slots = step_d_;
     for (int round = 0; round < 3; ++round) {
         {   // logits = tanh(eout + dout) x Wout (+ bias in the decision kernel)
             GemmArgs g; g.a0b = dout_; g.lda0 = d.joiner; g.K0 = d.joiner; g.a_op = AOP_TANH_ADD;
-            if (eout_rows) { g.a0 = eout_rows; g.aidx0 = nullptr; g.same_idx_b = 0; g.aidx0b = d_slots; }     // layer-major: this chunk's rows of the batched encoder output
+            if (dec_table_) { g.a0b = dec_table_; g.ctx_state = gstate_; g.ctx_vocab = d.vocab; }     // dout = the table row of the slot's context
+            if (io.eout) { g.a0 = io.eout; g.aidx0 = io.eout_rows; g.same_idx_b = 0; g.aidx0b = d_slots; }     // layer-major: this chunk's rows of the batched encoder output
             else { g.a0 = eout_; g.aidx0 = d_slots; }
             lin(g, L_.w_out); g.M = n; g.N = L_.vocab_pad; g.K = d.joiner; g.kz = kz_out_; g.epi = EPI_PARTIAL; g.out = ws_g_; g.m_stride = ws_mstride_;
             if (round > 0) { g.run_flag = flags_d_ + round; g.run_gen = gen; }
@@ -506,13 +563,13 @@ void Engine::run_greedy_rounds(int n, bool dump_logits, int chunk, const float *
         DecideArgs a;
         a.ws = ws_g_; a.parts = gemm_partials(n, L_.vocab_pad, kz_out_); a.m_stride = ws_mstride_; a.N = L_.vocab_pad; a.M = n; a.n_valid = d.vocab;
         a.bias = w_ + L_.b_out; a.blank = P_.blank_id; a.early_emit = round == 0 ? 1.0f : 0.0f;
-        a.slot_idx = d_slots; a.now_ms = d_now; a.active = active_d_; a.dirty = dirty_d_; a.tok_class = cls_; a.state = gstate_;
-        a.rec_ring = rec_d_; a.rec_off = rec_off_d_; a.round = round; a.gen = gen; a.rec_slot = chunk * 3 + round;
-        a.logits_dump = dump_logits ? logits_ + ((size_t)chunk * 3 + round) * n * d.vocab : nullptr;
-        a.dec = dec_params(); a.de_out = de_; a.ld_de = d.d_model;
+        a.slot_idx = d_slots; a.now_ms = io.now; a.active = active_d_; a.dirty = dirty_d_; a.tok_class = cls_; a.state = gstate_;
+        a.rec_ring = rec_d_; a.rec_off = io.rec_off; a.round = round; a.gen = gen; a.rec_slot = io.rec_slot0 + round;
+        a.logits_dump = io.dump ? io.dump + (size_t)round * n * d.vocab : nullptr;
+        a.dec = dec_params(); a.de_out = dec_table_ ? nullptr : de_; a.ld_de = d.d_model;
         a.run_flags = flags_d_; a.rerun_flags = flags_d_ + 4;
         timed_begin(T_DEC); launch_decide(a, stream_); timed_end(T_DEC);
-        run_decproj(n, d_slots, dirty_d_, flags_d_ + 4 + round, gen);
+        if (!dec_table_) run_decproj(n, d_slots, dirty_d_, flags_d_ + 4 + round, gen);
     }
 }
 
@@ -581,59 +638,98 @@ void Engine::lm_resid_ssq(const float *a, int K, size_t w_off, int kz, const flo
     timed_begin(T_ROW); launch_row(r, st); timed_end(T_ROW);
 }
 
+// The GEMMs of one layer stage as argument blocks: launched one by one (lm_stage_layer) or, for all layers of a wavefront, in
+// one launch each (run_lm_wavefront).
+GemmArgs Engine::lm_args_xpart(int l, int m, int t0, int t1) const
+{   // input half of the gates for the block's rows: P = (p0 + p1) * scale   (waves 0,1; the recurrent half sits this launch out)
+    const NetDims &d = L_.dims;
+    const int G = d.d_model / SSQ_COLS;
+    const PackedLayout::Layer &o = L_.layers[(size_t)l];
+    const size_t b0 = (size_t)t0 * m;
+    GemmArgs g; g.a0 = y_ + b0 * d.d_model; g.lda0 = d.d_model; g.K0 = d.d_model;
+    g.x_scale.ssq = ssq_ + b0 * G; g.x_scale.groups = G; g.x_scale.inv_n = 1.0f / (float)d.d_model; g.x_scale.eps = l == 0 ? L_.embed_eps : L_.norm_eps[(size_t)l - 1];
+    g.a1 = g.a0; g.lda1 = d.d_model; g.K1 = d.d_model;          // never read (wave_mask)
+    lin(g, o.wg); g.M = (t1 - t0) * m; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_XPART; g.wave_mask = 0x3;
+    g.out = p_lm_ + b0 * 4 * d.hidden; g.ldo = 4 * d.hidden;
+    return g;
+}
+
+GemmArgs Engine::lm_args_gates(int l, int m, int t) const
+{   // recurrent half + LSTM cell: ((P + p2) + p3) + bias
+    const NetDims &d = L_.dims;
+    const size_t S = (size_t)cfg_.max_slots;
+    const PackedLayout::Layer &o = L_.layers[(size_t)l];
+    const size_t r0 = (size_t)t * m;
+    GemmArgs g; g.a0 = y_ + r0 * d.d_model; g.lda0 = d.d_model; g.K0 = d.d_model;      // never read (wave_mask)
+    g.a1 = h_ + (size_t)l * S * d.d_model; g.lda1 = d.d_model; g.aidx1 = step_d_; g.K1 = d.d_model;
+    lin(g, o.wg); g.M = m; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_LSTM; g.wave_mask = 0xC;
+    g.p_add = p_lm_ + r0 * 4 * d.hidden; g.ldp = 4 * d.hidden;
+    g.out = u_ + r0 * d.hidden; g.ldo = d.hidden; g.bias = w_ + o.bg; g.c_state = c_ + (size_t)l * S * d.hidden; g.slot_idx = step_d_; g.hidden = d.hidden;
+    return g;
+}
+
+GemmArgs Engine::lm_args_whr(int l, int m, int t) const
+{   // h' = u x Whr ; state write + residual, in one launch however few workgroups (sequential step)
+    const NetDims &d = L_.dims;
+    const size_t S = (size_t)cfg_.max_slots;
+    const int G = d.d_model / SSQ_COLS;
+    const PackedLayout::Layer &o = L_.layers[(size_t)l];
+    const size_t r0 = (size_t)t * m;
+    GemmArgs g; g.a0 = u_ + r0 * d.hidden; g.lda0 = d.hidden; g.K0 = d.hidden; lin(g, o.whr);
+    g.M = m; g.N = d.d_model; g.K = d.hidden; g.kz = kz_hr_; g.force_fullk = 1;
+    g.epi = EPI_HR; g.state = h_ + (size_t)l * S * d.d_model; g.ld_state = d.d_model; g.slot_idx = step_d_; g.resid = y_ + r0 * d.d_model; g.ldr = d.d_model;
+    g.r_scale.ssq = ssq_ + r0 * G; g.r_scale.groups = G; g.r_scale.inv_n = 1.0f / (float)d.d_model; g.r_scale.eps = l == 0 ? L_.embed_eps : L_.norm_eps[(size_t)l - 1];
+    g.out = xb_ + r0 * d.d_model; g.ldo = d.d_model;
+    return g;
+}
+
+GemmArgs Engine::lm_args_ff1(int l, int m, int t0, int t1) const
+{   // FFN up + DoubleSwish, the block's rows
+    const NetDims &d = L_.dims;
+    const PackedLayout::Layer &o = L_.layers[(size_t)l];
+    const size_t b0 = (size_t)t0 * m;
+    GemmArgs g; g.a0 = xb_ + b0 * d.d_model; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, o.wff1);
+    g.M = (t1 - t0) * m; g.N = d.ffn; g.K = d.d_model; g.kz = 1; g.epi = EPI_BIAS_DSWISH; g.out = ff_ + b0 * d.ffn; g.ldo = d.ffn; g.bias = w_ + o.bff1;
+    return g;
+}
+
+GemmArgs Engine::lm_args_ff2(int l, int m, int t0, int t1) const
+{   // FFN down + bias + residual + sums of squares in one launch (the wavefront form; lm_resid_ssq picks by occupancy)
+    const NetDims &d = L_.dims;
+    const int G = d.d_model / SSQ_COLS;
+    const PackedLayout::Layer &o = L_.layers[(size_t)l];
+    const size_t b0 = (size_t)t0 * m;
+    GemmArgs g; g.a0 = ff_ + b0 * d.ffn; g.lda0 = d.ffn; g.K0 = d.ffn; lin(g, o.wff2);
+    g.M = (t1 - t0) * m; g.N = d.d_model; g.K = d.ffn; g.kz = kz_ff2_; g.force_fullk = 1;
+    g.epi = EPI_RESID_SSQ; g.bias = w_ + o.bff2; g.resid = xb_ + b0 * d.d_model; g.ldr = d.d_model; g.out = y_ + b0 * d.d_model; g.ldo = d.d_model; g.ssq_out = ssq_ + b0 * G;
+    return g;
+}
+
 void Engine::lm_stage_layer(int l, int m, int t0, int t1, hipStream_t st)
 {
     const NetDims &d = L_.dims;
     const size_t S = (size_t)cfg_.max_slots;
-    const int G = d.d_model / SSQ_COLS;
-    const int *d_slots = step_d_;
     const PackedLayout::Layer &o = L_.layers[(size_t)l];
-    float *h_l = h_ + (size_t)l * S * d.d_model;
-    float *c_l = c_ + (size_t)l * S * d.hidden;
     const size_t b0 = (size_t)t0 * m;
     const int brows = (t1 - t0) * m;
-    RowScale xs; xs.groups = G; xs.inv_n = 1.0f / (float)d.d_model; xs.eps = l == 0 ? L_.embed_eps : L_.norm_eps[(size_t)l - 1];
-    {   // input half of the gates for the block's rows: P = (p0 + p1) * scale   (waves 0,1; the recurrent half sits this launch out)
-        GemmArgs g; g.a0 = y_ + b0 * d.d_model; g.lda0 = d.d_model; g.K0 = d.d_model; g.x_scale = xs; g.x_scale.ssq = ssq_ + b0 * G;
-        g.a1 = g.a0; g.lda1 = d.d_model; g.K1 = d.d_model;          // never read (wave_mask)
-        lin(g, o.wg); g.M = brows; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_XPART; g.wave_mask = 0x3;
-        g.out = p_lm_ + b0 * 4 * d.hidden; g.ldo = 4 * d.hidden;
-        timed_begin(T_GATES); launch_gemm(g, st); timed_end(T_GATES);
-    }
+    timed_begin(T_GATES); launch_gemm(lm_args_xpart(l, m, t0, t1), st); timed_end(T_GATES);
     for (int t = t0; t < t1; ++t) {
         const size_t r0 = (size_t)t * m;
-        {   // recurrent half + LSTM cell: ((P + p2) + p3) + bias
-            GemmArgs g; g.a0 = y_ + r0 * d.d_model; g.lda0 = d.d_model; g.K0 = d.d_model;      // never read (wave_mask)
-            g.a1 = h_l; g.lda1 = d.d_model; g.aidx1 = d_slots; g.K1 = d.d_model;
-            lin(g, o.wg); g.M = m; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_LSTM; g.wave_mask = 0xC;
-            g.p_add = p_lm_ + r0 * 4 * d.hidden; g.ldp = 4 * d.hidden;
-            g.out = u_ + r0 * d.hidden; g.ldo = d.hidden; g.bias = w_ + o.bg; g.c_state = c_l; g.slot_idx = d_slots; g.hidden = d.hidden;
-            timed_begin(T_GATES); launch_gemm(g, st); timed_end(T_GATES);
-        }
-        {   // h' = u x Whr ; state write + residual
-            GemmArgs g; g.a0 = u_ + r0 * d.hidden; g.lda0 = d.hidden; g.K0 = d.hidden; lin(g, o.whr);
-            g.M = m; g.N = d.d_model; g.K = d.hidden; g.kz = kz_hr_;
-            RowScale rs = xs; rs.ssq = ssq_ + r0 * G;
-            if (gemm_fullk(m, d.d_model, kz_hr_, true)) {       // sequential step: one launch, however few workgroups
-                g.force_fullk = 1;
-                g.epi = EPI_HR; g.state = h_l; g.ld_state = d.d_model; g.slot_idx = d_slots; g.resid = y_ + r0 * d.d_model; g.ldr = d.d_model; g.r_scale = rs;
-                g.out = xb_ + r0 * d.d_model; g.ldo = d.d_model;
-                timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
-            } else {
-                g.epi = EPI_PARTIAL; g.out = ws_ + r0 * d.d_model; g.m_stride = ws_mstride_;
-                timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
-                RowArgs r; r.mode = ROW_HR; r.ws = ws_ + r0 * d.d_model; r.parts = gemm_partials(m, d.d_model, kz_hr_); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = m;
-                r.resid = y_ + r0 * d.d_model; r.ldr = d.d_model; r.r_scale = rs; r.out = xb_ + r0 * d.d_model; r.ldo = d.d_model;
-                r.slot_idx = d_slots; r.state = h_l; r.ld_state = d.d_model;
-                timed_begin(T_ROW); launch_row(r, st); timed_end(T_ROW);
-            }
+        timed_begin(T_GATES); launch_gemm(lm_args_gates(l, m, t), st); timed_end(T_GATES);
+        if (gemm_fullk(m, d.d_model, kz_hr_, true)) {
+            timed_begin(T_GEMM_OTHER); launch_gemm(lm_args_whr(l, m, t), st); timed_end(T_GEMM_OTHER);
+        } else {
+            const GemmArgs f = lm_args_whr(l, m, t);
+            GemmArgs g; g.a0 = f.a0; g.lda0 = f.lda0; g.K0 = f.K0; lin(g, o.whr); g.M = m; g.N = d.d_model; g.K = d.hidden; g.kz = kz_hr_;
+            g.epi = EPI_PARTIAL; g.out = ws_ + r0 * d.d_model; g.m_stride = ws_mstride_;
+            timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
+            RowArgs r; r.mode = ROW_HR; r.ws = ws_ + r0 * d.d_model; r.parts = gemm_partials(m, d.d_model, kz_hr_); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = m;
+            r.resid = f.resid; r.ldr = d.d_model; r.r_scale = f.r_scale; r.out = f.out; r.ldo = d.d_model;
+            r.slot_idx = step_d_; r.state = h_ + (size_t)l * S * d.d_model; r.ld_state = d.d_model;
+            timed_begin(T_ROW); launch_row(r, st); timed_end(T_ROW);
         }
     }
-    {   // FFN up + DoubleSwish, the block's rows
-        GemmArgs g; g.a0 = xb_ + b0 * d.d_model; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, o.wff1);
-        g.M = brows; g.N = d.ffn; g.K = d.d_model; g.kz = 1; g.epi = EPI_BIAS_DSWISH; g.out = ff_ + b0 * d.ffn; g.ldo = d.ffn; g.bias = w_ + o.bff1;
-        timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
-    }
+    timed_begin(T_GEMM_OTHER); launch_gemm(lm_args_ff1(l, m, t0, t1), st); timed_end(T_GEMM_OTHER);
     lm_resid_ssq(ff_ + b0 * d.ffn, d.ffn, o.wff2, kz_ff2_, w_ + o.bff2, xb_ + b0 * d.d_model, b0, brows, st);
 }
 
@@ -660,26 +756,16 @@ void Engine::lm_stage_proj(int m, int t0, int t1, hipStream_t st)
     }
 }
 
-// A stage of the pipelined form as a captured single-stream launch chain, replayed on the stage's stream (capturing the
-// whole multi-stream pipeline as ONE graph crashes inside the HIP runtime's capture of ROCm 7.2; stage graphs + runtime
-// events between them cost ~2 graph launches per chunk on the host instead).
-void Engine::lm_run_stage(int kind, int l, int m, int t0, int t1, hipStream_t st, const std::function<void(hipStream_t)> &fn)
+static int lm_block_steps()
 {
-    if (!use_graphs_) { fn(st); return; }
-    const std::array<int, 5> key{{kind, l, m, t0, t1}};
-    auto it = lm_stage_graphs_.find(key);
-    if (it == lm_stage_graphs_.end()) {
-        if (lm_stage_graphs_.size() >= 4096) { for (auto &g : lm_stage_graphs_) (void)hipGraphExecDestroy(g.second); lm_stage_graphs_.clear(); }
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        fn(st);
-        HIP_CHECK(hipStreamEndCapture(st, &graph));
-        HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        HIP_CHECK(hipGraphDestroy(graph));
-        it = lm_stage_graphs_.emplace(key, exec).first;
-    }
-    HIP_CHECK(hipGraphLaunch(it->second, st));
+    static const int v = std::max(1, getenv("APRIL_LM_BLOCK") ? atoi(getenv("APRIL_LM_BLOCK")) : 7);
+    return v;
+}
+
+static bool lm_wavefront_on()
+{
+    static const int v = getenv("APRIL_LM_WAVEFRONT") ? atoi(getenv("APRIL_LM_WAVEFRONT")) : 1;
+    return v != 0;
 }
 
 void Engine::run_lm_chain(int m, int T, bool dump_logits)
@@ -692,62 +778,141 @@ void Engine::run_lm_chain(int m, int T, bool dump_logits)
     a.dst = step_d_; a.dst_stride = MB; a.n_arrays = 4; a.len[0] = m; a.len[1] = a.len[2] = a.len[3] = m * T; a.rec_off = rec_off_d_;
     a.flags = flags_d_; a.n_flags = 8;
     launch_advance(a, stream_);
-    static const int lm_block = std::max(1, getenv("APRIL_LM_BLOCK") ? atoi(getenv("APRIL_LM_BLOCK")) : 7);
-    static const int lm_streams = getenv("APRIL_LM_STREAMS") ? atoi(getenv("APRIL_LM_STREAMS")) : 1;
-    const bool pipelined = lm_streams != 0 && !profiling_ && !dump_logits && T > lm_block;
-    if (!pipelined) {
-        lm_stage_embed(m, 0, T, stream_);
-        for (int l = 0; l < L; ++l) lm_stage_layer(l, m, 0, T, stream_);
-        lm_stage_proj(m, 0, T, stream_);
-        // the search stays sequential in time (the decoder input of chunk t + 1 depends on the tokens of chunk t)
-        for (int t = 0; t < T; ++t) run_greedy_rounds(m, dump_logits, t, eout_lm_ + (size_t)t * m * d.joiner);
-        return;
-    }
-    // Software pipeline over blocks of `lm_block` time steps: layer l works on block b while layer l + 1 works on block
-    // b - 1, ..., and the search on an earlier block still.  One stream per layer (its blocks in order = the recurrence),
-    // one for embed + proj, the engine's stream for the search; events carry "block b left stage s".  At one session every
-    // recurrent kernel is a latency-bound launch: this turns 12 serial chains into 12 concurrent ones.
-    const int NB = (T + lm_block - 1) / lm_block;
-    // (streams and events exist already: lm_step() creates them before any capture starts)
-    if ((int)lm_streams_.size() < L + 1 || lm_events_.size() < (size_t)(L + 2) * NB + 1) { LOGE("engine: layer-major streams not prepared"); abort(); }
-    auto ev = [&](int stage, int b) { return lm_events_[1 + (size_t)stage * NB + b]; };   // stage 0 embed, 1..L layers, L + 1 proj
-    // Measured on ROCm 7.2 (1 session, aprilv0 dims, 60 s in one feed): one stream per layer + one for embed / proj
-    // 131..145 us per chunk (sequential chain: 184); 2, 3, 4 or 6 layer streams with embed / proj on the engine's stream
-    // 147..214; more hardware queues (GPU_MAX_HW_QUEUES = 8, 16) 435..712.  Cross-stream events are expensive here and the
-    // runtime multiplexes streams onto 4 hardware queues, so the overlap stays far below the 12 the dependency graph allows.
-    static const int lm_nstreams_env = getenv("APRIL_LM_NSTREAMS") ? atoi(getenv("APRIL_LM_NSTREAMS")) : 0;
-    const int lm_nstreams = std::max(1, std::min(L, lm_nstreams_env > 0 ? lm_nstreams_env : L));      // per engine: models differ in depth
-    hipStream_t s_io = lm_streams_[(size_t)L];
+    lm_stage_embed(m, 0, T, stream_);
+    for (int l = 0; l < L; ++l) lm_stage_layer(l, m, 0, T, stream_);
+    lm_stage_proj(m, 0, T, stream_);
+    // the search stays sequential in time (the decoder input of chunk t + 1 depends on the tokens of chunk t)
+    for (int t = 0; t < T; ++t) run_greedy_rounds(m, dump_logits, t, eout_lm_ + (size_t)t * m * d.joiner);
+}
+
+// Wavefront form of the layer-major step (long feeds: T > block).  Time is cut into blocks of `blk` steps; at macro step W
+// layer l works on block W - 1 - l, the front end on block W, encoder_proj on block W - L - 1 -- all of them independent of
+// one another.  The SAME launch of different layers is therefore ONE launch (gemm_f32_zkernel: blockIdx.z picks the layer's
+// argument block): per macro step one launch for the input halves of the gates, 2 per time step of the block for the
+// recurrence, one each for the feed-forward GEMMs -- (2 blk + 3) launches for L layer stages instead of L (2 blk + 3), on ONE
+// stream, no cross-stream events.  At one session every recurrent kernel is a latency-bound launch of a few microseconds, and
+// twelve of them in one launch cost about the same as one.  The search (sequential in time) follows on the engine's stream,
+// one block behind, as ONE captured graph per block whose arguments do not depend on the block (launch_block_setup).
+// Arithmetic: the kernels and their arguments are those of lm_stage_layer; only the grouping into launches differs.
+void Engine::run_lm_wavefront(int m, int T, bool dump_logits)
+{
+    const NetDims &d = L_.dims;
+    const int MB = cfg_.max_batch;
+    const int L = d.n_layers;
+    const int blk = lm_block_steps();
+    const int NB = (T + blk - 1) / blk;
+    AdvanceArgs a;
+    a.host_ring = ring_h_; a.host_step_off = step_off_h_; a.host_rec_off = rec_off_h_; a.counter = counter_d_;
+    a.dst = step_d_; a.dst_stride = MB; a.n_arrays = 4; a.len[0] = m; a.len[1] = a.len[2] = a.len[3] = m * T; a.rec_off = rec_off_d_;
+    a.flags = flags_d_; a.n_flags = 8;
+    launch_advance(a, stream_);
+    hipStream_t cs = lm_stream_;
     HIP_CHECK(hipEventRecord(lm_events_[0], stream_));                 // the index block is on the device
-    for (int i = 0; i < lm_nstreams; ++i) HIP_CHECK(hipStreamWaitEvent(lm_streams_[(size_t)i], lm_events_[0], 0));
-    HIP_CHECK(hipStreamWaitEvent(s_io, lm_events_[0], 0));
-    // enqueue in wavefront order, so that every stream's queue is in the order its stages become ready
-    for (int wave = 0; wave < NB + L + 2; ++wave) {
-        for (int stage = 0; stage <= L + 1; ++stage) {
-            const int b = wave - stage;
-            if (b < 0 || b >= NB) continue;
-            const int t0 = b * lm_block, t1 = std::min(T, t0 + lm_block);
-            if (stage == 0) {
-                lm_run_stage(0, 0, m, t0, t1, s_io, [&](hipStream_t st) { lm_stage_embed(m, t0, t1, st); });
-                HIP_CHECK(hipEventRecord(ev(0, b), s_io));
-            } else if (stage <= L) {
-                hipStream_t st = lm_streams_[(size_t)((stage - 1) % lm_nstreams)];
-                HIP_CHECK(hipStreamWaitEvent(st, ev(stage - 1, b), 0));
-                lm_run_stage(1, stage - 1, m, t0, t1, st, [&](hipStream_t s2) { lm_stage_layer(stage - 1, m, t0, t1, s2); });
-                HIP_CHECK(hipEventRecord(ev(stage, b), st));
-            } else {
-                HIP_CHECK(hipStreamWaitEvent(s_io, ev(L, b), 0));
-                lm_run_stage(2, 0, m, t0, t1, s_io, [&](hipStream_t st) { lm_stage_proj(m, t0, t1, st); });
-                HIP_CHECK(hipEventRecord(ev(L + 1, b), s_io));
+    HIP_CHECK(hipStreamWaitEvent(cs, lm_events_[0], 0));
+
+    // argument blocks of this step: (NB + L + 1) macro steps x at most (2 blk + 6) launches x L layers, in one of three
+    // regions that are reused round robin once the step that used them has run (the host runs ahead of the GPU by whole steps)
+    const size_t need = (size_t)(NB + L + 1) * (size_t)(2 * blk + 6) * (size_t)L;
+    if (need > zargs_region_) {
+        HIP_CHECK(hipStreamSynchronize(cs));
+        if (zargs_h_) { (void)hipHostFree(zargs_h_); (void)hipFree(zargs_d_); }
+        zargs_region_ = need + need / 4;
+        zargs_h_ = hmalloc<GemmArgs>(3 * zargs_region_); zargs_d_ = dmalloc<GemmArgs>(3 * zargs_region_);
+        for (int i = 0; i < 3; ++i) zargs_busy_[i] = false;
+    }
+    const int zslot = zargs_next_;
+    zargs_next_ = (zargs_next_ + 1) % 3;
+    if (zargs_busy_[zslot]) HIP_CHECK(hipEventSynchronize(zargs_done_[zslot]));
+    zargs_pos_ = (size_t)zslot * zargs_region_;
+
+    static const bool timing = getenv("APRIL_LM_TIMING") != nullptr;        // measurement: host time of the enqueue by part
+    double tacc[6] = {0, 0, 0, 0, 0, 0};
+    auto now = [&]() { return timing ? std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0; };
+    struct Batch { size_t off; int n; };
+    std::vector<Batch> plan;
+    std::vector<GemmArgs> items;
+    struct Act { int l, t0, t1; };
+    std::vector<Act> act;
+    for (int W = 0; W <= NB + L; ++W) {
+        act.clear(); plan.clear();
+        for (int l = 0; l < L; ++l) { const int b = W - 1 - l; if (b >= 0 && b < NB) act.push_back({l, b * blk, std::min(T, (b + 1) * blk)}); }
+        const size_t first = zargs_pos_;
+        double tq = now();
+        auto lap = [&](int i) { if (timing) { const double t = now(); tacc[i] += t - tq; tq = t; } };
+        auto flush = [&]() {
+            if (items.empty()) return;
+            stage_gemm_z(items.data(), (int)items.size(), zargs_h_ + zargs_pos_);
+            plan.push_back({zargs_pos_, (int)items.size()});
+            zargs_pos_ += items.size(); items.clear();
+        };
+        // the block stages come in at most two lengths (full blocks, the tail): one launch per length
+        auto by_len = [&](auto make) {
+            for (int pass = 0; pass < 2; ++pass) {
+                for (const Act &x : act) if (((x.t1 - x.t0) == blk) == (pass == 0)) items.push_back(make(x));
+                flush();
             }
+        };
+        by_len([&](const Act &x) { return lm_args_xpart(x.l, m, x.t0, x.t1); });
+        for (int i = 0; i < blk; ++i) {
+            for (const Act &x : act) if (x.t0 + i < x.t1) items.push_back(lm_args_gates(x.l, m, x.t0 + i));
+            flush();
+            for (const Act &x : act) if (x.t0 + i < x.t1) items.push_back(lm_args_whr(x.l, m, x.t0 + i));
+            flush();
         }
-        const int bg = wave - (L + 2);                                  // the search follows proj by one wave
-        if (bg >= 0 && bg < NB) {
-            HIP_CHECK(hipStreamWaitEvent(stream_, ev(L + 1, bg), 0));
-            const int g0 = bg * lm_block, g1 = std::min(T, (bg + 1) * lm_block);
-            lm_run_stage(3, 0, m, g0, g1, stream_, [&](hipStream_t) { for (int t = g0; t < g1; ++t) run_greedy_rounds(m, false, t, eout_lm_ + (size_t)t * m * d.joiner); });
+        by_len([&](const Act &x) { return lm_args_ff1(x.l, m, x.t0, x.t1); });
+        by_len([&](const Act &x) { return lm_args_ff2(x.l, m, x.t0, x.t1); });
+        lap(0);
+        if (zargs_pos_ > first)
+            HIP_CHECK(hipMemcpyAsync(zargs_d_ + first, zargs_h_ + first, (zargs_pos_ - first) * sizeof(GemmArgs), hipMemcpyHostToDevice, cs));
+        lap(1);
+        if (W < NB) lm_stage_embed(m, W * blk, std::min(T, (W + 1) * blk), cs);
+        lap(2);
+        for (const Batch &b : plan) launch_gemm_z(zargs_h_ + b.off, b.n, zargs_d_ + b.off, cs);
+        lap(3);
+        const int bp = W - L - 1;
+        if (bp >= 0) {
+            const int t0 = bp * blk, t1 = std::min(T, t0 + blk), len = t1 - t0;
+            lm_stage_proj(m, t0, t1, cs);
+            hipEvent_t e = lm_events_[1 + (size_t)(bp % (int)(lm_events_.size() - 1))];
+            HIP_CHECK(hipEventRecord(e, cs));
+            HIP_CHECK(hipStreamWaitEvent(stream_, e, 0));
+            // the block's search: bookkeeping at fixed places, then the block-independent launch chain
+            BlockSetupArgs bs;
+            bs.now_src = step_d_ + 2 * MB + (size_t)t0 * m; bs.now_dst = lm_now_d_; bs.rows_dst = lm_rows_d_; bs.row0 = t0 * m; bs.count = len * m;
+            bs.rec_off_step = rec_off_d_; bs.rec_off_block = lm_rec_off_d_; bs.rec_add = t0 * 3 * m; bs.flags = flags_d_; bs.n_flags = 8;
+            launch_block_setup(bs, stream_);
+            lap(4);
+            auto search = [&]() {
+                for (int i = 0; i < len; ++i) {
+                    GreedyIo io;
+                    io.gen = i + 1; io.now = lm_now_d_ + (size_t)i * m; io.eout = eout_lm_; io.eout_rows = lm_rows_d_ + (size_t)i * m;
+                    io.rec_off = lm_rec_off_d_; io.rec_slot0 = i * 3;
+                    io.dump = dump_logits ? logits_ + (size_t)(t0 + i) * 3 * m * d.vocab : nullptr;
+                    run_greedy_rounds(m, io);
+                }
+            };
+            if (!use_graphs_ || dump_logits) { search(); continue; }
+            const std::pair<int, int> key(m, len);
+            auto it = lm_search_graphs_.find(key);
+            if (it == lm_search_graphs_.end()) {
+                if (lm_search_graphs_.size() >= 64) { for (auto &g : lm_search_graphs_) (void)hipGraphExecDestroy(g.second); lm_search_graphs_.clear(); }
+                hipGraph_t graph = nullptr;
+                hipGraphExec_t exec = nullptr;
+                HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+                search();
+                HIP_CHECK(hipStreamEndCapture(stream_, &graph));
+                HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                HIP_CHECK(hipGraphDestroy(graph));
+                it = lm_search_graphs_.emplace(key, exec).first;
+            }
+            HIP_CHECK(hipGraphLaunch(it->second, stream_));
+            lap(5);
         }
     }
+    HIP_CHECK(hipEventRecord(zargs_done_[zslot], cs));
+    zargs_busy_[zslot] = true;
+    if (timing) fprintf(stderr, "lm wavefront %d x %d: host us: args %.0f, arg copy %.0f, front end %.0f, layer launches %.0f, proj + events + setup %.0f, search graph %.0f\n",
+                        m, T, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5]);
 }
 
 int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const int *now_ms, float *logits_out)
@@ -760,10 +925,11 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
         p_lm_ = dmalloc<float>((size_t)cfg_.max_batch * 4 * d.hidden);
         eout_lm_ = dmalloc<float>((size_t)cfg_.max_batch * d.joiner);
     }
-    {   // streams / events of the pipelined form, created outside any stream capture (one event per stage and time step covers every block size)
-        while ((int)lm_streams_.size() < d.n_layers + 1) { hipStream_t st; HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); lm_streams_.push_back(st); }
-        const size_t need_ev = (size_t)(d.n_layers + 2) * T + 1;
-        while (lm_events_.size() < need_ev) { hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); lm_events_.push_back(e); }
+    if (!lm_stream_) {               // the wavefront's stream, events and block bookkeeping (created outside any stream capture)
+        HIP_CHECK(hipStreamCreateWithFlags(&lm_stream_, hipStreamNonBlocking));
+        for (int i = 0; i < 9; ++i) { hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); lm_events_.push_back(e); }
+        for (int i = 0; i < 3; ++i) HIP_CHECK(hipEventCreateWithFlags(&zargs_done_[i], hipEventDisableTiming));
+        lm_now_d_ = dmalloc<int>((size_t)cfg_.max_batch); lm_rows_d_ = dmalloc<int>((size_t)cfg_.max_batch); lm_rec_off_d_ = dmalloc<int>(1);
     }
     const int k = steps_++;
     int *blk = ring_h_ + ring_pos_;
@@ -773,15 +939,13 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
     for (int t = 0; t < T; ++t) memcpy(blk + m + 2 * rows + (size_t)t * m, slots, (size_t)m * 4);
     step_off_h_[k] = (int)ring_pos_; rec_off_h_[k] = (int)rec_pos_;
     ring_pos_ += (size_t)m + 3 * (size_t)rows; rec_pos_ += (size_t)3 * rows;
-    static const int lm_block_ = std::max(1, getenv("APRIL_LM_BLOCK") ? atoi(getenv("APRIL_LM_BLOCK")) : 7);
-    static const int lm_streams_on = getenv("APRIL_LM_STREAMS") ? atoi(getenv("APRIL_LM_STREAMS")) : 1;
-    const bool pipelined = lm_streams_on != 0 && !profiling_ && !logits_out && T > lm_block_;
-    if (pipelined) {                 // stage graphs on per-layer streams (run_lm_chain)
+    const bool wavefront = lm_wavefront_on() && !profiling_ && T > lm_block_steps() &&
+                           gemm_fullk(m, d.d_model, kz_hr_, true) && gemm_fullk(m, d.d_model, kz_ff2_, true);
+    if (wavefront) {                 // long feed: all layers of a wavefront per launch (run_lm_wavefront)
         std::lock_guard<std::mutex> cg(capture_mu_);
-        run_lm_chain(m, T, false);
-        return k;
-    }
-    if (use_graphs_ && !profiling_ && !logits_out) {
+        run_lm_wavefront(m, T, logits_out != nullptr);
+        if (!logits_out) return k;
+    } else if (use_graphs_ && !profiling_ && !logits_out) {
         const std::pair<int, int> key(m, T);
         auto it = lm_graphs_.find(key);
         if (it == lm_graphs_.end()) {
@@ -799,8 +963,7 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
         std::lock_guard<std::mutex> cg(capture_mu_);
         HIP_CHECK(hipGraphLaunch(it->second, stream_));
         return k;
-    }
-    {
+    } else {
         std::lock_guard<std::mutex> cg(capture_mu_);
         launch_count_ = 0;
         run_lm_chain(m, T, logits_out != nullptr);
@@ -878,6 +1041,7 @@ int Engine::step(int m, const int *slots, const int *ring_tails, const int *now_
 void Engine::decode_rows(int n, const int *slots, int op)
 {
     if (n <= 0) return;
+    if (dec_table_ && op == 0) return;          // the joiner reads the table row of the slot's context: nothing to refresh
     HIP_CHECK(hipSetDevice(cfg_.device));
     const NetDims &d = L_.dims;
     const int MB = cfg_.max_batch;
@@ -889,9 +1053,9 @@ void Engine::decode_rows(int n, const int *slots, int op)
         memcpy(blk, slots + o, (size_t)m * 4);
         ring_pos_ += (size_t)m;
         HIP_CHECK(hipMemcpyAsync(dec_slots_d_, blk, (size_t)m * 4, hipMemcpyHostToDevice, stream_));
-        DecRowsArgs a; a.slot_idx = dec_slots_d_; a.M = m; a.op = op; a.blank = P_.blank_id; a.state = gstate_; a.dec = dec_params(); a.de_out = de_; a.ld_de = d.d_model;
+        DecRowsArgs a; a.slot_idx = dec_slots_d_; a.M = m; a.op = op; a.blank = P_.blank_id; a.state = gstate_; a.dec = dec_params(); a.de_out = dec_table_ ? nullptr : de_; a.ld_de = d.d_model;
         timed_begin(T_DEC); launch_dec_rows(a, stream_); timed_end(T_DEC);
-        run_decproj(m, dec_slots_d_, nullptr, nullptr, 1);
+        if (!dec_table_) run_decproj(m, dec_slots_d_, nullptr, nullptr, 1);
     }
 }
 
@@ -951,6 +1115,16 @@ void Engine::debug_decoder(int n, const int64_t *ctx, float *dout)
     HIP_CHECK(hipSetDevice(cfg_.device));
     const NetDims &d = L_.dims;
     if (n > cfg_.max_batch) { LOGE("debug_decoder: n too large"); abort(); }
+    if (dec_table_) {                           // what the sessions read: rows of the table (built by the kernels below, build_dec_table)
+        bool in_range = true;
+        for (int i = 0; i < n * 2; ++i) if (ctx[i] < 0 || ctx[i] >= d.vocab) in_range = false;
+        if (in_range) {
+            sync();
+            for (int i = 0; i < n; ++i)
+                HIP_CHECK(hipMemcpy(dout + (size_t)i * d.joiner, dec_table_ + ((size_t)ctx[2 * i] * d.vocab + (size_t)ctx[2 * i + 1]) * d.joiner, (size_t)d.joiner * 4, hipMemcpyDeviceToHost));
+            return;
+        }
+    }
     std::vector<int> slots((size_t)n), c32((size_t)n * d.context);
     for (int i = 0; i < n; ++i) { slots[(size_t)i] = i; for (int t = 0; t < d.context; ++t) c32[(size_t)i * d.context + t] = (int)ctx[(size_t)i * d.context + t]; }
     int *ctx_d = dmalloc<int>(c32.size());

@@ -126,14 +126,30 @@ private:
     void upload_tables(const FbankHostTables &ft);
     void zero_slots(int n);
     void run_encoder_rows(int n, const int *d_slots, const int *d_tails, const float *x_direct);
-    void lm_run_stage(int kind, int l, int m, int t0, int t1, hipStream_t st, const std::function<void(hipStream_t)> &fn);
     void lm_stage_embed(int m, int t0, int t1, hipStream_t st);
     void lm_stage_layer(int l, int m, int t0, int t1, hipStream_t st);
     void lm_stage_proj(int m, int t0, int t1, hipStream_t st);
     void lm_resid_ssq(const float *a, int K, size_t w_off, int kz, const float *bias, const float *resid, size_t r0, int rows, hipStream_t st);
+    GemmArgs lm_args_xpart(int l, int m, int t0, int t1) const;
+    GemmArgs lm_args_gates(int l, int m, int t) const;
+    GemmArgs lm_args_whr(int l, int m, int t) const;
+    GemmArgs lm_args_ff1(int l, int m, int t0, int t1) const;
+    GemmArgs lm_args_ff2(int l, int m, int t0, int t1) const;
+    // where one chunk's search reads its inputs and writes its records
+    struct GreedyIo {
+        int gen = 1;                          // generation of the chunk for the round flags / active marks (unique until they are cleared)
+        const int *now = nullptr;             // [n] session times
+        const float *eout = nullptr;          // null: the sessions' slot rows of eout_; else rows eout_rows[i] (or i) of this matrix
+        const int *eout_rows = nullptr;
+        const int *rec_off = nullptr; int rec_slot0 = 0;
+        float *dump = nullptr;                // [3][n][vocab] or null
+    };
     void run_greedy_rounds(int n, bool dump_logits, int chunk = 0, const float *eout_rows = nullptr);
+    void run_greedy_rounds(int n, const GreedyIo &io);
     void run_lm_chain(int m, int T, bool dump_logits);
-    void run_decproj(int n, const int *d_slots, const int *row_mask, const int *run_flag, int run_gen);
+    void run_lm_wavefront(int m, int T, bool dump_logits);
+    void run_decproj(int n, const int *d_slots, const int *row_mask, const int *run_flag, int run_gen, float *out = nullptr);
+    void build_dec_table();
     void run_chain(int m, bool dump_logits);     // advance + encoder + greedy rounds with arguments that depend on m only
     void timed_begin(int cls);
     void timed_end(int cls);
@@ -149,6 +165,7 @@ private:
     void lin(GemmArgs &g, size_t off) const { if (wh_) { g.wp = wh_ + off; g.wt = 1; } else { g.wp = w_ + off; g.wt = 0; } }
     float *h_ = nullptr, *c_ = nullptr, *ring_ = nullptr, *eout_ = nullptr, *dout_ = nullptr;
     GreedyState *gstate_ = nullptr;            // [slots]
+    float *dec_table_ = nullptr;               // [vocab * vocab][joiner] decoder output of every context, or null (build_dec_table)
     uint8_t *cls_ = nullptr;                   // [vocab] token classes
     int ring_frames_ = 0;
     // work buffers
@@ -184,9 +201,14 @@ private:
     bool use_graphs_ = true;
     std::map<int, hipGraphExec_t> step_graphs_;
     std::map<std::pair<int, int>, hipGraphExec_t> lm_graphs_;      // (m, T)
-    std::map<std::array<int, 5>, hipGraphExec_t> lm_stage_graphs_;   // (kind, layer, m, t0, t1)
-    std::vector<hipStream_t> lm_streams_;                           // one per layer + one for embed / proj (layer-major pipeline)
+    // wavefront form of the layer-major step: its stream, events, per-launch argument blocks (pinned + device), the
+    // block-independent search graphs (m, block length) and their bookkeeping words
+    std::map<std::pair<int, int>, hipGraphExec_t> lm_search_graphs_;
+    hipStream_t lm_stream_ = nullptr;
     std::vector<hipEvent_t> lm_events_;
+    GemmArgs *zargs_h_ = nullptr, *zargs_d_ = nullptr; size_t zargs_region_ = 0, zargs_pos_ = 0;     // three regions, round robin
+    hipEvent_t zargs_done_[3] = {nullptr, nullptr, nullptr}; bool zargs_busy_[3] = {false, false, false}; int zargs_next_ = 0;
+    int *lm_now_d_ = nullptr, *lm_rows_d_ = nullptr, *lm_rec_off_d_ = nullptr;
     long kernels_per_step_ = 0, launch_count_ = 0;
     // profiling
     bool profiling_ = false;

@@ -56,12 +56,19 @@ struct RowScale {                  // BasicNorm scale of a row from its sum-of-s
     float eps = 0.0f;
 };
 
+// Per-slot search state (reference AprilASRSession_i: context tensor, last_emission_time_ms, the class of the
+// last active token; src/april_session.h:32-73); see "greedy search on the device" below.
+struct GreedyState { int32_t ctx0, ctx1; int32_t last_tok; uint32_t last_emit_ms; };
+
 struct GemmArgs {
     // A operand as up to two K segments with optional row indirection (slot ids)
     const float *a0 = nullptr; int lda0 = 0; const int *aidx0 = nullptr; int K0 = 0;
     const float *a1 = nullptr; int lda1 = 0; const int *aidx1 = nullptr; int K1 = 0;
     const float *a0b = nullptr;            // AOP_TANH_ADD second addend (same ld as a0; row index aidx0b, or aidx0 when same_idx_b)
     const int *aidx0b = nullptr; int same_idx_b = 1;
+    // decoder-output table (engine.h): when set, the second addend's row is table row ctx0 * ctx_vocab + ctx1 of the search
+    // state of the row's slot (the index aidx0b / aidx0 would have given), i.e. a0b = the table
+    const GreedyState *ctx_state = nullptr; int ctx_vocab = 0;
     int a_op = AOP_NONE;
     RowScale x_scale;                      // optional (ssq != null).  EPI_LSTM: the A-segment-0 half of the sum, ((p0+p1) * scale + p2) + p3;
                                            // EPI_SLOT_STORE: the whole sum, out = acc * scale + bias
@@ -100,6 +107,11 @@ struct GemmArgs {
     int debug = 0;                         // measurement only: 1 = skip the MFMA main loop, 2 = skip the epilogue math, 3 = all k blocks read block 0
 };
 void launch_gemm(const GemmArgs &g, hipStream_t s);
+// n independent GEMMs of ONE shape (same M, N, K, kz, epilogue; any pointers) in one launch.  stage_gemm_z finalizes the
+// argument blocks on the host; launch_gemm_z launches once they are in device memory at dev_args (in stream order).
+// Fused-epilogue forms only (EPI_LSTM, EPI_XPART, EPI_BIAS_DSWISH, and EPI_HR / EPI_RESID_SSQ where gemm_fullk says so).
+void stage_gemm_z(const GemmArgs *items, int n, GemmArgs *staged);
+void launch_gemm_z(const GemmArgs *staged, int n, const GemmArgs *dev_args, hipStream_t s);
 // number of partial planes launch_gemm will write for an EPI_PARTIAL GEMM of this shape
 int gemm_partials(int M, int N, int kz);
 // true when launch_gemm runs a GEMM of this shape on the full-K schedule, i.e. the caller may (must, for the row
@@ -132,7 +144,6 @@ void launch_row(const RowArgs &r, hipStream_t s);
 // Per-slot search state (reference AprilASRSession_i: context tensor, last_emission_time_ms, the class of the
 // last active token; src/april_session.h:32-73).  The host keeps the token list and runs the callbacks; the
 // device keeps what the NEXT network call depends on, so a chunk needs no host decision.
-struct GreedyState { int32_t ctx0, ctx1; int32_t last_tok; uint32_t last_emit_ms; };
 // One joiner round of one session.  flags: 1 = valid (the round ran), 2 = resolved to blank, 4 = context changed
 struct StepRecord { int32_t idx; float max_val; float blank_val; uint32_t flags; };
 enum { REC_VALID = 1, REC_BLANK = 2, REC_CTX = 4 };
@@ -219,6 +230,17 @@ struct ZeroSlotArgs {
     int slot = 0;
 };
 void launch_zero_slot(const ZeroSlotArgs &a, hipStream_t s);
+
+// Search bookkeeping of one BLOCK of time steps of a layer-major step, so that the search's launch chain has arguments that do
+// not depend on the block (one captured graph serves every block): the block's session times and encoder-output row numbers
+// are copied to fixed places, the record offset of the block is derived from the step's, the round flags are cleared.
+struct BlockSetupArgs {
+    const int *now_src = nullptr; int *now_dst = nullptr;     // [count] session times of the block's rows
+    int *rows_dst = nullptr; int row0 = 0; int count = 0;     // rows_dst[i] = row0 + i
+    const int *rec_off_step = nullptr; int *rec_off_block = nullptr; int rec_add = 0;
+    int *flags = nullptr; int n_flags = 0;
+};
+void launch_block_setup(const BlockSetupArgs &a, hipStream_t s);
 
 // ---------------------------------------------------------------- encoder front (conv 1+2, im2col for conv 3)
 struct ConvEmbedArgs {

@@ -50,7 +50,7 @@ template <> struct WQuad<1> { using type = h4; };
 // outputs per workgroup a wave has two accumulator tiles, i.e. chains of four DEPENDENT MFMAs back to back, which issue at
 // half rate (measured: 520 cycles per k-block instead of 256); a second wave on the same SIMD fills the gaps.
 template <int MT, int NT, int EPI, int AOP, int WT, int MODE, int ASM, int NW = 4>
-__global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kernel(GemmArgs g)
+__device__ __forceinline__ void gemm_body(const GemmArgs &g, const int zg, const unsigned wg_linear)
 {
     using Cfg = TileCfg<MT, NT, NW>;
     constexpr int NTH = NW * 64;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
     // measurement only (tools/gemm_bench built with -DAPRIL_GEMM_TRACE, run with GEMM_TRACE=1): wave 0 stamps s_memtime at
     // phase boundaries (uniform branch, all lanes store the same value); compiled out of the product
 #ifdef APRIL_GEMM_TRACE
-    auto stamp = [&](int i) { if (g.trace && wave == 0) g.trace[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + i] = __builtin_amdgcn_s_memtime(); };
+    auto stamp = [&](int i) { if (g.trace && wave == 0) g.trace[(size_t)wg_linear * 8 + i] = __builtin_amdgcn_s_memtime(); };
 #else
     auto stamp = [](int) {};
 #endif
@@ -77,21 +77,20 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
     if (g.trace && wave == 0) {   // where this workgroup runs: HW_ID (wave/simd/cu/sh/se fields) and XCC_ID
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n s_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
-        g.trace[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + 5] = ((unsigned long long)xcc << 32) | hw;
+        g.trace[(size_t)wg_linear * 8 + 5] = ((unsigned long long)xcc << 32) | hw;
     }
 #endif
     // XCD-aware mapping: consecutive blockIdx.x land on different XCDs, so keep the
     // M-blocks that share one weight column on the same XCD (same x mod 8).
     const int nt0 = blockIdx.x * NT;
     const int m0 = blockIdx.y * Cfg::BM;
-    const int zg = blockIdx.z;                 // GM_SLAB: this workgroup owns slabs [zg*zs, (zg+1)*zs)
+    // zg (GM_SLAB): this workgroup owns slabs [zg*zs, (zg+1)*zs)
     if (g.skew > 0) {
         // Two workgroups share a CU.  Dispatched together they run in lock-step: both stream MFMAs (halving each
         // other's rate), then both sit in their epilogues while the matrix pipe idles.  Delaying every second
         // "generation" of workgroups once, by about one epilogue, interleaves the phases for the rest of the launch.
         // Placement is only a heuristic here (speed, never correctness).
-        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        if ((lin >> 8) & 1) for (int i = 0; i < g.skew; ++i) __builtin_amdgcn_s_sleep(64);
+        if ((wg_linear >> 8) & 1) for (int i = 0; i < g.skew; ++i) __builtin_amdgcn_s_sleep(64);
     }
     const int KB = g.K >> 4;
 
@@ -138,7 +137,8 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
         const int r0 = g.aidx0 ? g.aidx0[row] : row;
         aoff0[mt] = (uint32_t)(((size_t)r0 * g.lda0 + kq * 4) * sizeof(float));
         if (AOP == AOP_TANH_ADD) {
-            const int rb = g.same_idx_b ? r0 : (g.aidx0b ? g.aidx0b[row] : row);
+            int rb = g.same_idx_b ? r0 : (g.aidx0b ? g.aidx0b[row] : row);
+            if (g.ctx_state) { const GreedyState st = g.ctx_state[rb]; rb = st.ctx0 * g.ctx_vocab + st.ctx1; }
             aoffb[mt] = (uint32_t)(((size_t)rb * g.lda0 + kq * 4) * sizeof(float));
         }
         aoff1[mt] = 0;
@@ -204,7 +204,10 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
 #ifndef APRIL_FULLK_DEPTH1
 #define APRIL_FULLK_DEPTH1 6     // measured: 12 stages are slower (whr 8.7 -> 9.9 us, FFN-down 11.9 -> 13.4 us at 256 rows)
 #endif
-    constexpr int DEPTH = FULLK ? ((MT == 1) ? APRIL_FULLK_DEPTH1 : (MT == 2 ? 4 : 3)) : ((MT == 1) ? 6 : (MT == 2 ? 3 : APRIL_DEPTH4));
+#ifndef APRIL_DEPTH1
+#define APRIL_DEPTH1 6
+#endif
+    constexpr int DEPTH = FULLK ? ((MT == 1) ? APRIL_FULLK_DEPTH1 : (MT == 2 ? 4 : 3)) : ((MT == 1) ? APRIL_DEPTH1 : (MT == 2 ? 3 : APRIL_DEPTH4));
     f32x4 a_st[DEPTH][MT];
     BQ b_st[DEPTH][NT];
     int ld_base = first_kb, ld_off = 0, ld_cnt = 0;
@@ -599,6 +602,30 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
     stamp(4);
 }
 
+template <int MT, int NT, int EPI, int AOP, int WT, int MODE, int ASM, int NW = 4>
+__global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kernel(GemmArgs g)
+{
+    gemm_body<MT, NT, EPI, AOP, WT, MODE, ASM, NW>(g, (int)blockIdx.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+}
+
+// The same GEMM for `gridDim.z / zdiv` INDEPENDENT problems of one shape in one launch: blockIdx.z / zdiv selects the argument
+// block (a device array written before the launch, read with scalar loads), blockIdx.z % zdiv is the slab group.  The
+// offline wavefront schedule (engine.cc) batches the same step of all encoder layers this way: at one session a layer's
+// recurrent step is a latency-bound launch, twelve of them in one launch cost about the same.
+template <int MT, int NT, int EPI, int AOP, int WT, int MODE>
+__global__ __launch_bounds__(256, MT == 4 ? 2 : 1) void gemm_f32_zkernel(const GemmArgs *zargs, int zdiv)
+{
+    const int zl = (int)blockIdx.z / zdiv;
+    static_assert(sizeof(GemmArgs) % 4 == 0, "argument block is copied by words");
+    typedef const __attribute__((address_space(4))) unsigned *ConstWords;     // constant address space: uniform scalar loads
+    ConstWords src = (ConstWords)(unsigned long long)(zargs + zl);
+    GemmArgs g;
+    unsigned *dst = reinterpret_cast<unsigned *>(&g);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(GemmArgs) / 4; ++i) dst[i] = src[i];
+    gemm_body<MT, NT, EPI, AOP, WT, MODE, 0, 4>(g, (int)blockIdx.z - zl * zdiv, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+}
+
 // ---------------------------------------------------------------- host side
 struct TilePlan { int mt, nt, zs, mode; };
 
@@ -705,9 +732,9 @@ static bool dispatch(const GemmArgs &g, hipStream_t s)
     return false;
 }
 
-void launch_gemm(const GemmArgs &g_in, hipStream_t s)
+// plan + checks + measurement knobs: everything launch_gemm decides on the host
+static TilePlan finalize_gemm(GemmArgs &g)
 {
-    GemmArgs g = g_in;
     static const int dbg = env_int("APRIL_GEMM_DEBUG", 0);
     g.debug = dbg;
     static const int skew = env_int("APRIL_GEMM_SKEW", 0);        // round 2: no start skew (measured below)
@@ -724,12 +751,74 @@ void launch_gemm(const GemmArgs &g_in, hipStream_t s)
     //   workgroups per CU): 91.3 / 170.4   compiler loop, no skew: 56.5 / 100.7 / 180.2;  FFN-up [2048,512]x[512,2048]: 42.3 vs 45.7
     g.asm_loop = asm_loop != 0;
     g.skew = (long)(g.N / (16 * t.nt)) * ((g.M + 16 * t.mt - 1) / (16 * t.mt)) * (t.mode == GM_FULLK ? 1 : g.kz / g.zs) >= 512 ? skew : 0;   // two workgroups per CU
+    return t;
+}
+
+void launch_gemm(const GemmArgs &g_in, hipStream_t s)
+{
+    GemmArgs g = g_in;
+    const TilePlan t = finalize_gemm(g);
     const int mt = t.mt, nt = t.nt;
     bool ok = false;
     if (mt == 1) { if (nt == 4) ok = dispatch<1, 4>(g, s); else if (nt == 2) ok = dispatch<1, 2>(g, s); else ok = dispatch<1, 1>(g, s); }
     else if (mt == 2) { if (nt == 4) ok = dispatch<2, 4>(g, s); else if (nt == 2) ok = dispatch<2, 2>(g, s); else ok = dispatch<2, 1>(g, s); }
     else { if (nt == 4) ok = dispatch<4, 4>(g, s); else if (nt == 2) ok = dispatch<4, 2>(g, s); else ok = dispatch<4, 1>(g, s); }
     if (!ok) { fprintf(stderr, "libapril(mi355x): launch_gemm: no kernel for epi %d a_op %d mode %d tile %dx%d\n", g.epi, g.a_op, g.mode, mt, nt); abort(); }
+}
+
+// ---- n independent problems of one shape in one launch (gemm_f32_zkernel)
+template <int MT, int NT, int EPI, int AOP, int MODE>
+static void launch_one_z(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s)
+{
+    using Cfg = TileCfg<MT, NT>;
+    const int zdiv = MODE == GM_FULLK ? 1 : g.kz / g.zs;
+    dim3 grid((unsigned)(g.N / Cfg::BN), (unsigned)((g.M + Cfg::BM - 1) / Cfg::BM), (unsigned)(zdiv * n));
+    const int sg = EPI == EPI_HR ? g.r_scale.groups : ((EPI == EPI_LSTM || EPI == EPI_SLOT_STORE || EPI == EPI_XPART) && g.x_scale.ssq ? g.x_scale.groups : 0);
+    const size_t lds = (size_t)(Cfg::LDS_FLOATS + Cfg::BM + (sg ? Cfg::BM * (sg + 1) : 0)) * sizeof(float);
+    if (g.wt == 1) hipLaunchKernelGGL((gemm_f32_zkernel<MT, NT, EPI, AOP, 1, MODE>), grid, dim3(256), lds, s, dev_args, zdiv);
+    else hipLaunchKernelGGL((gemm_f32_zkernel<MT, NT, EPI, AOP, 0, MODE>), grid, dim3(256), lds, s, dev_args, zdiv);
+}
+
+template <int MT, int NT>
+static bool dispatch_z(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s)
+{
+#define CASE(E, MD) if (g.epi == E && g.a_op == AOP_NONE && g.mode == MD) { launch_one_z<MT, NT, E, AOP_NONE, MD>(g, dev_args, n, s); return true; }
+    if constexpr (NT == 2) {
+        CASE(EPI_HR, GM_FULLK) CASE(EPI_RESID_SSQ, GM_FULLK)
+        CASE(EPI_HR, GM_SLAB) CASE(EPI_RESID_SSQ, GM_SLAB)
+    }
+    CASE(EPI_LSTM, GM_SLAB) CASE(EPI_XPART, GM_SLAB) CASE(EPI_BIAS_DSWISH, GM_SLAB)
+#undef CASE
+    return false;
+}
+
+void stage_gemm_z(const GemmArgs *items, int n, GemmArgs *staged)
+{
+    TilePlan t0{0, 0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        staged[i] = items[i];
+        const TilePlan t = finalize_gemm(staged[i]);
+        if (i == 0) t0 = t;
+        const GemmArgs &a = staged[i], &b = staged[0];
+        if (t.mt != t0.mt || t.nt != t0.nt || t.zs != t0.zs || t.mode != t0.mode || a.M != b.M || a.N != b.N || a.K != b.K || a.kz != b.kz || a.epi != b.epi || a.wt != b.wt ||
+            a.a_op != AOP_NONE || a.x_scale.groups != b.x_scale.groups || a.r_scale.groups != b.r_scale.groups || (a.x_scale.ssq == nullptr) != (b.x_scale.ssq == nullptr)) {
+            fprintf(stderr, "libapril(mi355x): stage_gemm_z: the problems of one launch must have one shape\n"); abort();
+        }
+    }
+}
+
+void launch_gemm_z(const GemmArgs *staged, int n, const GemmArgs *dev_args, hipStream_t s)
+{
+    if (n <= 0) return;
+    const GemmArgs &g = staged[0];
+    GemmArgs probe = g;
+    const TilePlan t = finalize_gemm(probe);
+    const int mt = t.mt, nt = t.nt;
+    bool ok = false;
+    if (mt == 1) { if (nt == 4) ok = dispatch_z<1, 4>(g, dev_args, n, s); else if (nt == 2) ok = dispatch_z<1, 2>(g, dev_args, n, s); else ok = dispatch_z<1, 1>(g, dev_args, n, s); }
+    else if (mt == 2) { if (nt == 4) ok = dispatch_z<2, 4>(g, dev_args, n, s); else if (nt == 2) ok = dispatch_z<2, 2>(g, dev_args, n, s); else ok = dispatch_z<2, 1>(g, dev_args, n, s); }
+    else { if (nt == 4) ok = dispatch_z<4, 4>(g, dev_args, n, s); else if (nt == 2) ok = dispatch_z<4, 2>(g, dev_args, n, s); else ok = dispatch_z<4, 1>(g, dev_args, n, s); }
+    if (!ok) { fprintf(stderr, "libapril(mi355x): launch_gemm_z: no kernel for epi %d mode %d tile %dx%d\n", g.epi, g.mode, mt, nt); abort(); }
 }
 
 }  // namespace aprilx

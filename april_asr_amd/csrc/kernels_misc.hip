@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void decide_kernel(DecideArgs a)
         s_ctx[0] = st.ctx0; s_ctx[1] = st.ctx1; s_ctx[2] = rerun ? 1 : 0;
     }
     __syncthreads();
-    if (s_ctx[2]) dec_embed_row(a.dec, s_ctx[0], s_ctx[1], a.de_out + (size_t)m * a.ld_de);
+    if (s_ctx[2] && a.de_out) dec_embed_row(a.dec, s_ctx[0], s_ctx[1], a.de_out + (size_t)m * a.ld_de);     // (no table: the decoder runs for this row)
 }
 
 void launch_decide(const DecideArgs &a, hipStream_t s)
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void dec_rows_kernel(DecRowsArgs a)
         s_ctx[0] = st.ctx0; s_ctx[1] = st.ctx1;
     }
     __syncthreads();
-    dec_embed_row(a.dec, s_ctx[0], s_ctx[1], a.de_out + (size_t)m * a.ld_de);
+    if (a.de_out) dec_embed_row(a.dec, s_ctx[0], s_ctx[1], a.de_out + (size_t)m * a.ld_de);
 }
 
 void launch_dec_rows(const DecRowsArgs &a, hipStream_t s)
@@ -262,6 +262,18 @@ __global__ __launch_bounds__(256) void zero_slot_kernel(ZeroSlotArgs a)
 void launch_zero_slot(const ZeroSlotArgs &a, hipStream_t s)
 {
     hipLaunchKernelGGL(zero_slot_kernel, dim3((unsigned)a.n_layers + 1), dim3(256), 0, s, a);
+}
+
+__global__ __launch_bounds__(256) void block_setup_kernel(BlockSetupArgs a)
+{
+    for (int i = threadIdx.x; i < a.count; i += 256) { a.now_dst[i] = a.now_src[i]; a.rows_dst[i] = a.row0 + i; }
+    if ((int)threadIdx.x < a.n_flags) a.flags[threadIdx.x] = 0;
+    if (threadIdx.x == 0) a.rec_off_block[0] = a.rec_off_step[0] + a.rec_add;
+}
+
+void launch_block_setup(const BlockSetupArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(block_setup_kernel, dim3(1), dim3(256), 0, s, a);
 }
 
 // ---------------------------------------------------------------- conv front end

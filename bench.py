@@ -254,9 +254,11 @@ def main():
         offline = {"audio_s": secs, "wall_ms": round((b - a) * 1e3, 2), "rtf": round((b - a) / secs, 6), "chunks": nchunks,
                    "us_per_chunk": round((b - a) * 1e6 / max(1, nchunks), 2), "layer_major_chunks": int(st_b.lm_chunks - st_a.lm_chunks),
                    "streaming_100ms_rtf_same_session": sweep.get("1") if sweep else None,
+                   "speedup_vs_streaming": round(sweep["1"] / ((b - a) / secs), 2) if sweep and sweep.get("1") else None,
+                   "schedule": "layer-major wavefront: blocks of time steps, the same launch of all layers z-batched into one (Engine::run_lm_wavefront)",
                    "recurrent_weight_bytes_per_chunk": int(wbytes),
                    "frac_of_hbm_peak_if_restreamed": round(wbytes * nchunks / (b - a) / 1e9 / HBM_PEAK_GBS, 4),
-                   "note": "recurrent weights (gate h-half + projection, 10 MB per layer) are re-read every time step but stay L2 / Infinity-Cache resident"}
+                   "note": "recurrent weights (gate h-half + projection, 10 MB per layer) are re-read every time step from the Infinity Cache (120 MB for 12 layers)"}
 
     # ---------------- CPU baseline: the oracle (plain-C port, 1 thread) on the host, bounded sample
     cpu = None
@@ -333,7 +335,7 @@ def main():
                        "sessions_per_gpu": B, "feed_ms": 100, "params": int(d.param_count), "parallelism": "sessions sharded, dp%d" % world},
             "rtf": round(rtf, 5), "sessions_total": world * B,
             "step_latency_ms": {"p50": round(float(np.percentile(step_wall, 50)) * 1e3, 3), "p99": round(float(np.percentile(step_wall, 99)) * 1e3, 3),
-                                "max": round(max(step_wall) * 1e3, 3), "what": "wall time of one aprilx_feed_many call (100 ms of audio for every session, callbacks delivered), rank 0"},
+                                "max": round(max(step_wall) * 1e3, 3), "series": [round(x * 1e3, 2) for x in step_wall[:200]], "what": "wall time of one aprilx_feed_many call (100 ms of audio for every session, callbacks delivered), rank 0"},
             "max_sessions_per_gpu_rtf_le_0.1_tested": max_ok, "rtf_by_sessions_per_gpu": sweep,
             "callbacks": int(counts[0]), "tokens_in_callbacks": int(counts[5]), "model_load_s": round(load_s, 2), "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2), "weight_broadcast": bcast_info,
             "engine_steps": int(st.steps), "host_phase_ms_total": host_ms, "max_batch_seen": int(st.max_batch_seen),

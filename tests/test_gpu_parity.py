@@ -203,8 +203,8 @@ def test_layer_major_equals_streaming(which, secs, request):
     assert n_s == n_o
     assert np.array_equal(lg_s, lg_o)
     assert ev_s == ev_o
-    # untraced: the captured, multi-stream pipelined form of the same step (layers overlap across blocks of time steps);
-    # the callbacks carry the emitted tokens' logits bit for bit
+    # (a long feed runs as a wavefront over blocks of time steps -- the same launch of all layers is ONE z-batched launch,
+    # Engine::run_lm_wavefront -- traced or not; untraced the search additionally runs as one captured graph per block)
     import april_asr_amd as A
     ev_p = []
     s = A.Session(gm, lambda t, toks: ev_p.append((t, toks)), raw_events=True)

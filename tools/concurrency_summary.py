@@ -24,8 +24,15 @@ print("kernels %d  span %.2f ms  union-busy %.2f ms (%.1f%%)  summed %.2f ms  av
 print("time share by kernels in flight:", {k: round(100.0 * v / span, 1) for k, v in sorted(hist.items())})
 q = collections.Counter(r[3] for r in rows)
 print("kernels per queue:", dict(q))
+for qid in sorted(q):      # per queue (= per stream here): busy time and the gaps between consecutive kernels
+    rs = [r for r in rows if r[3] == qid]
+    b = sum(e - s for s, e, _, _ in rs)
+    gaps = [max(0, rs[i + 1][0] - rs[i][1]) for i in range(len(rs) - 1)]
+    small = [g for g in gaps if g < 50000]
+    print("  queue %s: %d kernels, busy %.2f ms, active span %.2f ms, gaps < 50 us: sum %.2f ms (mean %.2f us), larger gaps: %d sum %.2f ms" % (
+        qid, len(rs), b / 1e6, (rs[-1][1] - rs[0][0]) / 1e6, sum(small) / 1e6, (sum(small) / max(1, len(small))) / 1e3, len(gaps) - len(small), (sum(gaps) - sum(small)) / 1e6))
 names = collections.defaultdict(lambda: [0, 0])
 for s, e, n, _ in rows:
     names[n][0] += 1; names[n][1] += e - s
-for n, (c, t) in sorted(names.items(), key=lambda x: -x[1][1])[:10]:
+for n, (c, t) in sorted(names.items(), key=lambda x: -x[1][1])[:16]:
     print("  %7d x %8.2f us  %s" % (c, t / c / 1e3, n[:110]))

@@ -1,4 +1,8 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-for shape in "256 512 2048 4 4" "256 512 1024 3 4" "256 2048 512 2 1" "256 512 2048 4 8" "256 512 1024 3 8"; do GEMM_TRACE=1 GEMM_TRACE_CU=1 timeout 60 tools/gemm_bench_trace $shape 200 12; done > gpurun_out/i_trace.txt 2>&1
-cat gpurun_out/i_trace.txt
+export APRIL_LOG_LEVEL=WARNING
+for i in 1 2 3; do
+timeout 300 python bench.py --no-cpu-baseline --no-sweep --profile-steps 0 > gpurun_out/i_bench$i.json 2>/dev/null
+python -c "
+import json; d=json.load(open('gpurun_out/i_bench$i.json')); print(d['ms_per_step'], d['step_latency_ms']['series'], d['host_phase_ms_total'])"
+done

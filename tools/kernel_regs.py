@@ -15,10 +15,14 @@ for l in out.splitlines():
         if m and cur is not None and k not in cur:
             cur[k] = int(m.group(1))
 names = subprocess.run(["c++filt"], input="\n".join(r["name"] for r in rows), capture_output=True, text=True).stdout.splitlines()
-EPI = ["PARTIAL", "LSTM", "DSWISH", "HR", "RESID_SSQ", "SLOT_STORE"]; AOP = ["-", "tanh", "scale"]
+EPI = ["PARTIAL", "LSTM", "DSWISH", "HR", "RESID_SSQ", "SLOT_STORE", "XPART"]; AOP = ["-", "tanh", "scale"]
 for r, n in sorted(zip(rows, names), key=lambda x: x[1]):
     m = re.search(r"gemm_f32_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", n)
     if m:
         mt, nt, e, a, wt, md, hand, nw = map(int, m.groups())
         n = "gemm %dx%d %-10s %-5s %s %s %s %dw" % (16 * mt, 16 * nt, EPI[e], AOP[a], "f16" if wt else "f32", "FULLK" if md else "slab ", "asm" if hand else "   ", nw)
+    m = re.search(r"gemm_f32_zkernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", n)
+    if m:
+        mt, nt, e, a, wt, md = map(int, m.groups())
+        n = "gemm-z %dx%d %-10s %-5s %s %s" % (16 * mt, 16 * nt, EPI[e], AOP[a], "f16" if wt else "f32", "FULLK" if md else "slab ")
     print("%-60s vgpr %3s agpr %3s scratch %4s occ %s sgpr %s" % (n[:60], r.get("VGPRs"), r.get("AGPRs"), r.get("ScratchSize"), r.get("Occupancy"), r.get("SGPRs")))
