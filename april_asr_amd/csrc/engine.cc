@@ -758,7 +758,7 @@ void Engine::lm_stage_proj(int m, int t0, int t1, hipStream_t st)
 
 static int lm_block_steps()
 {
-    static const int v = std::max(1, getenv("APRIL_LM_BLOCK") ? atoi(getenv("APRIL_LM_BLOCK")) : 7);
+    static const int v = std::max(1, getenv("APRIL_LM_BLOCK") ? atoi(getenv("APRIL_LM_BLOCK")) : 10);
     return v;
 }
 

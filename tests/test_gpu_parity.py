@@ -418,6 +418,40 @@ def test_model_broadcast_in_library(gpu_tiny, tiny_model):
     assert li.used_rccl == 1 and li.ranks == 1 and li.broadcast_bytes > 0 and li.broadcast_ms >= 0.0
 
 
+def test_decoder_table_equals_decoder_network(tiny_model, gpu_tiny):
+    """The decoder output of EVERY 2-token context is computed once at load (Engine::build_dec_table) and the joiner reads the
+    row of a session's context.  A model loaded with the table disabled runs the decoder network per context change as in
+    round 1: decoder outputs, every joiner logit and every callback of the two are equal BIT FOR BIT."""
+    import os
+    import april_asr_amd as A
+    from oracle import orc_py as O
+    old = os.environ.get("APRIL_DEC_TABLE_MB")
+    os.environ["APRIL_DEC_TABLE_MB"] = "0"
+    try:
+        direct = A.Model(tiny_model["path"])
+    finally:
+        if old is None:
+            del os.environ["APRIL_DEC_TABLE_MB"]
+        else:
+            os.environ["APRIL_DEC_TABLE_MB"] = old
+    try:
+        V = int(gpu_tiny.dims.vocab)
+        rng = np.random.RandomState(5)
+        ctx = rng.randint(0, V, size=(300, 2)).astype(np.int64)
+        ctx[:4] = [[0, 0], [V - 1, V - 1], [0, V - 1], [V - 1, 0]]
+        assert np.array_equal(gpu_tiny.run_decoder(ctx), direct.run_decoder(ctx))
+        pcm = O.lcg_pcm16_fast(16000 * 4, seed=77)
+        ev_t, lg_t, n_t = run_gpu(gpu_tiny, pcm, 1600)
+        ev_d, lg_d, n_d = run_gpu(direct, pcm, 1600)
+        assert n_t == n_d and np.array_equal(lg_t, lg_d) and ev_t == ev_d and len(ev_t) > 0
+        ev_t2, lg_t2, _ = run_gpu(gpu_tiny, pcm, pcm.size)          # long feed (wavefront) on both
+        ev_d2, lg_d2, _ = run_gpu(direct, pcm, pcm.size)
+        assert np.array_equal(lg_t2, lg_d2) and ev_t2 == ev_d2 and np.array_equal(lg_t2, lg_t)
+        assert direct.stats().replay_mismatch == 0
+    finally:
+        direct.close()
+
+
 def test_two_engines_on_one_device(tiny_model):
     """APRIL_GPU_DEVICES=0,0: two engines (stream + stepping thread + slot arrays each) on one GPU, the second one's
     weights are a device-to-device copy of the first (the multi-device load path without a second GPU); sessions are
