@@ -39,7 +39,8 @@ class AprilxStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("ticks", "steps", "chunks", "rounds", "frames", "max_batch_seen")] + \
                [("kernel_ms", C.c_double * 6), ("kernel_launches", C.c_uint64 * 6), ("host_ms", C.c_double * 8),
                 ("flights", C.c_uint64), ("replay_mismatch", C.c_uint64), ("kernels_per_step", C.c_uint64),
-                ("lm_steps", C.c_uint64), ("lm_chunks", C.c_uint64)]
+                ("lm_steps", C.c_uint64), ("lm_chunks", C.c_uint64),
+                ("wave_steps", C.c_uint64), ("wave_chunks", C.c_uint64)]
 
 
 class AprilxLoadInfo(C.Structure):

@@ -95,7 +95,8 @@ bool create_engines(Model &m, const float *blob_host, const float *blob_device)
     m.tok_class = classify_tokens(P);
     EngineConfig cfg;
     cfg.max_slots = env_int("APRIL_MAX_SESSIONS", 4096);
-    cfg.max_batch = std::min(cfg.max_slots, env_int("APRIL_MAX_BATCH", 2048));
+    // rows of the work buffers = sessions x chunks stepped together (a 100 ms feed of 2048 sessions is 3 x 2048 rows); < 1 GB at 8192
+    cfg.max_batch = std::max(1, env_int("APRIL_MAX_BATCH", 8192));
     if (const char *pv = getenv("APRIL_PRECISION")) {
         const std::string v(pv);
         if (v == "f16" || v == "fp16" || v == "half") cfg.precision = 1;
@@ -662,7 +663,7 @@ void aprilx_model_stats(AprilASRModel model, int device_index, AprilxStats *out)
     const SchedStats st = model->m.scheds[(size_t)device_index]->stats();
     out->ticks = st.ticks; out->steps = st.steps; out->chunks = st.chunks; out->rounds = st.rounds; out->frames = st.frames; out->max_batch_seen = st.max_batch_seen;
     for (int i = 0; i < 8; ++i) out->host_ms[i] = st.host_ms[i];
-    out->flights = st.flights; out->replay_mismatch = st.replay_mismatch; out->lm_steps = st.lm_steps; out->lm_chunks = st.lm_chunks;
+    out->flights = st.flights; out->replay_mismatch = st.replay_mismatch; out->lm_steps = st.lm_steps; out->lm_chunks = st.lm_chunks; out->wave_steps = st.wave_steps; out->wave_chunks = st.wave_chunks;
     Engine *e = model->m.engines[(size_t)device_index];
     out->kernels_per_step = (uint64_t)e->kernels_per_step();
     for (int i = 0; i < 6; ++i) { out->kernel_ms[i] = e->timing(i).ms; out->kernel_launches[i] = (uint64_t)e->timing(i).launches; }

@@ -203,7 +203,7 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     rec_cap_ = std::max<size_t>((size_t)1 << 20, 3 * MB * 8); rec_d_ = dmalloc<StepRecord>(rec_cap_); rec_h_ = hmalloc<StepRecord>(rec_cap_);
     counter_d_ = dmalloc<int>(1); rec_off_d_ = dmalloc<int>(1); flags_d_ = dmalloc<int>(8);
     step_d_ = dmalloc<int>(4 * MB); active_d_ = dmalloc<int>(MB); dirty_d_ = dmalloc<int>(MB);
-    dec_slots_d_ = dmalloc<int>(S);
+    dec_slots_d_ = dmalloc<int>(std::max(S, MB));
     HIP_CHECK(hipMemset(counter_d_, 0, 4)); HIP_CHECK(hipMemset(rec_off_d_, 0, 4)); HIP_CHECK(hipMemset(flags_d_, 0, 32));
 
     upload_tables(ft);
@@ -269,6 +269,7 @@ Engine::~Engine()
     for (auto &g : step_graphs_) (void)hipGraphExecDestroy(g.second);
     for (auto &g : lm_graphs_) (void)hipGraphExecDestroy(g.second);
     for (auto &g : lm_search_graphs_) (void)hipGraphExecDestroy(g.second);
+    for (auto &p : sw_plans_) { if (p.second.graph) (void)hipGraphExecDestroy(p.second.graph); if (p.second.dev) (void)hipFree(p.second.dev); }
     if (lm_stream_) { (void)hipStreamSynchronize(lm_stream_); (void)hipStreamDestroy(lm_stream_); }
     for (hipEvent_t e : lm_events_) (void)hipEventDestroy(e);
     if (zargs_h_) { (void)hipHostFree(zargs_h_); (void)hipFree(zargs_d_); }
@@ -668,6 +669,21 @@ GemmArgs Engine::lm_args_gates(int l, int m, int t) const
     return g;
 }
 
+GemmArgs Engine::sw_args_gates(int l, int m, int t) const
+{   // the one-launch gates GEMM of a chunk step (run_encoder_rows) on the rows of chunk t: [norm(y) | h_prev] x Wg, fused LSTM cell
+    const NetDims &d = L_.dims;
+    const size_t S = (size_t)cfg_.max_slots;
+    const int G = d.d_model / SSQ_COLS;
+    const PackedLayout::Layer &o = L_.layers[(size_t)l];
+    const size_t r0 = (size_t)t * m;
+    GemmArgs g; g.a0 = y_ + r0 * d.d_model; g.lda0 = d.d_model; g.K0 = d.d_model;
+    g.x_scale.ssq = ssq_ + r0 * G; g.x_scale.groups = G; g.x_scale.inv_n = 1.0f / (float)d.d_model; g.x_scale.eps = l == 0 ? L_.embed_eps : L_.norm_eps[(size_t)l - 1];
+    g.a1 = h_ + (size_t)l * S * d.d_model; g.lda1 = d.d_model; g.aidx1 = step_d_; g.K1 = d.d_model;
+    lin(g, o.wg); g.M = m; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_LSTM;
+    g.out = u_ + r0 * d.hidden; g.ldo = d.hidden; g.bias = w_ + o.bg; g.c_state = c_ + (size_t)l * S * d.hidden; g.slot_idx = step_d_; g.hidden = d.hidden;
+    return g;
+}
+
 GemmArgs Engine::lm_args_whr(int l, int m, int t) const
 {   // h' = u x Whr ; state write + residual, in one launch however few workgroups (sequential step)
     const NetDims &d = L_.dims;
@@ -915,7 +931,75 @@ void Engine::run_lm_wavefront(int m, int T, bool dump_logits)
                         m, T, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5]);
 }
 
-int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const int *now_ms, float *logits_out)
+// ---------------------------------------------------------------- chunk steps of one feed as a wavefront
+// A 100 ms feed carries 2..3 chunks per session.  Chunk t + 1 of layer l does not depend on chunk t of layer l + 1, so the T
+// chunk steps of a feed run as a wavefront over the layers: at macro step W layer l works on chunk W - 1 - l, and the same
+// launch of the (up to T) active layers is ONE z-batched launch.  Same kernels and arguments as T chunk steps in a row
+// (run_encoder_rows), on the rows of chunk t instead of rows 0..m-1: bit-identical.  What it buys: 4 (L + T - 1) layer
+// launches per feed instead of 4 L T, and -- the reason it pays at 256 sessions -- a launch holds T x the workgroups, so the
+// planner picks larger tiles for the N = d_model GEMMs (32x32 instead of 16x32 at 256 rows: 1.5 x fewer operand bytes per
+// flop, the bound of those kernels) and co-resident workgroups overlap each other's prologue / epilogue.
+// The argument blocks depend on (m, T) only: built once per shape, kept in device memory, and the whole chain is one graph.
+Engine::SwPlan &Engine::sw_plan(int m, int T)
+{
+    const std::pair<int, int> key(m, T);
+    auto it = sw_plans_.find(key);
+    if (it != sw_plans_.end()) return it->second;
+    if (sw_plans_.size() >= 64) {
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        for (auto &p : sw_plans_) { if (p.second.graph) (void)hipGraphExecDestroy(p.second.graph); if (p.second.dev) (void)hipFree(p.second.dev); }
+        sw_plans_.clear();
+    }
+    SwPlan &p = sw_plans_[key];
+    const int L = L_.dims.n_layers;
+    std::vector<GemmArgs> items;
+    for (int W = 0; W <= T + L; ++W) {
+        for (int kind = 0; kind < 4; ++kind) {
+            items.clear();
+            for (int l = 0; l < L; ++l) {
+                const int t = W - 1 - l;
+                if (t < 0 || t >= T) continue;
+                items.push_back(kind == 0 ? sw_args_gates(l, m, t) : kind == 1 ? lm_args_whr(l, m, t) : kind == 2 ? lm_args_ff1(l, m, t, t + 1) : lm_args_ff2(l, m, t, t + 1));
+            }
+            SwPlan::Batch b; b.off = p.host.size(); b.n = (int)items.size(); b.macro = W; b.kind = kind;
+            if (b.n == 0) continue;
+            p.host.resize(p.host.size() + items.size());
+            stage_gemm_z(items.data(), b.n, p.host.data() + b.off);
+            p.batches.push_back(b);
+        }
+    }
+    p.dev = dmalloc<GemmArgs>(p.host.size());
+    HIP_CHECK(hipMemcpy(p.dev, p.host.data(), p.host.size() * sizeof(GemmArgs), hipMemcpyHostToDevice));
+    return p;
+}
+
+void Engine::run_sw_chain(int m, int T, bool dump_logits, const SwPlan &p)
+{
+    const NetDims &d = L_.dims;
+    const int MB = cfg_.max_batch;
+    const int L = d.n_layers;
+    AdvanceArgs a;
+    a.host_ring = ring_h_; a.host_step_off = step_off_h_; a.host_rec_off = rec_off_h_; a.counter = counter_d_;
+    a.dst = step_d_; a.dst_stride = MB; a.n_arrays = 4; a.len[0] = m; a.len[1] = a.len[2] = a.len[3] = m * T; a.rec_off = rec_off_d_;
+    a.flags = flags_d_; a.n_flags = 8;
+    launch_advance(a, stream_);
+    size_t bi = 0;
+    static const int cls_of[4] = {T_GATES, T_GEMM_OTHER, T_GEMM_OTHER, T_GEMM_OTHER};
+    for (int W = 0; W <= T + L; ++W) {
+        if (W < T) lm_stage_embed(m, W, W + 1, stream_);
+        for (; bi < p.batches.size() && p.batches[bi].macro == W; ++bi) {
+            const SwPlan::Batch &b = p.batches[bi];
+            timed_begin(cls_of[b.kind]); launch_gemm_z(p.host.data() + b.off, b.n, p.dev + b.off, stream_); timed_end(cls_of[b.kind]);
+        }
+        const int tp = W - L - 1;
+        if (tp >= 0) {
+            lm_stage_proj(m, tp, tp + 1, stream_);
+            run_greedy_rounds(m, dump_logits, tp, eout_lm_ + (size_t)tp * m * d.joiner);
+        }
+    }
+}
+
+int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const int *now_ms, float *logits_out, int mode)
 {
     const int rows = m * T;
     if (m <= 0 || T <= 0 || rows > cfg_.max_batch || !flight_has_room(rows + m, 1)) { LOGE("engine: layer-major step %d x %d does not fit (max batch %d)", m, T, cfg_.max_batch); abort(); }
@@ -939,6 +1023,25 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
     for (int t = 0; t < T; ++t) memcpy(blk + m + 2 * rows + (size_t)t * m, slots, (size_t)m * 4);
     step_off_h_[k] = (int)ring_pos_; rec_off_h_[k] = (int)rec_pos_;
     ring_pos_ += (size_t)m + 3 * (size_t)rows; rec_pos_ += (size_t)3 * rows;
+    if (mode == 1) {                 // the chunk steps of one feed as a wavefront over the layers (run_sw_chain)
+        std::lock_guard<std::mutex> cg(capture_mu_);
+        SwPlan &p = sw_plan(m, T);
+        if (use_graphs_ && !profiling_ && !logits_out) {
+            if (!p.graph) {
+                hipGraph_t graph = nullptr;
+                HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+                run_sw_chain(m, T, false, p);
+                HIP_CHECK(hipStreamEndCapture(stream_, &graph));
+                HIP_CHECK(hipGraphInstantiate(&p.graph, graph, nullptr, nullptr, 0));
+                HIP_CHECK(hipGraphDestroy(graph));
+            }
+            HIP_CHECK(hipGraphLaunch(p.graph, stream_));
+            return k;
+        }
+        launch_count_ = 0;
+        run_sw_chain(m, T, logits_out != nullptr, p);
+        kernels_per_step_ = (launch_count_ + 1 + T - 1) / T;          // per chunk
+    } else {
     const bool wavefront = lm_wavefront_on() && !profiling_ && T > lm_block_steps() &&
                            gemm_fullk(m, d.d_model, kz_hr_, true) && gemm_fullk(m, d.d_model, kz_ff2_, true);
     if (wavefront) {                 // long feed: all layers of a wavefront per launch (run_lm_wavefront)
@@ -968,6 +1071,7 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
         launch_count_ = 0;
         run_lm_chain(m, T, logits_out != nullptr);
         kernels_per_step_ = launch_count_ + 1;
+    }
     }
     if (logits_out) {
         HIP_CHECK(hipMemcpyAsync(logits_h_, logits_, (size_t)3 * rows * d.vocab * 4, hipMemcpyDeviceToHost, stream_));

@@ -99,7 +99,9 @@ public:
     // feed-forward blocks, encoder_proj -- runs once over all T * m rows; only the recurrent half of the gates and the
     // projection run per time step.  Same chains, same order: logits and state are bit-identical to T one-chunk steps.
     // ring_tails / now_ms are [T][m].  Records: [T][3][m]; logits_out (tests) [T][3][m][vocab].
-    int lm_step(int m, int T, const int *slots, const int *ring_tails, const int *now_ms, float *logits_out = nullptr);
+    // mode 1: the T chunk steps of one feed (T >= 2) as a wavefront over the layers -- the one-launch gates GEMM per chunk as in
+    // step(), the same launch of the active layers z-batched (run_sw_chain); mode 0: layer-major (long feeds).
+    int lm_step(int m, int T, const int *slots, const int *ring_tails, const int *now_ms, float *logits_out = nullptr, int mode = 0);
     int lm_max_rows() const { return cfg_.max_batch; }
     // decoder output refresh for listed slots from the context held on the device; op 1 = end-of-flush reset first
     void decode_rows(int n, const int *slots, int op);
@@ -132,6 +134,7 @@ private:
     void lm_resid_ssq(const float *a, int K, size_t w_off, int kz, const float *bias, const float *resid, size_t r0, int rows, hipStream_t st);
     GemmArgs lm_args_xpart(int l, int m, int t0, int t1) const;
     GemmArgs lm_args_gates(int l, int m, int t) const;
+    GemmArgs sw_args_gates(int l, int m, int t) const;
     GemmArgs lm_args_whr(int l, int m, int t) const;
     GemmArgs lm_args_ff1(int l, int m, int t0, int t1) const;
     GemmArgs lm_args_ff2(int l, int m, int t0, int t1) const;
@@ -148,6 +151,12 @@ private:
     void run_greedy_rounds(int n, const GreedyIo &io);
     void run_lm_chain(int m, int T, bool dump_logits);
     void run_lm_wavefront(int m, int T, bool dump_logits);
+    struct SwPlan {                          // argument blocks + launch list of run_sw_chain for one (m, T), and its captured graph
+        struct Batch { size_t off; int n, macro, kind; };
+        std::vector<GemmArgs> host; GemmArgs *dev = nullptr; std::vector<Batch> batches; hipGraphExec_t graph = nullptr;
+    };
+    SwPlan &sw_plan(int m, int T);
+    void run_sw_chain(int m, int T, bool dump_logits, const SwPlan &p);
     void run_decproj(int n, const int *d_slots, const int *row_mask, const int *run_flag, int run_gen, float *out = nullptr);
     void build_dec_table();
     void run_chain(int m, bool dump_logits);     // advance + encoder + greedy rounds with arguments that depend on m only
@@ -204,6 +213,7 @@ private:
     // wavefront form of the layer-major step: its stream, events, per-launch argument blocks (pinned + device), the
     // block-independent search graphs (m, block length) and their bookkeeping words
     std::map<std::pair<int, int>, hipGraphExec_t> lm_search_graphs_;
+    std::map<std::pair<int, int>, SwPlan> sw_plans_;
     hipStream_t lm_stream_ = nullptr;
     std::vector<hipEvent_t> lm_events_;
     GemmArgs *zargs_h_ = nullptr, *zargs_d_ = nullptr; size_t zargs_region_ = 0, zargs_pos_ = 0;     // three regions, round robin

@@ -101,6 +101,7 @@ struct GemmArgs {
     const float *p_add = nullptr; int ldp = 0;
     int force_fullk = 0;                   // take the full-K plan even when it yields few workgroups (latency-bound sequential steps: one launch
                                            // instead of split-K + row kernel matters more than filling the chip)
+    int zcount = 1;                        // same-shape problems sharing the launch (set by stage_gemm_z): an occupancy hint for the tile planner
     int skew = 0;                          // start delay (x 4096 cycles) for every second generation of workgroups
     int asm_loop = 0;                      // != 0: hand-scheduled K loop (gemm_mainloop_asm.inc) in the fused-epilogue 64x64 fp32 tiles
     unsigned long long *trace = nullptr;   // measurement only: per-workgroup s_memtime stamps [wg][8] (wave 0, lane 0)

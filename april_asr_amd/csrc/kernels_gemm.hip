@@ -612,8 +612,8 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
 // block (a device array written before the launch, read with scalar loads), blockIdx.z % zdiv is the slab group.  The
 // offline wavefront schedule (engine.cc) batches the same step of all encoder layers this way: at one session a layer's
 // recurrent step is a latency-bound launch, twelve of them in one launch cost about the same.
-template <int MT, int NT, int EPI, int AOP, int WT, int MODE>
-__global__ __launch_bounds__(256, MT == 4 ? 2 : 1) void gemm_f32_zkernel(const GemmArgs *zargs, int zdiv)
+template <int MT, int NT, int EPI, int AOP, int WT, int MODE, int ASM>
+__global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_zkernel(const GemmArgs *zargs, int zdiv)
 {
     const int zl = (int)blockIdx.z / zdiv;
     static_assert(sizeof(GemmArgs) % 4 == 0, "argument block is copied by words");
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256, MT == 4 ? 2 : 1) void gemm_f32_zkernel(const G
     unsigned *dst = reinterpret_cast<unsigned *>(&g);
 #pragma unroll
     for (unsigned i = 0; i < sizeof(GemmArgs) / 4; ++i) dst[i] = src[i];
-    gemm_body<MT, NT, EPI, AOP, WT, MODE, 0, 4>(g, (int)blockIdx.z - zl * zdiv, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+    gemm_body<MT, NT, EPI, AOP, WT, MODE, ASM, 4>(g, (int)blockIdx.z - zl * zdiv, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
 }
 
 // ---------------------------------------------------------------- host side
@@ -633,15 +633,16 @@ static int env_int(const char *name, int def) { const char *v = getenv(name); re
 
 // The full-K schedule pays once output tiles alone occupy a good part of the chip.  Tiles: at most 64x32 (three
 // accumulator-sized register sets: chain, slab, tree level), at least 16x32 (a sum-of-squares granule is 32 columns).
-static bool plan_fullk(int M, int N, int kz, TilePlan &t, bool force = false)
+static bool plan_fullk(int M, int N, int kz, TilePlan &t, bool force = false, int zcount = 1)
 {
     static const int enabled = env_int("APRIL_FULLK", 1);
     static const int min_wgs = env_int("APRIL_FULLK_MIN_WGS", 96);
     if (!enabled || N % 32 != 0) return false;
     const int ncols = N / 32;
     int mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
-    while (mt > 1 && (long)ncols * ((M + 16 * mt - 1) / (16 * mt)) < 256) mt >>= 1;
-    const long wgs = (long)ncols * ((M + 16 * mt - 1) / (16 * mt));
+    // (zcount same-shape problems share a launch: the chip is filled by all of them together, so each can use larger tiles)
+    while (mt > 1 && (long)ncols * ((M + 16 * mt - 1) / (16 * mt)) * zcount < 256) mt >>= 1;
+    const long wgs = (long)ncols * ((M + 16 * mt - 1) / (16 * mt)) * zcount;
     if (wgs < min_wgs && !force) return false;
     t.mt = mt; t.nt = 2; t.zs = kz; t.mode = kz >= 4 ? GM_FULLK : GM_SLAB;    // kz 1 or 2: one workgroup walks the slabs (<= 2 meets)
     return true;
@@ -650,20 +651,20 @@ static bool plan_fullk(int M, int N, int kz, TilePlan &t, bool force = false)
 bool gemm_fullk(int M, int N, int kz, bool force) { TilePlan t; return plan_fullk(M, N, kz, t, force); }
 
 // Tile shape and slabs per workgroup.  Depends on M only through occupancy; numerics are tile-independent.
-static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = false)
+static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = false, int zcount = 1)
 {
     // measurement knobs (default 0): 1/2 = smaller tiles for the fused-epilogue GEMMs (measured slower on MI355X:
     // B=256 gates 27 -> 32..36 us, the kernel is limited by operand loads per MFMA, not by occupancy);
     // 5 = 64x32 tiles for split-K GEMMs at M > 32
     static const int tune = env_int("APRIL_GEMM_TUNE", 0);
     TilePlan t;
-    if (epi != EPI_LSTM && epi != EPI_BIAS_DSWISH && epi != EPI_XPART && plan_fullk(M, N, kz, t, force_fullk)) return t;
+    if (epi != EPI_LSTM && epi != EPI_BIAS_DSWISH && epi != EPI_XPART && plan_fullk(M, N, kz, t, force_fullk, zcount)) return t;
     const int ntiles = N / 16;
     t.mode = GM_SLAB;
     t.mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
     int mblocks = (M + t.mt * 16 - 1) / (t.mt * 16);
     t.nt = 4;
-    while (t.nt > 1 && ((ntiles % t.nt) != 0 || (long)(ntiles / t.nt) * mblocks * kz < 256)) t.nt >>= 1;
+    while (t.nt > 1 && ((ntiles % t.nt) != 0 || (long)(ntiles / t.nt) * mblocks * kz * zcount < 256)) t.nt >>= 1;
     if (tune && epi != EPI_PARTIAL && t.mt == 4 && (long)(ntiles / t.nt) * mblocks < 512) {
         if (tune == 1) { t.mt = 2; mblocks = (M + 31) / 32; }
         else if (tune == 2 && t.nt == 4) t.nt = 2;
@@ -739,7 +740,10 @@ static TilePlan finalize_gemm(GemmArgs &g)
     g.debug = dbg;
     static const int skew = env_int("APRIL_GEMM_SKEW", 0);        // round 2: no start skew (measured below)
     static const int asm_loop = env_int("APRIL_GEMM_ASM", 1);     // 0 = compiler-scheduled loop everywhere (A/B)
-    const TilePlan t = plan_tiles(g.M, g.N, g.kz, g.epi, g.force_fullk != 0);
+    static const int z_tiles = env_int("APRIL_Z_TILES", 2);      // A/B: 0 = plan z-batched problems as if each had the chip to itself, 1 = hint everywhere, 2 = fused-epilogue slab tiles only, 3 = full-K tiles only
+    const int zc = std::max(1, g.zcount);
+    const bool is_slab_epi = g.epi == EPI_LSTM || g.epi == EPI_BIAS_DSWISH || g.epi == EPI_XPART;
+    const TilePlan t = plan_tiles(g.M, g.N, g.kz, g.epi, g.force_fullk != 0, (z_tiles == 1 || (z_tiles == 2 && is_slab_epi) || (z_tiles == 3 && !is_slab_epi)) ? zc : 1);
     const bool row_epi = g.epi == EPI_HR || g.epi == EPI_RESID_SSQ || g.epi == EPI_SLOT_STORE;
     if (row_epi && t.zs != g.kz) { fprintf(stderr, "libapril(mi355x): launch_gemm: row epilogue %d needs the full-K plan (M=%d N=%d kz=%d)\n", g.epi, g.M, g.N, g.kz); abort(); }
     g.zs = t.zs; g.mode = t.mode;
@@ -775,8 +779,12 @@ static void launch_one_z(const GemmArgs &g, const GemmArgs *dev_args, int n, hip
     dim3 grid((unsigned)(g.N / Cfg::BN), (unsigned)((g.M + Cfg::BM - 1) / Cfg::BM), (unsigned)(zdiv * n));
     const int sg = EPI == EPI_HR ? g.r_scale.groups : ((EPI == EPI_LSTM || EPI == EPI_SLOT_STORE || EPI == EPI_XPART) && g.x_scale.ssq ? g.x_scale.groups : 0);
     const size_t lds = (size_t)(Cfg::LDS_FLOATS + Cfg::BM + (sg ? Cfg::BM * (sg + 1) : 0)) * sizeof(float);
-    if (g.wt == 1) hipLaunchKernelGGL((gemm_f32_zkernel<MT, NT, EPI, AOP, 1, MODE>), grid, dim3(256), lds, s, dev_args, zdiv);
-    else hipLaunchKernelGGL((gemm_f32_zkernel<MT, NT, EPI, AOP, 0, MODE>), grid, dim3(256), lds, s, dev_args, zdiv);
+    constexpr bool HAS_ASM = MODE == GM_SLAB && MT == 4 && (NT == 4 || NT == 2) && AOP == AOP_NONE && (EPI == EPI_LSTM || EPI == EPI_BIAS_DSWISH);
+    if (g.wt == 1) { hipLaunchKernelGGL((gemm_f32_zkernel<MT, NT, EPI, AOP, 1, MODE, 0>), grid, dim3(256), lds, s, dev_args, zdiv); return; }
+    if constexpr (HAS_ASM) {
+        if (g.asm_loop && g.debug != 1) { hipLaunchKernelGGL((gemm_f32_zkernel<MT, NT, EPI, AOP, 0, MODE, 1>), grid, dim3(256), lds, s, dev_args, zdiv); return; }
+    }
+    hipLaunchKernelGGL((gemm_f32_zkernel<MT, NT, EPI, AOP, 0, MODE, 0>), grid, dim3(256), lds, s, dev_args, zdiv);
 }
 
 template <int MT, int NT>
@@ -797,6 +805,7 @@ void stage_gemm_z(const GemmArgs *items, int n, GemmArgs *staged)
     TilePlan t0{0, 0, 0, 0};
     for (int i = 0; i < n; ++i) {
         staged[i] = items[i];
+        staged[i].zcount = n;
         const TilePlan t = finalize_gemm(staged[i]);
         if (i == 0) t0 = t;
         const GemmArgs &a = staged[i], &b = staged[0];

@@ -242,6 +242,8 @@ Scheduler::Scheduler(Model *m, Engine *e) : model_(m), eng_(e), pool_(host_helpe
     spin_step_us_ = env_us("APRIL_SPIN_STEP_US", 100);
     spin_wait_us_ = env_us("APRIL_SPIN_WAIT_US", 3000);
     lm_min_chunks_ = env_us("APRIL_LM_MIN_CHUNKS", 8);
+    wave_min_chunks_ = env_us("APRIL_WAVE_MIN_CHUNKS", 2);
+    wave_max_chunks_ = std::max(1, env_us("APRIL_WAVE_MAX_CHUNKS", 7));
     thread_ = std::thread([this] { loop(); });
 }
 
@@ -528,7 +530,7 @@ void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
 // Layer-major step for a group of sessions that all have at least T chunks waiting (a long feed: "whole file at once",
 // reference use case example.cpp:157-216 -> src/april_session.c:431-476).  The encoder does not depend on emitted tokens, so
 // the T chunks of a session go through each layer together; see Engine::lm_step.
-bool Scheduler::step_layer_major(std::vector<Session *> &group, int T)
+bool Scheduler::step_layer_major(std::vector<Session *> &group, int T, int mode)
 {
     const int m = (int)group.size();
     const int rows = m * T;
@@ -551,7 +553,7 @@ bool Scheduler::step_layer_major(std::vector<Session *> &group, int T)
         if (s->trace_buf) traced = true;
     }
     if (traced) logit_stage_.resize((size_t)3 * rows * d.vocab);
-    const int k = eng_->lm_step(m, T, slots_.data(), tails_.data(), now_.data(), traced ? logit_stage_.data() : nullptr);
+    const int k = eng_->lm_step(m, T, slots_.data(), tails_.data(), now_.data(), traced ? logit_stage_.data() : nullptr, mode);
     for (int i = 0; i < m; ++i) {
         Session *s = group[(size_t)i];
         for (int t = 0; t < T; ++t) {
@@ -573,7 +575,9 @@ bool Scheduler::step_layer_major(std::vector<Session *> &group, int T)
             }
         }
     }
-    tick_.steps++; tick_.lm_steps++; tick_.chunks += (uint64_t)rows; tick_.lm_chunks += (uint64_t)rows;
+    tick_.steps++; tick_.chunks += (uint64_t)rows;
+    if (mode == 1) { tick_.wave_steps++; tick_.wave_chunks += (uint64_t)rows; }
+    else { tick_.lm_steps++; tick_.lm_chunks += (uint64_t)rows; }
     if ((uint64_t)m > tick_.max_batch_seen) tick_.max_batch_seen = (uint64_t)m;
     return true;
 }
@@ -609,6 +613,18 @@ bool Scheduler::step_chunks(std::vector<Session *> &ready)
     }
 
     const int n = (int)one.size();
+    // A feed usually carries 2..3 chunks for every session (100 ms = 2.5 chunks): those chunk steps run as ONE wavefront over
+    // the layers (Engine::lm_step mode 1) when the rows fit the work buffers; what is left over goes chunk by chunk.
+    if (n > 0 && wave_min_chunks_ > 0) {
+        int T = MB / n;
+        for (Session *s : one) T = std::min(T, waiting(s));
+        T = std::min(T, wave_max_chunks_);
+        if (T >= wave_min_chunks_) {
+            const bool ok = step_layer_major(one, T, 1);
+            tick_.host_ms[3] += lap();
+            return ok;
+        }
+    }
     if (n > 0 && !eng_->flight_has_room(n, (n + MB - 1) / MB)) { tick_.host_ms[3] += lap(); return false; }
     const int stride_ms = model_->host.params.segment_step * model_->host.params.frame_shift_ms;
     for (int o = 0; o < n; o += MB) {

@@ -135,13 +135,13 @@ struct Session {
 };
 
 struct SchedStats {
-    uint64_t ticks = 0, steps = 0, chunks = 0, rounds = 0, frames = 0, max_batch_seen = 0, flights = 0, replay_mismatch = 0, lm_steps = 0, lm_chunks = 0;
+    uint64_t ticks = 0, steps = 0, chunks = 0, rounds = 0, frames = 0, max_batch_seen = 0, flights = 0, replay_mismatch = 0, lm_steps = 0, lm_chunks = 0, wave_steps = 0, wave_chunks = 0;
     // host wall time of the stepping thread by phase (ms): 0 collect, 1 cut frames (host), 2 fbank call, 3 step enqueue,
     // 4 end of flight (wait for the GPU), 5 replay (decisions + events), 6 decoder refresh enqueue, 7 deliver/complete
     double host_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     void add(const SchedStats &o) {
         ticks += o.ticks; steps += o.steps; chunks += o.chunks; rounds += o.rounds; frames += o.frames; flights += o.flights; replay_mismatch += o.replay_mismatch;
-        lm_steps += o.lm_steps; lm_chunks += o.lm_chunks;
+        lm_steps += o.lm_steps; lm_chunks += o.lm_chunks; wave_steps += o.wave_steps; wave_chunks += o.wave_chunks;
         if (o.max_batch_seen > max_batch_seen) max_batch_seen = o.max_batch_seen;
         for (int i = 0; i < 8; ++i) host_ms[i] += o.host_ms[i];
     }
@@ -169,7 +169,7 @@ private:
     void process(std::vector<Session *> &work);
     void cut_frames(std::vector<Session *> &work, bool &progressed);
     bool step_chunks(std::vector<Session *> &ready);     // false: the flight's rings are full, (some) work is left for the next flight
-    bool step_layer_major(std::vector<Session *> &group, int T);
+    bool step_layer_major(std::vector<Session *> &group, int T, int mode = 0);
     void replay(std::vector<Session *> &work);
 
     Model *model_;
@@ -181,6 +181,7 @@ private:
     // of a 2 ms step): submit() bumps work_seq_, the end of a tick bumps done_seq_
     std::atomic<uint64_t> work_seq_{0}, done_seq_{0};
     int spin_step_us_ = 100, spin_wait_us_ = 3000;   // APRIL_SPIN_STEP_US / APRIL_SPIN_WAIT_US
+    int wave_min_chunks_ = 2, wave_max_chunks_ = 7;  // APRIL_WAVE_MIN_CHUNKS (0 = chunk steps one by one) / APRIL_WAVE_MAX_CHUNKS: chunk steps of one feed as a wavefront
     int lm_min_chunks_ = 8;                          // APRIL_LM_MIN_CHUNKS: sessions with at least this many chunks waiting take the layer-major path (0 = never)
     void spin_for_done(uint64_t seen);
     std::vector<Session *> sessions_;

@@ -51,7 +51,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     lanes = int(os.environ.get("APRIL_LANES", "1"))        # engines (stream + stepping thread) per GPU
     os.environ.setdefault("APRIL_MAX_SESSIONS", "4096")
-    os.environ.setdefault("APRIL_MAX_BATCH", "4096")
+    os.environ.setdefault("APRIL_MAX_BATCH", "8192")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import numpy as np
@@ -183,7 +183,9 @@ def main():
             avg_ms = sp.kernel_ms[0] / launches
             rows = sp.chunks - st.chunks        # session-chunks processed while profiling
             steps_prof = sp.steps - st.steps
-            rows_per_launch = rows / max(1, steps_prof)
+            # rows per gates launch, averaged: every session-chunk passes the gates GEMM of each layer once; a launch covers one
+            # layer of one chunk step, or the same launch of up to T layers when a feed's chunk steps run as a wavefront (z-batched)
+            rows_per_launch = rows * d.n_layers / launches
             flops = 2.0 * rows_per_launch * (2 * d.d_model) * (4 * d.hidden)
             wbytes = (2 * d.d_model) * (4 * d.hidden) * 4
             sbytes = rows_per_launch * (d.d_model * 4 * 2 + d.hidden * 4 * 3)      # x,h read; c read+write; u write
@@ -203,13 +205,13 @@ def main():
             # HBM traffic per launch from the committed PMC pass of the same workload (bench.py cannot collect PMC itself)
             try:
                 tr = json.load(open(os.path.join(ROOT, "profiles", "r02_gates_traffic.json")))
-                if int(tr["sessions_per_gpu"]) == B and d.precision == 0:
+                if int(tr["sessions_per_gpu"]) == B and d.precision == 0 and abs(float(tr.get("rows_per_launch", B)) - rows_per_launch) < 0.05 * rows_per_launch:
                     roofline["traffic"] = int(tr["traffic_bytes_per_launch"])
                     roofline["traffic_source"] = "profiles/r02_gates_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950 x2 read correction)"
             except Exception:
                 pass
             roofline["algorithmic_bytes_per_launch"] = int(wbytes + sbytes)
-            roofline.update({"kernel": "gemm_f32_kernel<4,4,EPI_LSTM,...> (LSTM gates [B,1024]x[1024,4096] + BasicNorm row scale + cell)",
+            roofline.update({"kernel": "gemm_f32_zkernel<4,4,EPI_LSTM,...> / gemm_f32_kernel<4,4,EPI_LSTM,...> (LSTM gates [rows,1024]x[1024,4096] + BasicNorm row scale + cell; rows = sessions x layers sharing the launch)",
                              "avg_launch_us": round(avg_ms * 1e3, 2), "rows_per_launch": round(rows_per_launch, 1),
                              "launches": int(launches), "alt_frac_hbm": round(frac_hbm, 4), "alt_frac_mfma": round(frac_mfma, 4),
                              "class_ms": {k: round(sp.kernel_ms[i], 3) for i, k in enumerate(
@@ -221,14 +223,15 @@ def main():
     sweep = None
     if rank == 0 and world == 1 and not args.no_sweep:          # single-GPU runs only (the driver computes scaling from per-N values)
         sweep = {}
-        for nb in (1, 16, 64, 1024, 1280, 1536, 1792, 2048):
+        for nb in (1, 16, 64, 1024, 1536, 1792, 2048, 2304):
             ss, gg = make_group(nb, 0)
-            pp = pcm_for(nb, 12, 20_000_000)
-            run_steps(gg, pp, 0, 4)
+            wu, ts = 6, 20                                     # (both feed shapes -- 2 and 3 chunks -- are captured during warm-up)
+            pp = pcm_for(nb, wu + ts, 20_000_000)
+            run_steps(gg, pp, 0, wu)
             torch.cuda.synchronize(); a = time.perf_counter()
-            run_steps(gg, pp, 4, 12)
+            run_steps(gg, pp, wu, wu + ts)
             torch.cuda.synchronize(); b = time.perf_counter()
-            sweep[str(nb)] = round((b - a) / (8 * 0.1), 5)
+            sweep[str(nb)] = round((b - a) / (ts * 0.1), 5)
             for s in ss:
                 s.close()
         sweep[str(B)] = round(rtf, 5)

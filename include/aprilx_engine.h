@@ -116,6 +116,7 @@ typedef struct AprilxStats {
     uint64_t replay_mismatch;    /* rounds where the host state machine and the device decision disagreed (must stay 0) */
     uint64_t kernels_per_step;   /* launches of the last eagerly issued chunk chain (profiling / APRIL_NO_GRAPHS runs) */
     uint64_t lm_steps, lm_chunks;/* layer-major steps (long feeds) and the session-chunks they covered (included in steps / chunks) */
+    uint64_t wave_steps, wave_chunks;/* feeds whose 2..7 chunk steps ran as one wavefront over the layers, and the session-chunks they covered (included in steps / chunks) */
 } AprilxStats;
 APRIL_EXPORT void aprilx_model_stats(AprilASRModel model, int device_index, AprilxStats *out);
 /* bracket every launch with hipEvents on the engine's stream (measurement runs only) */
