@@ -983,20 +983,17 @@ void Engine::run_sw_chain(int m, int T, bool dump_logits, const SwPlan &p)
     a.dst = step_d_; a.dst_stride = MB; a.n_arrays = 4; a.len[0] = m; a.len[1] = a.len[2] = a.len[3] = m * T; a.rec_off = rec_off_d_;
     a.flags = flags_d_; a.n_flags = 8;
     launch_advance(a, stream_);
-    size_t bi = 0;
+    // Front end and encoder_proj do not take part in the wavefront: one launch chain each over all T x m rows (as in the
+    // layer-major step), before the first and after the last macro step; the searches follow in time order.
+    // (Measured and dropped: front end / encoder_proj / search on a second captured stream beside the layer launches, forked
+    // and joined by events inside the capture -- works, gains nothing: the graph executor does not overlap the branches.)
+    lm_stage_embed(m, 0, T, stream_);
     static const int cls_of[4] = {T_GATES, T_GEMM_OTHER, T_GEMM_OTHER, T_GEMM_OTHER};
-    for (int W = 0; W <= T + L; ++W) {
-        if (W < T) lm_stage_embed(m, W, W + 1, stream_);
-        for (; bi < p.batches.size() && p.batches[bi].macro == W; ++bi) {
-            const SwPlan::Batch &b = p.batches[bi];
-            timed_begin(cls_of[b.kind]); launch_gemm_z(p.host.data() + b.off, b.n, p.dev + b.off, stream_); timed_end(cls_of[b.kind]);
-        }
-        const int tp = W - L - 1;
-        if (tp >= 0) {
-            lm_stage_proj(m, tp, tp + 1, stream_);
-            run_greedy_rounds(m, dump_logits, tp, eout_lm_ + (size_t)tp * m * d.joiner);
-        }
+    for (const SwPlan::Batch &b : p.batches) {      // macro steps in order; inside one: gates, projection, FFN up, FFN down of the active layers
+        timed_begin(cls_of[b.kind]); launch_gemm_z(p.host.data() + b.off, b.n, p.dev + b.off, stream_); timed_end(cls_of[b.kind]);
     }
+    lm_stage_proj(m, 0, T, stream_);
+    for (int t = 0; t < T; ++t) run_greedy_rounds(m, dump_logits, t, eout_lm_ + (size_t)t * m * d.joiner);
 }
 
 int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const int *now_ms, float *logits_out, int mode)
