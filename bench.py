@@ -186,14 +186,14 @@ def main():
             # rows per gates launch, averaged: every session-chunk passes the gates GEMM of each layer once; a launch covers one
             # layer of one chunk step, or the same launch of up to T layers when a feed's chunk steps run as a wavefront (z-batched)
             rows_per_launch = rows * d.n_layers / launches
+            layers_per_launch = max(1.0, rows_per_launch / B)      # a z-batched launch holds that many layers' weight matrices
             flops = 2.0 * rows_per_launch * (2 * d.d_model) * (4 * d.hidden)
-            wbytes = (2 * d.d_model) * (4 * d.hidden) * 4
+            wbytes = (2 * d.d_model) * (4 * d.hidden) * 4 * layers_per_launch
             sbytes = rows_per_launch * (d.d_model * 4 * 2 + d.hidden * 4 * 3)      # x,h read; c read+write; u write
             tf = flops / (avg_ms * 1e-3) / 1e12
-            gbs = (wbytes + sbytes) / (avg_ms * 1e-3) / 1e9
             mfma_peak = FP16_MFMA_PEAK_TFLOPS if d.precision == 1 else FP32_MFMA_PEAK_TFLOPS
             if d.precision == 1:
-                wbytes //= 2                        # fp16 weight copies
+                wbytes /= 2                         # fp16 weight copies
             gbs = (wbytes + sbytes) / (avg_ms * 1e-3) / 1e9
             frac_mfma, frac_hbm = tf / mfma_peak, gbs / HBM_PEAK_GBS
             if frac_mfma >= frac_hbm:
@@ -202,12 +202,13 @@ def main():
             else:
                 roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(frac_hbm, 4), "traffic": None}
-            # HBM traffic per launch from the committed PMC pass of the same workload (bench.py cannot collect PMC itself)
+            # HBM traffic per launch from the committed PMC pass of the same workload (bench.py cannot collect PMC itself); per
+            # launch it is proportional to the layers sharing the launch (weights) and to the rows (activations), i.e. to rows
             try:
-                tr = json.load(open(os.path.join(ROOT, "profiles", "r02_gates_traffic.json")))
-                if int(tr["sessions_per_gpu"]) == B and d.precision == 0 and abs(float(tr.get("rows_per_launch", B)) - rows_per_launch) < 0.05 * rows_per_launch:
-                    roofline["traffic"] = int(tr["traffic_bytes_per_launch"])
-                    roofline["traffic_source"] = "profiles/r02_gates_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950 x2 read correction)"
+                tr = json.load(open(os.path.join(ROOT, "profiles", "r02b_gates_traffic.json")))
+                if int(tr["sessions_per_gpu"]) == B and d.precision == 0:
+                    roofline["traffic"] = int(tr["traffic_bytes_per_launch"] * rows_per_launch / float(tr["rows_per_launch"]))
+                    roofline["traffic_source"] = "profiles/r02b_gates_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950 x2 read correction; measured at %.1f rows per launch, scaled by rows)" % float(tr["rows_per_launch"])
             except Exception:
                 pass
             roofline["algorithmic_bytes_per_launch"] = int(wbytes + sbytes)
