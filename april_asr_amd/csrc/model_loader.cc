@@ -252,6 +252,37 @@ struct View {
     }
     bool is_const(const std::string &v) const { std::vector<float> t; return const_floats(v, t); }
 
+    // Value of a small integer expression: slice bounds as torch.onnx writes them for Tensor.chunk() with static shapes that it
+    // does not fold -- Shape -> Gather -> (Add, Div, Mul with constants).  `dim_of(tensor, axis, out)` supplies the static
+    // dimensions the caller knows (the width of the gate pre-activations, the number of layers of a state tensor).
+    typedef std::function<bool(const std::string &, long, long &)> DimOf;
+    bool const_index(const std::string &v, const DimOf &dim_of, long &out, int depth = 0) const {
+        if (depth > 32) return false;
+        std::vector<float> c;
+        if (const_floats(v, c)) { if (c.size() != 1) return false; out = (long)c[0]; return true; }
+        const ONode *p = producer(v);
+        if (!p) return false;
+        const std::string &op = p->op;
+        if (op == "Identity" || op == "Cast" || op == "Unsqueeze" || op == "Squeeze" || op == "Reshape" || (op == "Concat" && p->in.size() == 1))
+            return const_index(arg(*p, 0), dim_of, out, depth + 1);
+        if (op == "Add" || op == "Sub" || op == "Mul" || op == "Div") {
+            long a = 0, b = 0;
+            if (p->in.size() != 2 || !const_index(p->in[0], dim_of, a, depth + 1) || !const_index(p->in[1], dim_of, b, depth + 1)) return false;
+            if (op == "Add") out = a + b; else if (op == "Sub") out = a - b; else if (op == "Mul") out = a * b;
+            else { if (b == 0) return false; out = a / b; if ((a % b != 0) && ((a < 0) != (b < 0))) --out; }      // ONNX integer Div truncates; chunk sizes are non-negative
+            return true;
+        }
+        if (op == "Gather" && p->in.size() == 2) {
+            const ONode *sh = producer(p->in[0]);
+            long axis = 0;
+            std::vector<float> idx;
+            if (!sh || sh->op != "Shape" || sh->in.empty() || !const_floats(p->in[1], idx) || idx.size() != 1) return false;
+            axis = (long)idx[0];
+            return dim_of(sh->in[0], axis, out);
+        }
+        return false;
+    }
+
     // follow layout-only operators upwards to the value that carries the data
     std::string lineage(std::string v) const {
         for (int guard = 0; guard < 64; ++guard) {
@@ -473,6 +504,13 @@ bool extract_encoder(const OGraph &g, const ModelParams &P, HostModel &M, std::s
                 std::vector<float> b;
                 if (v.const_floats(o, b) && (int)b.size() == 4 * Hh) { extra_bias = b; gates = c->out[0]; break; }
             }
+            for (int guard = 0; guard < 8; ++guard) {          // layout-only operators between the sum and its four parts (2-D Gemm operands reshaped back)
+                auto cs = v.consumers(gates);
+                if (cs.size() != 1 || cs[0]->out.empty()) break;
+                const std::string &op = cs[0]->op;
+                if (op == "Reshape" || op == "Squeeze" || op == "Unsqueeze" || op == "Identity" || op == "Flatten" || op == "Cast") gates = cs[0]->out[0];
+                else break;
+            }
             std::string part[4];
             const ONode *split = nullptr;
             for (const ONode *c : v.consumers(gates)) if (c->op == "Split") split = c;
@@ -485,7 +523,15 @@ bool extract_encoder(const OGraph &g, const ModelParams &P, HostModel &M, std::s
                 for (const ONode *c : v.consumers(gates)) {
                     if (c->op != "Slice" || c->out.empty()) continue;
                     std::vector<float> st, en;
-                    if (c->in.size() >= 3) { if (!v.const_floats(c->in[1], st) || !v.const_floats(c->in[2], en)) continue; }
+                    if (c->in.size() >= 3) {
+                        if (!v.const_floats(c->in[1], st) || !v.const_floats(c->in[2], en)) {
+                            // bounds computed from Shape(gates) (torch.onnx, Tensor.chunk): the width of the sum is 4 * hidden
+                            const View::DimOf width = [&](const std::string &t, long, long &o) { if (!v.same(t, gates)) return false; o = 4L * Hh; return true; };
+                            long s1 = 0, e1 = 0;
+                            if (!v.const_index(c->in[1], width, s1) || !v.const_index(c->in[2], width, e1)) continue;
+                            st.assign(1, (float)s1); en.assign(1, (float)e1);
+                        }
+                    }
                     else { const OAttr *a = c->attr("starts"), *b = c->attr("ends"); if (!a || !b) continue; for (auto x : a->ints) st.push_back((float)x); for (auto x : b->ints) en.push_back((float)x); }
                     if (st.size() != 1 || en.size() != 1) continue;
                     const long s0 = (long)st[0], e0 = (long)en[0];

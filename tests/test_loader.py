@@ -263,3 +263,101 @@ def test_corrupted_models_never_crash(built, tiny_model, tmp_path):
                              capture_output=True, text=True, errors="replace", timeout=600)
         assert out.returncode == 0, "loader crashed (seed %d): %s" % (seed, (out.stdout + out.stderr)[-2000:])
         assert "accepted product=" in out.stdout
+
+
+# ---------------------------------------------------------------- a REAL exporter's spelling of the graphs
+ODD_DIMS = dict(SM.TINY_DIMS, n_layers=3, d_model=128, hidden=192, ffn=256, joiner=64, vocab=131)
+
+
+@pytest.fixture(scope="module")
+def torch_exported(built, tmp_path_factory):
+    """The network as PyTorch modules (icefall structure, LSTM with projection as explicit operations), exported by
+    torch.onnx.export exactly like the reference's extra/export-april.py:226-331 (opset 11, static shapes) and wrapped into a
+    .april container (tests/torch_export.py)."""
+    pytest.importorskip("torch")
+    import torch_export as TE
+    out = {}
+    for tag, dims in (("tiny", dict(SM.TINY_DIMS)), ("odd", ODD_DIMS)):
+        w = SM.make_weights(dims, seed=2023)
+        toks = SM.make_tokens(dims["vocab"])
+        nets, mods = TE.export_networks(w, dims)
+        d = tmp_path_factory.mktemp("torch_export_" + tag)
+        p_t, p_s = str(d / "torch.april"), str(d / "synth.april")
+        with open(p_t, "wb") as f:
+            f.write(SM.container_bytes(nets, SM.params_block(dims, toks), name="torch-export"))
+        SM.write_model(p_s, dims, seed=2023)
+        out[tag] = dict(torch=p_t, synth=p_s, dims=dims, weights=w, modules=mods)
+    return out
+
+
+@pytest.mark.parametrize("tag", ["tiny", "odd"])
+def test_torch_onnx_export_loads_to_the_same_weights(torch_exported, tag):
+    """Graphs written by torch.onnx.export (constant-folded transposed weights named onnx::MatMul_###, MatMul + Add for every
+    Linear, Tensor.chunk as Shape -> Gather -> Add/Div/Mul -> four Slices with computed bounds, per-layer state through
+    Slice, new states through Concat, BasicNorm as Pow / ReduceMean / Exp / Add / Pow / Mul) load to exactly the packed
+    weights of the same network written by the repo's own graph writer."""
+    t = torch_exported[tag]
+    a = A.Model.load_host_only(t["torch"]); b = A.Model.load_host_only(t["synth"])
+    assert (a.dims.n_layers, a.dims.d_model, a.dims.hidden, a.dims.ffn, a.dims.joiner, a.dims.vocab, a.dims.context) == \
+           (b.dims.n_layers, b.dims.d_model, b.dims.hidden, b.dims.ffn, b.dims.joiner, b.dims.vocab, b.dims.context)
+    assert np.array_equal(split_blob(a.export_blob()), split_blob(b.export_blob()))
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("tag", ["tiny", "odd"])
+def test_oracle_runs_torch_exported_graphs(torch_exported, tag):
+    """The CPU oracle's ONNX interpreter executes the torch-exported graphs (incl. the Shape / Gather / Div index arithmetic
+    they carry) and agrees with the PyTorch modules they were exported from."""
+    import torch
+    from oracle import orc_py as O
+    t = torch_exported[tag]
+    dims = t["dims"]
+    enc, dec, joi = t["modules"]
+    om = O.Model(t["torch"])
+    rng = np.random.RandomState(4)
+    for _ in range(2):
+        x = rng.uniform(-16, 8, size=(1, dims["seg"], dims["mel"])).astype(np.float32)
+        h = rng.uniform(-0.5, 0.5, size=(dims["n_layers"], 1, dims["d_model"])).astype(np.float32)
+        c = rng.uniform(-1, 1, size=(dims["n_layers"], 1, dims["hidden"])).astype(np.float32)
+        e0, h0, c0 = om.encoder(x, h, c)
+        with torch.no_grad():
+            e1, h1, c1 = enc(torch.from_numpy(x), torch.from_numpy(h), torch.from_numpy(c))
+        assert np.abs(e0.ravel() - e1.numpy().ravel()).max() < 2e-5
+        assert np.abs(h0.ravel() - h1.numpy().ravel()).max() < 2e-5 and np.abs(c0.ravel() - c1.numpy().ravel()).max() < 2e-5
+        ctx = rng.randint(0, dims["vocab"], size=dims["context"])
+        d0 = om.decoder(ctx).ravel()
+        with torch.no_grad():
+            d1 = dec(torch.from_numpy(ctx.astype(np.int64))[None]).numpy().ravel()
+            l1 = joi(e1, torch.from_numpy(d0.reshape(1, 1, -1))).numpy().ravel()
+        assert np.abs(d0 - d1).max() < 2e-5
+        l0 = om.joiner(e0.reshape(1, 1, -1), d0.reshape(1, 1, -1)).ravel()
+        assert np.abs(l0 - l1).max() < 5e-5
+    om.close()
+
+
+TORCH_EXPORT_STYLES = [
+    dict(opset=11, chunk="split", state="index", linear2d=False),
+    dict(opset=11, chunk="narrow", state="slice", linear2d=True),
+    dict(opset=11, chunk="chunk", state="index", linear2d=True),
+    dict(opset=13, chunk="chunk", state="slice", linear2d=False),
+    dict(opset=13, chunk="split", state="index", linear2d=True),
+    dict(opset=13, chunk="narrow", state="index", linear2d=False),
+    dict(opset=17, chunk="chunk", state="index", linear2d=True),
+    dict(opset=17, chunk="split", state="slice", linear2d=False),
+]
+
+
+@pytest.mark.parametrize("style", TORCH_EXPORT_STYLES, ids=lambda v: ",".join("%s=%s" % kv for kv in sorted(v.items())))
+def test_torch_onnx_export_styles(built, tiny_model, tmp_path, style):
+    """The same modules written with other PyTorch idioms (torch.split / narrow instead of chunk, h[i].unsqueeze + torch.stack
+    instead of h[i:i+1] + torch.cat, 2-D operands so that the exporter emits Gemm and reshapes around the gate sum) and other
+    opsets (13: Split / Squeeze / Unsqueeze take their sizes and axes as inputs; 17): identical packed weights."""
+    pytest.importorskip("torch")
+    import torch_export as TE
+    dims = dict(SM.TINY_DIMS)
+    nets, _ = TE.export_networks(tiny_model["weights"], dims, **style)
+    p = tmp_path / "styled.april"
+    p.write_bytes(SM.container_bytes(nets, SM.params_block(dims, tiny_model["tokens"])))
+    a = A.Model.load_host_only(tiny_model["path"]); b = A.Model.load_host_only(str(p))
+    assert np.array_equal(split_blob(a.export_blob()), split_blob(b.export_blob()))
+    a.close(); b.close()
