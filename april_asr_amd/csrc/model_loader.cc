@@ -298,6 +298,23 @@ struct View {
         return v;
     }
 
+    // follow layout-only operators DOWNWARDS while the value has exactly one consumer (unbind of a length-1 time axis, squeezes,
+    // reshapes between a product and the operator that uses it)
+    std::string downstream(std::string v) const {
+        for (int guard = 0; guard < 16; ++guard) {
+            auto cs = consumers(v);
+            if (cs.size() != 1 || cs[0]->out.empty()) return v;
+            const ONode &c = *cs[0];
+            const std::string &op = c.op;
+            const bool layout = op == "Reshape" || op == "Squeeze" || op == "Unsqueeze" || op == "Identity" || op == "Flatten" || op == "Cast" || op == "Dropout" ||
+                                (op == "Split" && c.out.size() == 1) || (op == "Concat" && c.in.size() == 1) ||
+                                (op == "Gather" && c.in.size() == 2 && same(c.in[0], v) && is_const(c.in[1]));
+            if (!layout || !same(arg(c, 0), v)) return v;
+            v = c.out[0];
+        }
+        return v;
+    }
+
     bool weighted(const ONode &n) const {
         OTensor t;
         if (n.op == "Conv") return n.in.size() >= 2 && const_tensor(n.in[1], t);
@@ -491,10 +508,11 @@ bool extract_encoder(const OGraph &g, const ModelParams &P, HostModel &M, std::s
         int part_of_gate[4] = {-1, -1, -1, -1};            // gate i,f,g,o -> index of the quarter of the 4H columns
         {
             const ONode *sum = nullptr;
-            for (const ONode *c : v.consumers(ih.out_value)) if (c->op == "Add" && c->in.size() == 2 && (v.same(c->in[0], hh.out_value) || v.same(c->in[1], hh.out_value))) sum = c;
+            const std::string ih_out = v.downstream(ih.out_value), hh_out = v.downstream(hh.out_value);
+            for (const ONode *c : v.consumers(ih_out)) if (c->op == "Add" && c->in.size() == 2 && (v.same(c->in[0], hh_out) || v.same(c->in[1], hh_out))) sum = c;
             if (!sum) {
                 std::string found;
-                for (const ONode *c : v.consumers(ih.out_value)) { found = "; the input product feeds " + View::describe(*c); break; }
+                for (const ONode *c : v.consumers(ih_out)) { found = "; the input product feeds " + View::describe(*c); break; }
                 return fail(err, lay + "gate pre-activations are not summed by one Add" + found);
             }
             std::string gates = sum->out[0];

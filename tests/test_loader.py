@@ -277,10 +277,10 @@ def torch_exported(built, tmp_path_factory):
     pytest.importorskip("torch")
     import torch_export as TE
     out = {}
-    for tag, dims in (("tiny", dict(SM.TINY_DIMS)), ("odd", ODD_DIMS)):
+    for tag, dims, style in (("tiny", dict(SM.TINY_DIMS), {}), ("odd", ODD_DIMS, {}), ("icefall", dict(SM.TINY_DIMS), dict(chunk="icefall"))):
         w = SM.make_weights(dims, seed=2023)
         toks = SM.make_tokens(dims["vocab"])
-        nets, mods = TE.export_networks(w, dims)
+        nets, mods = TE.export_networks(w, dims, **style)
         d = tmp_path_factory.mktemp("torch_export_" + tag)
         p_t, p_s = str(d / "torch.april"), str(d / "synth.april")
         with open(p_t, "wb") as f:
@@ -290,12 +290,14 @@ def torch_exported(built, tmp_path_factory):
     return out
 
 
-@pytest.mark.parametrize("tag", ["tiny", "odd"])
+@pytest.mark.parametrize("tag", ["tiny", "odd", "icefall"])
 def test_torch_onnx_export_loads_to_the_same_weights(torch_exported, tag):
     """Graphs written by torch.onnx.export (constant-folded transposed weights named onnx::MatMul_###, MatMul + Add for every
     Linear, Tensor.chunk as Shape -> Gather -> Add/Div/Mul -> four Slices with computed bounds, per-layer state through
     Slice, new states through Concat, BasicNorm as Pow / ReduceMean / Exp / Add / Pow / Mul) load to exactly the packed
-    weights of the same network written by the repo's own graph writer."""
+    weights of the same network written by the repo's own graph writer.  "icefall": the LSTM with projection in the shape of
+    icefall's own ONNX-exportable module -- input product in 3-D, unbind over time, recurrent product on 2-D operands (Gemm),
+    chunk along dim 1, outputs stacked, states squeezed / unsqueezed."""
     t = torch_exported[tag]
     a = A.Model.load_host_only(t["torch"]); b = A.Model.load_host_only(t["synth"])
     assert (a.dims.n_layers, a.dims.d_model, a.dims.hidden, a.dims.ffn, a.dims.joiner, a.dims.vocab, a.dims.context) == \
@@ -304,7 +306,7 @@ def test_torch_onnx_export_loads_to_the_same_weights(torch_exported, tag):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("tag", ["tiny", "odd"])
+@pytest.mark.parametrize("tag", ["tiny", "odd", "icefall"])
 def test_oracle_runs_torch_exported_graphs(torch_exported, tag):
     """The CPU oracle's ONNX interpreter executes the torch-exported graphs (incl. the Shape / Gather / Div index arithmetic
     they carry) and agrees with the PyTorch modules they were exported from."""
@@ -344,6 +346,8 @@ TORCH_EXPORT_STYLES = [
     dict(opset=13, chunk="narrow", state="index", linear2d=False),
     dict(opset=17, chunk="chunk", state="index", linear2d=True),
     dict(opset=17, chunk="split", state="slice", linear2d=False),
+    dict(opset=13, chunk="icefall", state="index"),
+    dict(opset=17, chunk="icefall", state="slice"),
 ]
 
 

@@ -75,6 +75,20 @@ class LSTMP(nn.Module):
 
     def forward(self, x, state):
         h, c = state                                     # x (T=1, N, d), h (1, N, d), c (1, N, H)
+        if STYLE["chunk"] == "icefall":
+            # the shape of icefall's own ONNX-exportable LSTM with projection (icefall/lstmp.py, as far as it is remembered
+            # here): input product over all time steps in 3-D, then per time step (unbind) the recurrent product on 2-D
+            # operands, chunk along dim 1, new states unsqueezed back, outputs stacked
+            h0, c0 = h.squeeze(0), c.squeeze(0)
+            wx = torch.nn.functional.linear(x, self.weight_ih, self.bias_ih)
+            ys = []
+            for xt in wx.unbind(dim=0):
+                gates = torch.nn.functional.linear(h0, self.weight_hh, self.bias_hh) + xt
+                i, f, g, o = gates.chunk(4, dim=1)
+                c0 = f.sigmoid() * c0 + i.sigmoid() * g.tanh()
+                h0 = torch.nn.functional.linear(o.sigmoid() * c0.tanh(), self.weight_hr)
+                ys.append(h0)
+            return torch.stack(ys, dim=0), (h0.unsqueeze(0), c0.unsqueeze(0))
         if STYLE["linear2d"]:                            # 2-D operands: the exporter writes Gemm
             gates = (torch.nn.functional.linear(x.reshape(-1, x.shape[-1]), self.weight_ih, self.bias_ih) +
                      torch.nn.functional.linear(h.reshape(-1, h.shape[-1]), self.weight_hh, self.bias_hh)).reshape(1, 1, -1)
