@@ -664,7 +664,10 @@ static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = fal
     t.mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
     int mblocks = (M + t.mt * 16 - 1) / (t.mt * 16);
     t.nt = 4;
-    while (t.nt > 1 && ((ntiles % t.nt) != 0 || (long)(ntiles / t.nt) * mblocks * kz * zcount < 256)) t.nt >>= 1;
+    // (problems sharing a z-batched launch fill the chip together: wider tiles, i.e. the hand-scheduled 64x32 / 64x64 forms, at
+    // fewer rows.  Only for 64-row tiles: the 16-row weight streams of the offline recurrence lose 12 % with 16x64 tiles.)
+    const int zc = t.mt == 4 ? zcount : 1;
+    while (t.nt > 1 && ((ntiles % t.nt) != 0 || (long)(ntiles / t.nt) * mblocks * kz * zc < 256)) t.nt >>= 1;
     if (tune && epi != EPI_PARTIAL && t.mt == 4 && (long)(ntiles / t.nt) * mblocks < 512) {
         if (tune == 1) { t.mt = 2; mblocks = (M + 31) / 32; }
         else if (tune == 2 && t.nt == 4) t.nt = 2;
