@@ -969,7 +969,9 @@ Engine::SwPlan &Engine::sw_plan(int m, int T)
         }
     }
     p.dev = dmalloc<GemmArgs>(p.host.size());
-    HIP_CHECK(hipMemcpy(p.dev, p.host.data(), p.host.size() * sizeof(GemmArgs), hipMemcpyHostToDevice));
+    // (stream-ordered on the engine's own stream: a blocking hipMemcpy goes through the legacy stream, which HIP refuses while
+    // ANOTHER engine's stepping thread is capturing a graph -- two engines on one device, several models in one process)
+    HIP_CHECK(hipMemcpyAsync(p.dev, p.host.data(), p.host.size() * sizeof(GemmArgs), hipMemcpyHostToDevice, stream_));
     return p;
 }
 

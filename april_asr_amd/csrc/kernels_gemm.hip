@@ -129,20 +129,63 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int zg, const
             if (k < ppt && sj0 + k < rsc.groups) stg[k] = rsc.ssq[(size_t)r * rsc.groups + sj0 + k];
     }
 
+    // Row indirections (session slots) of all m-tiles are loaded back to back under uniform conditions: ONE memory round trip
+    // before the first operand load instead of one per m-tile (the per-tile form compiled to load / s_waitcnt vmcnt(0) four
+    // times in a row: ~1.5 us of a 22 us gate GEMM at 256 rows).  Padding rows recompute the last row; never stored.
     uint32_t aoff0[MT], aoff1[MT], aoffb[AOP == AOP_TANH_ADD ? MT : 1];
+    int arow[MT], r0v[MT], r1v[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { const int row = m0 + mt * 16 + mrow; arow[mt] = row >= g.M ? g.M - 1 : row; }
+    if (g.aidx0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) r0v[mt] = g.aidx0[arow[mt]];
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) r0v[mt] = arow[mt];
+    }
+    if (g.K1 > 0 && g.aidx1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) r1v[mt] = g.aidx1[arow[mt]];
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) r1v[mt] = arow[mt];
+    }
+    // EPI_LSTM: the slots of this thread's output rows (see below), fetched in the same round trip
+    int qslot[EPI == EPI_LSTM ? QPT : 1];
+    if (EPI == EPI_LSTM) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            int r = m0 + (int)(threadIdx.x + i * NTH) / QROW;
+            if (r >= g.M) r = g.M - 1;
+            qslot[i] = g.slot_idx[r];
+        }
+    }
+    if (AOP == AOP_TANH_ADD) {
+        int rbv[MT];
+        if (g.same_idx_b) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) rbv[mt] = r0v[mt];
+        } else if (g.aidx0b) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) rbv[mt] = g.aidx0b[arow[mt]];
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) rbv[mt] = arow[mt];
+        }
+        if (g.ctx_state) {
+            GreedyState st[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) st[mt] = g.ctx_state[rbv[mt]];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) rbv[mt] = st[mt].ctx0 * g.ctx_vocab + st[mt].ctx1;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) aoffb[mt] = (uint32_t)(((size_t)rbv[mt] * g.lda0 + kq * 4) * sizeof(float));
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        int row = m0 + mt * 16 + mrow;
-        if (row >= g.M) row = g.M - 1;                        // padding rows recompute the last row; never stored
-        const int r0 = g.aidx0 ? g.aidx0[row] : row;
-        aoff0[mt] = (uint32_t)(((size_t)r0 * g.lda0 + kq * 4) * sizeof(float));
-        if (AOP == AOP_TANH_ADD) {
-            int rb = g.same_idx_b ? r0 : (g.aidx0b ? g.aidx0b[row] : row);
-            if (g.ctx_state) { const GreedyState st = g.ctx_state[rb]; rb = st.ctx0 * g.ctx_vocab + st.ctx1; }
-            aoffb[mt] = (uint32_t)(((size_t)rb * g.lda0 + kq * 4) * sizeof(float));
-        }
-        aoff1[mt] = 0;
-        if (g.K1 > 0) { const int r1 = g.aidx1 ? g.aidx1[row] : row; aoff1[mt] = (uint32_t)(((size_t)r1 * g.lda1 + kq * 4) * sizeof(float)); }
+        aoff0[mt] = (uint32_t)(((size_t)r0v[mt] * g.lda0 + kq * 4) * sizeof(float));
+        aoff1[mt] = g.K1 > 0 ? (uint32_t)(((size_t)r1v[mt] * g.lda1 + kq * 4) * sizeof(float)) : 0u;
     }
     const uint32_t boff = (uint32_t)lane * sizeof(BQ);
     const bool stream_once = gridDim.y == 1;   // weights read by exactly one workgroup: bypass-friendly loads
@@ -352,12 +395,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int zg, const
             const int n = nt0 * 16 + ul * 4;
             qunit[i] = n >> 2;
             qo[i] = row * Cfg::LDR + ul * 4;
-            const int slot = qok[i] ? g.slot_idx[qm[i]] : 0;
-            cptr[i] = g.c_state + (size_t)slot * g.hidden + qunit[i];
+            cptr[i] = g.c_state + (size_t)qslot[i] * g.hidden + qunit[i];       // (padding rows point at the last row's cell: read, never stored)
             qb[i] = *reinterpret_cast<const f32x4 *>(g.bias + n);
         }
 #pragma unroll
-        for (int i = 0; i < QPT; ++i) cprev[i] = qok[i] ? *cptr[i] : 0.0f;
+        for (int i = 0; i < QPT; ++i) cprev[i] = *cptr[i];
     }
 
     zero_acc();
