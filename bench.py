@@ -205,10 +205,10 @@ def main():
             # HBM traffic per launch from the committed PMC pass of the same workload (bench.py cannot collect PMC itself); per
             # launch it is proportional to the layers sharing the launch (weights) and to the rows (activations), i.e. to rows
             try:
-                tr = json.load(open(os.path.join(ROOT, "profiles", "r02b_gates_traffic.json")))
+                tr = json.load(open(os.path.join(ROOT, "profiles", "r02c_gates_traffic.json")))
                 if int(tr["sessions_per_gpu"]) == B and d.precision == 0:
                     roofline["traffic"] = int(tr["traffic_bytes_per_launch"] * rows_per_launch / float(tr["rows_per_launch"]))
-                    roofline["traffic_source"] = "profiles/r02b_gates_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950 x2 read correction; measured at %.1f rows per launch, scaled by rows)" % float(tr["rows_per_launch"])
+                    roofline["traffic_source"] = "profiles/r02c_gates_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950 x2 read correction; measured at %.1f rows per launch, scaled by rows)" % float(tr["rows_per_launch"])
             except Exception:
                 pass
             roofline["algorithmic_bytes_per_launch"] = int(wbytes + sbytes)
