@@ -672,16 +672,13 @@ __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_k
 // offline wavefront schedule (engine.cc) batches the same step of all encoder layers this way: at one session a layer's
 // recurrent step is a latency-bound launch, twelve of them in one launch cost about the same.
 template <int MT, int NT, int EPI, int AOP, int WT, int MODE, int ASM>
-__global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_zkernel(const GemmArgs *zargs, int zdiv)
+__global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_zkernel(const GemmArgs *__restrict__ zargs, int zdiv)
 {
     const int zl = (int)blockIdx.z / zdiv;
-    static_assert(sizeof(GemmArgs) % 4 == 0, "argument block is copied by words");
-    typedef const __attribute__((address_space(4))) unsigned *ConstWords;     // constant address space: uniform scalar loads
-    ConstWords src = (ConstWords)(unsigned long long)(zargs + zl);
-    GemmArgs g;
-    unsigned *dst = reinterpret_cast<unsigned *>(&g);
-#pragma unroll
-    for (unsigned i = 0; i < sizeof(GemmArgs) / 4; ++i) dst[i] = src[i];
+    // a plain copy through the read-only, non-aliased kernel argument: uniform address -> scalar loads.  (The pointer members
+    // are generic to the compiler -- flat_load / flat_store instead of global_load with an SGPR base -- and neither assumptions
+    // nor address-space round trips change that; measured against the by-value kernel at one problem per launch: no difference.)
+    const GemmArgs g = zargs[zl];
     gemm_body<MT, NT, EPI, AOP, WT, MODE, ASM, 4>(g, (int)blockIdx.z - zl * zdiv, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
 }
 
