@@ -97,11 +97,38 @@ def main():
         # RCCL/xGMI (aprilx_model_broadcast).  torch.distributed only carries the 128-byte RCCL id.
         ids = [A.Model.broadcast_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
-        model = A.Model.broadcast(model if rank == 0 else None, rank, world, ids[0])
-        li = model.load_info()
-        bcast_ms = li.broadcast_ms
-        bcast_info = {"where": "libaprilasr.so (RCCL ncclBroadcast)", "bytes": int(li.broadcast_bytes), "ranks": int(li.ranks),
-                      "comm_init_ms": round(li.comm_init_ms, 1)}
+        root = model if rank == 0 else None
+        try:
+            model = A.Model.broadcast(root, rank, world, ids[0])
+            ok = 1
+        except Exception as e:                      # the library reports RCCL failures as NULL -> exception, it does not abort
+            print("rank %d: library broadcast failed (%s)" % (rank, e), file=sys.stderr, flush=True)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            li = model.load_info()
+            bcast_ms = li.broadcast_ms
+            bcast_info = {"where": "libaprilasr.so (RCCL ncclBroadcast)", "bytes": int(li.broadcast_bytes), "ranks": int(li.ranks),
+                          "comm_init_ms": round(li.comm_init_ms, 1)}
+        else:
+            # fallback so that a scaling run still produces numbers: the same blob through torch.distributed's RCCL communicator
+            # into each rank's GPU memory, models built from the device copy (aprilx_model_from_blob)
+            if rank == 0:
+                blob = torch.from_numpy(root.export_blob()).to(dev)
+                size = torch.tensor([blob.numel()], dtype=torch.int64, device=dev)
+            else:
+                size = torch.zeros(1, dtype=torch.int64, device=dev)
+            dist.broadcast(size, 0)
+            if rank != 0:
+                blob = torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize(); t0 = time.time()
+            dist.broadcast(blob, 0)
+            torch.cuda.synchronize()
+            bcast_ms = (time.time() - t0) * 1e3
+            bcast_info = {"where": "torch.distributed nccl (fallback: the library's own RCCL broadcast failed)", "bytes": int(blob.numel()), "ranks": world}
+            model = root if rank == 0 else A.Model.from_blob(None, device_ptr=blob.data_ptr(), size=blob.numel())
+            del blob
     elif world > 1:
         # gloo test mode (ranks may share a GPU, no RCCL communicator possible): the same content as a host blob
         if rank == 0:
