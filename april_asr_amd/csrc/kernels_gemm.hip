@@ -621,13 +621,22 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int zg, const
             }
         }
     } else if (EPI == EPI_BIAS_DSWISH) {
+        // biases of all of this thread's quads first, settled once: a load inside the loop would make every quad wait for the
+        // previous quad's store (see EPI_LSTM below)
+        f32x4 bq[QPT];
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * NTH;
+            bq[i] = *reinterpret_cast<const f32x4 *>(g.bias + nt0 * 16 + (q < NQ ? (q % QROW) * 4 : 0));
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
             const int q = threadIdx.x + i * NTH;
             const int row = q / QROW, col = (q % QROW) * 4;
             const int m = m0 + row, n = nt0 * 16 + col;
             if (q < NQ && m < g.M) {
-                const f32x4 y = summed4(row * Cfg::LDR + col) + *reinterpret_cast<const f32x4 *>(g.bias + n);
+                const f32x4 y = summed4(row * Cfg::LDR + col) + bq[i];
                 f32x4 o;
                 o.x = y.x * fast_sigmoid(y.x - 1.0f); o.y = y.y * fast_sigmoid(y.y - 1.0f);
                 o.z = y.z * fast_sigmoid(y.z - 1.0f); o.w = y.w * fast_sigmoid(y.w - 1.0f);
@@ -635,6 +644,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int zg, const
             }
         }
     } else {   // EPI_LSTM: each 4-column group = gates i,f,g,o of one hidden unit
+        // (layer-major) the input halves of all of this thread's quads, fetched up front: a load inside the loop below makes
+        // the compiler wait for ALL outstanding memory operations at the loop's merge points, i.e. for the previous quad's
+        // STORES (~0.5 us each, three times per 64x64 tile) -- also on the streaming path, which loads nothing here
+        f32x4 pq[QPT];
+        if (g.p_add) {
+#pragma unroll
+            for (int i = 0; i < QPT; ++i) {
+                int m = qm[i];
+                if (m >= g.M) m = g.M - 1;
+                pq[i] = *reinterpret_cast<const f32x4 *>(g.p_add + (size_t)m * g.ldp + qunit[i] * 4);
+            }
+        }
+        // every load this epilogue depends on (previous cell values, biases, input halves) has been issued long ago: settle them
+        // here, once, so that nothing in the loop waits on the memory counter while the previous quad's stores are in flight
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) only (expcnt / lgkmcnt fields at their maxima)
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
             // x = y * scale(y) entered the GEMM as y: waves 0 and 1 hold the input half of the sum, which takes the row's scale here
@@ -644,7 +668,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int zg, const
                 const f32x4 p2 = *reinterpret_cast<const f32x4 *>(red + 2 * PLANE + o), p3 = *reinterpret_cast<const f32x4 *>(red + 3 * PLANE + o);
                 f32x4 xin;
                 if (g.p_add) {           // layer-major: the input half was computed for all time steps at once (EPI_XPART)
-                    xin = qok[i] ? *reinterpret_cast<const f32x4 *>(g.p_add + (size_t)qm[i] * g.ldp + qunit[i] * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    xin = pq[i];
                 } else {
                     const f32x4 p0 = *reinterpret_cast<const f32x4 *>(red + o), p1 = *reinterpret_cast<const f32x4 *>(red + PLANE + o);
                     xin = (p0 + p1) * scl[(threadIdx.x + i * NTH) / QROW];
