@@ -418,6 +418,59 @@ def test_model_broadcast_in_library(gpu_tiny, tiny_model):
     assert li.used_rccl == 1 and li.ranks == 1 and li.broadcast_bytes > 0 and li.broadcast_ms >= 0.0
 
 
+@pytest.mark.parametrize("which", ["tiny", "v0"])
+def test_feed_wavefront_equals_chunk_by_chunk(which, request):
+    """The 2..3 chunk steps of a 100 ms feed run as ONE wavefront over the layers (z-batched launches, Engine::lm_step mode 1).
+    A model loaded with APRIL_WAVE_MIN_CHUNKS=0 steps the same feeds chunk by chunk (round-1 form): every logit and every
+    callback of the two are equal BIT FOR BIT, alone and in a batch of different sessions."""
+    import os
+    import april_asr_amd as A
+    gm = request.getfixturevalue("gpu_" + which)
+    path = request.getfixturevalue(("tiny" if which == "tiny" else "v0") + "_model")["path"]
+    old = os.environ.get("APRIL_WAVE_MIN_CHUNKS")
+    os.environ["APRIL_WAVE_MIN_CHUNKS"] = "0"
+    try:
+        plain = A.Model(path)
+    finally:
+        if old is None:
+            del os.environ["APRIL_WAVE_MIN_CHUNKS"]
+        else:
+            os.environ["APRIL_WAVE_MIN_CHUNKS"] = old
+    try:
+        pcm = speech_like_pcm(3.0, seed=21, silence=(1.2, 1.7))
+        w0 = gm.stats().wave_chunks
+        ev_w, lg_w, n_w = run_gpu(gm, pcm, 1600)
+        assert gm.stats().wave_chunks - w0 >= n_w // 2                  # most chunks went through the wavefront
+        ev_p, lg_p, n_p = run_gpu(plain, pcm, 1600)
+        assert plain.stats().wave_chunks == 0
+        assert n_w == n_p and np.array_equal(lg_w, lg_p) and ev_w == ev_p
+        # a batch of different sessions (different feed sizes, so different chunk counts per feed)
+        n = 5
+        pcms = [speech_like_pcm(2.0, seed=300 + i) for i in range(n)]
+        outs = []
+        for m in (gm, plain):
+            evs = [[] for _ in range(n)]
+            sess = [A.Session(m, (lambda k: (lambda t, toks: evs[k].append((t, toks))))(i), raw_events=True) for i in range(n)]
+            for s_ in sess:
+                s_.trace_logits(4000)
+            grp = A.SessionGroup(sess)
+            step = [1600, 1600, 3200, 800, 2400]
+            pos = [0] * n
+            while any(pos[i] < pcms[i].size for i in range(n)):
+                grp.feed([pcms[i][pos[i]:pos[i] + step[i]] for i in range(n)])
+                pos = [pos[i] + step[i] for i in range(n)]
+            grp.flush()
+            outs.append(([s_.traced_logits().copy() for s_ in sess], evs))
+            for s_ in sess:
+                s_.close()
+        for i in range(n):
+            assert np.array_equal(outs[0][0][i], outs[1][0][i]), i
+            assert outs[0][1][i] == outs[1][1][i], i
+        assert gm.stats().replay_mismatch == 0 and plain.stats().replay_mismatch == 0
+    finally:
+        plain.close()
+
+
 def test_decoder_table_equals_decoder_network(tiny_model, gpu_tiny):
     """The decoder output of EVERY 2-token context is computed once at load (Engine::build_dec_table) and the joiner reads the
     row of a session's context.  A model loaded with the table disabled runs the decoder network per context change as in
