@@ -383,16 +383,20 @@ void Engine::fbank(int n_frames, const FbankFrameDesc *desc, const std::pair<con
         }
         desc_cap_ = std::max({n_frames * 2, desc_cap_, 1024});
         pcm_cap_ = std::max({n_pcm * 2, pcm_cap_, (size_t)1 << 16});
+        // one staging buffer per flip: the PCM windows, then (16-byte aligned, right behind the samples of THIS call) the frame
+        // descriptors -> one host-to-device copy per call instead of two
+        const size_t units = pcm_cap_ + 8 + ((size_t)desc_cap_ * sizeof(FbankFrameDesc) + 1) / 2;
         for (int b = 0; b < 2; ++b) {
-            hs_desc_[b] = hmalloc<FbankFrameDesc>((size_t)desc_cap_); ds_desc_[b] = dmalloc<FbankFrameDesc>((size_t)desc_cap_);
-            hs_pcm_[b] = hmalloc<int16_t>(pcm_cap_); ds_pcm_[b] = dmalloc<int16_t>(pcm_cap_);
+            hs_pcm_[b] = hmalloc<int16_t>(units); ds_pcm_[b] = dmalloc<int16_t>(units);
+            hs_desc_[b] = nullptr; ds_desc_[b] = nullptr;
             if (!fb_done_[b]) HIP_CHECK(hipEventCreateWithFlags(&fb_done_[b], hipEventDisableTiming));
         }
     }
     const int b = fb_flip_;
     fb_flip_ ^= 1;
     HIP_CHECK(hipEventSynchronize(fb_done_[b]));          // the launch that used this pair two calls ago has consumed it
-    memcpy(hs_desc_[b], desc, (size_t)n_frames * sizeof(FbankFrameDesc));
+    const size_t doff = (n_pcm * sizeof(int16_t) + 15) / 16 * 16;          // byte offset of the descriptors
+    memcpy(reinterpret_cast<char *>(hs_pcm_[b]) + doff, desc, (size_t)n_frames * sizeof(FbankFrameDesc));
     if (pool && n_parts >= 256) {
         part_off_.resize(n_parts);
         size_t off = 0;
@@ -403,10 +407,9 @@ void Engine::fbank(int n_frames, const FbankFrameDesc *desc, const std::pair<con
         size_t off = 0;
         for (size_t i = 0; i < n_parts; ++i) { memcpy(hs_pcm_[b] + off, parts[i].first, parts[i].second * sizeof(int16_t)); off += parts[i].second; }
     }
-    HIP_CHECK(hipMemcpyAsync(ds_desc_[b], hs_desc_[b], (size_t)n_frames * sizeof(FbankFrameDesc), hipMemcpyHostToDevice, stream_));
-    if (n_pcm) HIP_CHECK(hipMemcpyAsync(ds_pcm_[b], hs_pcm_[b], n_pcm * sizeof(int16_t), hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(ds_pcm_[b], hs_pcm_[b], doff + (size_t)n_frames * sizeof(FbankFrameDesc), hipMemcpyHostToDevice, stream_));
     FbankArgs a;
-    a.t = ft_; a.pcm = ds_pcm_[b]; a.desc = ds_desc_[b]; a.n_frames = n_frames; a.ring = ring_; a.ring_frames = ring_frames_; a.pad_value = pad_value_;
+    a.t = ft_; a.pcm = ds_pcm_[b]; a.desc = reinterpret_cast<const FbankFrameDesc *>(reinterpret_cast<const char *>(ds_pcm_[b]) + doff); a.n_frames = n_frames; a.ring = ring_; a.ring_frames = ring_frames_; a.pad_value = pad_value_;
     timed_begin(T_FBANK);
     launch_fbank(a, stream_);
     timed_end(T_FBANK);
