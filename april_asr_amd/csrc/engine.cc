@@ -597,7 +597,7 @@ void Engine::run_chain(int m, bool dump_logits)
 //                     projection; feed-forward over the block's rows   -> y, ssq rows of the block
 //   proj(block)       encoder_proj                                   -> eout_lm rows of the block
 // layer(l, b) needs layer(l - 1, b) (its input rows) and layer(l, b - 1) (the recurrent state): stages of different layers
-// on different blocks are independent and run on different streams (see run_lm_chain).  Work buffers are row-partitioned,
+// on different blocks are independent: their launches are z-batched into one (see run_lm_wavefront).  Work buffers are row-partitioned,
 // so concurrent stages never share a byte.
 void Engine::lm_stage_embed(int m, int t0, int t1, hipStream_t st)
 {
@@ -1107,7 +1107,7 @@ int Engine::step(int m, const int *slots, const int *ring_tails, const int *now_
     memcpy(blk, slots, (size_t)m * 4); memcpy(blk + m, ring_tails, (size_t)m * 4); memcpy(blk + 2 * m, now_ms, (size_t)m * 4);
     step_off_h_[k] = (int)ring_pos_; rec_off_h_[k] = (int)rec_pos_;
     ring_pos_ += (size_t)3 * m; rec_pos_ += (size_t)3 * m;
-    // The whole per-chunk chain (index fetch + ~55 kernels) is replayed from a hipGraph captured once per batch size:
+    // The whole per-chunk chain (index fetch + 58 kernels) is replayed from a hipGraph captured once per batch size:
     // at small batches the chain is launch-bound on the host (~3.5 us per launch), the replay is not.  Kernel arguments
     // depend only on m; the step's indices and its record offset reach the kernels through the device step counter.
     if (use_graphs_ && !profiling_ && !logits_out) {
