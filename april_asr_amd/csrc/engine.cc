@@ -1028,7 +1028,9 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
     if (mode == 1) {                 // the chunk steps of one feed as a wavefront over the layers (run_sw_chain)
         std::lock_guard<std::mutex> cg(capture_mu_);
         SwPlan &p = sw_plan(m, T);
-        if (use_graphs_ && !profiling_ && !logits_out) {
+        // a shape is captured into a graph the SECOND time it is seen: capturing costs a few milliseconds, which a batch shape
+        // that occurs once (sessions joining and leaving) never earns back; its launches go out one by one (~0.25 ms of host time)
+        if (use_graphs_ && !profiling_ && !logits_out && (p.graph || ++p.uses >= 2)) {
             if (!p.graph) {
                 hipGraph_t graph = nullptr;
                 HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
@@ -1110,10 +1112,10 @@ int Engine::step(int m, const int *slots, const int *ring_tails, const int *now_
     // The whole per-chunk chain (index fetch + 58 kernels) is replayed from a hipGraph captured once per batch size:
     // at small batches the chain is launch-bound on the host (~3.5 us per launch), the replay is not.  Kernel arguments
     // depend only on m; the step's indices and its record offset reach the kernels through the device step counter.
-    if (use_graphs_ && !profiling_ && !logits_out) {
+    if (use_graphs_ && !profiling_ && !logits_out && (step_graphs_.count(m) || ++step_seen_[m] >= 2)) {      // (captured at the second use, see lm_step)
         auto it = step_graphs_.find(m);
         if (it == step_graphs_.end()) {
-            if (step_graphs_.size() >= 128) { for (auto &g : step_graphs_) (void)hipGraphExecDestroy(g.second); step_graphs_.clear(); }
+            if (step_graphs_.size() >= 128) { for (auto &g : step_graphs_) (void)hipGraphExecDestroy(g.second); step_graphs_.clear(); step_seen_.clear(); }
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
             std::lock_guard<std::mutex> cg(capture_mu_);       // aas_free on another thread resets slots through this stream

@@ -153,7 +153,7 @@ private:
     void run_lm_wavefront(int m, int T, bool dump_logits);
     struct SwPlan {                          // argument blocks + launch list of run_sw_chain for one (m, T), and its captured graph
         struct Batch { size_t off; int n, macro, kind; };
-        std::vector<GemmArgs> host; GemmArgs *dev = nullptr; std::vector<Batch> batches; hipGraphExec_t graph = nullptr;
+        std::vector<GemmArgs> host; GemmArgs *dev = nullptr; std::vector<Batch> batches; hipGraphExec_t graph = nullptr; int uses = 0;
     };
     SwPlan &sw_plan(int m, int T);
     void run_sw_chain(int m, int T, bool dump_logits, const SwPlan &p);
@@ -209,6 +209,7 @@ private:
     // chunk-step launch chains captured per batch size
     bool use_graphs_ = true;
     std::map<int, hipGraphExec_t> step_graphs_;
+    std::map<int, int> step_seen_;             // batch size -> times seen (a chain is captured at its second use)
     std::map<std::pair<int, int>, hipGraphExec_t> lm_graphs_;      // (m, T)
     // wavefront form of the layer-major step: its stream, events, per-launch argument blocks (pinned + device), the
     // block-independent search graphs (m, block length) and their bookkeeping words
