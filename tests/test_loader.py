@@ -1,5 +1,6 @@
 """Weight extraction + MFMA packing (host-only load, no GPU): the packed blob the engine uploads must
 contain exactly the weights the synthetic exporter wrote, whatever ONNX spelling was used."""
+import os
 import struct
 
 import numpy as np
@@ -365,3 +366,22 @@ def test_torch_onnx_export_styles(built, tiny_model, tmp_path, style):
     a = A.Model.load_host_only(tiny_model["path"]); b = A.Model.load_host_only(str(p))
     assert np.array_equal(split_blob(a.export_blob()), split_blob(b.export_blob()))
     a.close(); b.close()
+
+
+def test_convert_cli(built, tiny_model, tmp_path):
+    """python -m april_asr_amd.convert: .april -> cache file on the host (no GPU); the cache loads to the same packed weights;
+    the fp16 variant is half the size of the matrices and carries its own magic; a broken input is refused with exit code 1."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    out32, out16 = str(tmp_path / "m.aprilx"), str(tmp_path / "m.aprilx16")
+    subprocess.check_call([sys.executable, "-m", "april_asr_amd.convert", tiny_model["path"], out32], env=env, cwd=str(tmp_path))
+    subprocess.check_call([sys.executable, "-m", "april_asr_amd.convert", tiny_model["path"], out16, "--f16"], env=env, cwd=str(tmp_path))
+    a = A.Model.load_host_only(tiny_model["path"]); b = A.Model.load_blob(out32, init_gpu=False)
+    assert np.array_equal(a.export_blob(), b.export_blob())
+    a.close(); b.close()
+    assert open(out16, "rb").read(8) == b"APXBLB16" and os.path.getsize(out16) < 0.62 * os.path.getsize(out32)
+    bad = tmp_path / "bad.april"; bad.write_bytes(open(tiny_model["path"], "rb").read()[:5000])
+    r = subprocess.run([sys.executable, "-m", "april_asr_amd.convert", str(bad), str(tmp_path / "x")], env=env, cwd=str(tmp_path), capture_output=True)
+    assert r.returncode == 1
