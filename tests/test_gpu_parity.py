@@ -471,6 +471,36 @@ def test_feed_wavefront_equals_chunk_by_chunk(which, request):
         plain.close()
 
 
+def test_many_batch_shapes(gpu_tiny):
+    """Sessions join one per feed, so every feed has a batch shape (sessions x chunks) never seen before: the launch chains of
+    one-off shapes go out eagerly (graphs are captured at the second use), more than 64 feed-wavefront plans are built (the
+    plan cache is emptied once on the way), and every session still equals itself streamed alone, bit for bit."""
+    import april_asr_amd as A
+    from oracle import orc_py as O
+    n = 72
+    pcms = [O.lcg_pcm16_fast(1600 * (n + 6), seed=900 + i) for i in range(n)]
+    evs = [[] for _ in range(n)]
+    sess, pos = [], []
+    for step in range(n + 6):
+        if step < n:
+            sess.append(A.Session(gpu_tiny, (lambda k: (lambda t, toks: evs[k].append((t, toks))))(step), raw_events=True))
+            pos.append(0)
+            if step in (0, 35, 71):
+                sess[-1].trace_logits(1200)
+        grp = A.SessionGroup(sess)
+        grp.feed([pcms[i][pos[i]:pos[i] + 1600] for i in range(len(sess))])
+        pos = [p + 1600 for p in pos]
+    A.SessionGroup(sess).flush()
+    assert gpu_tiny.stats().replay_mismatch == 0
+    for i in (0, 35, 71):
+        fed = pcms[i][:pos[i]]
+        ev1, lg1, _ = run_gpu(gpu_tiny, fed, 1600)
+        assert np.array_equal(lg1, sess[i].traced_logits()), i
+        assert ev1 == evs[i], i
+    for s_ in sess:
+        s_.close()
+
+
 def test_decoder_table_equals_decoder_network(tiny_model, gpu_tiny):
     """The decoder output of EVERY 2-token context is computed once at load (Engine::build_dec_table) and the joiner reads the
     row of a session's context.  A model loaded with the table disabled runs the decoder network per context change as in
