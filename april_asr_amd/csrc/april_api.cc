@@ -53,20 +53,43 @@ bool broadcast_local(Model &m)
     for (Engine *e : m.engines) if (std::find(devs.begin(), devs.end(), e->device()) == devs.end()) { devs.push_back(e->device()); peers.push_back(e); }
     const size_t count = m.layout.total;
     if (devs.size() > 1) {
+        // Every exit path destroys the communicators; an RCCL failure is loud, fails the load under APRIL_STRICT_RCCL=1 and
+        // otherwise falls back to a peer copy from the root device (the weights are already there), so a node whose RCCL
+        // cannot initialise still serves.
         const double t0 = now_ms();
-        std::vector<ncclComm_t> comms(devs.size());
-        RCCL_TRY(ncclCommInitAll(comms.data(), (int)devs.size(), devs.data()));
-        const double t1 = now_ms();
-        RCCL_TRY(ncclGroupStart());
-        for (size_t i = 0; i < peers.size(); ++i) {
-            HIP_CHECK(hipSetDevice(devs[i]));
-            RCCL_TRY(ncclBroadcast(peers[0]->weights_device(), peers[i]->weights_mut(), count, ncclFloat, 0, comms[i], peers[i]->stream()));
+        std::vector<ncclComm_t> comms(devs.size(), nullptr);
+        double t1 = t0;
+        auto rccl_path = [&]() -> bool {
+            RCCL_TRY(ncclCommInitAll(comms.data(), (int)devs.size(), devs.data()));
+            t1 = now_ms();
+            RCCL_TRY(ncclGroupStart());
+            bool ok = true;
+            for (size_t i = 0; i < peers.size() && ok; ++i) {
+                HIP_CHECK(hipSetDevice(devs[i]));
+                const ncclResult_t r = ncclBroadcast(peers[0]->weights_device(), peers[i]->weights_mut(), count, ncclFloat, 0, comms[i], peers[i]->stream());
+                if (r != ncclSuccess) { LOGE("RCCL: ncclBroadcast (device %d) failed: %s", devs[i], ncclGetErrorString(r)); ok = false; }
+            }
+            const ncclResult_t ge = ncclGroupEnd();          // (always closes the group that was opened)
+            if (ge != ncclSuccess) { LOGE("RCCL: ncclGroupEnd failed: %s", ncclGetErrorString(ge)); ok = false; }
+            for (size_t i = 0; i < peers.size(); ++i) { HIP_CHECK(hipSetDevice(devs[i])); HIP_CHECK(hipStreamSynchronize(peers[i]->stream())); }
+            return ok;
+        };
+        const bool used = rccl_path();
+        for (ncclComm_t c : comms) if (c) (void)ncclCommDestroy(c);
+        if (used) {
+            m.load.broadcast_ms = now_ms() - t1; m.load.comm_init_ms = t1 - t0;
+            m.load.broadcast_bytes = count * 4; m.load.ranks = (int)devs.size(); m.load.used_rccl = 1;
+        } else {
+            if (env_int("APRIL_STRICT_RCCL", 0)) { LOGE("aam: RCCL weight broadcast failed and APRIL_STRICT_RCCL=1: giving up"); return false; }
+            LOGE("aam: RCCL weight broadcast failed: falling back to peer copies from device %d (used_rccl = 0)", devs[0]);
+            const double t2 = now_ms();
+            for (size_t i = 1; i < peers.size(); ++i) {
+                HIP_CHECK(hipSetDevice(devs[i]));
+                HIP_CHECK(hipMemcpyPeer(peers[i]->weights_mut(), devs[i], peers[0]->weights_device(), devs[0], count * 4));
+            }
+            m.load.broadcast_ms = now_ms() - t2; m.load.comm_init_ms = 0;
+            m.load.broadcast_bytes = count * 4; m.load.ranks = (int)devs.size(); m.load.used_rccl = 0;
         }
-        RCCL_TRY(ncclGroupEnd());
-        for (size_t i = 0; i < peers.size(); ++i) { HIP_CHECK(hipSetDevice(devs[i])); HIP_CHECK(hipStreamSynchronize(peers[i]->stream())); }
-        m.load.broadcast_ms = now_ms() - t1; m.load.comm_init_ms = t1 - t0;
-        m.load.broadcast_bytes = count * 4; m.load.ranks = (int)devs.size(); m.load.used_rccl = 1;
-        for (ncclComm_t c : comms) (void)ncclCommDestroy(c);
     }
     // further engines on a device that already holds the weights ("lanes"): a device-to-device copy
     for (Engine *e : m.engines) {
@@ -325,16 +348,18 @@ float aas_realtime_get_speedup(AprilASRSession session)
 {
     Session *s = &session->s;
     if (!s->realtime_flag) return 1.0f;
-    s->sched->wait_idle(s);
-    return (float)s->speed_needed;
+    // like the reference (april_session.c:95-97) this only reads the field: no wait, so it is safe inside a result handler
+    // (the stepping thread) and never blocks behind a continuously fed stream
+    return (float)s->speed_needed.load(std::memory_order_relaxed);
 }
 
 void aas_free(AprilASRSession session)
 {
     if (!session) return;
     Session *s = &session->s;
-    if (s->sched->on_loop_thread()) { s->sched->detach(s); return; }      // refused with an error message (see Scheduler::detach)
-    s->sched->detach(s);
+    // refused (with an error message) only from inside the session's OWN handler; freeing another, idle session from a
+    // handler is a normal free
+    if (!s->sched->detach(s)) return;
     s->eng->free_slot(s->slot);
     delete session;
 }
@@ -522,13 +547,26 @@ AprilASRModel aprilx_model_broadcast(AprilASRModel root_model, int rank, int wor
     const int dev = rank == 0 ? root_model->m.engines[0]->device() : g_devices[0];
     HIP_CHECK(hipSetDevice(dev));
     const double t0 = now_ms();
-    ncclComm_t comm;
+    ncclComm_t comm = nullptr;
+    hipStream_t st = nullptr;
+    uint64_t *hdr_d = nullptr; char *meta_d = nullptr; float *scratch = nullptr;
+    // everything this call allocates is released on every exit path (communicator, stream, staging buffers)
+    struct Cleanup {
+        ncclComm_t &comm; hipStream_t &st; uint64_t *&hdr_d; char *&meta_d; float *&scratch;
+        ~Cleanup() {
+            if (hdr_d) (void)hipFree(hdr_d);
+            if (meta_d) (void)hipFree(meta_d);
+            if (scratch) (void)hipFree(scratch);
+            if (comm) (void)ncclCommDestroy(comm);
+            if (st) (void)hipStreamDestroy(st);
+        }
+    } cleanup{comm, st, hdr_d, meta_d, scratch};
     ncclResult_t r = ncclCommInitRank(&comm, world, id, rank);
-    if (r != ncclSuccess) return fail("ncclCommInitRank", r);
+    if (r != ncclSuccess) { comm = nullptr; return fail("ncclCommInitRank", r); }
     const double t1 = now_ms();
-    hipStream_t st; HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     // 1. sizes, 2. metadata (names, PARAMS, token table, dimensions), 3. the packed weights straight into the engine
-    uint64_t *hdr_d; HIP_CHECK(hipMalloc((void **)&hdr_d, 16));
+    HIP_CHECK(hipMalloc((void **)&hdr_d, 16));
     std::string meta;
     uint64_t hdr[2] = {0, 0};
     if (rank == 0) { meta = make_meta(root_model->m); hdr[0] = meta.size(); hdr[1] = root_model->m.layout.total; HIP_CHECK(hipMemcpy(hdr_d, hdr, 16, hipMemcpyHostToDevice)); }
@@ -536,7 +574,7 @@ AprilASRModel aprilx_model_broadcast(AprilASRModel root_model, int rank, int wor
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipMemcpy(hdr, hdr_d, 16, hipMemcpyDeviceToHost));
     if (hdr[0] == 0 || hdr[0] > ((uint64_t)1 << 30) || hdr[1] == 0) { LOGE("aprilx_model_broadcast: implausible sizes"); return nullptr; }
-    char *meta_d; HIP_CHECK(hipMalloc((void **)&meta_d, (size_t)hdr[0]));
+    HIP_CHECK(hipMalloc((void **)&meta_d, (size_t)hdr[0]));
     if (rank == 0) HIP_CHECK(hipMemcpy(meta_d, meta.data(), meta.size(), hipMemcpyHostToDevice));
     if ((r = ncclBroadcast(meta_d, meta_d, (size_t)hdr[0], ncclUint8, 0, comm, st)) != ncclSuccess) return fail("ncclBroadcast(metadata)", r);
     HIP_CHECK(hipStreamSynchronize(st));
@@ -551,16 +589,12 @@ AprilASRModel aprilx_model_broadcast(AprilASRModel root_model, int rank, int wor
         }
     }
     // every rank takes part in the weight broadcast even if its model could not be built (a missing rank would hang the others)
-    float *scratch = nullptr;
     float *buf = h ? h->m.engines[0]->weights_mut() : nullptr;
     if (!buf) { HIP_CHECK(hipMalloc((void **)&scratch, (size_t)hdr[1] * 4)); buf = scratch; }
     const double t2 = now_ms();
     r = ncclBroadcast(buf, buf, (size_t)hdr[1], ncclFloat, 0, comm, st);
     if (r == ncclSuccess) HIP_CHECK(hipStreamSynchronize(st));
     const double t3 = now_ms();
-    (void)hipFree(hdr_d); (void)hipFree(meta_d); if (scratch) (void)hipFree(scratch);
-    (void)ncclCommDestroy(comm);
-    (void)hipStreamDestroy(st);
     if (r != ncclSuccess) { if (rank != 0 && h) delete h; return fail("ncclBroadcast(weights)", r); }
     if (!h) return nullptr;
     if (rank != 0 && !distribute_weights(h->m)) { delete h; return nullptr; }

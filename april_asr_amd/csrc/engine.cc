@@ -914,7 +914,7 @@ void Engine::run_lm_wavefront(int m, int T, bool dump_logits)
             const std::pair<int, int> key(m, len);
             auto it = lm_search_graphs_.find(key);
             if (it == lm_search_graphs_.end()) {
-                if (lm_search_graphs_.size() >= 64) { for (auto &g : lm_search_graphs_) (void)hipGraphExecDestroy(g.second); lm_search_graphs_.clear(); }
+                if (lm_search_graphs_.size() >= 64) { HIP_CHECK(hipStreamSynchronize(stream_)); /* execs launched earlier in this flight may still run */ for (auto &g : lm_search_graphs_) (void)hipGraphExecDestroy(g.second); lm_search_graphs_.clear(); }
                 hipGraph_t graph = nullptr;
                 hipGraphExec_t exec = nullptr;
                 HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
@@ -1056,7 +1056,7 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
         const std::pair<int, int> key(m, T);
         auto it = lm_graphs_.find(key);
         if (it == lm_graphs_.end()) {
-            if (lm_graphs_.size() >= 16) { for (auto &g : lm_graphs_) (void)hipGraphExecDestroy(g.second); lm_graphs_.clear(); }
+            if (lm_graphs_.size() >= 16) { HIP_CHECK(hipStreamSynchronize(stream_)); for (auto &g : lm_graphs_) (void)hipGraphExecDestroy(g.second); lm_graphs_.clear(); }
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
             std::lock_guard<std::mutex> cg(capture_mu_);
@@ -1115,7 +1115,7 @@ int Engine::step(int m, const int *slots, const int *ring_tails, const int *now_
     if (use_graphs_ && !profiling_ && !logits_out && (step_graphs_.count(m) || ++step_seen_[m] >= 2)) {      // (captured at the second use, see lm_step)
         auto it = step_graphs_.find(m);
         if (it == step_graphs_.end()) {
-            if (step_graphs_.size() >= 128) { for (auto &g : step_graphs_) (void)hipGraphExecDestroy(g.second); step_graphs_.clear(); step_seen_.clear(); }
+            if (step_graphs_.size() >= 128) { HIP_CHECK(hipStreamSynchronize(stream_)); for (auto &g : step_graphs_) (void)hipGraphExecDestroy(g.second); step_graphs_.clear(); step_seen_.clear(); }
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
             std::lock_guard<std::mutex> cg(capture_mu_);       // aas_free on another thread resets slots through this stream

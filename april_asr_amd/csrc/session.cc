@@ -273,20 +273,21 @@ void Scheduler::attach(Session *s)
     sessions_.push_back(s);
 }
 
-void Scheduler::detach(Session *s)
+bool Scheduler::detach(Session *s)
 {
     std::unique_lock<std::mutex> lk(mu_);
     if (on_loop_thread() && s->busy) {
         // aas_free from inside this session's own asynchronous result handler: the stepping thread would wait for itself
         // (the reference joins its own thread there, src/proc_thread.c:101-116).  Refuse loudly instead of hanging.
         LOGE("aas_free called from inside the session's result handler: not supported, the session is left alive");
-        return;
+        return false;
     }
     s->closing = true;
     cv_done_.wait(lk, [&] { return !s->busy; });
     sessions_.erase(std::remove(sessions_.begin(), sessions_.end(), s), sessions_.end());
     s->inbox.clear();
     s->borrow_ptr = nullptr; s->borrow_cnt = 0;
+    return true;
 }
 
 SchedStats Scheduler::stats() { std::lock_guard<std::mutex> g(mu_); return stats_; }
@@ -295,6 +296,7 @@ void Scheduler::submit(int n, Session *const *ss, const short *const *pcm, const
 {
     std::vector<Session *> overflowed;
     std::vector<uint64_t> tickets((size_t)n, 0);
+    uint64_t done_seen = 0;
     {
         std::unique_lock<std::mutex> lk(mu_);
         for (int i = 0; i < n; ++i) {
@@ -313,8 +315,10 @@ void Scheduler::submit(int n, Session *const *ss, const short *const *pcm, const
             }
             tickets[(size_t)i] = ++s->submitted;
         }
+        // read while mu_ is still held: the tick that takes this work cannot have ended yet (it needs mu_ to collect it), so a
+        // later change of done_seq_ is never missed and the spin below never waits on a counter that has already moved
+        done_seen = done_seq_.load(std::memory_order_acquire);
     }
-    const uint64_t done_seen = done_seq_.load(std::memory_order_acquire);
     work_seq_.fetch_add(1, std::memory_order_release);
     cv_work_.notify_one();
     for (Session *s : overflowed) s->handler(s->userdata, APRIL_RESULT_ERROR_CANT_KEEP_UP, 0, nullptr);
@@ -336,10 +340,11 @@ void Scheduler::wait_idle(Session *s)
 void Scheduler::wait_idle_many(Session *const *ss, int n)
 {
     {   // called right after a submit: poll for the end of the tick that took the work before sleeping
-        const uint64_t seen = done_seq_.load(std::memory_order_acquire);
+        uint64_t seen;
         bool idle;
         {
             std::lock_guard<std::mutex> g(mu_);
+            seen = done_seq_.load(std::memory_order_acquire);      // under the lock, as in submit()
             idle = true;
             for (int i = 0; i < n && idle; ++i) { const Session *s = ss[i]; idle = s->closing || (s->completed >= s->submitted && !s->busy && !s->fed && !s->flush_requested); }
         }
@@ -421,7 +426,10 @@ void Scheduler::loop()
             const double stride_ms = (double)(model_->host.params.segment_step * model_->host.params.frame_shift_ms);
             for (Session *s : work) {
                 const uint64_t n = s->chunks - s->chunks_at_tick_start;
-                for (uint64_t i = 0; i < n; ++i) s->speed_needed = (s->speed_needed * 9.0 + (tick_ms / (double)n) * 1.1 / stride_ms) / 10.0;
+                if (!n) continue;
+                double v = s->speed_needed.load(std::memory_order_relaxed);
+                for (uint64_t i = 0; i < n; ++i) v = (v * 9.0 + (tick_ms / (double)n) * 1.1 / stride_ms) / 10.0;
+                s->speed_needed.store(v, std::memory_order_relaxed);
             }
         }
         // async sessions: deliver on this (library) thread, outside the lock

@@ -123,7 +123,8 @@ struct Session {
     bool compact_pending = false;
     struct Replay { int step; int row; int rows; uint32_t now_ms; int kind; int chunk; };   // kind 0: chunk `chunk` of step (3 rounds of records), 1: end of flush
     std::vector<Replay> replay;               // what the flight in progress did for this session, in order
-    double speed_needed = 1.0;                // reference src/april_session.c:79,456-462 (EMA of processing time / audio time x 1.1)
+    std::atomic<double> speed_needed{1.0};    // reference src/april_session.c:79,456-462 (EMA of processing time / audio time x 1.1);
+                                              // written by the stepping thread, read by aas_realtime_get_speedup from any thread
     uint64_t chunks_at_tick_start = 0;
     bool was_flushed = false;
     int flush_phase = 0;                      // 0 none, 1 pad-drain, 2 zeros, 3 pad-drain, 4 finish
@@ -152,7 +153,7 @@ public:
     Scheduler(Model *m, Engine *e);
     ~Scheduler();
     void attach(Session *s);
-    void detach(Session *s);                       // waits until the session is idle
+    bool detach(Session *s);                       // waits until the session is idle; false = refused (called from the session's own handler)
     // queue work for n sessions at once and (for sync sessions / wait=true) block until it is done
     // `borrow`: the caller keeps the PCM buffers alive and unchanged until the sessions are idle again (it blocks in this
     // call, or drains afterwards), so they are read in place by the stepping thread instead of being copied under the lock
