@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 FP16_MFMA_PEAK_TFLOPS = 2500.0     # dense fp16 MFMA peak (--precision f16 only)
 HBM_PEAK_GBS = 8000.0              # spec; ~6300 measured achievable
+TRAFFIC_JSON = "r02c_gates_traffic.json"      # the committed PMC pass the roofline's `traffic` is taken from
 
 
 def main():
@@ -39,6 +40,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=10)
+    ap.add_argument("--steady-steps", type=int, default=200, help="length of the fixed steady-state series reported next to the driver's K steps (0 = skip)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] leg (larger encoder, 512 sessions, fp16 MFMA path vs fp32)")
     ap.add_argument("--precision", choices=["f32", "f16"], default="f32",
                     help="f16 = opt-in fp16-operand mode (BASELINE configs[4]); the headline metric is quoted on f32")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -92,6 +95,7 @@ def main():
                 SM.write_model(path, SM.APRILV0_DIMS)
         model = A.Model(path)
     bcast_info = None
+    rccl_fallback = False
     if world > 1 and args.backend == "nccl":
         # the one collective of the job, inside the library: rank 0's packed weights -> every other rank's GPU over
         # RCCL/xGMI (aprilx_model_broadcast).  torch.distributed only carries the 128-byte RCCL id.
@@ -113,7 +117,12 @@ def main():
                           "comm_init_ms": round(li.comm_init_ms, 1)}
         else:
             # fallback so that a scaling run still produces numbers: the same blob through torch.distributed's RCCL communicator
-            # into each rank's GPU memory, models built from the device copy (aprilx_model_from_blob)
+            # into each rank's GPU memory, models built from the device copy (aprilx_model_from_blob).  LOUD: a top-level
+            # "rccl_fallback": true in the line, a message on stderr, and a non-zero exit under APRIL_STRICT_RCCL=1.
+            rccl_fallback = True
+            print("bench.py rank %d: RCCL FALLBACK -- the library's own ncclBroadcast failed, weights go through torch.distributed" % rank, file=sys.stderr, flush=True)
+            if os.environ.get("APRIL_STRICT_RCCL", "0") not in ("", "0"):
+                sys.exit(3)
             if rank == 0:
                 blob = torch.from_numpy(root.export_blob()).to(dev)
                 size = torch.tensor([blob.numel()], dtype=torch.int64, device=dev)
@@ -193,57 +202,85 @@ def main():
         elapsed = float(tt.item())
     st = model.stats()
     host_ms = [round(x, 2) for x in st.host_ms]
+    # a longer, fixed-length series next to the driver's K steps (20 steps = 33 ms decide little; box-to-box spread
+    # is +-5 %): the same sessions keep streaming, `steady_steps` further feeds, per-step wall times on rank 0, the mean as the
+    # max over ranks.  Not `value`: that stays the driver's K steps.
+    steady = None
+    if args.steady_steps > 0:
+        more_s = pcm_for(B, args.steady_steps, 30_000_000 + rank * B)
+        sw = []
+        run_steps(grp, more_s, 0, 4)                     # (plan + the first feeds outside the series)
+        barrier()
+        a = time.perf_counter()
+        run_steps(grp, more_s, 4, args.steady_steps, sw)
+        barrier()
+        el = time.perf_counter() - a
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        nst = args.steady_steps - 4
+        steady = {"steps": nst, "ms_per_step": round(el / nst * 1e3, 3), "p50": round(float(np.percentile(sw, 50)) * 1e3, 3),
+                  "p90": round(float(np.percentile(sw, 90)) * 1e3, 3), "p99": round(float(np.percentile(sw, 99)) * 1e3, 3),
+                  "min": round(min(sw) * 1e3, 3), "rtf": round(el / (nst * 0.1), 5),
+                  "what": "%d further 100 ms feeds of the same %d sessions per GPU after the timed region (max over ranks for the mean, rank 0 for the percentiles)" % (nst, B)}
+        del more_s
+        st = model.stats()
     audio_per_session = args.steps * step_samples / 16000.0
     value = world * B * audio_per_session / elapsed
     rtf = elapsed / audio_per_session
 
     # ---------------- roofline of the dominant kernel (gates GEMM + fused LSTM cell), live hipEvent timing
-    roofline = None
-    if rank == 0:
-        more = pcm_for(B, args.profile_steps, 10_000_000)
-        model.profile(True)
-        run_steps(grp, more, 0, args.profile_steps)
-        sp = model.stats()
-        model.profile(False)
-        launches = sp.kernel_launches[0]
-        if launches:
-            avg_ms = sp.kernel_ms[0] / launches
-            rows = sp.chunks - st.chunks        # session-chunks processed while profiling
-            steps_prof = sp.steps - st.steps
-            # rows per gates launch, averaged: every session-chunk passes the gates GEMM of each layer once; a launch covers one
-            # layer of one chunk step, or the same launch of up to T layers when a feed's chunk steps run as a wavefront (z-batched)
-            rows_per_launch = rows * d.n_layers / launches
-            layers_per_launch = max(1.0, rows_per_launch / B)      # a z-batched launch holds that many layers' weight matrices
-            flops = 2.0 * rows_per_launch * (2 * d.d_model) * (4 * d.hidden)
-            wbytes = (2 * d.d_model) * (4 * d.hidden) * 4 * layers_per_launch
-            sbytes = rows_per_launch * (d.d_model * 4 * 2 + d.hidden * 4 * 3)      # x,h read; c read+write; u write
-            tf = flops / (avg_ms * 1e-3) / 1e12
-            mfma_peak = FP16_MFMA_PEAK_TFLOPS if d.precision == 1 else FP32_MFMA_PEAK_TFLOPS
-            if d.precision == 1:
-                wbytes /= 2                         # fp16 weight copies
-            gbs = (wbytes + sbytes) / (avg_ms * 1e-3) / 1e9
-            frac_mfma, frac_hbm = tf / mfma_peak, gbs / HBM_PEAK_GBS
-            if frac_mfma >= frac_hbm:
-                roofline = {"bound": "mfma", "achieved": round(tf, 2), "peak": mfma_peak, "unit": "TFLOP/s",
-                            "frac": round(frac_mfma, 4), "traffic": None}
-            else:
-                roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(frac_hbm, 4), "traffic": None}
-            # HBM traffic per launch from the committed PMC pass of the same workload (bench.py cannot collect PMC itself); per
-            # launch it is proportional to the layers sharing the launch (weights) and to the rows (activations), i.e. to rows
+    def gates_roofline(mdl, group, nsess, before, traffic_json):
+        """profile_steps further feeds with the engine's per-class hipEvents on; returns (roofline dict, stats after)."""
+        dd = mdl.dims
+        more = pcm_for(nsess, args.profile_steps, 10_000_000)
+        mdl.profile(True)
+        run_steps(group, more, 0, args.profile_steps)
+        sp_ = mdl.stats()
+        mdl.profile(False)
+        launches = sp_.kernel_launches[0]
+        if not launches:
+            return None, sp_
+        avg_ms = sp_.kernel_ms[0] / launches
+        rows = sp_.chunks - before.chunks        # session-chunks processed while profiling
+        # rows per gates launch, averaged: every session-chunk passes the gates GEMM of each layer once; a launch covers one
+        # layer of one chunk step, or the same launch of up to T layers when a feed's chunk steps run as a wavefront (z-batched)
+        rows_per_launch = rows * dd.n_layers / launches
+        layers_per_launch = max(1.0, rows_per_launch / nsess)      # a z-batched launch holds that many layers' weight matrices
+        flops = 2.0 * rows_per_launch * (2 * dd.d_model) * (4 * dd.hidden)
+        wbytes = (2 * dd.d_model) * (4 * dd.hidden) * 4 * layers_per_launch
+        sbytes = rows_per_launch * (dd.d_model * 4 * 2 + dd.hidden * 4 * 3)      # x,h read; c read+write; u write
+        tf = flops / (avg_ms * 1e-3) / 1e12
+        mfma_peak = FP16_MFMA_PEAK_TFLOPS if dd.precision == 1 else FP32_MFMA_PEAK_TFLOPS
+        if dd.precision == 1:
+            wbytes /= 2                         # fp16 weight copies
+        gbs = (wbytes + sbytes) / (avg_ms * 1e-3) / 1e9
+        frac_mfma, frac_hbm = tf / mfma_peak, gbs / HBM_PEAK_GBS
+        if frac_mfma >= frac_hbm:
+            rl = {"bound": "mfma", "achieved": round(tf, 2), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(frac_mfma, 4), "traffic": None}
+        else:
+            rl = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac_hbm, 4), "traffic": None}
+        # HBM traffic per launch from the committed PMC pass of the same workload (bench.py cannot collect PMC itself); per
+        # launch it is proportional to the layers sharing the launch (weights) and to the rows (activations), i.e. to rows
+        if traffic_json:
             try:
-                tr = json.load(open(os.path.join(ROOT, "profiles", "r02c_gates_traffic.json")))
-                if int(tr["sessions_per_gpu"]) == B and d.precision == 0:
-                    roofline["traffic"] = int(tr["traffic_bytes_per_launch"] * rows_per_launch / float(tr["rows_per_launch"]))
-                    roofline["traffic_source"] = "profiles/r02c_gates_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950 x2 read correction; measured at %.1f rows per launch, scaled by rows)" % float(tr["rows_per_launch"])
+                tr = json.load(open(os.path.join(ROOT, "profiles", traffic_json)))
+                if int(tr["sessions_per_gpu"]) == nsess and dd.precision == 0:
+                    rl["traffic"] = int(tr["traffic_bytes_per_launch"] * rows_per_launch / float(tr["rows_per_launch"]))
+                    rl["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950 x2 read correction; measured at %.1f rows per launch, scaled by rows)" % (traffic_json, float(tr["rows_per_launch"]))
             except Exception:
                 pass
-            roofline["algorithmic_bytes_per_launch"] = int(wbytes + sbytes)
-            roofline.update({"kernel": "gemm_f32_zkernel<4,4,EPI_LSTM,...> / gemm_f32_kernel<4,4,EPI_LSTM,...> (LSTM gates [rows,1024]x[1024,4096] + BasicNorm row scale + cell; rows = sessions x layers sharing the launch)",
-                             "avg_launch_us": round(avg_ms * 1e3, 2), "rows_per_launch": round(rows_per_launch, 1),
-                             "launches": int(launches), "alt_frac_hbm": round(frac_hbm, 4), "alt_frac_mfma": round(frac_mfma, 4),
-                             "class_ms": {k: round(sp.kernel_ms[i], 3) for i, k in enumerate(
-                                 ["gates", "gemm_other", "row", "conv", "fbank", "dec_joint"])}})
+        rl["algorithmic_bytes_per_launch"] = int(wbytes + sbytes)
+        rl.update({"kernel": "LSTM gates GEMM [rows,%d]x[%d,%d] + BasicNorm row scale + LSTM cell epilogue (rows = sessions x layers sharing the z-batched launch)" % (2 * dd.d_model, 2 * dd.d_model, 4 * dd.hidden),
+                   "avg_launch_us": round(avg_ms * 1e3, 2), "rows_per_launch": round(rows_per_launch, 1),
+                   "launches": int(launches), "alt_frac_hbm": round(frac_hbm, 4), "alt_frac_mfma": round(frac_mfma, 4),
+                   "class_ms": {k: round(sp_.kernel_ms[i], 3) for i, k in enumerate(["gates", "gemm_other", "row", "conv", "fbank", "dec_joint"])}})
+        return rl, sp_
+
+    roofline = None
+    if rank == 0:
+        roofline, sp = gates_roofline(model, grp, B, st, TRAFFIC_JSON)
     for s in sess:
         s.close()
 
@@ -290,6 +327,45 @@ def main():
                    "recurrent_weight_bytes_per_chunk": int(wbytes),
                    "frac_of_hbm_peak_if_restreamed": round(wbytes * nchunks / (b - a) / 1e9 / HBM_PEAK_GBS, 4),
                    "note": "recurrent weights (gate h-half + projection, 10 MB per layer) are re-read every time step from the Infinity Cache (120 MB for 12 layers)"}
+
+    # ---------------- BASELINE configs[4]: larger encoder (icefall lstm-transducer-stateless2-sized: 16 layers, d 768, cell 1536,
+    # ffn 3072), 512 concurrent sessions on one GPU, fp16 MFMA path -- and the same model in fp32 beside it
+    config5 = None
+    if rank == 0 and world == 1 and not args.no_config5:
+        model.close()
+        model = None
+        lpath = os.environ.get("APRIL_MODEL_LARGE") or os.path.join(tempfile.gettempdir(), "bench_large_synth.april")
+        if not os.path.exists(lpath):
+            SM.write_model(lpath, SM.LARGE_DIMS)
+        nb5, wu5, ts5 = 512, 6, 20
+        config5 = {"sessions": nb5, "dims": "large (16 layers, d_model 768, cell 1536, ffn 3072; synthetic seeded weights)", "feed_ms": 100, "steps": ts5}
+        prev = os.environ.get("APRIL_PRECISION")
+        for prec in ("f16", "f32"):
+            os.environ["APRIL_PRECISION"] = prec
+            m5 = A.Model(lpath)
+            s5 = [A.Session(m5, None, counters=counts) for _ in range(nb5)]
+            g5 = A.SessionGroup(s5)
+            pp = pcm_for(nb5, wu5 + ts5, 40_000_000)
+            run_steps(g5, pp, 0, wu5)
+            torch.cuda.synchronize(); a = time.perf_counter()
+            run_steps(g5, pp, wu5, wu5 + ts5)
+            torch.cuda.synchronize(); b = time.perf_counter()
+            ms = (b - a) / ts5 * 1e3
+            leg = {"ms_per_step": round(ms, 3), "rtf": round(ms / 100.0, 5), "audio_s_per_s": round(nb5 * 0.1 / (ms * 1e-3), 1), "params": int(m5.dims.param_count)}
+            rl5, _ = gates_roofline(m5, g5, nb5, m5.stats(), None)
+            if rl5:
+                rl5["note"] = "fp16 operands: priced against the dense fp16 MFMA peak (2.5 PFLOP/s) and against HBM; the larger fraction is the binding bound" if prec == "f16" else "fp32 operands"
+            leg["roofline"] = rl5
+            leg["replay_mismatch"] = int(m5.stats().replay_mismatch)
+            config5[prec] = leg
+            for s_ in s5:
+                s_.close()
+            m5.close()
+        if prev is None:
+            del os.environ["APRIL_PRECISION"]
+        else:
+            os.environ["APRIL_PRECISION"] = prev
+        config5["f16_speedup_vs_f32"] = round(config5["f32"]["ms_per_step"] / config5["f16"]["ms_per_step"], 3)
 
     # ---------------- CPU baseline: the oracle (plain-C port, 1 thread) on the host, bounded sample
     cpu = None
@@ -364,7 +440,8 @@ def main():
             "config": {"workload": "aprilv0_en-us dims (synthetic seeded weights), %d concurrent streaming sessions per GPU, "
                                    "100 ms PCM16 feeds via aprilx_feed_many (BASELINE configs[2]; configs[3] at 8 GPUs)" % B,
                        "sessions_per_gpu": B, "feed_ms": 100, "params": int(d.param_count), "parallelism": "sessions sharded, dp%d" % world},
-            "rtf": round(rtf, 5), "sessions_total": world * B,
+            "rtf": round(rtf, 5), "sessions_total": world * B, "steady": steady, "config5_f16": config5,
+            "rccl_fallback": rccl_fallback, "rccl_libs_mapped": sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln}),
             "step_latency_ms": {"p50": round(float(np.percentile(step_wall, 50)) * 1e3, 3), "p99": round(float(np.percentile(step_wall, 99)) * 1e3, 3),
                                 "max": round(max(step_wall) * 1e3, 3), "series": [round(x * 1e3, 2) for x in step_wall[:200]], "what": "wall time of one aprilx_feed_many call (100 ms of audio for every session, callbacks delivered), rank 0"},
             "max_sessions_per_gpu_rtf_le_0.1_tested": max_ok, "rtf_by_sessions_per_gpu": sweep,
@@ -375,7 +452,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    model.close()
+    if model is not None:
+        model.close()
     if world > 1:
         barrier()                                  # rank 0 runs the roofline pass after the timed region; leave together
         dist.destroy_process_group()
