@@ -662,6 +662,13 @@ int aprilx_run_joiner(AprilASRModel model, int n, const float *eout, const float
     model->m.engines[0]->debug_joiner(n, eout, dout, logits);
     return 0;
 }
+int aprilx_run_decide(AprilASRModel model, int n, int op, const float *logits, float early_emit, const int32_t *now_ms, int round, int32_t *state_io, void *records_out)
+{
+    if (!model || n <= 0 || model->m.engines.empty() || n > model->m.engines[0]->max_slots() || !state_io) return -1;
+    if (op == 0 && (!logits || !now_ms || !records_out || round < 0 || round > 2)) return -1;
+    model->m.engines[0]->debug_decide(n, op, logits, early_emit, (const int *)now_ms, round, state_io, (StepRecord *)records_out);
+    return 0;
+}
 int aprilx_run_fbank(AprilASRModel model, int n_frames, const int16_t *pcm_frames, float *out)
 {
     if (!model || model->m.engines.empty() || n_frames <= 0 || n_frames > model->m.engines[0]->ring_frames()) return -1;

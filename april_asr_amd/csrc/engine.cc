@@ -1273,6 +1273,47 @@ void Engine::debug_joiner(int n, const float *eout, const float *dout, float *lo
     zero_slots(n);
 }
 
+void Engine::debug_decide(int n, int op, const float *logits, float early_emit, const int *now_ms, int round, int32_t *state_io, StepRecord *rec_out)
+{
+    const NetDims &d = L_.dims;
+    HIP_CHECK(hipSetDevice(cfg_.device));
+    if (n > cfg_.max_batch || n > cfg_.max_slots) { LOGE("debug_decide: n too large"); abort(); }
+    static_assert(sizeof(GreedyState) == 16, "GreedyState is 4 x int32 in the ABI");
+    std::vector<int> slots((size_t)n);
+    for (int i = 0; i < n; ++i) slots[(size_t)i] = i;
+    int *slots_d = dmalloc<int>((size_t)n), *now_d = dmalloc<int>((size_t)n), *active_d = dmalloc<int>((size_t)n), *dirty_d = dmalloc<int>((size_t)n);
+    StepRecord *rec_d = dmalloc<StepRecord>((size_t)n);
+    HIP_CHECK(hipMemcpy(slots_d, slots.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(gstate_, state_io, (size_t)n * sizeof(GreedyState), hipMemcpyHostToDevice));
+    if (op == 1) {
+        DecRowsArgs a; a.slot_idx = slots_d; a.M = n; a.op = 1; a.blank = P_.blank_id; a.state = gstate_; a.dec = dec_params(); a.de_out = nullptr;
+        launch_dec_rows(a, stream_);
+    } else {
+        // the logits enter as ONE partial plane with a zero bias: decide_kernel's tree sum + bias returns them unchanged
+        std::vector<float> plane((size_t)n * L_.vocab_pad, -1000.0f);
+        for (int i = 0; i < n; ++i) memcpy(plane.data() + (size_t)i * L_.vocab_pad, logits + (size_t)i * d.vocab, (size_t)d.vocab * 4);
+        float *plane_d = dmalloc<float>(plane.size()), *zero_d = dmalloc<float>((size_t)L_.vocab_pad);
+        HIP_CHECK(hipMemcpy(plane_d, plane.data(), plane.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemset(zero_d, 0, (size_t)L_.vocab_pad * 4));
+        std::vector<int> gen((size_t)n, 1);
+        HIP_CHECK(hipMemcpy(active_d, gen.data(), (size_t)n * 4, hipMemcpyHostToDevice));      // every row still searches
+        HIP_CHECK(hipMemcpy(now_d, now_ms, (size_t)n * 4, hipMemcpyHostToDevice));
+        DecideArgs a;
+        a.ws = plane_d; a.parts = 1; a.m_stride = n; a.N = L_.vocab_pad; a.M = n; a.n_valid = d.vocab;
+        a.bias = zero_d; a.blank = P_.blank_id; a.early_emit = early_emit;
+        a.slot_idx = slots_d; a.now_ms = now_d; a.active = active_d; a.dirty = dirty_d; a.tok_class = cls_; a.state = gstate_;
+        a.rec = rec_d; a.round = round; a.gen = 1; a.dec = dec_params(); a.de_out = nullptr;
+        launch_decide(a, stream_);
+        sync();
+        HIP_CHECK(hipMemcpy(rec_out, rec_d, (size_t)n * sizeof(StepRecord), hipMemcpyDeviceToHost));
+        (void)hipFree(plane_d); (void)hipFree(zero_d);
+    }
+    sync();
+    HIP_CHECK(hipMemcpy(state_io, gstate_, (size_t)n * sizeof(GreedyState), hipMemcpyDeviceToHost));
+    (void)hipFree(slots_d); (void)hipFree(now_d); (void)hipFree(active_d); (void)hipFree(dirty_d); (void)hipFree(rec_d);
+    zero_slots(n);
+}
+
 void Engine::debug_fbank(int n_frames, const int16_t *pcm_frames, float *out)
 {
     // every frame goes to slot 0, consecutive ring rows (n_frames <= ring_frames)

@@ -113,6 +113,9 @@ public:
     void debug_encoder(int n, const float *x, const float *h, const float *c, float *eout, float *h2, float *c2);
     void debug_decoder(int n, const int64_t *ctx, float *dout);
     void debug_joiner(int n, const float *eout, const float *dout, float *logits);
+    // parity tests of the device's copy of the search decision: one decide_kernel round (op 0) or the end-of-flush reset
+    // (op 1) on slots 0..n-1 with GIVEN logits rows and search states; returns the records and the new states
+    void debug_decide(int n, int op, const float *logits, float early_emit, const int *now_ms, int round, int32_t *state_io, StepRecord *rec_out);
     void debug_fbank(int n_frames, const int16_t *pcm_frames /*[n][padded]*/, float *out /*[n][nbins]*/);
     void read_ring(int slot, int row, int n_rows, float *out);
     void read_greedy_state(int slot, GreedyState *out);

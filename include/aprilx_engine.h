@@ -90,6 +90,14 @@ APRIL_EXPORT int aprilx_run_encoder(AprilASRModel model, int n, const float *x, 
 APRIL_EXPORT int aprilx_run_decoder(AprilASRModel model, int n, const int64_t *context, float *dout);
 APRIL_EXPORT int aprilx_run_joiner(AprilASRModel model, int n, const float *eout, const float *dout, float *logits);
 APRIL_EXPORT int aprilx_run_fbank(AprilASRModel model, int n_frames, const int16_t *pcm_frames, float *out);
+/* The device's copy of the search decision (reference src/april_session.c:306-429, the part the next network call depends
+ * on) in isolation: op 0 = one joiner round for n rows with GIVEN logits[n][vocab], session times now_ms[n] and search states
+ * state_io[n][4] = {context[0], context[1], last active token or -1, time of the last emission in ms}; writes the 16-byte
+ * records {idx, max, blank logit, flags: 1 valid | 2 blank | 4 context changed} to records_out[n][4 x 32 bit] and the new states
+ * to state_io.  op 1 = the end-of-flush reset (:561-563: tokens forgotten, context cleared unless it starts with blank).
+ * Tests only (uses slots 0..n-1; must not be mixed with live sessions). */
+APRIL_EXPORT int aprilx_run_decide(AprilASRModel model, int n, int op, const float *logits, float early_emit, const int32_t *now_ms,
+                                   int round, int32_t *state_io, void *records_out);
 
 /* ---- tracing / statistics ---------------------------------------------------------------*/
 /* every joiner evaluation of this session appends `vocab` floats to buf (tests only; chunk steps of a traced session are
