@@ -155,8 +155,9 @@ private:
     void run_lm_chain(int m, int T, bool dump_logits);
     void run_lm_wavefront(int m, int T, bool dump_logits);
     struct SwPlan {                          // argument blocks + launch list of run_sw_chain for one (m, T), and its captured graph
-        struct Batch { size_t off; int n, macro, kind; };
+        struct Batch { size_t off; int n, macro, kind; size_t roff; int rn; };      // rn > 0: the GEMMs write partial planes, rn row problems finish them
         std::vector<GemmArgs> host; GemmArgs *dev = nullptr; std::vector<Batch> batches; hipGraphExec_t graph = nullptr; int uses = 0;
+        std::vector<RowArgs> rhost; RowArgs *rdev = nullptr;
     };
     SwPlan &sw_plan(int m, int T);
     void run_sw_chain(int m, int T, bool dump_logits, const SwPlan &p);

@@ -45,7 +45,10 @@ enum GemmAOp { AOP_NONE = 0, AOP_TANH_ADD = 1 };
 //   - a GEMM over x (LSTM gates' input half, encoder_proj) runs over y and multiplies the finished partial sum by the row's
 //     scale in its epilogue (`x_scale`): scale * sum_k(y_k w_k), one rounding away from sum_k((scale y_k) w_k);
 //   - the residual x + h' reads y and multiplies (`r_scale`).
-enum GemmMode { GM_SLAB = 0, GM_FULLK = 1 };
+enum GemmMode { GM_SLAB = 0, GM_FULLK = 1, GM_TILE = 2 };
+//     GM_TILE   (kernels_gemm_tile.hip) the four waves split the OUTPUT tile and share both operands through LDS; every wave
+//               folds chunk -> slab -> tree in registers over the workgroup's zs slabs.  zs == kz: row epilogue fused;
+//               zs < kz: kz / zs partial planes, finished by the row kernels exactly as for GM_SLAB.
 
 constexpr int SSQ_COLS = 32;       // columns per sum-of-squares partial (one granule = 8 consecutive 4-column quads)
 
@@ -102,22 +105,32 @@ struct GemmArgs {
     int force_fullk = 0;                   // take the full-K plan even when it yields few workgroups (latency-bound sequential steps: one launch
                                            // instead of split-K + row kernel matters more than filling the chip)
     int zcount = 1;                        // same-shape problems sharing the launch (set by stage_gemm_z): an occupancy hint for the tile planner
+    int tile_ok = 0;                       // the caller planned this GEMM with gemm_fullk / gemm_partials(..., tile_ok = true): GM_TILE may be
+                                           // chosen (plain fp32 A in one K segment, N % 64 == 0, row epilogue or partial planes)
     int skew = 0;                          // start delay (x 4096 cycles) for every second generation of workgroups
     int asm_loop = 0;                      // != 0: hand-scheduled K loop (gemm_mainloop_asm.inc) in the fused-epilogue 64x64 fp32 tiles
     unsigned long long *trace = nullptr;   // measurement only: per-workgroup s_memtime stamps [wg][8] (wave 0, lane 0)
     int debug = 0;                         // measurement only: 1 = skip the MFMA main loop, 2 = skip the epilogue math, 3 = all k blocks read block 0
 };
 void launch_gemm(const GemmArgs &g, hipStream_t s);
+// (internal) GM_TILE launch, called by launch_gemm / launch_gemm_z once the plan is made: tile rows 16 * mt; dev_args != null: n z-batched problems
+void launch_gemm_tile(const GemmArgs &g, int mt, const GemmArgs *dev_args, int n, hipStream_t s);
 // n independent GEMMs of ONE shape (same M, N, K, kz, epilogue; any pointers) in one launch.  stage_gemm_z finalizes the
 // argument blocks on the host; launch_gemm_z launches once they are in device memory at dev_args (in stream order).
 // Fused-epilogue forms only (EPI_LSTM, EPI_XPART, EPI_BIAS_DSWISH, and EPI_HR / EPI_RESID_SSQ where gemm_fullk says so).
 void stage_gemm_z(const GemmArgs *items, int n, GemmArgs *staged);
 void launch_gemm_z(const GemmArgs *staged, int n, const GemmArgs *dev_args, hipStream_t s);
 // number of partial planes launch_gemm will write for an EPI_PARTIAL GEMM of this shape
-int gemm_partials(int M, int N, int kz);
+// (zcount = same-shape problems sharing a z-batched launch; tile_ok = the GM_TILE schedule is allowed for this call site:
+// callers pass the same values here and in GemmArgs::zcount / tile_ok so that both sides make the same plan)
+int gemm_partials(int M, int N, int kz, int zcount = 1, bool tile_ok = false);
 // true when launch_gemm runs a GEMM of this shape on the full-K schedule, i.e. the caller may (must, for the row
 // epilogues EPI_HR / EPI_RESID_SSQ / EPI_SLOT_STORE) fuse the row work; false: EPI_PARTIAL + row kernel
-bool gemm_fullk(int M, int N, int kz, bool force = false);
+bool gemm_fullk(int M, int N, int kz, bool force = false, int zcount = 1, bool tile_ok = false);
+// true when a tile_ok GEMM of this shape runs on the GM_TILE schedule (whose K split is a matter of occupancy, not of need)
+bool gemm_tile_planned(int M, int N, int kz, int zcount = 1);
+// measurement only (tools/tile_bench): enable -1 = environment default, 0 / 1 = off / on; mt, zs = 0 (planner's choice) or pinned
+void gemm_tile_pin(int enable, int mt, int zs);
 
 // ---------------------------------------------------------------- row kernels (one workgroup per row; small-batch path)
 enum RowMode {
@@ -140,6 +153,8 @@ struct RowArgs {
     int run_gen = 1;
 };
 void launch_row(const RowArgs &r, hipStream_t s);
+// n row problems of one mode and shape (same M, N, parts) in one launch: blockIdx.y picks the argument block (device array)
+void launch_row_z(const RowArgs *host_args, int n, const RowArgs *dev_args, hipStream_t s);
 
 // ---------------------------------------------------------------- greedy search on the device
 // Per-slot search state (reference AprilASRSession_i: context tensor, last_emission_time_ms, the class of the

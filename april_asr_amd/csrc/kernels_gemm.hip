@@ -728,16 +728,51 @@ static bool plan_fullk(int M, int N, int kz, TilePlan &t, bool force = false, in
     return true;
 }
 
-bool gemm_fullk(int M, int N, int kz, bool force) { TilePlan t; return plan_fullk(M, N, kz, t, force); }
+// GM_TILE (kernels_gemm_tile.hip): 64-column tiles of 64 or 32 rows whose waves share the operands through LDS; K is cut
+// across workgroups at slab boundaries until the launch holds enough workgroups for the chip (the row kernel then finishes
+// the slab tree), and not at all once the output tiles alone do.  APRIL_TILE_MT / APRIL_TILE_ZS pin the choice (measurement).
+static int g_tile_pin_mt = env_int("APRIL_TILE_MT", 0), g_tile_pin_zs = env_int("APRIL_TILE_ZS", 0), g_tile_enable = -1;
+void gemm_tile_pin(int enable, int mt, int zs) { g_tile_enable = enable; g_tile_pin_mt = mt; g_tile_pin_zs = zs; }
+
+static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePlan &t)
+{
+    static const int enabled = env_int("APRIL_GM_TILE", 1);
+    static const int min_rows = env_int("APRIL_TILE_MIN_ROWS", 32);
+    static const int target = env_int("APRIL_TILE_TARGET_WGS", 512);      // two workgroups per CU
+    const int pin_mt = g_tile_pin_mt, pin_zs = g_tile_pin_zs;
+    if (!(g_tile_enable < 0 ? enabled : g_tile_enable) || N % 64 != 0 || M < min_rows) return false;
+    const long zc = std::max(1, zcount);
+    int mt = 4;
+    long tiles = (long)(N / 64) * ((M + 63) / 64) * zc;
+    if ((pin_mt == 2) || (pin_mt == 0 && tiles * kz < target)) { mt = 2; tiles = (long)(N / 64) * ((M + 31) / 32) * zc; }
+    int zs = kz;
+    if (!force_full) while (zs > 1 && tiles * (kz / zs) < target) zs >>= 1;
+    if (pin_zs > 0 && !force_full) zs = std::min(kz, pin_zs);
+    t.mt = mt; t.nt = 4; t.zs = zs; t.mode = GM_TILE;
+    return true;
+}
+
+bool gemm_tile_planned(int M, int N, int kz, int zcount) { TilePlan t; return plan_tile(M, N, kz, zcount, false, t); }
+
+bool gemm_fullk(int M, int N, int kz, bool force, int zcount, bool tile_ok)
+{
+    TilePlan t;
+    if (tile_ok && plan_tile(M, N, kz, zcount, force, t)) return t.zs == kz;
+    return plan_fullk(M, N, kz, t, force);
+}
 
 // Tile shape and slabs per workgroup.  Depends on M only through occupancy; numerics are tile-independent.
-static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = false, int zcount = 1)
+static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = false, int zcount = 1, bool tile_ok = false, int zcount_true = 1)
 {
     // measurement knobs (default 0): 1/2 = smaller tiles for the fused-epilogue GEMMs (measured slower on MI355X:
     // B=256 gates 27 -> 32..36 us, the kernel is limited by operand loads per MFMA, not by occupancy);
     // 5 = 64x32 tiles for split-K GEMMs at M > 32
     static const int tune = env_int("APRIL_GEMM_TUNE", 0);
     TilePlan t;
+    if (tile_ok && (epi == EPI_PARTIAL || epi == EPI_HR || epi == EPI_RESID_SSQ || epi == EPI_SLOT_STORE)) {
+        // the caller asked gemm_fullk first: a row epilogue arrives only when that plan keeps all of K in the workgroup
+        if (plan_tile(M, N, kz, zcount_true, force_fullk || epi != EPI_PARTIAL, t)) return t;
+    }
     if (epi != EPI_LSTM && epi != EPI_BIAS_DSWISH && epi != EPI_XPART && plan_fullk(M, N, kz, t, force_fullk, zcount)) return t;
     const int ntiles = N / 16;
     t.mode = GM_SLAB;
@@ -765,9 +800,9 @@ static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = fal
     return t;
 }
 
-int gemm_partials(int M, int N, int kz)
+int gemm_partials(int M, int N, int kz, int zcount, bool tile_ok)
 {
-    const TilePlan t = plan_tiles(M, N, kz, EPI_PARTIAL);
+    const TilePlan t = plan_tiles(M, N, kz, EPI_PARTIAL, false, 1, tile_ok, zcount);
     return t.mode == GM_FULLK ? 1 : kz / t.zs;
 }
 
@@ -826,7 +861,8 @@ static TilePlan finalize_gemm(GemmArgs &g)
     static const int z_tiles = env_int("APRIL_Z_TILES", 2);      // A/B: 0 = plan z-batched problems as if each had the chip to itself, 1 = hint everywhere, 2 = fused-epilogue slab tiles only, 3 = full-K tiles only
     const int zc = std::max(1, g.zcount);
     const bool is_slab_epi = g.epi == EPI_LSTM || g.epi == EPI_BIAS_DSWISH || g.epi == EPI_XPART;
-    const TilePlan t = plan_tiles(g.M, g.N, g.kz, g.epi, g.force_fullk != 0, (z_tiles == 1 || (z_tiles == 2 && is_slab_epi) || (z_tiles == 3 && !is_slab_epi)) ? zc : 1);
+    const bool tile_ok = g.tile_ok && g.a_op == AOP_NONE && g.K1 == 0 && g.wt == 0 && g.wave_mask == 0xF && g.N % 64 == 0;
+    const TilePlan t = plan_tiles(g.M, g.N, g.kz, g.epi, g.force_fullk != 0, (z_tiles == 1 || (z_tiles == 2 && is_slab_epi) || (z_tiles == 3 && !is_slab_epi)) ? zc : 1, tile_ok, zc);
     const bool row_epi = g.epi == EPI_HR || g.epi == EPI_RESID_SSQ || g.epi == EPI_SLOT_STORE;
     if (row_epi && t.zs != g.kz) { fprintf(stderr, "libapril(mi355x): launch_gemm: row epilogue %d needs the full-K plan (M=%d N=%d kz=%d)\n", g.epi, g.M, g.N, g.kz); abort(); }
     g.zs = t.zs; g.mode = t.mode;
@@ -845,6 +881,7 @@ void launch_gemm(const GemmArgs &g_in, hipStream_t s)
 {
     GemmArgs g = g_in;
     const TilePlan t = finalize_gemm(g);
+    if (t.mode == GM_TILE) { launch_gemm_tile(g, t.mt, nullptr, 0, s); return; }
     const int mt = t.mt, nt = t.nt;
     bool ok = false;
     if (mt == 1) { if (nt == 4) ok = dispatch<1, 4>(g, s); else if (nt == 2) ok = dispatch<1, 2>(g, s); else ok = dispatch<1, 1>(g, s); }
@@ -905,6 +942,7 @@ void launch_gemm_z(const GemmArgs *staged, int n, const GemmArgs *dev_args, hipS
     const GemmArgs &g = staged[0];
     GemmArgs probe = g;
     const TilePlan t = finalize_gemm(probe);
+    if (t.mode == GM_TILE) { launch_gemm_tile(g, t.mt, dev_args, n, s); return; }
     const int mt = t.mt, nt = t.nt;
     bool ok = false;
     if (mt == 1) { if (nt == 4) ok = dispatch_z<1, 4>(g, dev_args, n, s); else if (nt == 2) ok = dispatch_z<1, 2>(g, dev_args, n, s); else ok = dispatch_z<1, 1>(g, dev_args, n, s); }

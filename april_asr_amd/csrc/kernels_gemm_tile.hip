@@ -1,0 +1,372 @@
+// GM_TILE schedule of the MFMA GEMM (kernels.h) for gfx950: the workgroup's four waves split the OUTPUT tile (2 x 2) and
+// every wave walks all of the workgroup's K range, so both operands are shared between waves through LDS.
+//
+// Why it exists: the N = d_model GEMMs (LSTM projection K = hidden, FFN down K = ffn, embed linear, encoder_proj) have few
+// outputs and a long K.  The K-split schedules (GM_SLAB / GM_FULLK) give every wave its own k range, so nothing is shared
+// and the workgroup's operand traffic is that of its tile shape: 16 x 32 tiles at 256 rows = 5.3 flop per byte through L1,
+// which held those kernels at 0.27 .. 0.36 of the fp32 MFMA peak (round-2 profile), 0.44 .. 0.50 with 64 x 32 tiles at
+// thousands of rows.  Here a 64 x 64 tile moves (64 + 64) * 4 bytes per k for 2 * 64 * 64 flops = 16 flop per byte, the
+// activations arrive in full 128-byte lines (LDS DMA, global_load_lds_dwordx4) instead of 16 rows x 64 bytes per
+// instruction, and the chip is filled by cutting K across workgroups at slab boundaries (grid.z = kz / zs) when the
+// output tiles alone are too few.
+//
+// Canonical summation (kernels.h) is kept exactly: a chunk is one in-order MFMA chain over its k blocks, a slab is
+// ((c0 + c1) + c2) + c3, slabs meet pairwise in slab order.  A wave folds chunk -> slab -> tree levels in registers (as
+// GM_FULLK does); a workgroup that owns all kz slabs finishes the row epilogue itself, otherwise it writes the tree sum of
+// its zs slabs as one partial plane and the row kernel (or decide_kernel) finishes the same tree.  Same chains, same tree
+// => bit-identical to GM_SLAB / GM_FULLK, whatever the batch size picks.
+//
+// LDS image of one stage (two k blocks = 32 k = 128 bytes per activation row):
+//   A: [16 MT rows][128 B], 16-byte segment g of row R stored at segment g ^ ((R >> 1) & 7): the MFMA A fragment read
+//      (lane (i, kq) reads row i, segment 4 p + kq) is then conflict-free for ds_read_b128's lane groups.  The DMA writes
+//      LDS linearly (wave-uniform base + lane * 16), so the swizzle is applied to the per-lane SOURCE address.
+//   B: [2 k blocks][4 n tiles][1 KB] in the packed weight order, i.e. already the B fragment of every lane.
+// Three stage buffers; per stage ONE s_barrier: wait for this wave's pieces of stage s (counted vmcnt, two stages stay in
+// flight), barrier, issue stage s + 2 into the buffer stage s - 1 was read from, compute stage s.
+// Replaces the ORT MatMul nodes inside the encoder / joiner graphs (reference call sites src/april_session.c:145,176).
+#include "kernels.h"
+#include "device_utils.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace aprilx {
+
+namespace {
+
+constexpr int TILE_BN = 64, TILE_LDR = TILE_BN + 4, TILE_STAGES = 3;
+
+template <int MT> struct TileGeom {
+    static constexpr int BM = 16 * MT;
+    static constexpr int A_BYTES = BM * 128, B_BYTES = 8 * 1024, STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int PIECES = 2 * MT + 8, PPW = PIECES / 4;      // 1 KB DMA pieces per stage / per wave
+    static constexpr int MTW = MT / 2;                              // m tiles per wave (waves: 2 x 2)
+    static constexpr int PLANE_FLOATS = BM * TILE_LDR;
+    static constexpr int LDS_MAIN = (TILE_STAGES * STAGE_BYTES > PLANE_FLOATS * 4) ? TILE_STAGES * STAGE_BYTES : PLANE_FLOATS * 4;
+    static_assert(PIECES % 4 == 0, "pieces are dealt evenly to the four waves");
+};
+
+template <int N> __device__ __forceinline__ void wait_vm()
+{
+    // s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt[3:0] in bits 3:0, vmcnt[5:4] in bits 15:14; expcnt / lgkmcnt at their maxima)
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+
+template <int MT, int EPI>
+__device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
+{
+    using G = TileGeom<MT>;
+    constexpr int BM = G::BM, MTW = G::MTW, NTH = 256, LDR = TILE_LDR;
+    constexpr bool ROW_EPI = EPI == EPI_HR || EPI == EPI_RESID_SSQ || EPI == EPI_SLOT_STORE;
+    static_assert(ROW_EPI || EPI == EPI_PARTIAL, "GM_TILE serves the row epilogues and partial planes");
+    extern __shared__ __attribute__((aligned(1024))) float red[];
+    char *lds = reinterpret_cast<char *>(red);
+
+    if (g.run_flag && *g.run_flag != g.run_gen) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * TILE_BN;                 // first output column
+    const int m0 = blockIdx.y * BM;
+    const int KB = g.K >> 4;
+    const int c = KB / (4 * g.kz);                       // k blocks per chunk
+    const int T = 4 * c * g.zs;                          // k blocks of this workgroup (even)
+    const int first_kb = zg * T;
+    const int nstage = T >> 1;
+
+    // ---- BasicNorm scales of the tile's rows (EPI_HR: residual; EPI_SLOT_STORE: the whole sum), as in gemm_body: the partials
+    // make one trip from global memory at kernel start and are added up after the K loop
+    const RowScale &rsc = EPI == EPI_HR ? g.r_scale : g.x_scale;
+    const bool NEED_SCL = (EPI == EPI_HR || EPI == EPI_SLOT_STORE) && rsc.ssq != nullptr;
+    float *scl = red + G::LDS_MAIN / 4;
+    float stg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr int TPR = NTH / BM;
+    const int ppt = (rsc.groups + TPR - 1) / TPR;
+    const bool staged = NEED_SCL && ppt <= 4;
+    const int srow = threadIdx.x / TPR, sj0 = (threadIdx.x % TPR) * ppt;
+    if (NEED_SCL && staged) {
+        int r = m0 + srow;
+        if (r >= g.M) r = g.M - 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < ppt && sj0 + k < rsc.groups) stg[k] = rsc.ssq[(size_t)r * rsc.groups + sj0 + k];
+    }
+
+    // ---- DMA pieces of this wave: piece P = wave + 4 i; P < 2 MT: activation rows 8 P .. 8 P + 7 (lane -> row P 8 + (lane >> 3),
+    // 16-byte segment lane & 7 of the stage's 128 bytes, swizzled); otherwise weight piece (k block p, n tile nt) of the stage
+    const char *src[G::PPW];
+    int inc[G::PPW], dst[G::PPW];
+    {
+        int arows[G::PPW];
+#pragma unroll
+        for (int i = 0; i < G::PPW; ++i) {
+            const int P = wave + 4 * i;
+            int row = m0 + P * 8 + (lane >> 3);
+            arows[i] = row >= g.M ? g.M - 1 : row;       // padding rows recompute the last row; never stored
+        }
+        if (g.aidx0) {                                    // row -> slot indirections, one round trip for all pieces
+#pragma unroll
+            for (int i = 0; i < G::PPW; ++i) if (wave + 4 * i < 2 * MT) arows[i] = g.aidx0[arows[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < G::PPW; ++i) {
+            const int P = wave + 4 * i;
+            if (P < 2 * MT) {
+                const int R = P * 8 + (lane >> 3);
+                const int gseg = (lane & 7) ^ ((R >> 1) & 7);
+                src[i] = reinterpret_cast<const char *>(g.a0) + ((size_t)arows[i] * g.lda0 + (size_t)first_kb * 16 + gseg * 4) * sizeof(float);
+                inc[i] = 128; dst[i] = P * 1024;
+            } else {
+                const int q = P - 2 * MT, p = q >> 2, nt = q & 3;
+                src[i] = reinterpret_cast<const char *>(g.wp) + ((size_t)(blockIdx.x * 4 + nt) * KB + first_kb + p) * 1024 + lane * 16;
+                inc[i] = 2048; dst[i] = G::A_BYTES + q * 1024;
+            }
+        }
+    }
+    auto issue = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < G::PPW; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i]),
+                                             (__attribute__((address_space(3))) void *)(lds + buf * G::STAGE_BYTES + dst[i]), 16, 0, 0);
+            src[i] += inc[i];
+        }
+    };
+
+    // ---- what the row epilogue reads besides the sums: fetched before the K loop (as in gemm_body)
+    constexpr int QROW = TILE_BN / 4, NQ = BM * QROW, QPT = (NQ + NTH - 1) / NTH;
+    f32x4 e_bias[ROW_EPI ? QPT : 1], e_res[ROW_EPI ? QPT : 1];
+    int e_slot[ROW_EPI ? QPT : 1];
+    bool e_ok[ROW_EPI ? QPT : 1];
+    if (ROW_EPI) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * NTH;
+            int m = m0 + q / QROW;
+            const int n = n0 + (q % QROW) * 4;
+            e_ok[i] = q < NQ && m < g.M;
+            if (m >= g.M) m = g.M - 1;
+            const int qn = q < NQ ? n : n0;
+            e_slot[i] = (EPI != EPI_RESID_SSQ && g.slot_idx) ? g.slot_idx[m] : m;
+            if (EPI == EPI_SLOT_STORE && g.row_mask && !g.row_mask[m]) e_ok[i] = false;
+            e_bias[i] = (EPI != EPI_HR) ? *reinterpret_cast<const f32x4 *>(g.bias + qn) : f32x4{0.f, 0.f, 0.f, 0.f};
+            e_res[i] = (EPI == EPI_HR || (EPI == EPI_RESID_SSQ && g.resid)) ? *reinterpret_cast<const f32x4 *>(g.resid + (size_t)m * g.ldr + qn) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+
+    // ---- fragment addresses inside a stage buffer
+    const int mrow = lane & 15, kq = lane >> 4;
+    int a_rd[2];                                          // k block p of the stage: row mrow, segment (4 p + kq) ^ ((mrow >> 1) & 7)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) a_rd[p] = (wm * MTW * 16 + mrow) * 128 + (((p * 4 + kq) ^ ((mrow >> 1) & 7)) << 4);
+    const int b_rd = G::A_BYTES + wn * 2 * 1024 + lane * 16;
+
+    // chunk chain, slab sum, the three levels of the pairwise slab tree (named, not an array: a level array indexed under the
+    // carry conditions is not promoted to registers and lands in scratch memory), the workgroup's result
+    f32x4 acc[MTW][2], S[MTW][2], lvl0[MTW][2], lvl1[MTW][2], lvl2[MTW][2], res[MTW][2];
+#define APRIL_TILE_EACH(expr) _Pragma("unroll") for (int mt = 0; mt < MTW; ++mt) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) { expr; }
+    APRIL_TILE_EACH(acc[mt][nt] = (f32x4{0.f, 0.f, 0.f, 0.f}); S[mt][nt] = acc[mt][nt]; res[mt][nt] = acc[mt][nt];
+                    lvl0[mt][nt] = acc[mt][nt]; lvl1[mt][nt] = acc[mt][nt]; lvl2[mt][nt] = acc[mt][nt])
+    int top = 0;
+    while ((1 << top) < g.zs) ++top;
+    int chunk_i = 0, slab_done = 0, in_chunk = 0;
+    auto chunk_end = [&]() {
+        if (chunk_i == 0) { APRIL_TILE_EACH(S[mt][nt] = acc[mt][nt]) }
+        else { APRIL_TILE_EACH(S[mt][nt] = S[mt][nt] + acc[mt][nt]) }
+        APRIL_TILE_EACH(acc[mt][nt] = (f32x4{0.f, 0.f, 0.f, 0.f}))
+        if (++chunk_i == 4) {                             // slab complete: S = ((c0 + c1) + c2) + c3 enters the pairwise tree (binary counter)
+            chunk_i = 0;
+            bool done = false;                            // true once the value has been parked in a level
+            if (top > 0) {
+                if (slab_done & 1) { APRIL_TILE_EACH(S[mt][nt] = lvl0[mt][nt] + S[mt][nt]) }
+                else { APRIL_TILE_EACH(lvl0[mt][nt] = S[mt][nt]) done = true; }
+            }
+            if (!done && top > 1) {
+                if (slab_done & 2) { APRIL_TILE_EACH(S[mt][nt] = lvl1[mt][nt] + S[mt][nt]) }
+                else { APRIL_TILE_EACH(lvl1[mt][nt] = S[mt][nt]) done = true; }
+            }
+            if (!done && top > 2) {
+                if (slab_done & 4) { APRIL_TILE_EACH(S[mt][nt] = lvl2[mt][nt] + S[mt][nt]) }
+                else { APRIL_TILE_EACH(lvl2[mt][nt] = S[mt][nt]) done = true; }
+            }
+            if (!done) { APRIL_TILE_EACH(res[mt][nt] = S[mt][nt]) }      // all zs slabs of this workgroup are in
+            ++slab_done;
+        }
+    };
+
+    // ---- K loop
+    if (g.debug != 1) {
+        issue(0);
+        if (nstage > 1) issue(1);
+        int buf = 0;
+        for (int s = 0; s < nstage; ++s) {
+            if (s + 1 < nstage) wait_vm<G::PPW>(); else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();                 // every wave's pieces of stage s have landed; stage s - 1 has been read
+            if (s + 2 < nstage) { int nb = buf + 2; if (nb >= TILE_STAGES) nb -= TILE_STAGES; issue(nb); }
+            const char *sb = lds + buf * G::STAGE_BYTES;
+            // all fragments of the stage first (counted lgkmcnt waits let the first MFMAs start while the rest arrive)
+            f32x4 a[2][MTW], b[2][2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) a[p][mt] = *reinterpret_cast<const f32x4 *>(sb + a_rd[p] + mt * 2048);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) b[p][nt] = *reinterpret_cast<const f32x4 *>(sb + b_rd + (p * 4 + nt) * 1024);
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                // k step outermost: consecutive MFMAs go to different accumulators (a dependent MFMA issues 8 cycles late);
+                // per accumulator the order is k = j, j + 4, j + 8, j + 12 inside the MFMA, j = 0..3 across MFMAs: the canonical chain
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][mt][j], b[p][nt][j], acc[mt][nt], 0, 0, 0);
+                if (++in_chunk == c) { in_chunk = 0; chunk_end(); }
+            }
+            if (++buf == TILE_STAGES) buf = 0;
+        }
+    }
+
+    // ---- the workgroup's sums -> LDS plane (each wave owns its columns; no cross-wave addition) -> 4-column quads per thread
+    __syncthreads();                                       // the last stage has been read by every wave
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[((wm * MTW + mt) * 16 + kq * 4 + r) * LDR + (wn * 2 + nt) * 16 + mrow] = res[mt][nt][r];
+    __syncthreads();
+    f32x4 v[QPT];
+#pragma unroll
+    for (int i = 0; i < QPT; ++i) {
+        const int q = threadIdx.x + i * NTH;
+        v[i] = q < NQ ? *reinterpret_cast<const f32x4 *>(red + (q / QROW) * LDR + (q % QROW) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    if (NEED_SCL) {
+        const int Gn = rsc.groups;
+        float *part = scl + BM;
+        if (staged) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k < ppt && sj0 + k < Gn) part[srow * (Gn + 1) + sj0 + k] = stg[k];
+        } else {
+            for (int i = threadIdx.x; i < BM * Gn; i += NTH) {
+                int r = m0 + i / Gn;
+                if (r >= g.M) r = g.M - 1;
+                part[(i / Gn) * (Gn + 1) + i % Gn] = rsc.ssq[(size_t)r * Gn + i % Gn];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < BM) {
+            float t = 0.0f;
+            for (int j = 0; j < Gn; ++j) t += part[threadIdx.x * (Gn + 1) + j];
+            scl[threadIdx.x] = __builtin_amdgcn_rsqf(t * rsc.inv_n + rsc.eps);
+        }
+        __syncthreads();
+    }
+
+    if (EPI == EPI_PARTIAL) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * NTH;
+            const int m = m0 + q / QROW;
+            if (q < NQ && m < g.M)
+                *reinterpret_cast<f32x4 *>(g.out + ((size_t)zg * g.m_stride + m) * g.N + n0 + (q % QROW) * 4) = v[i];
+        }
+    } else if (EPI == EPI_HR) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * NTH;
+            const int m = m0 + q / QROW, n = n0 + (q % QROW) * 4;
+            if (e_ok[i]) {
+                const float rs = scl[q / QROW];
+                *reinterpret_cast<f32x4 *>(g.state + (size_t)e_slot[i] * g.ld_state + n) = v[i];
+                *reinterpret_cast<f32x4 *>(g.out + (size_t)m * g.ldo + n) = e_res[i] * rs + v[i];
+            }
+        }
+    } else if (EPI == EPI_RESID_SSQ) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * NTH;
+            const int m = m0 + q / QROW, n = n0 + (q % QROW) * 4;
+            const bool ok = e_ok[i];
+            f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                y = v[i] + e_bias[i];
+                if (g.resid) y = e_res[i] + y;
+                *reinterpret_cast<f32x4 *>(g.out + (size_t)m * g.ldo + n) = y;
+            }
+            const float ss = granule_ssq(y);               // all lanes take part in the shuffles
+            if (ok && (q & 7) == 0) g.ssq_out[(size_t)m * (g.N / SSQ_COLS) + n / SSQ_COLS] = ss;
+        }
+    } else {   // EPI_SLOT_STORE
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * NTH;
+            const int n = n0 + (q % QROW) * 4;
+            if (e_ok[i])
+                *reinterpret_cast<f32x4 *>(g.out + (size_t)e_slot[i] * g.ldo + n) = NEED_SCL ? v[i] * scl[q / QROW] + e_bias[i] : v[i] + e_bias[i];
+        }
+    }
+}
+
+template <int MT, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs g)
+{
+    gemm_tile_body<MT, EPI>(g, (int)blockIdx.z);
+}
+
+// n independent same-shape problems in one launch (see gemm_f32_zkernel): blockIdx.z / zdiv picks the argument block
+template <int MT, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_tile_zkernel(const GemmArgs *__restrict__ zargs, int zdiv)
+{
+    const int zl = (int)blockIdx.z / zdiv;
+    const GemmArgs g = zargs[zl];
+    gemm_tile_body<MT, EPI>(g, (int)blockIdx.z - zl * zdiv);
+}
+
+template <int MT> size_t tile_lds_bytes(const GemmArgs &g)
+{
+    using G = TileGeom<MT>;
+    const int sg = g.epi == EPI_HR ? g.r_scale.groups : (g.epi == EPI_SLOT_STORE && g.x_scale.ssq ? g.x_scale.groups : 0);
+    return (size_t)G::LDS_MAIN + (size_t)(G::BM + (sg ? G::BM * (sg + 1) : 0)) * sizeof(float);
+}
+
+template <int MT, int EPI>
+void launch_tile_one(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s)
+{
+    using G = TileGeom<MT>;
+    const int zdiv = g.kz / g.zs;
+    dim3 grid((unsigned)(g.N / TILE_BN), (unsigned)((g.M + G::BM - 1) / G::BM), (unsigned)(zdiv * std::max(1, n)));
+    const size_t lds = tile_lds_bytes<MT>(g);
+    if (dev_args) hipLaunchKernelGGL((gemm_tile_zkernel<MT, EPI>), grid, dim3(256), lds, s, dev_args, zdiv);
+    else hipLaunchKernelGGL((gemm_tile_kernel<MT, EPI>), grid, dim3(256), lds, s, g);
+}
+
+template <int MT>
+bool dispatch_tile(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s)
+{
+    switch (g.epi) {
+    case EPI_PARTIAL: launch_tile_one<MT, EPI_PARTIAL>(g, dev_args, n, s); return true;
+    case EPI_HR: launch_tile_one<MT, EPI_HR>(g, dev_args, n, s); return true;
+    case EPI_RESID_SSQ: launch_tile_one<MT, EPI_RESID_SSQ>(g, dev_args, n, s); return true;
+    case EPI_SLOT_STORE: launch_tile_one<MT, EPI_SLOT_STORE>(g, dev_args, n, s); return true;
+    default: return false;
+    }
+}
+
+}  // namespace
+
+// launch of a GEMM whose plan (kernels_gemm.hip) chose GM_TILE: g.zs slabs per workgroup, tile rows 16 * mt
+void launch_gemm_tile(const GemmArgs &g, int mt, const GemmArgs *dev_args, int n, hipStream_t s)
+{
+    bool ok = false;
+    if (mt == 4) ok = dispatch_tile<4>(g, dev_args, n, s);
+    else if (mt == 2) ok = dispatch_tile<2>(g, dev_args, n, s);
+    if (!ok) { fprintf(stderr, "libapril(mi355x): launch_gemm_tile: no kernel for epi %d tile rows %d\n", g.epi, 16 * mt); abort(); }
+}
+
+}  // namespace aprilx

@@ -20,7 +20,7 @@ __device__ __forceinline__ float dswish_dev(float y) { return y * sigmoid_dev(y 
 // EPI_SLOT_STORE), so a session computes the same bits whichever schedule its batch size selects.
 // Thread t owns the 4-column quad t, t + 256, ... of the row.
 template <int MODE>
-__global__ __launch_bounds__(256) void row_kernel(RowArgs r)
+__device__ __forceinline__ void row_body(const RowArgs &r)
 {
     if (r.run_flag && *r.run_flag != r.run_gen) return;
     const int m = blockIdx.x;
@@ -61,6 +61,18 @@ __global__ __launch_bounds__(256) void row_kernel(RowArgs r)
     }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(256) void row_kernel(RowArgs r) { row_body<MODE>(r); }
+
+// the same rows for several problems of one shape in one launch (the layers active in a feed wavefront): blockIdx.y picks the
+// argument block, read with scalar loads through the read-only kernel argument
+template <int MODE>
+__global__ __launch_bounds__(256) void row_zkernel(const RowArgs *__restrict__ zargs)
+{
+    const RowArgs r = zargs[blockIdx.y];
+    row_body<MODE>(r);
+}
+
 void launch_row(const RowArgs &r, hipStream_t s)
 {
     dim3 grid((unsigned)r.M), block(256);
@@ -68,6 +80,22 @@ void launch_row(const RowArgs &r, hipStream_t s)
     case ROW_HR: hipLaunchKernelGGL(row_kernel<ROW_HR>, grid, block, 0, s, r); break;
     case ROW_RESID_SSQ: hipLaunchKernelGGL(row_kernel<ROW_RESID_SSQ>, grid, block, 0, s, r); break;
     default: hipLaunchKernelGGL(row_kernel<ROW_SLOT_STORE>, grid, block, 0, s, r); break;
+    }
+}
+
+void launch_row_z(const RowArgs *host_args, int n, const RowArgs *dev_args, hipStream_t s)
+{
+    if (n <= 0) return;
+    const RowArgs &r = host_args[0];
+    for (int i = 1; i < n; ++i)
+        if (host_args[i].mode != r.mode || host_args[i].M != r.M || host_args[i].N != r.N || host_args[i].parts != r.parts) {
+            fprintf(stderr, "libapril(mi355x): launch_row_z: the problems of one launch must have one shape\n"); abort();
+        }
+    dim3 grid((unsigned)r.M, (unsigned)n), block(256);
+    switch (r.mode) {
+    case ROW_HR: hipLaunchKernelGGL(row_zkernel<ROW_HR>, grid, block, 0, s, dev_args); break;
+    case ROW_RESID_SSQ: hipLaunchKernelGGL(row_zkernel<ROW_RESID_SSQ>, grid, block, 0, s, dev_args); break;
+    default: hipLaunchKernelGGL(row_zkernel<ROW_SLOT_STORE>, grid, block, 0, s, dev_args); break;
     }
 }
 
