@@ -443,15 +443,15 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
     // y = A x W + bias (+ residual) with sums of squares: fused into the GEMM where its tiles own all of K, else split-K + row kernel
     auto resid_ssq = [&](const float *a, int K, size_t w_off, int kz, const float *bias, const float *resid) {
         GemmArgs g; g.a0 = a; g.lda0 = K; g.K0 = K; lin(g, w_off);
-        g.M = n; g.N = d.d_model; g.K = K; g.kz = kz; g.tile_ok = 1;
-        if (gemm_fullk(n, d.d_model, kz, false, 1, true)) {
+        g.M = n; g.N = d.d_model; g.K = K; g.kz = kz; g.tile_ok = tile_ok();
+        if (gemm_fullk(n, d.d_model, kz, false, 1, tile_ok())) {
             g.epi = EPI_RESID_SSQ; g.bias = bias; g.resid = resid; g.ldr = d.d_model; g.out = y_; g.ldo = d.d_model; g.ssq_out = ssq_;
             timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
             return;
         }
         g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
         timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
-        RowArgs r; r.mode = ROW_RESID_SSQ; r.ws = ws_; r.parts = gemm_partials(n, d.d_model, kz, 1, true); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = n;
+        RowArgs r; r.mode = ROW_RESID_SSQ; r.ws = ws_; r.parts = gemm_partials(n, d.d_model, kz, 1, tile_ok()); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = n;
         r.bias = bias; r.resid = resid; r.ldr = d.d_model; r.out = y_; r.ldo = d.d_model; r.ssq_out = ssq_;
         timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
     };
@@ -472,14 +472,14 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
         }
         {   // h' = u x Whr ; state write + residual: xb = norm(y) + h'
             GemmArgs g; g.a0 = u_; g.lda0 = d.hidden; g.K0 = d.hidden; lin(g, o.whr);
-            g.M = n; g.N = d.d_model; g.K = d.hidden; g.kz = kz_hr_; g.tile_ok = 1;
-            if (gemm_fullk(n, d.d_model, kz_hr_, false, 1, true)) {
+            g.M = n; g.N = d.d_model; g.K = d.hidden; g.kz = kz_hr_; g.tile_ok = tile_ok();
+            if (gemm_fullk(n, d.d_model, kz_hr_, false, 1, tile_ok())) {
                 g.epi = EPI_HR; g.state = h_l; g.ld_state = d.d_model; g.slot_idx = d_slots; g.resid = y_; g.ldr = d.d_model; g.r_scale = xs; g.out = xb_; g.ldo = d.d_model;
                 timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
             } else {
                 g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
                 timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
-                RowArgs r; r.mode = ROW_HR; r.ws = ws_; r.parts = gemm_partials(n, d.d_model, kz_hr_, 1, true); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = n;
+                RowArgs r; r.mode = ROW_HR; r.ws = ws_; r.parts = gemm_partials(n, d.d_model, kz_hr_, 1, tile_ok()); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = n;
                 r.resid = y_; r.ldr = d.d_model; r.r_scale = xs; r.out = xb_; r.ldo = d.d_model; r.slot_idx = d_slots; r.state = h_l; r.ld_state = d.d_model;
                 timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
             }
@@ -496,14 +496,14 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
     {   // encoder_proj(norm(y)) -> eout[slot]
         const RowScale ys = scale_of(eps_in);
         GemmArgs g; g.a0 = y_; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, L_.w_encproj);
-        g.M = n; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_; g.tile_ok = 1;
-        if (gemm_fullk(n, d.joiner, kz_proj_, false, 1, true)) {
+        g.M = n; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_; g.tile_ok = tile_ok();
+        if (gemm_fullk(n, d.joiner, kz_proj_, false, 1, tile_ok())) {
             g.epi = EPI_SLOT_STORE; g.bias = w_ + L_.b_encproj; g.out = eout_; g.ldo = d.joiner; g.slot_idx = d_slots; g.x_scale = ys;
             timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
         } else {
             g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
             timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
-            RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_; r.parts = gemm_partials(n, d.joiner, kz_proj_, 1, true); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = n;
+            RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_; r.parts = gemm_partials(n, d.joiner, kz_proj_, 1, tile_ok()); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = n;
             r.bias = w_ + L_.b_encproj; r.out = eout_; r.ldo = d.joiner; r.slot_idx = d_slots; r.r_scale = ys;
             timed_begin(T_ROW); launch_row(r, stream_); timed_end(T_ROW);
         }
@@ -525,15 +525,15 @@ void Engine::run_decproj(int n, const int *d_slots, const int *row_mask, const i
     const NetDims &d = L_.dims;
     if (!out) out = dout_;
     GemmArgs g; g.a0 = de_; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, L_.w_decproj);
-    g.M = n; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_; g.tile_ok = 1; g.run_flag = run_flag; g.run_gen = run_gen;
-    if (gemm_fullk(n, d.joiner, kz_proj_, false, 1, true)) {
+    g.M = n; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_; g.tile_ok = tile_ok(); g.run_flag = run_flag; g.run_gen = run_gen;
+    if (gemm_fullk(n, d.joiner, kz_proj_, false, 1, tile_ok())) {
         g.epi = EPI_SLOT_STORE; g.bias = w_ + L_.b_decproj; g.out = out; g.ldo = d.joiner; g.slot_idx = d_slots; g.row_mask = row_mask;
         timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
         return;
     }
     g.epi = EPI_PARTIAL; g.out = ws_g_; g.m_stride = ws_mstride_;
     timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
-    RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_g_; r.parts = gemm_partials(n, d.joiner, kz_proj_, 1, true); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = n;
+    RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_g_; r.parts = gemm_partials(n, d.joiner, kz_proj_, 1, tile_ok()); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = n;
     r.bias = w_ + L_.b_decproj; r.out = out; r.ldo = d.joiner; r.slot_idx = d_slots; r.row_mask = row_mask; r.run_flag = run_flag; r.run_gen = run_gen;
     timed_begin(T_DEC); launch_row(r, stream_); timed_end(T_DEC);
 }
@@ -628,16 +628,16 @@ void Engine::lm_resid_ssq(const float *a, int K, size_t w_off, int kz, const flo
     const NetDims &d = L_.dims;
     const int G = d.d_model / SSQ_COLS;
     GemmArgs g; g.a0 = a; g.lda0 = K; g.K0 = K; lin(g, w_off);
-    g.M = rows; g.N = d.d_model; g.K = K; g.kz = kz; g.tile_ok = 1;
+    g.M = rows; g.N = d.d_model; g.K = K; g.kz = kz; g.tile_ok = tile_ok();
     float *yo = y_ + r0 * d.d_model, *so = ssq_ + r0 * G;
-    if (gemm_fullk(rows, d.d_model, kz, false, 1, true)) {
+    if (gemm_fullk(rows, d.d_model, kz, false, 1, tile_ok())) {
         g.epi = EPI_RESID_SSQ; g.bias = bias; g.resid = resid; g.ldr = d.d_model; g.out = yo; g.ldo = d.d_model; g.ssq_out = so;
         timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
         return;
     }
     g.epi = EPI_PARTIAL; g.out = ws_ + r0 * d.d_model; g.m_stride = ws_mstride_;
     timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
-    RowArgs r; r.mode = ROW_RESID_SSQ; r.ws = ws_ + r0 * d.d_model; r.parts = gemm_partials(rows, d.d_model, kz, 1, true); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = rows;
+    RowArgs r; r.mode = ROW_RESID_SSQ; r.ws = ws_ + r0 * d.d_model; r.parts = gemm_partials(rows, d.d_model, kz, 1, tile_ok()); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = rows;
     r.bias = bias; r.resid = resid; r.ldr = d.d_model; r.out = yo; r.ldo = d.d_model; r.ssq_out = so;
     timed_begin(T_ROW); launch_row(r, st); timed_end(T_ROW);
 }
@@ -695,7 +695,7 @@ GemmArgs Engine::lm_args_whr(int l, int m, int t) const
     const PackedLayout::Layer &o = L_.layers[(size_t)l];
     const size_t r0 = (size_t)t * m;
     GemmArgs g; g.a0 = u_ + r0 * d.hidden; g.lda0 = d.hidden; g.K0 = d.hidden; lin(g, o.whr);
-    g.M = m; g.N = d.d_model; g.K = d.hidden; g.kz = kz_hr_; g.tile_ok = 1; g.force_fullk = 1;
+    g.M = m; g.N = d.d_model; g.K = d.hidden; g.kz = kz_hr_; g.tile_ok = tile_ok(); g.force_fullk = 1;
     g.epi = EPI_HR; g.state = h_ + (size_t)l * S * d.d_model; g.ld_state = d.d_model; g.slot_idx = step_d_; g.resid = y_ + r0 * d.d_model; g.ldr = d.d_model;
     g.r_scale.ssq = ssq_ + r0 * G; g.r_scale.groups = G; g.r_scale.inv_n = 1.0f / (float)d.d_model; g.r_scale.eps = l == 0 ? L_.embed_eps : L_.norm_eps[(size_t)l - 1];
     g.out = xb_ + r0 * d.d_model; g.ldo = d.d_model;
@@ -719,7 +719,7 @@ GemmArgs Engine::lm_args_ff2(int l, int m, int t0, int t1) const
     const PackedLayout::Layer &o = L_.layers[(size_t)l];
     const size_t b0 = (size_t)t0 * m;
     GemmArgs g; g.a0 = ff_ + b0 * d.ffn; g.lda0 = d.ffn; g.K0 = d.ffn; lin(g, o.wff2);
-    g.M = (t1 - t0) * m; g.N = d.d_model; g.K = d.ffn; g.kz = kz_ff2_; g.tile_ok = 1; g.force_fullk = 1;
+    g.M = (t1 - t0) * m; g.N = d.d_model; g.K = d.ffn; g.kz = kz_ff2_; g.tile_ok = tile_ok(); g.force_fullk = 1;
     g.epi = EPI_RESID_SSQ; g.bias = w_ + o.bff2; g.resid = xb_ + b0 * d.d_model; g.ldr = d.d_model; g.out = y_ + b0 * d.d_model; g.ldo = d.d_model; g.ssq_out = ssq_ + b0 * G;
     return g;
 }
@@ -735,14 +735,14 @@ void Engine::lm_stage_layer(int l, int m, int t0, int t1, hipStream_t st)
     for (int t = t0; t < t1; ++t) {
         const size_t r0 = (size_t)t * m;
         timed_begin(T_GATES); launch_gemm(lm_args_gates(l, m, t), st); timed_end(T_GATES);
-        if (gemm_fullk(m, d.d_model, kz_hr_, true, 1, true)) {
+        if (gemm_fullk(m, d.d_model, kz_hr_, true, 1, tile_ok())) {
             timed_begin(T_GEMM_OTHER); launch_gemm(lm_args_whr(l, m, t), st); timed_end(T_GEMM_OTHER);
         } else {
             const GemmArgs f = lm_args_whr(l, m, t);
-            GemmArgs g; g.a0 = f.a0; g.lda0 = f.lda0; g.K0 = f.K0; lin(g, o.whr); g.M = m; g.N = d.d_model; g.K = d.hidden; g.kz = kz_hr_; g.tile_ok = 1;
+            GemmArgs g; g.a0 = f.a0; g.lda0 = f.lda0; g.K0 = f.K0; lin(g, o.whr); g.M = m; g.N = d.d_model; g.K = d.hidden; g.kz = kz_hr_; g.tile_ok = tile_ok();
             g.epi = EPI_PARTIAL; g.out = ws_ + r0 * d.d_model; g.m_stride = ws_mstride_;
             timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
-            RowArgs r; r.mode = ROW_HR; r.ws = ws_ + r0 * d.d_model; r.parts = gemm_partials(m, d.d_model, kz_hr_, 1, true); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = m;
+            RowArgs r; r.mode = ROW_HR; r.ws = ws_ + r0 * d.d_model; r.parts = gemm_partials(m, d.d_model, kz_hr_, 1, tile_ok()); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = m;
             r.resid = f.resid; r.ldr = d.d_model; r.r_scale = f.r_scale; r.out = f.out; r.ldo = d.d_model;
             r.slot_idx = step_d_; r.state = h_ + (size_t)l * S * d.d_model; r.ld_state = d.d_model;
             timed_begin(T_ROW); launch_row(r, st); timed_end(T_ROW);
@@ -760,16 +760,16 @@ void Engine::lm_stage_proj(int m, int t0, int t1, hipStream_t st)
     const int brows = (t1 - t0) * m;
     RowScale ys; ys.ssq = ssq_ + b0 * G; ys.groups = G; ys.inv_n = 1.0f / (float)d.d_model; ys.eps = L_.norm_eps[(size_t)d.n_layers - 1];
     GemmArgs g; g.a0 = y_ + b0 * d.d_model; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, L_.w_encproj);
-    g.M = brows; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_; g.tile_ok = 1;
+    g.M = brows; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_; g.tile_ok = tile_ok();
     float *eo = eout_lm_ + b0 * d.joiner;
-    if (gemm_fullk(brows, d.joiner, kz_proj_, true, 1, true)) {
+    if (gemm_fullk(brows, d.joiner, kz_proj_, true, 1, tile_ok())) {
         g.force_fullk = 1;
         g.epi = EPI_SLOT_STORE; g.bias = w_ + L_.b_encproj; g.out = eo; g.ldo = d.joiner; g.x_scale = ys;
         timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
     } else {
         g.epi = EPI_PARTIAL; g.out = ws_ + b0 * d.d_model; g.m_stride = ws_mstride_;     // (joiner width == a d_model-wide slice or less: see the constructor's workspace size)
         timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
-        RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_ + b0 * d.d_model; r.parts = gemm_partials(brows, d.joiner, kz_proj_, 1, true); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = brows;
+        RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_ + b0 * d.d_model; r.parts = gemm_partials(brows, d.joiner, kz_proj_, 1, tile_ok()); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = brows;
         r.bias = w_ + L_.b_encproj; r.out = eo; r.ldo = d.joiner; r.r_scale = ys;
         timed_begin(T_ROW); launch_row(r, st); timed_end(T_ROW);
     }
@@ -969,7 +969,7 @@ Engine::SwPlan &Engine::sw_plan(int m, int T)
             // chip too few 64 x 64 tiles, K is cut across workgroups and ONE z-batched row launch finishes the slab tree with the
             // epilogue (state write + residual / bias + residual + sums of squares) -- the same arithmetic as the fused form.
             const int kz = kind == 1 ? kz_hr_ : kz_ff2_;
-            const bool split = (kind == 1 || kind == 3) && gemm_tile_planned(m, d.d_model, kz, n_act) && !gemm_fullk(m, d.d_model, kz, false, n_act, true);
+            const bool split = (kind == 1 || kind == 3) && tile_ok() && gemm_tile_planned(m, d.d_model, kz, n_act) && !gemm_fullk(m, d.d_model, kz, false, n_act, true);
             for (int l = 0; l < L; ++l) {
                 const int t = W - 1 - l;
                 if (t < 0 || t >= T) continue;
@@ -1074,7 +1074,7 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
         kernels_per_step_ = (launch_count_ + 1 + T - 1) / T;          // per chunk
     } else {
     const bool wavefront = lm_wavefront_on() && !profiling_ && T > lm_block_steps() &&
-                           gemm_fullk(m, d.d_model, kz_hr_, true, 1, true) && gemm_fullk(m, d.d_model, kz_ff2_, true, 1, true);
+                           gemm_fullk(m, d.d_model, kz_hr_, true, 1, tile_ok()) && gemm_fullk(m, d.d_model, kz_ff2_, true, 1, tile_ok());
     if (wavefront) {                 // long feed: all layers of a wavefront per launch (run_lm_wavefront)
         std::lock_guard<std::mutex> cg(capture_mu_);
         run_lm_wavefront(m, T, logits_out != nullptr);

@@ -77,6 +77,7 @@ public:
     float *weights_mut() { return w_; }        // load time only: the constructor leaves the weights unset when it is given no blob
     void finish_weights();                     // after the weights are in place (upload, copy or RCCL broadcast): derived copies (fp16)
     int precision() const { return cfg_.precision; }
+    bool tile_ok() const { return cfg_.precision == 0; }      // the GM_TILE schedule exists for fp32 operands
     const PackedLayout &layout() const { return L_; }
 
     int alloc_slot();                 // -1 when full; state zeroed (reference calloc, april_session.c:40-58)

@@ -728,9 +728,14 @@ static bool plan_fullk(int M, int N, int kz, TilePlan &t, bool force = false, in
     return true;
 }
 
-// GM_TILE (kernels_gemm_tile.hip): 64-column tiles of 64 or 32 rows whose waves share the operands through LDS; K is cut
-// across workgroups at slab boundaries until the launch holds enough workgroups for the chip (the row kernel then finishes
-// the slab tree), and not at all once the output tiles alone do.  APRIL_TILE_MT / APRIL_TILE_ZS pin the choice (measurement).
+// GM_TILE (kernels_gemm_tile.hip): 64-column tiles of 32 (or 64) rows whose waves share the operands through LDS.
+// Measured on MI355X (tools/tile_bench, profiles/r03_tile_bench.txt; us per launch, round-2 schedule -> GM_TILE):
+//   FFN down 2048 rows x 2 problems 110 -> 83 (32-row tiles, all of K per workgroup), 1024 x 2: 60 -> 46, projection 2048 x 2:
+//   64 -> 51, larger encoder 512 x 3: 105 -> 77 (K cut in four, row kernel);  256 rows x 1..3 problems: no gain (a launch of a few
+//   hundred short workgroups is bound by its fixed costs -- pipeline fill, the second launch), so small launches keep the
+//   round-2 schedules.  Rule: no GM_TILE below 256 32-row tiles per launch; 64-row tiles once the launch holds 512 of them,
+//   32-row tiles otherwise; slabs per workgroup from a small cost model (below).
+// APRIL_TILE_MT / APRIL_TILE_ZS (or gemm_tile_pin) pin the choice for measurements.
 static int g_tile_pin_mt = env_int("APRIL_TILE_MT", 0), g_tile_pin_zs = env_int("APRIL_TILE_ZS", 0), g_tile_enable = -1;
 void gemm_tile_pin(int enable, int mt, int zs) { g_tile_enable = enable; g_tile_pin_mt = mt; g_tile_pin_zs = zs; }
 
@@ -738,16 +743,31 @@ static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePla
 {
     static const int enabled = env_int("APRIL_GM_TILE", 1);
     static const int min_rows = env_int("APRIL_TILE_MIN_ROWS", 32);
-    static const int target = env_int("APRIL_TILE_TARGET_WGS", 512);      // two workgroups per CU
+    static const int fused_tiles = env_int("APRIL_TILE_FUSED_TILES", 512), split_tiles = env_int("APRIL_TILE_SPLIT_TILES", 256);
     const int pin_mt = g_tile_pin_mt, pin_zs = g_tile_pin_zs;
     if (!(g_tile_enable < 0 ? enabled : g_tile_enable) || N % 64 != 0 || M < min_rows) return false;
     const long zc = std::max(1, zcount);
-    int mt = 4;
-    long tiles = (long)(N / 64) * ((M + 63) / 64) * zc;
-    if ((pin_mt == 2) || (pin_mt == 0 && tiles * kz < target)) { mt = 2; tiles = (long)(N / 64) * ((M + 31) / 32) * zc; }
+    const long tiles4 = (long)(N / 64) * ((M + 63) / 64) * zc, tiles2 = (long)(N / 64) * ((M + 31) / 32) * zc;
+    const int mt = pin_mt ? (pin_mt == 4 ? 4 : 2) : (tiles4 >= fused_tiles ? 4 : 2);
+    const long tiles = mt == 4 ? tiles4 : tiles2;
     int zs = kz;
-    if (!force_full) while (zs > 1 && tiles * (kz / zs) < target) zs >>= 1;
-    if (pin_zs > 0 && !force_full) zs = std::min(kz, pin_zs);
+    if (pin_zs > 0) { if (!force_full) zs = std::min(kz, pin_zs); }
+    else if (pin_mt > 0) { /* measurement: pinned tile rows, all of K */ }
+    else {
+        if (tiles2 < split_tiles) return false;          // small launches keep the round-2 schedules
+        if (!force_full) {
+            // workgroups are dealt to the 256 CUs round robin, a CU works through its share at the MFMA rate: cost = (workgroups
+            // per CU) x (stages per workgroup + ~3 stages of fill / epilogue), a K cut pays the row kernel on top (~5 %).  A slab is
+            // taken as 8 stages (chunks of 4 k blocks); mt = 4 stages hold twice the MFMAs of mt = 2 stages (same for every zs).
+            long best = -1;
+            for (int z = kz; z >= 1; z >>= 1) {
+                const long wgs = tiles * (kz / z), per_cu = (wgs + 255) / 256;
+                long cost = per_cu * (8L * z + 3) * 100;
+                if (z < kz) cost += cost / 20 + 300;
+                if (best < 0 || cost < best) { best = cost; zs = z; }
+            }
+        }
+    }
     t.mt = mt; t.nt = 4; t.zs = zs; t.mode = GM_TILE;
     return true;
 }

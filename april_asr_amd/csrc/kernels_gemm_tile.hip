@@ -21,8 +21,8 @@
 //      (lane (i, kq) reads row i, segment 4 p + kq) is then conflict-free for ds_read_b128's lane groups.  The DMA writes
 //      LDS linearly (wave-uniform base + lane * 16), so the swizzle is applied to the per-lane SOURCE address.
 //   B: [2 k blocks][4 n tiles][1 KB] in the packed weight order, i.e. already the B fragment of every lane.
-// Three stage buffers; per stage ONE s_barrier: wait for this wave's pieces of stage s (counted vmcnt, two stages stay in
-// flight), barrier, issue stage s + 2 into the buffer stage s - 1 was read from, compute stage s.
+// Four stage buffers, ONE s_barrier per stage, placed between the stage's two k blocks (see the K loop): counted vmcnt keeps
+// two to three stages of DMA in flight, the fragments of the next k block are read from LDS while the current MFMAs issue.
 // Replaces the ORT MatMul nodes inside the encoder / joiner graphs (reference call sites src/april_session.c:145,176).
 #include "kernels.h"
 #include "device_utils.h"
@@ -34,7 +34,11 @@ namespace aprilx {
 
 namespace {
 
-constexpr int TILE_BN = 64, TILE_LDR = TILE_BN + 4, TILE_STAGES = 3;
+#ifndef APRIL_TILE_STAGES
+#define APRIL_TILE_STAGES 3
+#endif
+constexpr int TILE_BN = 64, TILE_LDR = TILE_BN + 4, TILE_STAGES = APRIL_TILE_STAGES;
+static_assert(TILE_STAGES == 4 || TILE_STAGES == 3, "the tail of the K loop counts in-flight stages for 3 or 4 buffers");
 
 template <int MT> struct TileGeom {
     static constexpr int BM = 16 * MT;
@@ -124,6 +128,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
         }
     }
     auto issue = [&](int buf) {
+        if (g.debug == 4) return;                          // measurement: no DMA (the MFMA + LDS read loop alone, on stale LDS contents)
 #pragma unroll
         for (int i = 0; i < G::PPW; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i]),
@@ -193,39 +198,64 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
         }
     };
 
-    // ---- K loop
+    // ---- K loop.  Stage s = k blocks (2 s, 2 s + 1) of the workgroup's range, buffer s % NS.  The fragments of the NEXT k block
+    // are read while the MFMAs of the current one issue, across the stage boundary too: the one barrier of a stage sits between its
+    // two k blocks -- behind it every wave's pieces of stage s + 1 have landed (counted vmcnt before the barrier) and every wave has
+    // issued its reads of stage s, so the buffer of stage s - 1 (read an iteration ago, consumed by MFMAs since) takes stage s + NS - 1.
     if (g.debug != 1) {
-        issue(0);
-        if (nstage > 1) issue(1);
+        constexpr int NS = TILE_STAGES;
+#pragma unroll
+        for (int i = 0; i < NS - 1; ++i) if (i < nstage) issue(i);
+        // stage 0 landed: at most the NS - 2 younger stages may still be in flight
+        if (nstage >= NS - 1) wait_vm<(NS - 2) * G::PPW>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        f32x4 a0[MTW], b0[2], a1[MTW], b1[2];
+        auto read_frags = [&](const char *sb, int p, f32x4 (&a)[MTW], f32x4 (&b)[2]) {
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) a[mt] = *reinterpret_cast<const f32x4 *>(sb + a_rd[p] + mt * 2048);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(sb + b_rd + (p * 4 + nt) * 1024);
+        };
+        auto mfma_block = [&](const f32x4 (&a)[MTW], const f32x4 (&b)[2]) {
+            if (g.debug == 5) {                            // measurement: no MFMAs (DMA + barriers + LDS reads alone); the fragments stay live
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) asm volatile("" :: "v"(a[mt]));
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) asm volatile("" :: "v"(b[nt]));
+                return;
+            }
+            // k step outermost: consecutive MFMAs go to different accumulators (a dependent MFMA issues 8 cycles late); per
+            // accumulator the order is k = j, j + 4, j + 8, j + 12 inside the MFMA, j = 0..3 across MFMAs: the canonical chain
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
+        };
+        read_frags(lds, 0, a0, b0);
         int buf = 0;
         for (int s = 0; s < nstage; ++s) {
-            if (s + 1 < nstage) wait_vm<G::PPW>(); else wait_vm<0>();
-            __builtin_amdgcn_s_barrier();                 // every wave's pieces of stage s have landed; stage s - 1 has been read
-            if (s + 2 < nstage) { int nb = buf + 2; if (nb >= TILE_STAGES) nb -= TILE_STAGES; issue(nb); }
             const char *sb = lds + buf * G::STAGE_BYTES;
-            // all fragments of the stage first (counted lgkmcnt waits let the first MFMAs start while the rest arrive)
-            f32x4 a[2][MTW], b[2][2];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-#pragma unroll
-                for (int mt = 0; mt < MTW; ++mt) a[p][mt] = *reinterpret_cast<const f32x4 *>(sb + a_rd[p] + mt * 2048);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) b[p][nt] = *reinterpret_cast<const f32x4 *>(sb + b_rd + (p * 4 + nt) * 1024);
+            int nbuf = buf + 1; if (nbuf == NS) nbuf = 0;
+            read_frags(sb, 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);             // the reads go out BEFORE the MFMAs they overlap with (left alone, the scheduler sinks them behind)
+            mfma_block(a0, b0);
+            if (++in_chunk == c) { in_chunk = 0; chunk_end(); }
+            if (s + 1 < nstage) {
+                // stage s + 1 must have landed; younger stages still in flight: s + 2 .. min(s + NS - 2, nstage - 1)
+                if (s + NS - 2 < nstage) wait_vm<(NS - 3) * G::PPW>();
+                else if (NS > 4 && s + NS - 3 < nstage) wait_vm<(NS > 4 ? NS - 4 : 0) * G::PPW>();
+                else wait_vm<0>();
             }
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                // k step outermost: consecutive MFMAs go to different accumulators (a dependent MFMA issues 8 cycles late);
-                // per accumulator the order is k = j, j + 4, j + 8, j + 12 inside the MFMA, j = 0..3 across MFMAs: the canonical chain
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][mt][j], b[p][nt][j], acc[mt][nt], 0, 0, 0);
-                if (++in_chunk == c) { in_chunk = 0; chunk_end(); }
-            }
-            if (++buf == TILE_STAGES) buf = 0;
+            __builtin_amdgcn_s_barrier();
+            if (s + NS - 1 < nstage) { int ib = buf - 1; if (ib < 0) ib += NS; issue(ib); }
+            if (s + 1 < nstage) read_frags(lds + nbuf * G::STAGE_BYTES, 0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_block(a1, b1);
+            if (++in_chunk == c) { in_chunk = 0; chunk_end(); }
+            buf = nbuf;
         }
     }
 
@@ -342,6 +372,12 @@ void launch_tile_one(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStre
     const int zdiv = g.kz / g.zs;
     dim3 grid((unsigned)(g.N / TILE_BN), (unsigned)((g.M + G::BM - 1) / G::BM), (unsigned)(zdiv * std::max(1, n)));
     const size_t lds = tile_lds_bytes<MT>(g);
+    static bool attr_set = false;                        // (per instantiation) dynamic LDS beyond 64 KB has to be announced
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tile_kernel<MT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tile_zkernel<MT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
     if (dev_args) hipLaunchKernelGGL((gemm_tile_zkernel<MT, EPI>), grid, dim3(256), lds, s, dev_args, zdiv);
     else hipLaunchKernelGGL((gemm_tile_kernel<MT, EPI>), grid, dim3(256), lds, s, g);
 }

@@ -145,6 +145,8 @@ static double time_chain(const Chain &c, hipStream_t s, int iters)
 int main(int argc, char **argv)
 {
     const int iters = argc > 1 ? atoi(argv[1]) : 200;
+    // optional: only shape number `only` (0-based), only the pinned (mt, zs) -- for profiler runs
+    const int only = argc > 2 ? atoi(argv[2]) : -1, only_mt = argc > 3 ? atoi(argv[3]) : -1, only_zs = argc > 4 ? atoi(argv[4]) : -1;
     hipStream_t s; CK(hipStreamCreate(&s));
     struct Shape { const char *name; int M, N, K, kz, epi, n; };
     const Shape shapes[] = {
@@ -167,6 +169,7 @@ int main(int argc, char **argv)
     };
     int bad = 0;
     for (const Shape &sh : shapes) {
+        if (only >= 0 && (&sh - shapes) != only) continue;
         std::vector<Problem> ps;
         for (int i = 0; i < sh.n; ++i) ps.push_back(make_problem(sh.M, sh.N, sh.K, sh.kz, sh.epi, 1000u * (unsigned)(&sh - shapes) + 10u * (unsigned)i));
         const double flops = 2.0 * sh.M * sh.N * sh.K * sh.n;
@@ -182,6 +185,7 @@ int main(int argc, char **argv)
         std::vector<Pin> pins = {{0, 0}};
         for (int mt : {4, 2}) for (int zs = 1; zs <= sh.kz; zs *= 2) pins.push_back({mt, zs});
         for (const Pin &pin : pins) {
+            if (only_mt >= 0 && (pin.mt != only_mt || pin.zs != only_zs)) continue;
             gemm_tile_pin(1, pin.mt, pin.zs);
             if (!gemm_tile_planned(sh.M, sh.N, sh.kz, sh.n)) { printf("    (GM_TILE not planned for this shape)\n"); break; }
             Chain c = make_chain(ps, true);
