@@ -128,11 +128,11 @@ void pack_weights(const HostModel &m, PackedLayout &L, std::vector<float> &blob)
 template <typename T> static T *dmalloc(size_t n) { T *p = nullptr; HIP_CHECK(hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T))); return p; }
 template <typename T> static T *hmalloc(size_t n) { T *p = nullptr; HIP_CHECK(hipHostMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault)); return p; }
 
-static int pick_kz(int K, int N)
+static int pick_kz(int K, int N, int kblk = 16)
 {
     int kz = 256 / std::max(1, N / 16);
     kz = std::max(1, std::min(kz, 8));
-    while (kz > 1 && ((K / 16) / kz < 4 || (K / 16) % (4 * kz) != 0)) kz >>= 1;   // every wave gets whole blocks of every slab
+    while (kz > 1 && ((K / kblk) / kz < 4 || (K / kblk) % (4 * kz) != 0)) kz >>= 1;   // every wave gets whole blocks of every slab
     return kz;
 }
 
@@ -181,6 +181,18 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     kz_ff2_ = pick_kz(d.ffn, d.d_model);
     kz_proj_ = pick_kz(d.d_model, d.joiner);
     kz_out_ = pick_kz(d.joiner, L_.vocab_pad);
+    {   // fp16 tile path: all four layer GEMMs must cut into 4 chunks of whole 32-k blocks (and the gates' y half into whole stages)
+        const char *e = getenv("APRIL_F16_TILE");
+        const bool want = cfg_.precision == 1 && !(e && *e && atoi(e) == 0);
+        f16_tile_ = want && d.d_model % 128 == 0 && d.hidden % 128 == 0 && d.ffn % 128 == 0 && d.hidden % 16 == 0;
+        if (f16_tile_) {
+            kzx_hr_ = pick_kz(d.hidden, d.d_model, 32); kzx_ff2_ = pick_kz(d.ffn, d.d_model, 32);
+            y16_ = dmalloc<uint16_t>(MB * d.d_model); xb16_ = dmalloc<uint16_t>(MB * d.d_model);
+            u16_ = dmalloc<uint16_t>(MB * d.hidden); ff16_ = dmalloc<uint16_t>(MB * d.ffn);
+            h16_ = dmalloc<uint16_t>((size_t)d.n_layers * S * d.d_model);
+            HIP_CHECK(hipMemset(h16_, 0, (size_t)d.n_layers * S * d.d_model * 2));
+        }
+    }
     ws_mstride_ = cfg_.max_batch;
     const size_t ws_n = (size_t)std::max({kz_embed_ * d.d_model, kz_hr_ * d.d_model, kz_ff2_ * d.d_model, kz_proj_ * d.joiner, kz_out_ * L_.vocab_pad});
     ws_ = dmalloc<float>(ws_n * MB);
@@ -222,6 +234,18 @@ void Engine::finish_weights()
         // packed element order (round-to-nearest-even, on the device); convolutions, biases, embeddings stay fp32
         wh_ = dmalloc<uint16_t>(L_.total);
         for (const auto &sec : gemm_sections(L_)) launch_cvt_f16(w_ + sec.first, wh_ + sec.first, sec.second, nullptr);
+        if (f16_tile_) {
+            // the layer GEMMs once more, in the order of the 32-k MFMA's B fragment (the other GEMMs -- embed, encoder_proj,
+            // decoder, joiner -- stay on the round-2 kernels and the copies above)
+            const NetDims &d = L_.dims;
+            wx_ = dmalloc<uint16_t>(L_.total);
+            for (const PackedLayout::Layer &o : L_.layers) {
+                launch_repack_x32(w_ + o.wg, wx_ + o.wg, 2 * d.d_model, 4 * d.hidden, nullptr);
+                launch_repack_x32(w_ + o.whr, wx_ + o.whr, d.hidden, d.d_model, nullptr);
+                launch_repack_x32(w_ + o.wff1, wx_ + o.wff1, d.d_model, d.ffn, nullptr);
+                launch_repack_x32(w_ + o.wff2, wx_ + o.wff2, d.ffn, d.d_model, nullptr);
+            }
+        }
         HIP_CHECK(hipDeviceSynchronize());
     }
     build_dec_table();
@@ -333,7 +357,7 @@ void Engine::free_slot(int slot)
         const NetDims &d = L_.dims;
         ZeroSlotArgs z;
         z.h = h_; z.c = c_; z.n_layers = d.n_layers; z.slots = (size_t)cfg_.max_slots; z.d_model = d.d_model; z.hidden = d.hidden;
-        z.eout = eout_; z.dout = dout_; z.joiner = d.joiner; z.state = gstate_; z.blank = P_.blank_id; z.slot = slot;
+        z.eout = eout_; z.dout = dout_; z.joiner = d.joiner; z.state = gstate_; z.blank = P_.blank_id; z.slot = slot; z.h16 = h16_;
         launch_zero_slot(z, stream_);
     }
     std::lock_guard<std::mutex> g(slot_mu_);
@@ -458,7 +482,19 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
     // embed linear + bias (BasicNorm deferred)
     resid_ssq(xin_, d.embed_in, L_.w_embed, kz_embed_, w_ + L_.b_embed, nullptr);
     float eps_in = L_.embed_eps;                          // epsilon of the BasicNorm that produced this layer's input
-    for (int l = 0; l < d.n_layers; ++l) {
+    if (f16_tile_) {
+        // fp16 tile path: the four GEMMs of every layer read binary16 activations (row block 0 of the work buffers, d_slots ==
+        // step_d_) -- the same argument blocks as the feed wavefront at chunk 0; embed and encoder_proj stay on the fp32-A kernels
+        launch_cvt_f16(y_, y16_, (size_t)n * d.d_model, stream_);
+        for (int l = 0; l < d.n_layers; ++l) {
+            timed_begin(T_GATES); launch_gemm(sw_args_gates(l, n, 0), stream_); timed_end(T_GATES);
+            launch_rowepi(lm_args_whr(l, n, 0), 0, stream_);
+            timed_begin(T_GEMM_OTHER); launch_gemm(lm_args_ff1(l, n, 0, 1), stream_); timed_end(T_GEMM_OTHER);
+            launch_rowepi(lm_args_ff2(l, n, 0, 1), 0, stream_);
+        }
+        eps_in = L_.norm_eps[(size_t)d.n_layers - 1];
+    }
+    for (int l = 0; l < (f16_tile_ ? 0 : d.n_layers); ++l) {
         const PackedLayout::Layer &o = L_.layers[(size_t)l];
         float *h_l = h_ + (size_t)l * S * d.d_model;
         float *c_l = c_ + (size_t)l * S * d.hidden;
@@ -620,6 +656,7 @@ void Engine::lm_stage_embed(int m, int t0, int t1, hipStream_t st)
         timed_begin(T_CONV); launch_gemm(g, st); timed_end(T_CONV);
     }
     lm_resid_ssq(xin_ + r0 * d.embed_in, d.embed_in, L_.w_embed, kz_embed_, w_ + L_.b_embed, nullptr, r0, rows, st);
+    if (f16_tile_) launch_cvt_f16(y_ + r0 * d.d_model, y16_ + r0 * d.d_model, (size_t)rows * d.d_model, st);      // layer 0 reads binary16 rows
 }
 
 // y[r0 .. r0 + rows) = A x W + bias (+ residual) with sums of squares; fused where the tiles own all of K
@@ -684,6 +721,10 @@ GemmArgs Engine::sw_args_gates(int l, int m, int t) const
     g.a1 = h_ + (size_t)l * S * d.d_model; g.lda1 = d.d_model; g.aidx1 = step_d_; g.K1 = d.d_model;
     lin(g, o.wg); g.M = m; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_LSTM;
     g.out = u_ + r0 * d.hidden; g.ldo = d.hidden; g.bias = w_ + o.bg; g.c_state = c_ + (size_t)l * S * d.hidden; g.slot_idx = step_d_; g.hidden = d.hidden;
+    if (f16_tile_) {                  // binary16 operands: [y16 | h16(slot)], u leaves as binary16 only (its one reader is the projection)
+        g.a0 = reinterpret_cast<const float *>(y16_ + r0 * d.d_model); g.a1 = reinterpret_cast<const float *>(h16_ + (size_t)l * S * d.d_model);
+        lin16(g, o.wg); g.out = nullptr; g.out16 = u16_ + r0 * d.hidden;
+    }
     return g;
 }
 
@@ -699,6 +740,10 @@ GemmArgs Engine::lm_args_whr(int l, int m, int t) const
     g.epi = EPI_HR; g.state = h_ + (size_t)l * S * d.d_model; g.ld_state = d.d_model; g.slot_idx = step_d_; g.resid = y_ + r0 * d.d_model; g.ldr = d.d_model;
     g.r_scale.ssq = ssq_ + r0 * G; g.r_scale.groups = G; g.r_scale.inv_n = 1.0f / (float)d.d_model; g.r_scale.eps = l == 0 ? L_.embed_eps : L_.norm_eps[(size_t)l - 1];
     g.out = xb_ + r0 * d.d_model; g.ldo = d.d_model;
+    if (f16_tile_) {
+        g.a0 = reinterpret_cast<const float *>(u16_ + r0 * d.hidden); lin16(g, o.whr); g.kz = kzx_hr_;
+        g.state16 = h16_ + (size_t)l * S * d.d_model; g.out16 = xb16_ + r0 * d.d_model;
+    }
     return g;
 }
 
@@ -709,6 +754,7 @@ GemmArgs Engine::lm_args_ff1(int l, int m, int t0, int t1) const
     const size_t b0 = (size_t)t0 * m;
     GemmArgs g; g.a0 = xb_ + b0 * d.d_model; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, o.wff1);
     g.M = (t1 - t0) * m; g.N = d.ffn; g.K = d.d_model; g.kz = 1; g.epi = EPI_BIAS_DSWISH; g.out = ff_ + b0 * d.ffn; g.ldo = d.ffn; g.bias = w_ + o.bff1;
+    if (f16_tile_) { g.a0 = reinterpret_cast<const float *>(xb16_ + b0 * d.d_model); lin16(g, o.wff1); g.out = nullptr; g.out16 = ff16_ + b0 * d.ffn; }
     return g;
 }
 
@@ -721,7 +767,36 @@ GemmArgs Engine::lm_args_ff2(int l, int m, int t0, int t1) const
     GemmArgs g; g.a0 = ff_ + b0 * d.ffn; g.lda0 = d.ffn; g.K0 = d.ffn; lin(g, o.wff2);
     g.M = (t1 - t0) * m; g.N = d.d_model; g.K = d.ffn; g.kz = kz_ff2_; g.tile_ok = tile_ok(); g.force_fullk = 1;
     g.epi = EPI_RESID_SSQ; g.bias = w_ + o.bff2; g.resid = xb_ + b0 * d.d_model; g.ldr = d.d_model; g.out = y_ + b0 * d.d_model; g.ldo = d.d_model; g.ssq_out = ssq_ + b0 * G;
+    if (f16_tile_) { g.a0 = reinterpret_cast<const float *>(ff16_ + b0 * d.ffn); lin16(g, o.wff2); g.kz = kzx_ff2_; g.out16 = y16_ + b0 * d.d_model; }
     return g;
+}
+
+// A row-epilogue GEMM given in its fused form (EPI_HR / EPI_RESID_SSQ): the partial-plane form of the same GEMM over the
+// workspace rows of its output, and the row problem that finishes it (same arithmetic as the fused epilogue)
+static GemmArgs partial_form(const GemmArgs &f, float *ws, int m_stride)
+{
+    GemmArgs g = f;
+    g.epi = EPI_PARTIAL; g.force_fullk = 0; g.out = ws; g.m_stride = m_stride;
+    g.bias = nullptr; g.resid = nullptr; g.state = nullptr; g.slot_idx = nullptr; g.ssq_out = nullptr; g.r_scale = RowScale(); g.out16 = nullptr; g.state16 = nullptr;
+    return g;
+}
+static RowArgs row_form(const GemmArgs &f, const float *ws, int m_stride, int parts)
+{
+    RowArgs r; r.ws = ws; r.parts = parts; r.m_stride = m_stride; r.N = f.N; r.M = f.M;
+    r.resid = f.resid; r.ldr = f.ldr; r.out = f.out; r.ldo = f.ldo; r.out16 = f.out16;
+    if (f.epi == EPI_HR) { r.mode = ROW_HR; r.r_scale = f.r_scale; r.slot_idx = f.slot_idx; r.state = f.state; r.ld_state = f.ld_state; r.state16 = f.state16; }
+    else { r.mode = ROW_RESID_SSQ; r.bias = f.bias; r.ssq_out = f.ssq_out; }
+    return r;
+}
+
+// one row-epilogue GEMM outside the z-batched chains: fused when the plan keeps all of K in the workgroup, else planes + row kernel
+void Engine::launch_rowepi(GemmArgs f, size_t ws_row0, hipStream_t st)
+{
+    f.force_fullk = 0;
+    if (gemm_fullk(f.M, f.N, f.kz, false, 1, f.tile_ok)) { timed_begin(T_GEMM_OTHER); launch_gemm(f, st); timed_end(T_GEMM_OTHER); return; }
+    float *ws = ws_ + ws_row0 * f.N;
+    timed_begin(T_GEMM_OTHER); launch_gemm(partial_form(f, ws, ws_mstride_), st); timed_end(T_GEMM_OTHER);
+    timed_begin(T_ROW); launch_row(row_form(f, ws, ws_mstride_, gemm_partials(f.M, f.N, f.kz, 1, f.tile_ok)), st); timed_end(T_ROW);
 }
 
 void Engine::lm_stage_layer(int l, int m, int t0, int t1, hipStream_t st)
@@ -968,22 +1043,18 @@ Engine::SwPlan &Engine::sw_plan(int m, int T)
             // The N = d_model GEMMs (projection, FFN down) on the GM_TILE schedule: when the n_act problems of this launch give the
             // chip too few 64 x 64 tiles, K is cut across workgroups and ONE z-batched row launch finishes the slab tree with the
             // epilogue (state write + residual / bias + residual + sums of squares) -- the same arithmetic as the fused form.
-            const int kz = kind == 1 ? kz_hr_ : kz_ff2_;
-            const bool split = (kind == 1 || kind == 3) && tile_ok() && gemm_tile_planned(m, d.d_model, kz, n_act) && !gemm_fullk(m, d.d_model, kz, false, n_act, true);
+            const int kz = kind == 1 ? kz_hr() : kz_ff2();
+            const int tk = f16_tile_ ? 2 : tile_ok();
+            const bool split = (kind == 1 || kind == 3) && tk && (tk == 2 || gemm_tile_planned(m, d.d_model, kz, n_act)) && !gemm_fullk(m, d.d_model, kz, false, n_act, tk);
             for (int l = 0; l < L; ++l) {
                 const int t = W - 1 - l;
                 if (t < 0 || t >= T) continue;
                 GemmArgs g = kind == 0 ? sw_args_gates(l, m, t) : kind == 1 ? lm_args_whr(l, m, t) : kind == 2 ? lm_args_ff1(l, m, t, t + 1) : lm_args_ff2(l, m, t, t + 1);
                 if (split) {
-                    const size_t r0 = (size_t)t * m;
-                    RowArgs r; r.ws = ws_ + r0 * d.d_model; r.parts = gemm_partials(m, d.d_model, kz, n_act, true); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = m;
-                    r.resid = g.resid; r.ldr = g.ldr; r.out = g.out; r.ldo = g.ldo;
-                    if (kind == 1) { r.mode = ROW_HR; r.r_scale = g.r_scale; r.slot_idx = g.slot_idx; r.state = h_ + (size_t)l * S * d.d_model; r.ld_state = d.d_model; }
-                    else { r.mode = ROW_RESID_SSQ; r.bias = g.bias; r.ssq_out = g.ssq_out; }
-                    rows.push_back(r);
-                    g.epi = EPI_PARTIAL; g.force_fullk = 0; g.out = ws_ + r0 * d.d_model; g.m_stride = ws_mstride_;
-                    g.bias = nullptr; g.resid = nullptr; g.state = nullptr; g.slot_idx = nullptr; g.ssq_out = nullptr; g.r_scale = RowScale();
-                }
+                    float *ws = ws_ + (size_t)t * m * d.d_model;
+                    rows.push_back(row_form(g, ws, ws_mstride_, gemm_partials(m, d.d_model, kz, n_act, tk)));
+                    g = partial_form(g, ws, ws_mstride_);
+                } else if (tk == 2) g.force_fullk = 0;
                 items.push_back(g);
             }
             SwPlan::Batch b; b.off = p.host.size(); b.n = (int)items.size(); b.macro = W; b.kind = kind; b.roff = p.rhost.size(); b.rn = (int)rows.size();
@@ -1209,7 +1280,7 @@ void Engine::zero_slots(int n)
     for (int i = 0; i < n; ++i) {
         ZeroSlotArgs z;
         z.h = h_; z.c = c_; z.n_layers = d.n_layers; z.slots = (size_t)cfg_.max_slots; z.d_model = d.d_model; z.hidden = d.hidden;
-        z.eout = eout_; z.dout = dout_; z.joiner = d.joiner; z.state = gstate_; z.blank = P_.blank_id; z.slot = i;
+        z.eout = eout_; z.dout = dout_; z.joiner = d.joiner; z.state = gstate_; z.blank = P_.blank_id; z.slot = i; z.h16 = h16_;
         launch_zero_slot(z, stream_);
     }
     HIP_CHECK(hipStreamSynchronize(stream_));
@@ -1232,6 +1303,8 @@ void Engine::debug_encoder(int n, const float *x, const float *h, const float *c
             HIP_CHECK(hipMemcpy(c_ + ((size_t)l * S + i) * d.hidden, c + ((size_t)i * d.n_layers + l) * d.hidden, (size_t)d.hidden * 4, hipMemcpyHostToDevice));
         }
     HIP_CHECK(hipMemcpy(step_d_, slots.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    if (f16_tile_)                              // the binary16 copy of the uploaded h rows (slots 0..n-1 of every layer)
+        for (int l = 0; l < d.n_layers; ++l) launch_cvt_f16(h_ + (size_t)l * S * d.d_model, h16_ + (size_t)l * S * d.d_model, (size_t)n * d.d_model, stream_);
     run_encoder_rows(n, step_d_, step_d_, xd);
     sync();
     for (int i = 0; i < n; ++i) {

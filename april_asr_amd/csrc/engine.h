@@ -77,7 +77,10 @@ public:
     float *weights_mut() { return w_; }        // load time only: the constructor leaves the weights unset when it is given no blob
     void finish_weights();                     // after the weights are in place (upload, copy or RCCL broadcast): derived copies (fp16)
     int precision() const { return cfg_.precision; }
-    bool tile_ok() const { return cfg_.precision == 0; }      // the GM_TILE schedule exists for fp32 operands
+    // GM_TILE for the fp32-A row-epilogue GEMMs (embed, projection, FFN down, encoder_proj, decoder projection): by the planner's
+    // occupancy rule on fp32 engines, never on fp16 engines (whose LAYER GEMMs take the fp16 tile path through lin16, always)
+    int tile_ok() const { return cfg_.precision == 0 ? 1 : 0; }
+    bool f16_tile() const { return f16_tile_; }
     const PackedLayout &layout() const { return L_; }
 
     int alloc_slot();                 // -1 when full; state zeroed (reference calloc, april_session.c:40-58)
@@ -162,6 +165,7 @@ private:
     };
     SwPlan &sw_plan(int m, int T);
     void run_sw_chain(int m, int T, bool dump_logits, const SwPlan &p);
+    void launch_rowepi(GemmArgs fused_form, size_t ws_row0, hipStream_t st);
     void run_decproj(int n, const int *d_slots, const int *row_mask, const int *run_flag, int run_gen, float *out = nullptr);
     void build_dec_table();
     void run_chain(int m, bool dump_logits);     // advance + encoder + greedy rounds with arguments that depend on m only
@@ -177,6 +181,16 @@ private:
     float *w_ = nullptr;                       // packed weights
     uint16_t *wh_ = nullptr;                   // fp16 copies of the GEMM weight sections (same offsets, in elements), precision 1 only
     void lin(GemmArgs &g, size_t off) const { if (wh_) { g.wp = wh_ + off; g.wt = 1; } else { g.wp = w_ + off; g.wt = 0; } }
+    // fp16 tile path (BASELINE configs[4]; kernels_gemm_tile.hip WT = 1): the four GEMMs of a layer read binary16 activations
+    // (written by the producing epilogues) and weights re-packed for v_mfma_f32_16x16x32_f16; every batch size takes it
+    bool f16_tile_ = false;
+    uint16_t *wx_ = nullptr;                   // x32-order binary16 copies of the layer GEMM weights (same offsets as w_)
+    uint16_t *y16_ = nullptr, *xb16_ = nullptr, *u16_ = nullptr, *ff16_ = nullptr;   // [max_batch][d_model | d_model | hidden | ffn]
+    uint16_t *h16_ = nullptr;                  // [L][slots][d_model] binary16 copy of h
+    int kzx_hr_ = 1, kzx_ff2_ = 1;             // K slabs of the projection / FFN-down GEMMs on 32-k blocks
+    void lin16(GemmArgs &g, size_t off) const { g.wp = wx_ + off; g.wt = 1; g.tile_ok = 2; }
+    int kz_hr() const { return f16_tile_ ? kzx_hr_ : kz_hr_; }
+    int kz_ff2() const { return f16_tile_ ? kzx_ff2_ : kz_ff2_; }
     float *h_ = nullptr, *c_ = nullptr, *ring_ = nullptr, *eout_ = nullptr, *dout_ = nullptr;
     GreedyState *gstate_ = nullptr;            // [slots]
     float *dec_table_ = nullptr;               // [vocab * vocab][joiner] decoder output of every context, or null (build_dec_table)

@@ -84,6 +84,10 @@ struct GemmArgs {
     int mode = GM_SLAB;                    // set by launch_gemm
     int epi = EPI_PARTIAL;
     float *out = nullptr; int ldo = 0;     // EPI_PARTIAL: workspace [planes][m_stride][N]; others: [M][ldo] (EPI_SLOT_STORE: [slots][ldo])
+    // fp16-operand engines (GM_TILE, wt == 1): activations are READ as binary16 (a0 / a1 point at binary16 rows, lda in elements)
+    // and the producing epilogues leave binary16 copies beside (or instead of: out == null) the fp32 rows, same leading dimensions
+    void *out16 = nullptr;                 // EPI_LSTM (u), EPI_BIAS_DSWISH (ff), EPI_HR (x + h'), EPI_RESID_SSQ (y)
+    void *state16 = nullptr;               // EPI_HR: binary16 copy of the h state rows [slots][ld_state]
     int m_stride = 0;
     const float *bias = nullptr;
     float *c_state = nullptr;              // EPI_LSTM: [slots][hidden] for this layer
@@ -105,8 +109,9 @@ struct GemmArgs {
     int force_fullk = 0;                   // take the full-K plan even when it yields few workgroups (latency-bound sequential steps: one launch
                                            // instead of split-K + row kernel matters more than filling the chip)
     int zcount = 1;                        // same-shape problems sharing the launch (set by stage_gemm_z): an occupancy hint for the tile planner
-    int tile_ok = 0;                       // the caller planned this GEMM with gemm_fullk / gemm_partials(..., tile_ok = true): GM_TILE may be
-                                           // chosen (plain fp32 A in one K segment, N % 64 == 0, row epilogue or partial planes)
+    int tile_ok = 0;                       // the caller planned this GEMM with gemm_fullk / gemm_partials(..., tile_ok): 1 = GM_TILE may be chosen by
+                                           // the planner's occupancy rule (fp32 A in one K segment, N % 64 == 0, row epilogue or partial planes);
+                                           // 2 = GM_TILE always (the fp16 tile path of an fp16 engine: every batch size runs the same chains)
     int skew = 0;                          // start delay (x 4096 cycles) for every second generation of workgroups
     int asm_loop = 0;                      // != 0: hand-scheduled K loop (gemm_mainloop_asm.inc) in the fused-epilogue 64x64 fp32 tiles
     unsigned long long *trace = nullptr;   // measurement only: per-workgroup s_memtime stamps [wg][8] (wave 0, lane 0)
@@ -123,10 +128,10 @@ void launch_gemm_z(const GemmArgs *staged, int n, const GemmArgs *dev_args, hipS
 // number of partial planes launch_gemm will write for an EPI_PARTIAL GEMM of this shape
 // (zcount = same-shape problems sharing a z-batched launch; tile_ok = the GM_TILE schedule is allowed for this call site:
 // callers pass the same values here and in GemmArgs::zcount / tile_ok so that both sides make the same plan)
-int gemm_partials(int M, int N, int kz, int zcount = 1, bool tile_ok = false);
+int gemm_partials(int M, int N, int kz, int zcount = 1, int tile_ok = 0);
 // true when launch_gemm runs a GEMM of this shape on the full-K schedule, i.e. the caller may (must, for the row
 // epilogues EPI_HR / EPI_RESID_SSQ / EPI_SLOT_STORE) fuse the row work; false: EPI_PARTIAL + row kernel
-bool gemm_fullk(int M, int N, int kz, bool force = false, int zcount = 1, bool tile_ok = false);
+bool gemm_fullk(int M, int N, int kz, bool force = false, int zcount = 1, int tile_ok = 0);
 // true when a tile_ok GEMM of this shape runs on the GM_TILE schedule (whose K split is a matter of occupancy, not of need)
 bool gemm_tile_planned(int M, int N, int kz, int zcount = 1);
 // measurement only (tools/tile_bench): enable -1 = environment default, 0 / 1 = off / on; mt, zs = 0 (planner's choice) or pinned
@@ -148,6 +153,7 @@ struct RowArgs {
     const int *slot_idx = nullptr;         // row -> slot for state / slot-indexed outputs
     float *state = nullptr; int ld_state = 0;   // ROW_HR: h state of this layer
     float *ssq_out = nullptr;              // ROW_RESID_SSQ
+    void *out16 = nullptr, *state16 = nullptr;   // fp16 tile engines: binary16 copies of out (ROW_HR, ROW_RESID_SSQ) and of the h state rows (ROW_HR)
     const int *row_mask = nullptr;         // ROW_SLOT_STORE
     const int *run_flag = nullptr;         // optional device word: the kernel returns at once unless it holds run_gen
     int run_gen = 1;
@@ -244,6 +250,7 @@ struct ZeroSlotArgs {
     float *eout = nullptr, *dout = nullptr; int joiner = 0;
     GreedyState *state = nullptr; int blank = 0;
     int slot = 0;
+    void *h16 = nullptr;                   // fp16 tile engines: the binary16 copy of h, zeroed too
 };
 void launch_zero_slot(const ZeroSlotArgs &a, hipStream_t s);
 
@@ -277,6 +284,10 @@ void launch_conv_embed(const ConvEmbedArgs &a, hipStream_t s);
 
 // fp32 -> fp16 (round to nearest even), elementwise; used once at load for the fp16 weight copies
 void launch_cvt_f16(const float *src, void *dst, size_t n, hipStream_t s);
+// fp32 packed weights (16-k blocks, kernels.h top) -> binary16 in the order of v_mfma_f32_16x16x32_f16's B fragment:
+//   dst[((ntile * (K / 32) + kb) * 64 + lane) * 8 + j] = W[kb * 32 + (lane >> 4) * 8 + j][ntile * 16 + (lane & 15)]
+// (one 16-byte read per lane and 32-k block; K a multiple of 32)
+void launch_repack_x32(const float *src_packed, void *dst, int K, int N, hipStream_t s);
 
 // ---------------------------------------------------------------- fbank
 struct FbankTables {                       // device pointers

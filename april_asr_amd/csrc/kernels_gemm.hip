@@ -739,13 +739,14 @@ static bool plan_fullk(int M, int N, int kz, TilePlan &t, bool force = false, in
 static int g_tile_pin_mt = env_int("APRIL_TILE_MT", 0), g_tile_pin_zs = env_int("APRIL_TILE_ZS", 0), g_tile_enable = -1;
 void gemm_tile_pin(int enable, int mt, int zs) { g_tile_enable = enable; g_tile_pin_mt = mt; g_tile_pin_zs = zs; }
 
-static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePlan &t)
+static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePlan &t, bool always = false)
 {
     static const int enabled = env_int("APRIL_GM_TILE", 1);
     static const int min_rows = env_int("APRIL_TILE_MIN_ROWS", 32);
     static const int fused_tiles = env_int("APRIL_TILE_FUSED_TILES", 512), split_tiles = env_int("APRIL_TILE_SPLIT_TILES", 256);
     const int pin_mt = g_tile_pin_mt, pin_zs = g_tile_pin_zs;
-    if (!(g_tile_enable < 0 ? enabled : g_tile_enable) || N % 64 != 0 || M < min_rows) return false;
+    if (N % 64 != 0) return false;
+    if (!always && (!(g_tile_enable < 0 ? enabled : g_tile_enable) || M < min_rows)) return false;
     const long zc = std::max(1, zcount);
     const long tiles4 = (long)(N / 64) * ((M + 63) / 64) * zc, tiles2 = (long)(N / 64) * ((M + 31) / 32) * zc;
     const int mt = pin_mt ? (pin_mt == 4 ? 4 : 2) : (tiles4 >= fused_tiles ? 4 : 2);
@@ -754,7 +755,7 @@ static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePla
     if (pin_zs > 0) { if (!force_full) zs = std::min(kz, pin_zs); }
     else if (pin_mt > 0) { /* measurement: pinned tile rows, all of K */ }
     else {
-        if (tiles2 < split_tiles) return false;          // small launches keep the round-2 schedules
+        if (tiles2 < split_tiles && !always) return false;          // small launches keep the round-2 schedules
         if (!force_full) {
             // workgroups are dealt to the 256 CUs round robin, a CU works through its share at the MFMA rate: cost = (workgroups
             // per CU) x (stages per workgroup + ~3 stages of fill / epilogue), a K cut pays the row kernel on top (~5 %).  A slab is
@@ -774,24 +775,25 @@ static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePla
 
 bool gemm_tile_planned(int M, int N, int kz, int zcount) { TilePlan t; return plan_tile(M, N, kz, zcount, false, t); }
 
-bool gemm_fullk(int M, int N, int kz, bool force, int zcount, bool tile_ok)
+bool gemm_fullk(int M, int N, int kz, bool force, int zcount, int tile_ok)
 {
     TilePlan t;
-    if (tile_ok && plan_tile(M, N, kz, zcount, force, t)) return t.zs == kz;
+    if (tile_ok && plan_tile(M, N, kz, zcount, force, t, tile_ok == 2)) return t.zs == kz;
     return plan_fullk(M, N, kz, t, force);
 }
 
 // Tile shape and slabs per workgroup.  Depends on M only through occupancy; numerics are tile-independent.
-static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = false, int zcount = 1, bool tile_ok = false, int zcount_true = 1)
+static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = false, int zcount = 1, int tile_ok = 0, int zcount_true = 1)
 {
     // measurement knobs (default 0): 1/2 = smaller tiles for the fused-epilogue GEMMs (measured slower on MI355X:
     // B=256 gates 27 -> 32..36 us, the kernel is limited by operand loads per MFMA, not by occupancy);
     // 5 = 64x32 tiles for split-K GEMMs at M > 32
     static const int tune = env_int("APRIL_GEMM_TUNE", 0);
     TilePlan t;
-    if (tile_ok && (epi == EPI_PARTIAL || epi == EPI_HR || epi == EPI_RESID_SSQ || epi == EPI_SLOT_STORE)) {
+    if (tile_ok && (epi == EPI_PARTIAL || epi == EPI_HR || epi == EPI_RESID_SSQ || epi == EPI_SLOT_STORE || epi == EPI_LSTM || epi == EPI_BIAS_DSWISH)) {
         // the caller asked gemm_fullk first: a row epilogue arrives only when that plan keeps all of K in the workgroup
-        if (plan_tile(M, N, kz, zcount_true, force_fullk || epi != EPI_PARTIAL, t)) return t;
+        if (plan_tile(M, N, kz, zcount_true, force_fullk || epi != EPI_PARTIAL, t, tile_ok == 2)) return t;
+        if (tile_ok == 2) { fprintf(stderr, "libapril(mi355x): launch_gemm: no GM_TILE plan for an always-tile GEMM (M=%d N=%d kz=%d)\n", M, N, kz); abort(); }
     }
     if (epi != EPI_LSTM && epi != EPI_BIAS_DSWISH && epi != EPI_XPART && plan_fullk(M, N, kz, t, force_fullk, zcount)) return t;
     const int ntiles = N / 16;
@@ -820,7 +822,7 @@ static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = fal
     return t;
 }
 
-int gemm_partials(int M, int N, int kz, int zcount, bool tile_ok)
+int gemm_partials(int M, int N, int kz, int zcount, int tile_ok)
 {
     const TilePlan t = plan_tiles(M, N, kz, EPI_PARTIAL, false, 1, tile_ok, zcount);
     return t.mode == GM_FULLK ? 1 : kz / t.zs;
@@ -881,7 +883,11 @@ static TilePlan finalize_gemm(GemmArgs &g)
     static const int z_tiles = env_int("APRIL_Z_TILES", 2);      // A/B: 0 = plan z-batched problems as if each had the chip to itself, 1 = hint everywhere, 2 = fused-epilogue slab tiles only, 3 = full-K tiles only
     const int zc = std::max(1, g.zcount);
     const bool is_slab_epi = g.epi == EPI_LSTM || g.epi == EPI_BIAS_DSWISH || g.epi == EPI_XPART;
-    const bool tile_ok = g.tile_ok && g.a_op == AOP_NONE && g.K1 == 0 && g.wt == 0 && g.wave_mask == 0xF && g.N % 64 == 0;
+    // GM_TILE eligibility: planner-rule GEMMs (tile_ok 1) are the fp32 row-epilogue / partial GEMMs over one A segment; always-tile
+    // GEMMs (tile_ok 2, fp16 tile engines) may also carry two segments and the LSTM / DoubleSwish epilogues
+    const bool plain = g.a_op == AOP_NONE && g.wave_mask == 0xF && g.N % 64 == 0 && !g.p_add;
+    const int tile_ok = !plain ? 0 : (g.tile_ok == 2 ? 2 : ((g.tile_ok == 1 && g.K1 == 0 && g.wt == 0 && g.epi != EPI_LSTM && g.epi != EPI_BIAS_DSWISH) ? 1 : 0));
+    if (g.tile_ok == 2 && !tile_ok) { fprintf(stderr, "libapril(mi355x): launch_gemm: always-tile GEMM with a prologue / wave mask / odd N\n"); abort(); }
     const TilePlan t = plan_tiles(g.M, g.N, g.kz, g.epi, g.force_fullk != 0, (z_tiles == 1 || (z_tiles == 2 && is_slab_epi) || (z_tiles == 3 && !is_slab_epi)) ? zc : 1, tile_ok, zc);
     const bool row_epi = g.epi == EPI_HR || g.epi == EPI_RESID_SSQ || g.epi == EPI_SLOT_STORE;
     if (row_epi && t.zs != g.kz) { fprintf(stderr, "libapril(mi355x): launch_gemm: row epilogue %d needs the full-K plan (M=%d N=%d kz=%d)\n", g.epi, g.M, g.N, g.kz); abort(); }

@@ -23,6 +23,14 @@
 //   B: [2 k blocks][4 n tiles][1 KB] in the packed weight order, i.e. already the B fragment of every lane.
 // Four stage buffers, ONE s_barrier per stage, placed between the stage's two k blocks (see the K loop): counted vmcnt keeps
 // two to three stages of DMA in flight, the fragments of the next k block are read from LDS while the current MFMAs issue.
+// WT = 1 (fp16-operand mode, BASELINE configs[4]): the same kernel on binary16 operands -- a k block is 32 k
+// (v_mfma_f32_16x16x32_f16, the gfx950 shape; fp32 accumulate), weights packed per (n tile, 32-k block) as the B fragment of
+// that instruction, activations READ as binary16 (written by the producing epilogue: out16 / state16), so a stage is again
+// 128 bytes per activation row and 1 KB per weight piece and everything above holds unchanged.  The summation structure
+// (chunks, slabs, tree) is the same; the chains are MFMA-internal sums of 32 products instead of in-order fp32 FMAs.
+// Epilogues: the row epilogues and partial planes, plus (for the gates and FFN-up GEMMs of fp16 engines, and for
+// measurements in fp32) EPI_LSTM over two A segments [y | h(slot)] with the BasicNorm scale folded in after the second
+// chunk, and EPI_BIAS_DSWISH.
 // Replaces the ORT MatMul nodes inside the encoder / joiner graphs (reference call sites src/april_session.c:145,176).
 #include "kernels.h"
 #include "device_utils.h"
@@ -56,13 +64,18 @@ template <int N> __device__ __forceinline__ void wait_vm()
     __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
 }
 
-template <int MT, int EPI>
+using h4 = __attribute__((ext_vector_type(4))) _Float16;
+using h8 = __attribute__((ext_vector_type(8))) _Float16;
+__device__ __forceinline__ h4 to_h4(const f32x4 &v) { return h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; }
+
+template <int MT, int EPI, int WT>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
 {
     using G = TileGeom<MT>;
     constexpr int BM = G::BM, MTW = G::MTW, NTH = 256, LDR = TILE_LDR;
+    constexpr int KBLK = WT ? 32 : 16, AE = WT ? 2 : 4;          // k per k block, bytes per activation element
     constexpr bool ROW_EPI = EPI == EPI_HR || EPI == EPI_RESID_SSQ || EPI == EPI_SLOT_STORE;
-    static_assert(ROW_EPI || EPI == EPI_PARTIAL, "GM_TILE serves the row epilogues and partial planes");
+    static_assert(ROW_EPI || EPI == EPI_PARTIAL || EPI == EPI_LSTM || EPI == EPI_BIAS_DSWISH, "no GM_TILE form of this epilogue");
     extern __shared__ __attribute__((aligned(1024))) float red[];
     char *lds = reinterpret_cast<char *>(red);
 
@@ -72,7 +85,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
     const int wm = wave >> 1, wn = wave & 1;
     const int n0 = blockIdx.x * TILE_BN;                 // first output column
     const int m0 = blockIdx.y * BM;
-    const int KB = g.K >> 4;
+    const int KB = g.K / KBLK;
     const int c = KB / (4 * g.kz);                       // k blocks per chunk
     const int T = 4 * c * g.zs;                          // k blocks of this workgroup (even)
     const int first_kb = zg * T;
@@ -81,7 +94,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
     // ---- BasicNorm scales of the tile's rows (EPI_HR: residual; EPI_SLOT_STORE: the whole sum), as in gemm_body: the partials
     // make one trip from global memory at kernel start and are added up after the K loop
     const RowScale &rsc = EPI == EPI_HR ? g.r_scale : g.x_scale;
-    const bool NEED_SCL = (EPI == EPI_HR || EPI == EPI_SLOT_STORE) && rsc.ssq != nullptr;
+    const bool NEED_SCL = (EPI == EPI_HR || EPI == EPI_SLOT_STORE || EPI == EPI_LSTM) && rsc.ssq != nullptr;
     float *scl = red + G::LDS_MAIN / 4;
     float stg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int TPR = NTH / BM;
@@ -97,28 +110,46 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
     }
 
     // ---- DMA pieces of this wave: piece P = wave + 4 i; P < 2 MT: activation rows 8 P .. 8 P + 7 (lane -> row P 8 + (lane >> 3),
-    // 16-byte segment lane & 7 of the stage's 128 bytes, swizzled); otherwise weight piece (k block p, n tile nt) of the stage
-    const char *src[G::PPW];
+    // 16-byte segment lane & 7 of the stage's 128 bytes, swizzled); otherwise weight piece (k block p, n tile nt) of the stage.
+    // The activations may come in two K segments (gates: [y | h(slot)], K0 a multiple of the stage's 2 KBLK k): the piece
+    // pointers switch to segment 1 at stage `seg1_stage` of this workgroup.
+    const char *src[G::PPW], *src1[G::PPW];
     int inc[G::PPW], dst[G::PPW];
+    const int k_begin = first_kb * KBLK;
+    const bool two_seg = g.K1 > 0;
+    const bool start_in_1 = two_seg && k_begin >= g.K0;
+    const int seg1_stage = (two_seg && !start_in_1) ? (g.K0 - k_begin) / (2 * KBLK) : 0x7fffffff;
     {
-        int arows[G::PPW];
+        int arows[G::PPW], arows1[G::PPW];
 #pragma unroll
         for (int i = 0; i < G::PPW; ++i) {
             const int P = wave + 4 * i;
             int row = m0 + P * 8 + (lane >> 3);
             arows[i] = row >= g.M ? g.M - 1 : row;       // padding rows recompute the last row; never stored
+            arows1[i] = arows[i];
         }
         if (g.aidx0) {                                    // row -> slot indirections, one round trip for all pieces
 #pragma unroll
             for (int i = 0; i < G::PPW; ++i) if (wave + 4 * i < 2 * MT) arows[i] = g.aidx0[arows[i]];
         }
+        if (two_seg && g.aidx1) {
+#pragma unroll
+            for (int i = 0; i < G::PPW; ++i) if (wave + 4 * i < 2 * MT) arows1[i] = g.aidx1[arows1[i]];
+        }
 #pragma unroll
         for (int i = 0; i < G::PPW; ++i) {
             const int P = wave + 4 * i;
+            src1[i] = nullptr;
             if (P < 2 * MT) {
                 const int R = P * 8 + (lane >> 3);
                 const int gseg = (lane & 7) ^ ((R >> 1) & 7);
-                src[i] = reinterpret_cast<const char *>(g.a0) + ((size_t)arows[i] * g.lda0 + (size_t)first_kb * 16 + gseg * 4) * sizeof(float);
+                const char *p0 = reinterpret_cast<const char *>(g.a0) + ((size_t)arows[i] * g.lda0 + (size_t)k_begin) * AE + gseg * 16;
+                if (two_seg) {
+                    const char *p1 = reinterpret_cast<const char *>(g.a1) + (size_t)arows1[i] * g.lda1 * AE + gseg * 16;
+                    src1[i] = p1;
+                    if (start_in_1) p0 = p1 + (size_t)(k_begin - g.K0) * AE;
+                }
+                src[i] = p0;
                 inc[i] = 128; dst[i] = P * 1024;
             } else {
                 const int q = P - 2 * MT, p = q >> 2, nt = q & 3;
@@ -127,8 +158,14 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
             }
         }
     }
+    int issued = 0;
     auto issue = [&](int buf) {
         if (g.debug == 4) return;                          // measurement: no DMA (the MFMA + LDS read loop alone, on stale LDS contents)
+        if (issued == seg1_stage) {
+#pragma unroll
+            for (int i = 0; i < G::PPW; ++i) if (wave + 4 * i < 2 * MT) src[i] = src1[i];
+        }
+        ++issued;
 #pragma unroll
         for (int i = 0; i < G::PPW; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i]),
@@ -158,6 +195,40 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
         }
     }
 
+    // EPI_LSTM: this thread's (row, hidden unit) pairs: slot -> previous cell value and the gate biases, fetched up front
+    // (columns are unit-major: the 4-column quad = gates i, f, g, o of one unit)
+    int l_unit[EPI == EPI_LSTM ? QPT : 1], l_m[EPI == EPI_LSTM ? QPT : 1];
+    bool l_ok[EPI == EPI_LSTM ? QPT : 1];
+    float *l_cptr[EPI == EPI_LSTM ? QPT : 1];
+    float l_cprev[EPI == EPI_LSTM ? QPT : 1];
+    f32x4 l_bias[(EPI == EPI_LSTM || EPI == EPI_BIAS_DSWISH) ? QPT : 1];
+    if (EPI == EPI_LSTM) {
+        int qslot[QPT];
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * NTH;
+            int r = m0 + q / QROW;
+            l_m[i] = r;
+            l_ok[i] = q < NQ && r < g.M;
+            if (r >= g.M) r = g.M - 1;
+            qslot[i] = g.slot_idx[r];
+        }
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * NTH;
+            const int n = n0 + (q % QROW) * 4;
+            l_unit[i] = n >> 2;
+            l_cptr[i] = g.c_state + (size_t)qslot[i] * g.hidden + l_unit[i];      // (padding rows point at the last row's cell: read, never stored)
+            l_bias[i] = *reinterpret_cast<const f32x4 *>(g.bias + n);
+        }
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) l_cprev[i] = *l_cptr[i];
+    }
+    if (EPI == EPI_BIAS_DSWISH) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) l_bias[i] = *reinterpret_cast<const f32x4 *>(g.bias + n0 + ((threadIdx.x + i * NTH) % QROW) * 4);
+    }
+
     // ---- fragment addresses inside a stage buffer
     const int mrow = lane & 15, kq = lane >> 4;
     int a_rd[2];                                          // k block p of the stage: row mrow, segment (4 p + kq) ^ ((mrow >> 1) & 7)
@@ -174,28 +245,69 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
     int top = 0;
     while ((1 << top) < g.zs) ++top;
     int chunk_i = 0, slab_done = 0, in_chunk = 0;
+    // EPI_LSTM with x_scale: x = y * scale(y) entered the GEMM as y, the first two chunks are exactly the y half of K (kz = 1,
+    // K0 = K / 2, checked on the host): ((c0 + c1) * scale + c2) + c3, the scale of this lane's accumulator rows held in registers
+    float xrs[MTW][4];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xrs[mt][r] = 1.0f;
+    const bool fold_scale = EPI == EPI_LSTM && NEED_SCL;
     auto chunk_end = [&]() {
         if (chunk_i == 0) { APRIL_TILE_EACH(S[mt][nt] = acc[mt][nt]) }
         else { APRIL_TILE_EACH(S[mt][nt] = S[mt][nt] + acc[mt][nt]) }
+        if (EPI == EPI_LSTM && fold_scale && chunk_i == 1) {
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) S[mt][nt][r] = S[mt][nt][r] * xrs[mt][r];
+        }
         APRIL_TILE_EACH(acc[mt][nt] = (f32x4{0.f, 0.f, 0.f, 0.f}))
         if (++chunk_i == 4) {                             // slab complete: S = ((c0 + c1) + c2) + c3 enters the pairwise tree (binary counter)
             chunk_i = 0;
             bool done = false;                            // true once the value has been parked in a level
-            if (top > 0) {
+            constexpr bool TREE = !(EPI == EPI_LSTM || EPI == EPI_BIAS_DSWISH);      // (those GEMMs have one slab: kz = 1)
+            if (TREE && top > 0) {
                 if (slab_done & 1) { APRIL_TILE_EACH(S[mt][nt] = lvl0[mt][nt] + S[mt][nt]) }
                 else { APRIL_TILE_EACH(lvl0[mt][nt] = S[mt][nt]) done = true; }
             }
-            if (!done && top > 1) {
+            if (TREE && !done && top > 1) {
                 if (slab_done & 2) { APRIL_TILE_EACH(S[mt][nt] = lvl1[mt][nt] + S[mt][nt]) }
                 else { APRIL_TILE_EACH(lvl1[mt][nt] = S[mt][nt]) done = true; }
             }
-            if (!done && top > 2) {
+            if (TREE && !done && top > 2) {
                 if (slab_done & 4) { APRIL_TILE_EACH(S[mt][nt] = lvl2[mt][nt] + S[mt][nt]) }
                 else { APRIL_TILE_EACH(lvl2[mt][nt] = S[mt][nt]) done = true; }
             }
             if (!done) { APRIL_TILE_EACH(res[mt][nt] = S[mt][nt]) }      // all zs slabs of this workgroup are in
             ++slab_done;
         }
+    };
+
+    // the rows' BasicNorm scales: partials (in registers since the first instruction of the kernel) -> LDS, BM threads add them in
+    // column order (the order of row_scale()); rows are padded to G + 1 floats (conflict-free column walks)
+    auto compute_scl = [&]() {
+        const int Gn = rsc.groups;
+        float *part = scl + BM;
+        if (staged) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k < ppt && sj0 + k < Gn) part[srow * (Gn + 1) + sj0 + k] = stg[k];
+        } else {
+            for (int i = threadIdx.x; i < BM * Gn; i += NTH) {
+                int r = m0 + i / Gn;
+                if (r >= g.M) r = g.M - 1;
+                part[(i / Gn) * (Gn + 1) + i % Gn] = rsc.ssq[(size_t)r * Gn + i % Gn];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < BM) {
+            float t = 0.0f;
+            for (int j = 0; j < Gn; ++j) t += part[threadIdx.x * (Gn + 1) + j];
+            scl[threadIdx.x] = __builtin_amdgcn_rsqf(t * rsc.inv_n + rsc.eps);
+        }
+        __syncthreads();
     };
 
     // ---- K loop.  Stage s = k blocks (2 s, 2 s + 1) of the workgroup's range, buffer s % NS.  The fragments of the NEXT k block
@@ -206,6 +318,15 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
         constexpr int NS = TILE_STAGES;
 #pragma unroll
         for (int i = 0; i < NS - 1; ++i) if (i < nstage) issue(i);
+        if (EPI == EPI_LSTM && fold_scale) {
+            // the scales are needed INSIDE the loop (after the second chunk): reduce them now, behind the first DMA stages (the
+            // compiler settles every outstanding memory operation here, which the first stage needs anyway)
+            compute_scl();
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xrs[mt][r] = scl[(wm * MTW + mt) * 16 + (lane >> 4) * 4 + r];
+        }
         // stage 0 landed: at most the NS - 2 younger stages may still be in flight
         if (nstage >= NS - 1) wait_vm<(NS - 2) * G::PPW>(); else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
@@ -226,13 +347,22 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
             }
             // k step outermost: consecutive MFMAs go to different accumulators (a dependent MFMA issues 8 cycles late); per
             // accumulator the order is k = j, j + 4, j + 8, j + 12 inside the MFMA, j = 0..3 across MFMAs: the canonical chain
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
+            if constexpr (WT == 1) {
+                // one v_mfma_f32_16x16x32_f16 per tile and k block: lane (i, kq) holds k = 8 kq .. 8 kq + 7 of the block for A and B alike
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a[mt]), __builtin_bit_cast(h8, b[nt]), acc[mt][nt], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
+            }
         };
         read_frags(lds, 0, a0, b0);
         int buf = 0;
@@ -276,27 +406,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
         v[i] = q < NQ ? *reinterpret_cast<const f32x4 *>(red + (q / QROW) * LDR + (q % QROW) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    if (NEED_SCL) {
-        const int Gn = rsc.groups;
-        float *part = scl + BM;
-        if (staged) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (k < ppt && sj0 + k < Gn) part[srow * (Gn + 1) + sj0 + k] = stg[k];
-        } else {
-            for (int i = threadIdx.x; i < BM * Gn; i += NTH) {
-                int r = m0 + i / Gn;
-                if (r >= g.M) r = g.M - 1;
-                part[(i / Gn) * (Gn + 1) + i % Gn] = rsc.ssq[(size_t)r * Gn + i % Gn];
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < BM) {
-            float t = 0.0f;
-            for (int j = 0; j < Gn; ++j) t += part[threadIdx.x * (Gn + 1) + j];
-            scl[threadIdx.x] = __builtin_amdgcn_rsqf(t * rsc.inv_n + rsc.eps);
-        }
-        __syncthreads();
-    }
+    if (NEED_SCL && EPI != EPI_LSTM) compute_scl();
 
     if (EPI == EPI_PARTIAL) {
 #pragma unroll
@@ -313,8 +423,11 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
             const int m = m0 + q / QROW, n = n0 + (q % QROW) * 4;
             if (e_ok[i]) {
                 const float rs = scl[q / QROW];
+                const f32x4 o = e_res[i] * rs + v[i];
                 *reinterpret_cast<f32x4 *>(g.state + (size_t)e_slot[i] * g.ld_state + n) = v[i];
-                *reinterpret_cast<f32x4 *>(g.out + (size_t)m * g.ldo + n) = e_res[i] * rs + v[i];
+                *reinterpret_cast<f32x4 *>(g.out + (size_t)m * g.ldo + n) = o;
+                if (g.state16) *reinterpret_cast<h4 *>(reinterpret_cast<_Float16 *>(g.state16) + (size_t)e_slot[i] * g.ld_state + n) = to_h4(v[i]);
+                if (g.out16) *reinterpret_cast<h4 *>(reinterpret_cast<_Float16 *>(g.out16) + (size_t)m * g.ldo + n) = to_h4(o);
             }
         }
     } else if (EPI == EPI_RESID_SSQ) {
@@ -328,11 +441,12 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
                 y = v[i] + e_bias[i];
                 if (g.resid) y = e_res[i] + y;
                 *reinterpret_cast<f32x4 *>(g.out + (size_t)m * g.ldo + n) = y;
+                if (g.out16) *reinterpret_cast<h4 *>(reinterpret_cast<_Float16 *>(g.out16) + (size_t)m * g.ldo + n) = to_h4(y);
             }
             const float ss = granule_ssq(y);               // all lanes take part in the shuffles
             if (ok && (q & 7) == 0) g.ssq_out[(size_t)m * (g.N / SSQ_COLS) + n / SSQ_COLS] = ss;
         }
-    } else {   // EPI_SLOT_STORE
+    } else if (EPI == EPI_SLOT_STORE) {
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
             const int q = threadIdx.x + i * NTH;
@@ -340,32 +454,59 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
             if (e_ok[i])
                 *reinterpret_cast<f32x4 *>(g.out + (size_t)e_slot[i] * g.ldo + n) = NEED_SCL ? v[i] * scl[q / QROW] + e_bias[i] : v[i] + e_bias[i];
         }
+    } else if (EPI == EPI_BIAS_DSWISH) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * NTH;
+            const int m = m0 + q / QROW, n = n0 + (q % QROW) * 4;
+            if (q < NQ && m < g.M) {
+                const f32x4 y = v[i] + l_bias[i];
+                f32x4 o;
+                o.x = y.x * fast_sigmoid(y.x - 1.0f); o.y = y.y * fast_sigmoid(y.y - 1.0f);
+                o.z = y.z * fast_sigmoid(y.z - 1.0f); o.w = y.w * fast_sigmoid(y.w - 1.0f);
+                if (g.out) *reinterpret_cast<f32x4 *>(g.out + (size_t)m * g.ldo + n) = o;
+                if (g.out16) *reinterpret_cast<h4 *>(reinterpret_cast<_Float16 *>(g.out16) + (size_t)m * g.ldo + n) = to_h4(o);
+            }
+        }
+    } else {   // EPI_LSTM: the quad = gates i, f, g, o of one hidden unit; the BasicNorm scale of the y half was folded in after chunk 1
+        // (every load this epilogue depends on was issued before the K loop: nothing below waits on memory while stores are in flight)
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const f32x4 gt = v[i] + l_bias[i];
+            const float c_new = fast_sigmoid(gt.y) * l_cprev[i] + fast_sigmoid(gt.x) * fast_tanh(gt.z);
+            const float u = fast_sigmoid(gt.w) * fast_tanh(c_new);
+            if (l_ok[i]) {
+                *l_cptr[i] = c_new;
+                if (g.out) g.out[(size_t)l_m[i] * g.ldo + l_unit[i]] = u;
+                if (g.out16) reinterpret_cast<_Float16 *>(g.out16)[(size_t)l_m[i] * g.ldo + l_unit[i]] = (_Float16)u;
+            }
+        }
     }
 }
 
-template <int MT, int EPI>
+template <int MT, int EPI, int WT>
 __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs g)
 {
-    gemm_tile_body<MT, EPI>(g, (int)blockIdx.z);
+    gemm_tile_body<MT, EPI, WT>(g, (int)blockIdx.z);
 }
 
 // n independent same-shape problems in one launch (see gemm_f32_zkernel): blockIdx.z / zdiv picks the argument block
-template <int MT, int EPI>
+template <int MT, int EPI, int WT>
 __global__ __launch_bounds__(256, 2) void gemm_tile_zkernel(const GemmArgs *__restrict__ zargs, int zdiv)
 {
     const int zl = (int)blockIdx.z / zdiv;
     const GemmArgs g = zargs[zl];
-    gemm_tile_body<MT, EPI>(g, (int)blockIdx.z - zl * zdiv);
+    gemm_tile_body<MT, EPI, WT>(g, (int)blockIdx.z - zl * zdiv);
 }
 
 template <int MT> size_t tile_lds_bytes(const GemmArgs &g)
 {
     using G = TileGeom<MT>;
-    const int sg = g.epi == EPI_HR ? g.r_scale.groups : (g.epi == EPI_SLOT_STORE && g.x_scale.ssq ? g.x_scale.groups : 0);
+    const int sg = g.epi == EPI_HR ? g.r_scale.groups : ((g.epi == EPI_SLOT_STORE || g.epi == EPI_LSTM) && g.x_scale.ssq ? g.x_scale.groups : 0);
     return (size_t)G::LDS_MAIN + (size_t)(G::BM + (sg ? G::BM * (sg + 1) : 0)) * sizeof(float);
 }
 
-template <int MT, int EPI>
+template <int MT, int EPI, int WT>
 void launch_tile_one(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s)
 {
     using G = TileGeom<MT>;
@@ -374,22 +515,24 @@ void launch_tile_one(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStre
     const size_t lds = tile_lds_bytes<MT>(g);
     static bool attr_set = false;                        // (per instantiation) dynamic LDS beyond 64 KB has to be announced
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tile_kernel<MT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tile_zkernel<MT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tile_kernel<MT, EPI, WT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tile_zkernel<MT, EPI, WT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (dev_args) hipLaunchKernelGGL((gemm_tile_zkernel<MT, EPI>), grid, dim3(256), lds, s, dev_args, zdiv);
-    else hipLaunchKernelGGL((gemm_tile_kernel<MT, EPI>), grid, dim3(256), lds, s, g);
+    if (dev_args) hipLaunchKernelGGL((gemm_tile_zkernel<MT, EPI, WT>), grid, dim3(256), lds, s, dev_args, zdiv);
+    else hipLaunchKernelGGL((gemm_tile_kernel<MT, EPI, WT>), grid, dim3(256), lds, s, g);
 }
 
-template <int MT>
+template <int MT, int WT>
 bool dispatch_tile(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s)
 {
     switch (g.epi) {
-    case EPI_PARTIAL: launch_tile_one<MT, EPI_PARTIAL>(g, dev_args, n, s); return true;
-    case EPI_HR: launch_tile_one<MT, EPI_HR>(g, dev_args, n, s); return true;
-    case EPI_RESID_SSQ: launch_tile_one<MT, EPI_RESID_SSQ>(g, dev_args, n, s); return true;
-    case EPI_SLOT_STORE: launch_tile_one<MT, EPI_SLOT_STORE>(g, dev_args, n, s); return true;
+    case EPI_PARTIAL: launch_tile_one<MT, EPI_PARTIAL, WT>(g, dev_args, n, s); return true;
+    case EPI_HR: launch_tile_one<MT, EPI_HR, WT>(g, dev_args, n, s); return true;
+    case EPI_RESID_SSQ: launch_tile_one<MT, EPI_RESID_SSQ, WT>(g, dev_args, n, s); return true;
+    case EPI_SLOT_STORE: launch_tile_one<MT, EPI_SLOT_STORE, WT>(g, dev_args, n, s); return true;
+    case EPI_LSTM: launch_tile_one<MT, EPI_LSTM, WT>(g, dev_args, n, s); return true;
+    case EPI_BIAS_DSWISH: launch_tile_one<MT, EPI_BIAS_DSWISH, WT>(g, dev_args, n, s); return true;
     default: return false;
     }
 }
@@ -400,8 +543,9 @@ bool dispatch_tile(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream
 void launch_gemm_tile(const GemmArgs &g, int mt, const GemmArgs *dev_args, int n, hipStream_t s)
 {
     bool ok = false;
-    if (mt == 4) ok = dispatch_tile<4>(g, dev_args, n, s);
-    else if (mt == 2) ok = dispatch_tile<2>(g, dev_args, n, s);
+    if (g.wt == 1) { if (mt == 4) ok = dispatch_tile<4, 1>(g, dev_args, n, s); else if (mt == 2) ok = dispatch_tile<2, 1>(g, dev_args, n, s); }
+    else if (mt == 4) ok = dispatch_tile<4, 0>(g, dev_args, n, s);
+    else if (mt == 2) ok = dispatch_tile<2, 0>(g, dev_args, n, s);
     if (!ok) { fprintf(stderr, "libapril(mi355x): launch_gemm_tile: no kernel for epi %d tile rows %d\n", g.epi, 16 * mt); abort(); }
 }
 

@@ -11,6 +11,7 @@
 
 namespace aprilx {
 
+using h4 = __attribute__((ext_vector_type(4))) _Float16;
 __device__ __forceinline__ float sigmoid_dev(float x) { return fast_sigmoid(x); }
 __device__ __forceinline__ float dswish_dev(float y) { return y * sigmoid_dev(y - 1.0f); }
 
@@ -40,8 +41,11 @@ __device__ __forceinline__ void row_body(const RowArgs &r)
         if (MODE == ROW_HR) {
             if (ok) {
                 const f32x4 y = *reinterpret_cast<const f32x4 *>(r.resid + (size_t)m * r.ldr + n);
+                const f32x4 o = y * rs + s;
                 *reinterpret_cast<f32x4 *>(r.state + (size_t)slot * r.ld_state + n) = s;
-                *reinterpret_cast<f32x4 *>(r.out + (size_t)m * r.ldo + n) = y * rs + s;
+                *reinterpret_cast<f32x4 *>(r.out + (size_t)m * r.ldo + n) = o;
+                if (r.state16) *reinterpret_cast<h4 *>(reinterpret_cast<_Float16 *>(r.state16) + (size_t)slot * r.ld_state + n) = h4{(_Float16)s.x, (_Float16)s.y, (_Float16)s.z, (_Float16)s.w};
+                if (r.out16) *reinterpret_cast<h4 *>(reinterpret_cast<_Float16 *>(r.out16) + (size_t)m * r.ldo + n) = h4{(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
             }
         } else if (MODE == ROW_RESID_SSQ) {
             f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -49,6 +53,7 @@ __device__ __forceinline__ void row_body(const RowArgs &r)
                 y = s + *reinterpret_cast<const f32x4 *>(r.bias + n);
                 if (r.resid) y = *reinterpret_cast<const f32x4 *>(r.resid + (size_t)m * r.ldr + n) + y;
                 *reinterpret_cast<f32x4 *>(r.out + (size_t)m * r.ldo + n) = y;
+                if (r.out16) *reinterpret_cast<h4 *>(reinterpret_cast<_Float16 *>(r.out16) + (size_t)m * r.ldo + n) = h4{(_Float16)y.x, (_Float16)y.y, (_Float16)y.z, (_Float16)y.w};
             }
             const float ss = granule_ssq(y);           // every lane takes part in the shuffles
             if (ok && (q & 7) == 0) r.ssq_out[(size_t)m * (r.N / SSQ_COLS) + n / SSQ_COLS] = ss;
@@ -280,6 +285,7 @@ __global__ __launch_bounds__(256) void zero_slot_kernel(ZeroSlotArgs a)
     if (l < a.n_layers) {
         float *h = a.h + ((size_t)l * a.slots + s) * a.d_model, *c = a.c + ((size_t)l * a.slots + s) * a.hidden;
         for (int i = threadIdx.x; i < a.d_model; i += 256) h[i] = 0.0f;
+        if (a.h16) { _Float16 *hh = reinterpret_cast<_Float16 *>(a.h16) + ((size_t)l * a.slots + s) * a.d_model; for (int i = threadIdx.x; i < a.d_model; i += 256) hh[i] = (_Float16)0.0f; }
         for (int i = threadIdx.x; i < a.hidden; i += 256) c[i] = 0.0f;
     } else {
         for (int i = threadIdx.x; i < a.joiner; i += 256) { a.eout[s * a.joiner + i] = 0.0f; a.dout[s * a.joiner + i] = 0.0f; }
@@ -430,6 +436,28 @@ void launch_cvt_f16(const float *src, void *dst, size_t n, hipStream_t s)
 {
     const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
     hipLaunchKernelGGL(cvt_f16_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, src, reinterpret_cast<_Float16 *>(dst), n);
+}
+
+// one thread per output element: (ntile, 32-k block, lane, j) of the x32 B-fragment order <- the fp32 16-k-block pack
+__global__ __launch_bounds__(256) void repack_x32_kernel(const float *src, _Float16 *dst, int K, int N)
+{
+    const size_t total = (size_t)K * N;
+    const int KB32 = K / 32, KB16 = K / 16;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        const int j = (int)(o & 7), lane = (int)((o >> 3) & 63);
+        const size_t blk = o >> 9;                           // ntile * KB32 + kb
+        const int kb = (int)(blk % KB32), ntile = (int)(blk / KB32);
+        const int k = kb * 32 + (lane >> 4) * 8 + j, n16 = lane & 15;
+        // fp32 pack: Wp[((ntile * KB16 + k / 16) * 64 + ((k % 16) / 4) * 16 + n16) * 4 + k % 4]
+        dst[o] = (_Float16)src[(((size_t)ntile * KB16 + (k >> 4)) * 64 + ((k & 15) >> 2) * 16 + n16) * 4 + (k & 3)];
+    }
+}
+
+void launch_repack_x32(const float *src_packed, void *dst, int K, int N, hipStream_t s)
+{
+    const size_t n = (size_t)K * N;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 65535);
+    hipLaunchKernelGGL(repack_x32_kernel, dim3(blocks), dim3(256), 0, s, src_packed, reinterpret_cast<_Float16 *>(dst), K, N);
 }
 
 }  // namespace aprilx

@@ -31,6 +31,72 @@ HBM_PEAK_GBS = 8000.0              # spec; ~6300 measured achievable
 TRAFFIC_JSON = "r02c_gates_traffic.json"      # the committed PMC pass the roofline's `traffic` is taken from
 
 
+def config5_leg(args, A, SM, torch, np):
+    """BASELINE configs[4]: larger encoder (icefall lstm-transducer-stateless2-sized: 16 layers, d 768, cell 1536, ffn 3072),
+    512 concurrent sessions on one GPU, fp16 MFMA path -- and the same model in fp32 beside it."""
+    step_samples = 1600
+    counts = np.zeros(6, np.uint64)
+    lpath = os.environ.get("APRIL_MODEL_LARGE") or os.path.join(tempfile.gettempdir(), "bench_large_synth.april")
+    if not os.path.exists(lpath):
+        SM.write_model(lpath, SM.LARGE_DIMS)
+    nb5, wu5, ts5 = 512, 6, 20
+    config5 = {"sessions": nb5, "dims": "large (16 layers, d_model 768, cell 1536, ffn 3072; synthetic seeded weights)", "feed_ms": 100, "steps": ts5}
+    prev = os.environ.get("APRIL_PRECISION")
+    for prec in ("f16", "f32"):
+        os.environ["APRIL_PRECISION"] = prec
+        m5 = A.Model(lpath)
+        s5 = [A.Session(m5, None, counters=counts) for _ in range(nb5)]
+        g5 = A.SessionGroup(s5)
+        pp = [SM.lcg_pcm16(step_samples * (wu5 + ts5), seed=12345 + 40_000_000 + i) for i in range(nb5)]
+        g5.plan(pp, step_samples)
+        for s in range(wu5):
+            g5.feed_planned(s)
+        torch.cuda.synchronize(); a = time.perf_counter()
+        for s in range(wu5, wu5 + ts5):
+            g5.feed_planned(s)
+        torch.cuda.synchronize(); b = time.perf_counter()
+        ms = (b - a) / ts5 * 1e3
+        leg = {"ms_per_step": round(ms, 3), "rtf": round(ms / 100.0, 5), "audio_s_per_s": round(nb5 * 0.1 / (ms * 1e-3), 1), "params": int(m5.dims.param_count)}
+        # gates GEMM of this model by the engine's hipEvents: priced against the MFMA peak of the precision AND against HBM
+        dd = m5.dims
+        before = m5.stats()
+        more = [SM.lcg_pcm16(step_samples * args.profile_steps, seed=12345 + 50_000_000 + i) for i in range(nb5)]
+        m5.profile(True)
+        g5.plan(more, step_samples)
+        for s in range(args.profile_steps):
+            g5.feed_planned(s)
+        sp_ = m5.stats()
+        m5.profile(False)
+        launches = sp_.kernel_launches[0]
+        if launches:
+            avg_ms = sp_.kernel_ms[0] / launches
+            rows_per_launch = (sp_.chunks - before.chunks) * dd.n_layers / launches
+            layers_per_launch = max(1.0, rows_per_launch / nb5)
+            flops = 2.0 * rows_per_launch * (2 * dd.d_model) * (4 * dd.hidden)
+            esz = 2 if dd.precision == 1 else 4
+            wbytes = (2 * dd.d_model) * (4 * dd.hidden) * esz * layers_per_launch
+            sbytes = rows_per_launch * (dd.d_model * esz * 2 + dd.hidden * 4 * 2 + dd.hidden * esz)      # x,h read; c read+write; u write
+            tf = flops / (avg_ms * 1e-3) / 1e12
+            peak = FP16_MFMA_PEAK_TFLOPS if dd.precision == 1 else FP32_MFMA_PEAK_TFLOPS
+            gbs = (wbytes + sbytes) / (avg_ms * 1e-3) / 1e9
+            leg["gates_gemm"] = {"avg_launch_us": round(avg_ms * 1e3, 2), "rows_per_launch": round(rows_per_launch, 1), "tflops": round(tf, 1),
+                                 "frac_of_mfma_peak": round(tf / peak, 4), "mfma_peak_tflops": peak, "algorithmic_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                                 "class_ms": {k: round(sp_.kernel_ms[i], 3) for i, k in enumerate(["gates", "gemm_other", "row", "conv", "fbank", "dec_joint"])}}
+        leg["replay_mismatch"] = int(m5.stats().replay_mismatch)
+        config5[prec] = leg
+        for s_ in s5:
+            s_.close()
+        m5.close()
+    if prev is None:
+        del os.environ["APRIL_PRECISION"]
+    else:
+        os.environ["APRIL_PRECISION"] = prev
+    config5["f16_speedup_vs_f32"] = round(config5["f32"]["ms_per_step"] / config5["f16"]["ms_per_step"], 3)
+    config5["bound"] = ("fp16: with 64 x 64 tiles a k block moves 8 KB through LDS for 64 SIMD cycles of MFMA, so the step is bound by the "
+                        "CU's L2 -> LDS operand traffic (and the fixed costs of ~70 launches per feed), not by the matrix pipe or HBM; see DESIGN.md")
+    return config5
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -41,6 +107,7 @@ def main():
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--steady-steps", type=int, default=200, help="length of the fixed steady-state series reported next to the driver's K steps (0 = skip)")
+    ap.add_argument("--config5-only", action="store_true", help="measurement aid: run only the configs[4] leg and print its object")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] leg (larger encoder, 512 sessions, fp16 MFMA path vs fp32)")
     ap.add_argument("--precision", choices=["f32", "f16"], default="f32",
                     help="f16 = opt-in fp16-operand mode (BASELINE configs[4]); the headline metric is quoted on f32")
@@ -68,6 +135,9 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.config5_only:
+        print(json.dumps(config5_leg(args, A, SM, torch, np)), flush=True)
+        return
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -328,44 +398,12 @@ def main():
                    "frac_of_hbm_peak_if_restreamed": round(wbytes * nchunks / (b - a) / 1e9 / HBM_PEAK_GBS, 4),
                    "note": "recurrent weights (gate h-half + projection, 10 MB per layer) are re-read every time step from the Infinity Cache (120 MB for 12 layers)"}
 
-    # ---------------- BASELINE configs[4]: larger encoder (icefall lstm-transducer-stateless2-sized: 16 layers, d 768, cell 1536,
-    # ffn 3072), 512 concurrent sessions on one GPU, fp16 MFMA path -- and the same model in fp32 beside it
+    # ---------------- BASELINE configs[4]: larger encoder, 512 sessions, fp16 MFMA path (and the same model in fp32)
     config5 = None
     if rank == 0 and world == 1 and not args.no_config5:
         model.close()
         model = None
-        lpath = os.environ.get("APRIL_MODEL_LARGE") or os.path.join(tempfile.gettempdir(), "bench_large_synth.april")
-        if not os.path.exists(lpath):
-            SM.write_model(lpath, SM.LARGE_DIMS)
-        nb5, wu5, ts5 = 512, 6, 20
-        config5 = {"sessions": nb5, "dims": "large (16 layers, d_model 768, cell 1536, ffn 3072; synthetic seeded weights)", "feed_ms": 100, "steps": ts5}
-        prev = os.environ.get("APRIL_PRECISION")
-        for prec in ("f16", "f32"):
-            os.environ["APRIL_PRECISION"] = prec
-            m5 = A.Model(lpath)
-            s5 = [A.Session(m5, None, counters=counts) for _ in range(nb5)]
-            g5 = A.SessionGroup(s5)
-            pp = pcm_for(nb5, wu5 + ts5, 40_000_000)
-            run_steps(g5, pp, 0, wu5)
-            torch.cuda.synchronize(); a = time.perf_counter()
-            run_steps(g5, pp, wu5, wu5 + ts5)
-            torch.cuda.synchronize(); b = time.perf_counter()
-            ms = (b - a) / ts5 * 1e3
-            leg = {"ms_per_step": round(ms, 3), "rtf": round(ms / 100.0, 5), "audio_s_per_s": round(nb5 * 0.1 / (ms * 1e-3), 1), "params": int(m5.dims.param_count)}
-            rl5, _ = gates_roofline(m5, g5, nb5, m5.stats(), None)
-            if rl5:
-                rl5["note"] = "fp16 operands: priced against the dense fp16 MFMA peak (2.5 PFLOP/s) and against HBM; the larger fraction is the binding bound" if prec == "f16" else "fp32 operands"
-            leg["roofline"] = rl5
-            leg["replay_mismatch"] = int(m5.stats().replay_mismatch)
-            config5[prec] = leg
-            for s_ in s5:
-                s_.close()
-            m5.close()
-        if prev is None:
-            del os.environ["APRIL_PRECISION"]
-        else:
-            os.environ["APRIL_PRECISION"] = prev
-        config5["f16_speedup_vs_f32"] = round(config5["f32"]["ms_per_step"] / config5["f16"]["ms_per_step"], 3)
+        config5 = config5_leg(args, A, SM, torch, np)
 
     # ---------------- CPU baseline: the oracle (plain-C port, 1 thread) on the host, bounded sample
     cpu = None

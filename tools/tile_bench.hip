@@ -91,14 +91,14 @@ static Chain make_chain(const std::vector<Problem> &ps, bool tile_ok)
 {
     Chain c; c.n = (int)ps.size();
     const Problem &p0 = ps[0];
-    const bool fused = gemm_fullk(p0.M, p0.N, p0.kz, /*force*/ !tile_ok && c.n > 1, c.n, tile_ok);
+    const bool fused = gemm_fullk(p0.M, p0.N, p0.kz, /*force*/ !tile_ok && c.n > 1, c.n, tile_ok ? 1 : 0);
     c.split = !fused;
     std::vector<GemmArgs> items;
     for (const Problem &p : ps) {
         GemmArgs g = gemm_of(p, fused, tile_ok, c.n);
         if (fused && !tile_ok && c.n > 1) g.force_fullk = 1;         // what the round-2 feed wavefront does
         items.push_back(g);
-        if (!fused) c.rh.push_back(row_of(p, gemm_partials(p.M, p.N, p.kz, c.n, tile_ok)));
+        if (!fused) c.rh.push_back(row_of(p, gemm_partials(p.M, p.N, p.kz, c.n, tile_ok ? 1 : 0)));
     }
     if (c.n == 1) c.gh = items;
     else {
