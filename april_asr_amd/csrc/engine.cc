@@ -504,6 +504,7 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
             g.a1 = h_l; g.lda1 = d.d_model; g.aidx1 = d_slots; g.K1 = d.d_model;
             lin(g, o.wg); g.M = n; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_LSTM;
             g.out = u_; g.ldo = d.hidden; g.bias = w_ + o.bg; g.c_state = c_l; g.slot_idx = d_slots; g.hidden = d.hidden;
+            if (cfg_.precision == 0 && gates_tile_rows(n)) g.tile_ok = 2;
             timed_begin(T_GATES); launch_gemm(g, stream_); timed_end(T_GATES);
         }
         {   // h' = u x Whr ; state write + residual: xb = norm(y) + h'
@@ -709,6 +710,17 @@ GemmArgs Engine::lm_args_gates(int l, int m, int t) const
     return g;
 }
 
+// fp32 gates GEMM on the GM_TILE schedule (same chains, same bits as the hand-scheduled K-split tiles -- tests/test_gpu_gates_tile.py):
+// measured 2..5 % per feed faster from ~2000 rows per launch (1024 sessions: RTF 0.0533 vs 0.055..0.058, 2048: 0.096..0.097 vs
+// 0.099..0.104), slower at 256 sessions (53.5 vs 46.5 us per launch) and at one session.  APRIL_GATES_TILE: 0 never, 1 always,
+// 2 (default) from APRIL_GATES_TILE_ROWS (2048) rows per launch.
+bool Engine::gates_tile_rows(long rows) const
+{
+    static const int mode = getenv("APRIL_GATES_TILE") ? atoi(getenv("APRIL_GATES_TILE")) : 2;
+    static const long min_rows = getenv("APRIL_GATES_TILE_ROWS") ? atol(getenv("APRIL_GATES_TILE_ROWS")) : 2048;
+    return mode == 1 || (mode == 2 && rows >= min_rows);
+}
+
 GemmArgs Engine::sw_args_gates(int l, int m, int t) const
 {   // the one-launch gates GEMM of a chunk step (run_encoder_rows) on the rows of chunk t: [norm(y) | h_prev] x Wg, fused LSTM cell
     const NetDims &d = L_.dims;
@@ -721,6 +733,7 @@ GemmArgs Engine::sw_args_gates(int l, int m, int t) const
     g.a1 = h_ + (size_t)l * S * d.d_model; g.lda1 = d.d_model; g.aidx1 = step_d_; g.K1 = d.d_model;
     lin(g, o.wg); g.M = m; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_LSTM;
     g.out = u_ + r0 * d.hidden; g.ldo = d.hidden; g.bias = w_ + o.bg; g.c_state = c_ + (size_t)l * S * d.hidden; g.slot_idx = step_d_; g.hidden = d.hidden;
+    if (gates_tile_rows(m) && cfg_.precision == 0) g.tile_ok = 2;      // (one problem per launch; sw_plan decides again for z-batched launches)
     if (f16_tile_) {                  // binary16 operands: [y16 | h16(slot)], u leaves as binary16 only (its one reader is the projection)
         g.a0 = reinterpret_cast<const float *>(y16_ + r0 * d.d_model); g.a1 = reinterpret_cast<const float *>(h16_ + (size_t)l * S * d.d_model);
         lin16(g, o.wg); g.out = nullptr; g.out16 = u16_ + r0 * d.hidden;
@@ -1050,6 +1063,7 @@ Engine::SwPlan &Engine::sw_plan(int m, int T)
                 const int t = W - 1 - l;
                 if (t < 0 || t >= T) continue;
                 GemmArgs g = kind == 0 ? sw_args_gates(l, m, t) : kind == 1 ? lm_args_whr(l, m, t) : kind == 2 ? lm_args_ff1(l, m, t, t + 1) : lm_args_ff2(l, m, t, t + 1);
+                if (kind == 0 && cfg_.precision == 0) g.tile_ok = gates_tile_rows((long)m * n_act) ? 2 : 0;
                 if (split) {
                     float *ws = ws_ + (size_t)t * m * d.d_model;
                     rows.push_back(row_form(g, ws, ws_mstride_, gemm_partials(m, d.d_model, kz, n_act, tk)));

@@ -739,7 +739,7 @@ static bool plan_fullk(int M, int N, int kz, TilePlan &t, bool force = false, in
 static int g_tile_pin_mt = env_int("APRIL_TILE_MT", 0), g_tile_pin_zs = env_int("APRIL_TILE_ZS", 0), g_tile_enable = -1;
 void gemm_tile_pin(int enable, int mt, int zs) { g_tile_enable = enable; g_tile_pin_mt = mt; g_tile_pin_zs = zs; }
 
-static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePlan &t, bool always = false)
+static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePlan &t, bool always = false, bool big_ok = false)
 {
     static const int enabled = env_int("APRIL_GM_TILE", 1);
     static const int min_rows = env_int("APRIL_TILE_MIN_ROWS", 32);
@@ -749,8 +749,17 @@ static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePla
     if (!always && (!(g_tile_enable < 0 ? enabled : g_tile_enable) || M < min_rows)) return false;
     const long zc = std::max(1, zcount);
     const long tiles4 = (long)(N / 64) * ((M + 63) / 64) * zc, tiles2 = (long)(N / 64) * ((M + 31) / 32) * zc;
-    const int mt = pin_mt ? (pin_mt == 4 ? 4 : 2) : (tiles4 >= fused_tiles ? 4 : 2);
+    // (fp16 tile engines: 64-row tiles for the N = d_model GEMMs measured no better than 32-row ones at 512 sessions -- 13.2 vs 12.7 ms
+    // of projection + FFN time per 10 feeds -- so the same rule serves both precisions; APRIL_TILE_F16_MT pins it for measurements)
+    static const int f16_mt = env_int("APRIL_TILE_F16_MT", 0);
+    const int mt = pin_mt ? (pin_mt == 4 ? 4 : 2) : ((always && f16_mt) ? f16_mt : (tiles4 >= fused_tiles ? 4 : 2));
     const long tiles = mt == 4 ? tiles4 : tiles2;
+    if (big_ok && kz == 1 && N % 128 == 0 && pin_mt == 0) {
+        // fp16 gates / FFN up: 128 x 128 tiles (eight waves) once they give most CUs a workgroup -- twice the flops per operand byte
+        static const int big = env_int("APRIL_TILE_BIG", 1), big_tiles = env_int("APRIL_TILE_BIG_TILES", 192), big_min_n = env_int("APRIL_TILE_BIG_MIN_N", 0);
+        const long tiles8 = (long)(N / 128) * ((M + 127) / 128) * zc;
+        if (big && tiles8 >= big_tiles && N >= big_min_n) { t.mt = 8; t.nt = 8; t.zs = 1; t.mode = GM_TILE; return true; }
+    }
     int zs = kz;
     if (pin_zs > 0) { if (!force_full) zs = std::min(kz, pin_zs); }
     else if (pin_mt > 0) { /* measurement: pinned tile rows, all of K */ }
@@ -783,7 +792,7 @@ bool gemm_fullk(int M, int N, int kz, bool force, int zcount, int tile_ok)
 }
 
 // Tile shape and slabs per workgroup.  Depends on M only through occupancy; numerics are tile-independent.
-static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = false, int zcount = 1, int tile_ok = 0, int zcount_true = 1)
+static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = false, int zcount = 1, int tile_ok = 0, int zcount_true = 1, bool f16 = false)
 {
     // measurement knobs (default 0): 1/2 = smaller tiles for the fused-epilogue GEMMs (measured slower on MI355X:
     // B=256 gates 27 -> 32..36 us, the kernel is limited by operand loads per MFMA, not by occupancy);
@@ -792,7 +801,7 @@ static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = fal
     TilePlan t;
     if (tile_ok && (epi == EPI_PARTIAL || epi == EPI_HR || epi == EPI_RESID_SSQ || epi == EPI_SLOT_STORE || epi == EPI_LSTM || epi == EPI_BIAS_DSWISH)) {
         // the caller asked gemm_fullk first: a row epilogue arrives only when that plan keeps all of K in the workgroup
-        if (plan_tile(M, N, kz, zcount_true, force_fullk || epi != EPI_PARTIAL, t, tile_ok == 2)) return t;
+        if (plan_tile(M, N, kz, zcount_true, force_fullk || epi != EPI_PARTIAL, t, tile_ok == 2, f16 && tile_ok == 2 && (epi == EPI_LSTM || epi == EPI_BIAS_DSWISH))) return t;
         if (tile_ok == 2) { fprintf(stderr, "libapril(mi355x): launch_gemm: no GM_TILE plan for an always-tile GEMM (M=%d N=%d kz=%d)\n", M, N, kz); abort(); }
     }
     if (epi != EPI_LSTM && epi != EPI_BIAS_DSWISH && epi != EPI_XPART && plan_fullk(M, N, kz, t, force_fullk, zcount)) return t;
@@ -888,7 +897,7 @@ static TilePlan finalize_gemm(GemmArgs &g)
     const bool plain = g.a_op == AOP_NONE && g.wave_mask == 0xF && g.N % 64 == 0 && !g.p_add;
     const int tile_ok = !plain ? 0 : (g.tile_ok == 2 ? 2 : ((g.tile_ok == 1 && g.K1 == 0 && g.wt == 0 && g.epi != EPI_LSTM && g.epi != EPI_BIAS_DSWISH) ? 1 : 0));
     if (g.tile_ok == 2 && !tile_ok) { fprintf(stderr, "libapril(mi355x): launch_gemm: always-tile GEMM with a prologue / wave mask / odd N\n"); abort(); }
-    const TilePlan t = plan_tiles(g.M, g.N, g.kz, g.epi, g.force_fullk != 0, (z_tiles == 1 || (z_tiles == 2 && is_slab_epi) || (z_tiles == 3 && !is_slab_epi)) ? zc : 1, tile_ok, zc);
+    const TilePlan t = plan_tiles(g.M, g.N, g.kz, g.epi, g.force_fullk != 0, (z_tiles == 1 || (z_tiles == 2 && is_slab_epi) || (z_tiles == 3 && !is_slab_epi)) ? zc : 1, tile_ok, zc, g.wt == 1);
     const bool row_epi = g.epi == EPI_HR || g.epi == EPI_RESID_SSQ || g.epi == EPI_SLOT_STORE;
     if (row_epi && t.zs != g.kz) { fprintf(stderr, "libapril(mi355x): launch_gemm: row epilogue %d needs the full-K plan (M=%d N=%d kz=%d)\n", g.epi, g.M, g.N, g.kz); abort(); }
     g.zs = t.zs; g.mode = t.mode;

@@ -45,17 +45,22 @@ namespace {
 #ifndef APRIL_TILE_STAGES
 #define APRIL_TILE_STAGES 3
 #endif
-constexpr int TILE_BN = 64, TILE_LDR = TILE_BN + 4, TILE_STAGES = APRIL_TILE_STAGES;
-static_assert(TILE_STAGES == 4 || TILE_STAGES == 3, "the tail of the K loop counts in-flight stages for 3 or 4 buffers");
+constexpr int TILE_STAGES = APRIL_TILE_STAGES;
 
-template <int MT> struct TileGeom {
-    static constexpr int BM = 16 * MT;
-    static constexpr int A_BYTES = BM * 128, B_BYTES = 8 * 1024, STAGE_BYTES = A_BYTES + B_BYTES;
-    static constexpr int PIECES = 2 * MT + 8, PPW = PIECES / 4;      // 1 KB DMA pieces per stage / per wave
-    static constexpr int MTW = MT / 2;                              // m tiles per wave (waves: 2 x 2)
-    static constexpr int PLANE_FLOATS = BM * TILE_LDR;
-    static constexpr int LDS_MAIN = (TILE_STAGES * STAGE_BYTES > PLANE_FLOATS * 4) ? TILE_STAGES * STAGE_BYTES : PLANE_FLOATS * 4;
-    static_assert(PIECES % 4 == 0, "pieces are dealt evenly to the four waves");
+// Tile shape: 16 MT rows x 16 NT columns per workgroup, NWM x NWN waves, each owning (MT / NWM) x (NT / NWN) MFMA tiles.
+//   <2, 4, 2, 2>, <4, 4, 2, 2>   32 / 64 rows x 64 columns, four waves (all epilogues, fp32 and fp16)
+//   <8, 8, 2, 4>                 128 x 128, eight waves: twice the flops per operand byte -- the fp16 gates and FFN-up GEMMs, whose
+//                                k block is 64 SIMD cycles of MFMA against 8 KB of operands at 64 x 64 (bound by the CU's L2 -> LDS rate)
+template <int MT, int NT = 4, int NWM = 2, int NWN = 2, int NS_ = TILE_STAGES> struct TileGeom {
+    static constexpr int NS = NS_;                                        // stage buffers
+    static constexpr int BM = 16 * MT, BN = 16 * NT, LDR = BN + 4, NW = NWM * NWN, NTH = 64 * NW;
+    static constexpr int A_BYTES = BM * 128, B_BYTES = 2 * NT * 1024, STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int PIECES = 2 * MT + 2 * NT, PPW = PIECES / NW;      // 1 KB DMA pieces per stage / per wave
+    static constexpr int MTW = MT / NWM, NTW = NT / NWN;                  // MFMA tiles per wave
+    static constexpr int PLANE_FLOATS = BM * LDR;
+    static constexpr int LDS_MAIN = (NS * STAGE_BYTES > PLANE_FLOATS * 4) ? NS * STAGE_BYTES : PLANE_FLOATS * 4;
+    static_assert(NS == 3 || NS == 4, "the tail of the K loop counts in-flight stages for 3 or 4 buffers");
+    static_assert(PIECES % NW == 0 && MT % NWM == 0 && NT % NWN == 0, "pieces and tiles are dealt evenly to the waves");
 };
 
 template <int N> __device__ __forceinline__ void wait_vm()
@@ -68,11 +73,11 @@ using h4 = __attribute__((ext_vector_type(4))) _Float16;
 using h8 = __attribute__((ext_vector_type(8))) _Float16;
 __device__ __forceinline__ h4 to_h4(const f32x4 &v) { return h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; }
 
-template <int MT, int EPI, int WT>
+template <int MT, int EPI, int WT, int NT = 4, int NWM = 2, int NWN = 2, int NSB = TILE_STAGES>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
 {
-    using G = TileGeom<MT>;
-    constexpr int BM = G::BM, MTW = G::MTW, NTH = 256, LDR = TILE_LDR;
+    using G = TileGeom<MT, NT, NWM, NWN, NSB>;
+    constexpr int BM = G::BM, MTW = G::MTW, NTW = G::NTW, NTH = G::NTH, LDR = G::LDR, TILE_BN = G::BN;
     constexpr int KBLK = WT ? 32 : 16, AE = WT ? 2 : 4;          // k per k block, bytes per activation element
     constexpr bool ROW_EPI = EPI == EPI_HR || EPI == EPI_RESID_SSQ || EPI == EPI_SLOT_STORE;
     static_assert(ROW_EPI || EPI == EPI_PARTIAL || EPI == EPI_LSTM || EPI == EPI_BIAS_DSWISH, "no GM_TILE form of this epilogue");
@@ -82,7 +87,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
     if (g.run_flag && *g.run_flag != g.run_gen) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
     const int n0 = blockIdx.x * TILE_BN;                 // first output column
     const int m0 = blockIdx.y * BM;
     const int KB = g.K / KBLK;
@@ -123,22 +128,22 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
         int arows[G::PPW], arows1[G::PPW];
 #pragma unroll
         for (int i = 0; i < G::PPW; ++i) {
-            const int P = wave + 4 * i;
+            const int P = wave + G::NW * i;
             int row = m0 + P * 8 + (lane >> 3);
             arows[i] = row >= g.M ? g.M - 1 : row;       // padding rows recompute the last row; never stored
             arows1[i] = arows[i];
         }
         if (g.aidx0) {                                    // row -> slot indirections, one round trip for all pieces
 #pragma unroll
-            for (int i = 0; i < G::PPW; ++i) if (wave + 4 * i < 2 * MT) arows[i] = g.aidx0[arows[i]];
+            for (int i = 0; i < G::PPW; ++i) if (wave + G::NW * i < 2 * MT) arows[i] = g.aidx0[arows[i]];
         }
         if (two_seg && g.aidx1) {
 #pragma unroll
-            for (int i = 0; i < G::PPW; ++i) if (wave + 4 * i < 2 * MT) arows1[i] = g.aidx1[arows1[i]];
+            for (int i = 0; i < G::PPW; ++i) if (wave + G::NW * i < 2 * MT) arows1[i] = g.aidx1[arows1[i]];
         }
 #pragma unroll
         for (int i = 0; i < G::PPW; ++i) {
-            const int P = wave + 4 * i;
+            const int P = wave + G::NW * i;
             src1[i] = nullptr;
             if (P < 2 * MT) {
                 const int R = P * 8 + (lane >> 3);
@@ -152,8 +157,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
                 src[i] = p0;
                 inc[i] = 128; dst[i] = P * 1024;
             } else {
-                const int q = P - 2 * MT, p = q >> 2, nt = q & 3;
-                src[i] = reinterpret_cast<const char *>(g.wp) + ((size_t)(blockIdx.x * 4 + nt) * KB + first_kb + p) * 1024 + lane * 16;
+                const int q = P - 2 * MT, p = q / NT, nt = q % NT;
+                src[i] = reinterpret_cast<const char *>(g.wp) + ((size_t)(blockIdx.x * NT + nt) * KB + first_kb + p) * 1024 + lane * 16;
                 inc[i] = 2048; dst[i] = G::A_BYTES + q * 1024;
             }
         }
@@ -163,7 +168,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
         if (g.debug == 4) return;                          // measurement: no DMA (the MFMA + LDS read loop alone, on stale LDS contents)
         if (issued == seg1_stage) {
 #pragma unroll
-            for (int i = 0; i < G::PPW; ++i) if (wave + 4 * i < 2 * MT) src[i] = src1[i];
+            for (int i = 0; i < G::PPW; ++i) if (wave + G::NW * i < 2 * MT) src[i] = src1[i];
         }
         ++issued;
 #pragma unroll
@@ -234,12 +239,12 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
     int a_rd[2];                                          // k block p of the stage: row mrow, segment (4 p + kq) ^ ((mrow >> 1) & 7)
 #pragma unroll
     for (int p = 0; p < 2; ++p) a_rd[p] = (wm * MTW * 16 + mrow) * 128 + (((p * 4 + kq) ^ ((mrow >> 1) & 7)) << 4);
-    const int b_rd = G::A_BYTES + wn * 2 * 1024 + lane * 16;
+    const int b_rd = G::A_BYTES + wn * NTW * 1024 + lane * 16;
 
     // chunk chain, slab sum, the three levels of the pairwise slab tree (named, not an array: a level array indexed under the
     // carry conditions is not promoted to registers and lands in scratch memory), the workgroup's result
-    f32x4 acc[MTW][2], S[MTW][2], lvl0[MTW][2], lvl1[MTW][2], lvl2[MTW][2], res[MTW][2];
-#define APRIL_TILE_EACH(expr) _Pragma("unroll") for (int mt = 0; mt < MTW; ++mt) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) { expr; }
+    f32x4 acc[MTW][NTW], S[MTW][NTW], lvl0[MTW][NTW], lvl1[MTW][NTW], lvl2[MTW][NTW], res[MTW][NTW];
+#define APRIL_TILE_EACH(expr) _Pragma("unroll") for (int mt = 0; mt < MTW; ++mt) _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) { expr; }
     APRIL_TILE_EACH(acc[mt][nt] = (f32x4{0.f, 0.f, 0.f, 0.f}); S[mt][nt] = acc[mt][nt]; res[mt][nt] = acc[mt][nt];
                     lvl0[mt][nt] = acc[mt][nt]; lvl1[mt][nt] = acc[mt][nt]; lvl2[mt][nt] = acc[mt][nt])
     int top = 0;
@@ -260,7 +265,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) S[mt][nt][r] = S[mt][nt][r] * xrs[mt][r];
         }
@@ -315,7 +320,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
     // two k blocks -- behind it every wave's pieces of stage s + 1 have landed (counted vmcnt before the barrier) and every wave has
     // issued its reads of stage s, so the buffer of stage s - 1 (read an iteration ago, consumed by MFMAs since) takes stage s + NS - 1.
     if (g.debug != 1) {
-        constexpr int NS = TILE_STAGES;
+        constexpr int NS = G::NS;
 #pragma unroll
         for (int i = 0; i < NS - 1; ++i) if (i < nstage) issue(i);
         if (EPI == EPI_LSTM && fold_scale) {
@@ -330,19 +335,19 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
         // stage 0 landed: at most the NS - 2 younger stages may still be in flight
         if (nstage >= NS - 1) wait_vm<(NS - 2) * G::PPW>(); else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
-        f32x4 a0[MTW], b0[2], a1[MTW], b1[2];
-        auto read_frags = [&](const char *sb, int p, f32x4 (&a)[MTW], f32x4 (&b)[2]) {
+        f32x4 a0[MTW], b0[NTW], a1[MTW], b1[NTW];
+        auto read_frags = [&](const char *sb, int p, f32x4 (&a)[MTW], f32x4 (&b)[NTW]) {
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) a[mt] = *reinterpret_cast<const f32x4 *>(sb + a_rd[p] + mt * 2048);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(sb + b_rd + (p * 4 + nt) * 1024);
+            for (int nt = 0; nt < NTW; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(sb + b_rd + (p * NT + nt) * 1024);
         };
-        auto mfma_block = [&](const f32x4 (&a)[MTW], const f32x4 (&b)[2]) {
+        auto mfma_block = [&](const f32x4 (&a)[MTW], const f32x4 (&b)[NTW]) {
             if (g.debug == 5) {                            // measurement: no MFMAs (DMA + barriers + LDS reads alone); the fragments stay live
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) asm volatile("" :: "v"(a[mt]));
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) asm volatile("" :: "v"(b[nt]));
+                for (int nt = 0; nt < NTW; ++nt) asm volatile("" :: "v"(b[nt]));
                 return;
             }
             // k step outermost: consecutive MFMAs go to different accumulators (a dependent MFMA issues 8 cycles late); per
@@ -352,7 +357,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
+                    for (int nt = 0; nt < NTW; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a[mt]), __builtin_bit_cast(h8, b[nt]), acc[mt][nt], 0, 0, 0);
             } else {
 #pragma unroll
@@ -360,7 +365,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
 #pragma unroll
                     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
+                        for (int nt = 0; nt < NTW; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
             }
         };
@@ -394,10 +399,10 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                red[((wm * MTW + mt) * 16 + kq * 4 + r) * LDR + (wn * 2 + nt) * 16 + mrow] = res[mt][nt][r];
+                red[((wm * MTW + mt) * 16 + kq * 4 + r) * LDR + (wn * NTW + nt) * 16 + mrow] = res[mt][nt][r];
     __syncthreads();
     f32x4 v[QPT];
 #pragma unroll
@@ -484,43 +489,48 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
     }
 }
 
-template <int MT, int EPI, int WT>
-__global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs g)
+template <int MT, int EPI, int WT, int NT = 4, int NWM = 2, int NWN = 2, int NSB = TILE_STAGES>
+__global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void gemm_tile_kernel(GemmArgs g)
 {
-    gemm_tile_body<MT, EPI, WT>(g, (int)blockIdx.z);
+    gemm_tile_body<MT, EPI, WT, NT, NWM, NWN, NSB>(g, (int)blockIdx.z);
 }
 
 // n independent same-shape problems in one launch (see gemm_f32_zkernel): blockIdx.z / zdiv picks the argument block
-template <int MT, int EPI, int WT>
-__global__ __launch_bounds__(256, 2) void gemm_tile_zkernel(const GemmArgs *__restrict__ zargs, int zdiv)
+template <int MT, int EPI, int WT, int NT = 4, int NWM = 2, int NWN = 2, int NSB = TILE_STAGES>
+__global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void gemm_tile_zkernel(const GemmArgs *__restrict__ zargs, int zdiv)
 {
     const int zl = (int)blockIdx.z / zdiv;
     const GemmArgs g = zargs[zl];
-    gemm_tile_body<MT, EPI, WT>(g, (int)blockIdx.z - zl * zdiv);
+    gemm_tile_body<MT, EPI, WT, NT, NWM, NWN, NSB>(g, (int)blockIdx.z - zl * zdiv);
 }
 
-template <int MT> size_t tile_lds_bytes(const GemmArgs &g)
+template <class G> size_t tile_lds_bytes(const GemmArgs &g)
 {
-    using G = TileGeom<MT>;
     const int sg = g.epi == EPI_HR ? g.r_scale.groups : ((g.epi == EPI_SLOT_STORE || g.epi == EPI_LSTM) && g.x_scale.ssq ? g.x_scale.groups : 0);
     return (size_t)G::LDS_MAIN + (size_t)(G::BM + (sg ? G::BM * (sg + 1) : 0)) * sizeof(float);
 }
 
-template <int MT, int EPI, int WT>
+// fp16 operands: a stage is a few dozen SIMD cycles of MFMA against 12 .. 32 KB of DMA, so the depth of the DMA pipeline decides:
+// four stage buffers (two to three stages in flight); fp32 stages are MFMA-bound and measured the same with three (less LDS)
+template <int MT, int EPI, int WT, int NT = 4, int NWM = 2, int NWN = 2>
 void launch_tile_one(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s)
 {
-    using G = TileGeom<MT>;
+#ifndef APRIL_TILE_STAGES_F16
+#define APRIL_TILE_STAGES_F16 4
+#endif
+    constexpr int NSB = WT ? APRIL_TILE_STAGES_F16 : TILE_STAGES;
+    using G = TileGeom<MT, NT, NWM, NWN, NSB>;
     const int zdiv = g.kz / g.zs;
-    dim3 grid((unsigned)(g.N / TILE_BN), (unsigned)((g.M + G::BM - 1) / G::BM), (unsigned)(zdiv * std::max(1, n)));
-    const size_t lds = tile_lds_bytes<MT>(g);
+    dim3 grid((unsigned)(g.N / G::BN), (unsigned)((g.M + G::BM - 1) / G::BM), (unsigned)(zdiv * std::max(1, n)));
+    const size_t lds = tile_lds_bytes<G>(g);
     static bool attr_set = false;                        // (per instantiation) dynamic LDS beyond 64 KB has to be announced
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tile_kernel<MT, EPI, WT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tile_zkernel<MT, EPI, WT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tile_kernel<MT, EPI, WT, NT, NWM, NWN, NSB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tile_zkernel<MT, EPI, WT, NT, NWM, NWN, NSB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (dev_args) hipLaunchKernelGGL((gemm_tile_zkernel<MT, EPI, WT>), grid, dim3(256), lds, s, dev_args, zdiv);
-    else hipLaunchKernelGGL((gemm_tile_kernel<MT, EPI, WT>), grid, dim3(256), lds, s, g);
+    if (dev_args) hipLaunchKernelGGL((gemm_tile_zkernel<MT, EPI, WT, NT, NWM, NWN, NSB>), grid, dim3(G::NTH), lds, s, dev_args, zdiv);
+    else hipLaunchKernelGGL((gemm_tile_kernel<MT, EPI, WT, NT, NWM, NWN, NSB>), grid, dim3(G::NTH), lds, s, g);
 }
 
 template <int MT, int WT>
@@ -543,7 +553,11 @@ bool dispatch_tile(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream
 void launch_gemm_tile(const GemmArgs &g, int mt, const GemmArgs *dev_args, int n, hipStream_t s)
 {
     bool ok = false;
-    if (g.wt == 1) { if (mt == 4) ok = dispatch_tile<4, 1>(g, dev_args, n, s); else if (mt == 2) ok = dispatch_tile<2, 1>(g, dev_args, n, s); }
+    if (mt == 8) {                   // 128 x 128, eight waves: the fp16 gates / FFN-up GEMMs
+        if (g.wt == 1 && g.epi == EPI_LSTM) { launch_tile_one<8, EPI_LSTM, 1, 8, 2, 4>(g, dev_args, n, s); ok = true; }
+        else if (g.wt == 1 && g.epi == EPI_BIAS_DSWISH) { launch_tile_one<8, EPI_BIAS_DSWISH, 1, 8, 2, 4>(g, dev_args, n, s); ok = true; }
+    }
+    else if (g.wt == 1) { if (mt == 4) ok = dispatch_tile<4, 1>(g, dev_args, n, s); else if (mt == 2) ok = dispatch_tile<2, 1>(g, dev_args, n, s); }
     else if (mt == 4) ok = dispatch_tile<4, 0>(g, dev_args, n, s);
     else if (mt == 2) ok = dispatch_tile<2, 0>(g, dev_args, n, s);
     if (!ok) { fprintf(stderr, "libapril(mi355x): launch_gemm_tile: no kernel for epi %d tile rows %d\n", g.epi, 16 * mt); abort(); }

@@ -30,11 +30,18 @@ static void fill(std::vector<float> &h, unsigned seed, float scale)
     for (auto &v : h) { s = s * 1664525u + 1013904223u; v = ((float)((s >> 8) & 0xffff) / 65536.0f - 0.5f) * scale; }
 }
 
+static int g_apad = 0;      // TB_APAD: floats of padding behind every activation row (leading dimension K + pad): L2 channel spread experiment
+
 static Problem make_problem(int M, int N, int K, int kz, int epi, unsigned seed)
 {
     Problem p{M, N, K, kz, epi};
     std::vector<float> h;
-    h.resize((size_t)M * K); fill(h, seed, 2.0f); p.a = dalloc<float>(h.size()); CK(hipMemcpy(p.a, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    {   // rows of K floats at a leading dimension of K + g_apad
+        std::vector<float> dense((size_t)M * K); fill(dense, seed, 2.0f);
+        h.assign((size_t)M * (K + g_apad), 0.0f);
+        for (int m = 0; m < M; ++m) memcpy(&h[(size_t)m * (K + g_apad)], &dense[(size_t)m * K], (size_t)K * 4);
+        p.a = dalloc<float>(h.size()); CK(hipMemcpy(p.a, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    }
     h.resize((size_t)K * N); fill(h, seed + 1, 0.1f); p.w = dalloc<float>(h.size()); CK(hipMemcpy(p.w, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     h.resize((size_t)N); fill(h, seed + 2, 1.0f); p.bias = dalloc<float>(h.size()); CK(hipMemcpy(p.bias, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     h.resize((size_t)M * N); fill(h, seed + 3, 1.0f); p.resid = dalloc<float>(h.size()); CK(hipMemcpy(p.resid, h.data(), h.size() * 4, hipMemcpyHostToDevice));
@@ -56,7 +63,7 @@ static Problem make_problem(int M, int N, int K, int kz, int epi, unsigned seed)
 static GemmArgs gemm_of(const Problem &p, bool fused, bool tile_ok, int zcount)
 {
     GemmArgs g;
-    g.a0 = p.a; g.lda0 = p.K; g.K0 = p.K; g.wp = p.w; g.M = p.M; g.N = p.N; g.K = p.K; g.kz = p.kz; g.tile_ok = tile_ok ? 1 : 0; g.zcount = zcount;
+    g.a0 = p.a; g.lda0 = p.K + g_apad; g.K0 = p.K; g.wp = p.w; g.M = p.M; g.N = p.N; g.K = p.K; g.kz = p.kz; g.tile_ok = tile_ok ? 1 : 0; g.zcount = zcount;
     if (p.epi == EPI_SLOT_STORE) { g.x_scale.ssq = p.ssq_in; g.x_scale.groups = p.K / 32; g.x_scale.inv_n = 1.0f / p.K; g.x_scale.eps = 0.25f; }
     if (!fused) { g.epi = EPI_PARTIAL; g.out = p.ws; g.m_stride = p.M; return g; }
     g.epi = p.epi; g.out = p.out; g.ldo = p.N; g.bias = p.bias;
@@ -145,6 +152,7 @@ static double time_chain(const Chain &c, hipStream_t s, int iters)
 int main(int argc, char **argv)
 {
     const int iters = argc > 1 ? atoi(argv[1]) : 200;
+    if (getenv("TB_APAD")) g_apad = atoi(getenv("TB_APAD"));
     // optional: only shape number `only` (0-based), only the pinned (mt, zs) -- for profiler runs
     const int only = argc > 2 ? atoi(argv[2]) : -1, only_mt = argc > 3 ? atoi(argv[3]) : -1, only_zs = argc > 4 ? atoi(argv[4]) : -1;
     hipStream_t s; CK(hipStreamCreate(&s));
