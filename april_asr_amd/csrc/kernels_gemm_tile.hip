@@ -88,6 +88,15 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / NWN, wn = wave % NWN;
+    // measurement only (tools/tile_bench built with -DAPRIL_GEMM_TRACE): wave 0 accumulates s_memtime intervals of the K loop's
+    // phases: [0] reads + first MFMA block, [1] chunk ends, [2] DMA wait + barrier, [3] DMA issue + reads + second MFMA block,
+    // [4] whole loop, [5] prologue up to the loop, [6] epilogue; compiled out of the product
+#ifdef APRIL_GEMM_TRACE
+    unsigned long long tr_acc[7] = {0, 0, 0, 0, 0, 0, 0}, tr_t = __builtin_amdgcn_s_memtime(), tr_start = tr_t;
+    auto lapt = [&](int i) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tr_acc[i] += now - tr_t; tr_t = now; };
+#else
+    auto lapt = [](int) {};
+#endif
     const int n0 = blockIdx.x * TILE_BN;                 // first output column
     const int m0 = blockIdx.y * BM;
     const int KB = g.K / KBLK;
@@ -164,19 +173,26 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
         }
     }
     int issued = 0;
-    auto issue = [&](int buf) {
-        if (g.debug == 4) return;                          // measurement: no DMA (the MFMA + LDS read loop alone, on stale LDS contents)
-        if (issued == seg1_stage) {
+    auto issue_begin = [&]() {                             // once per stage, before its pieces
+        if (two_seg) {                                     // (selects, not a branch: the stage body stays one scheduling region)
+            const bool sw = issued == seg1_stage;
 #pragma unroll
-            for (int i = 0; i < G::PPW; ++i) if (wave + G::NW * i < 2 * MT) src[i] = src1[i];
+            for (int i = 0; i < G::PPW; ++i) if (wave + G::NW * i < 2 * MT) src[i] = sw ? src1[i] : src[i];
         }
         ++issued;
+    };
+    auto issue_piece = [&](int i, int buf) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i]),
+                                         (__attribute__((address_space(3))) void *)(lds + buf * G::STAGE_BYTES + dst[i]), 16, 0, 0);
+        src[i] += inc[i];
+    };
+    auto issue = [&](int buf) {
+#ifdef APRIL_GEMM_TRACE
+        if (g.debug == 4) return;                          // measurement build: no DMA (the MFMA + LDS read loop alone, on stale LDS contents)
+#endif
+        issue_begin();
 #pragma unroll
-        for (int i = 0; i < G::PPW; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i]),
-                                             (__attribute__((address_space(3))) void *)(lds + buf * G::STAGE_BYTES + dst[i]), 16, 0, 0);
-            src[i] += inc[i];
-        }
+        for (int i = 0; i < G::PPW; ++i) issue_piece(i, buf);
     };
 
     // ---- what the row epilogue reads besides the sums: fetched before the K loop (as in gemm_body)
@@ -343,13 +359,15 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
             for (int nt = 0; nt < NTW; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(sb + b_rd + (p * NT + nt) * 1024);
         };
         auto mfma_block = [&](const f32x4 (&a)[MTW], const f32x4 (&b)[NTW]) {
-            if (g.debug == 5) {                            // measurement: no MFMAs (DMA + barriers + LDS reads alone); the fragments stay live
+#ifdef APRIL_GEMM_TRACE
+            if (g.debug == 5) {                            // measurement build: no MFMAs (DMA + barriers + LDS reads alone); the fragments stay live
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) asm volatile("" :: "v"(a[mt]));
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) asm volatile("" :: "v"(b[nt]));
                 return;
             }
+#endif
             // k step outermost: consecutive MFMAs go to different accumulators (a dependent MFMA issues 8 cycles late); per
             // accumulator the order is k = j, j + 4, j + 8, j + 12 inside the MFMA, j = 0..3 across MFMAs: the canonical chain
             if constexpr (WT == 1) {
@@ -371,13 +389,82 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
         };
         read_frags(lds, 0, a0, b0);
         int buf = 0;
-        for (int s = 0; s < nstage; ++s) {
+        lapt(5);
+        int s = 0;
+        // Fast path (chunks of whole stages: c even).  A wave issues in order, so whatever sits BETWEEN two MFMA blocks -- fragment
+        // reads, DMA issue and its address arithmetic, loop control -- runs while the matrix pipe drains (measured with one workgroup
+        // per CU: 1885 cycles per stage for 1024 cycles of MFMA, and 1032 with the MFMAs removed: additive).  Here the stage body is
+        // branch-free (DMA issue and next-stage reads unconditional: the last NS - 1 stages and odd chunk lengths take the generic
+        // loop below) and sched_group_barrier spreads the reads and the DMA issue through the MFMAs of the same scheduling region.
+        if ((c & 1) == 0 && g.debug != 6) {
+            constexpr int TILES = MTW * NTW, NM = TILES * (WT ? 1 : 4), NR = MTW + NTW, NV = G::PPW;      // MFMAs per k block, fragment reads, DMA pieces
+            // MFMA q of a k block: k step q / TILES (fp32), tile q % TILES -- consecutive MFMAs on different accumulators, the k steps of
+            // one accumulator in order (the canonical chain)
+            auto mfma_one = [&](int q, const f32x4 (&a)[MTW], const f32x4 (&b)[NTW]) {
+                const int t = q % TILES, mt = t / NTW, nt = t % NTW;
+                if constexpr (WT == 1) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a[mt]), __builtin_bit_cast(h8, b[nt]), acc[mt][nt], 0, 0, 0);
+                else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][q / TILES], b[nt][q / TILES], acc[mt][nt], 0, 0, 0);
+            };
+            auto read_one = [&](int f, const char *sb, int p, f32x4 (&a)[MTW], f32x4 (&b)[NTW]) {
+                if (f < MTW) a[f] = *reinterpret_cast<const f32x4 *>(sb + a_rd[p] + f * 2048);
+                else b[f - MTW] = *reinterpret_cast<const f32x4 *>(sb + b_rd + (p * NT + (f - MTW)) * 1024);
+            };
+            // fillers are front-loaded, PF / PF2 behind each of the first MFMAs, so that the rest of the block covers their latency
+            // (fp32: one per MFMA; fp16 blocks have fewer MFMAs than fillers)
+            constexpr int PF = (2 * NR + NM - 1) / NM > 1 ? (2 * NR + NM - 1) / NM : 1, PF2 = (2 * (NV + NR) + NM - 1) / NM > 1 ? (2 * (NV + NR) + NM - 1) / NM : 1;
+            const int spc = c >> 1, main_end = nstage - (NS - 1);
+            while (s + spc <= main_end) {
+                for (int j = 0; j < spc; ++j, ++s) {
+                    const char *sb = lds + buf * G::STAGE_BYTES;
+                    int nbuf = buf + 1; if (nbuf == NS) nbuf = 0;
+                    int ib = buf - 1; if (ib < 0) ib += NS;
+                    const char *nsb = lds + nbuf * G::STAGE_BYTES;
+#ifdef APRIL_GEMM_TRACE
+                    lapt(3); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); lapt(6);      // [6] = time waiting for the fragments of k block 0
+#endif
+                    // k block 0 of the stage; the fragment reads of k block 1 go out between its MFMAs (pinned by sched_barrier: left
+                    // to itself the scheduler clusters them at one end, and the solver behind sched_group_barrier reorders the chains)
+#pragma unroll
+                    for (int q = 0; q < NM; ++q) {
+                        mfma_one(q, a0, b0);
+#pragma unroll
+                        for (int f = q * PF; f < (q + 1) * PF && f < NR; ++f) read_one(f, sb, 1, a1, b1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    lapt(0);
+                    wait_vm<(NS - 3) * G::PPW>();          // stage s + 1 has landed (this wave's pieces); NS - 3 younger stages stay in flight
+                    __builtin_amdgcn_s_barrier();
+                    lapt(2);
+#ifdef APRIL_GEMM_TRACE
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); lapt(5);                // [5] = time waiting for the fragments of k block 1
+#endif
+                    issue_begin();
+                    // k block 1; DMA pieces of stage s + NS - 1 first, then the reads of stage s + 1's k block 0
+#pragma unroll
+                    for (int q = 0; q < NM; ++q) {
+                        mfma_one(q, a1, b1);
+#pragma unroll
+                        for (int f = q * PF2; f < (q + 1) * PF2 && f < NV + NR; ++f) {
+                            if (f < NV) issue_piece(f, ib); else read_one(f - NV, nsb, 0, a0, b0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    buf = nbuf;
+                    lapt(3);
+                }
+                chunk_end();
+                lapt(1);
+            }
+        }
+        for (; s < nstage; ++s) {
             const char *sb = lds + buf * G::STAGE_BYTES;
             int nbuf = buf + 1; if (nbuf == NS) nbuf = 0;
             read_frags(sb, 1, a1, b1);
             __builtin_amdgcn_sched_barrier(0);             // the reads go out BEFORE the MFMAs they overlap with (left alone, the scheduler sinks them behind)
             mfma_block(a0, b0);
+            lapt(0);
             if (++in_chunk == c) { in_chunk = 0; chunk_end(); }
+            lapt(1);
             if (s + 1 < nstage) {
                 // stage s + 1 must have landed; younger stages still in flight: s + 2 .. min(s + NS - 2, nstage - 1)
                 if (s + NS - 2 < nstage) wait_vm<(NS - 3) * G::PPW>();
@@ -385,14 +472,21 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
                 else wait_vm<0>();
             }
             __builtin_amdgcn_s_barrier();
+            lapt(2);
             if (s + NS - 1 < nstage) { int ib = buf - 1; if (ib < 0) ib += NS; issue(ib); }
             if (s + 1 < nstage) read_frags(lds + nbuf * G::STAGE_BYTES, 0, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
             mfma_block(a1, b1);
+            lapt(3);
             if (++in_chunk == c) { in_chunk = 0; chunk_end(); }
+            lapt(1);
             buf = nbuf;
         }
     }
+#ifdef APRIL_GEMM_TRACE
+    tr_acc[4] = __builtin_amdgcn_s_memtime() - tr_start - tr_acc[5];
+    tr_t = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- the workgroup's sums -> LDS plane (each wave owns its columns; no cross-wave addition) -> 4-column quads per thread
     __syncthreads();                                       // the last stage has been read by every wave
@@ -487,6 +581,14 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
             }
         }
     }
+#ifdef APRIL_GEMM_TRACE
+    lapt(6);
+    if (g.trace && wave == 0 && lane == 0) {
+        const size_t wg = blockIdx.x + gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+        for (int i = 0; i < 7; ++i) g.trace[wg * 8 + i] = tr_acc[i];
+        g.trace[wg * 8 + 7] = (unsigned long long)nstage;
+    }
+#endif
 }
 
 template <int MT, int EPI, int WT, int NT = 4, int NWM = 2, int NWN = 2, int NSB = TILE_STAGES>
@@ -556,6 +658,8 @@ void launch_gemm_tile(const GemmArgs &g, int mt, const GemmArgs *dev_args, int n
     if (mt == 8) {                   // 128 x 128, eight waves: the fp16 gates / FFN-up GEMMs
         if (g.wt == 1 && g.epi == EPI_LSTM) { launch_tile_one<8, EPI_LSTM, 1, 8, 2, 4>(g, dev_args, n, s); ok = true; }
         else if (g.wt == 1 && g.epi == EPI_BIAS_DSWISH) { launch_tile_one<8, EPI_BIAS_DSWISH, 1, 8, 2, 4>(g, dev_args, n, s); ok = true; }
+        else if (g.wt == 0 && g.epi == EPI_LSTM) { launch_tile_one<8, EPI_LSTM, 0, 8, 2, 4>(g, dev_args, n, s); ok = true; }
+        else if (g.wt == 0 && g.epi == EPI_BIAS_DSWISH) { launch_tile_one<8, EPI_BIAS_DSWISH, 0, 8, 2, 4>(g, dev_args, n, s); ok = true; }
     }
     else if (g.wt == 1) { if (mt == 4) ok = dispatch_tile<4, 1>(g, dev_args, n, s); else if (mt == 2) ok = dispatch_tile<2, 1>(g, dev_args, n, s); }
     else if (mt == 4) ok = dispatch_tile<4, 0>(g, dev_args, n, s);

@@ -206,6 +206,16 @@ int main(int argc, char **argv)
             clear_outputs(ps); for (int i = 0; i < 5; ++i) c.run(s); CK(hipStreamSynchronize(s));
             const std::vector<float> got2 = snapshot(ps);
             size_t diff2 = 0; for (size_t i = 0; i < want.size(); ++i) if (memcmp(&want[i], &got2[i], 4) != 0) ++diff2;
+            if (getenv("TB_TRACE") && c.n == 1) {      // (binary built with -DAPRIL_GEMM_TRACE) per-phase s_memtime sums of wave 0, averaged over the workgroups
+                const int nwg = 16384;
+                unsigned long long *tr = dalloc<unsigned long long>((size_t)nwg * 8); CK(hipMemset(tr, 0, (size_t)nwg * 8 * 8));
+                Chain ct = c; ct.gh[0].trace = tr; ct.run(s); CK(hipStreamSynchronize(s));
+                std::vector<unsigned long long> ht((size_t)nwg * 8); CK(hipMemcpy(ht.data(), tr, ht.size() * 8, hipMemcpyDeviceToHost));
+                double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int nw = 0;
+                for (int i = 0; i < nwg; ++i) if (ht[(size_t)i * 8 + 7]) { ++nw; for (int k = 0; k < 8; ++k) acc[k] += (double)ht[(size_t)i * 8 + k]; }
+                if (nw) printf("      trace (%d workgroups, %.0f stages each; s_memtime ticks per stage): first k block %.0f | chunk ends %.0f | wait+barrier %.0f | issue + second k block %.0f | loop total %.0f ; prologue %.0f, epilogue %.0f ticks\n",
+                               nw, acc[7] / nw, acc[0] / acc[7], acc[1] / acc[7], acc[2] / acc[7], acc[3] / acc[7], acc[4] / acc[7], acc[5] / nw, acc[6] / nw);
+            }
             const int parts = c.split ? c.rh[0].parts : 1;
             printf("    tile mt=%d zs=%d%s -> %s planes=%d : %7.2f us (%.3f of peak, %.2fx)  %s\n", pin.mt, pin.zs, pin.mt == 0 ? " (planner)" : "", c.split ? "split+row" : "fused", parts, t,
                    flops / (t * 1e-6) / 157.3e12, t_ref / t, (diff || diff2) ? "MISMATCH" : "bit-identical");
