@@ -721,6 +721,13 @@ bool Engine::gates_tile_rows(long rows) const
     return mode == 1 || (mode == 2 && rows >= min_rows);
 }
 
+// (the same for the FFN-up GEMM; measurement knob APRIL_FF1_TILE_ROWS, default off)
+bool Engine::ff1_tile_rows(long rows) const
+{
+    static const long min_rows = getenv("APRIL_FF1_TILE_ROWS") ? atol(getenv("APRIL_FF1_TILE_ROWS")) : 0;
+    return min_rows > 0 && rows >= min_rows;
+}
+
 GemmArgs Engine::sw_args_gates(int l, int m, int t) const
 {   // the one-launch gates GEMM of a chunk step (run_encoder_rows) on the rows of chunk t: [norm(y) | h_prev] x Wg, fused LSTM cell
     const NetDims &d = L_.dims;
@@ -768,6 +775,7 @@ GemmArgs Engine::lm_args_ff1(int l, int m, int t0, int t1) const
     GemmArgs g; g.a0 = xb_ + b0 * d.d_model; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, o.wff1);
     g.M = (t1 - t0) * m; g.N = d.ffn; g.K = d.d_model; g.kz = 1; g.epi = EPI_BIAS_DSWISH; g.out = ff_ + b0 * d.ffn; g.ldo = d.ffn; g.bias = w_ + o.bff1;
     if (f16_tile_) { g.a0 = reinterpret_cast<const float *>(xb16_ + b0 * d.d_model); lin16(g, o.wff1); g.out = nullptr; g.out16 = ff16_ + b0 * d.ffn; }
+    else if (cfg_.precision == 0 && ff1_tile_rows((long)(t1 - t0) * m)) g.tile_ok = 2;
     return g;
 }
 
@@ -1064,6 +1072,7 @@ Engine::SwPlan &Engine::sw_plan(int m, int T)
                 if (t < 0 || t >= T) continue;
                 GemmArgs g = kind == 0 ? sw_args_gates(l, m, t) : kind == 1 ? lm_args_whr(l, m, t) : kind == 2 ? lm_args_ff1(l, m, t, t + 1) : lm_args_ff2(l, m, t, t + 1);
                 if (kind == 0 && cfg_.precision == 0) g.tile_ok = gates_tile_rows((long)m * n_act) ? 2 : 0;
+                if (kind == 2 && cfg_.precision == 0) g.tile_ok = ff1_tile_rows((long)m * n_act) ? 2 : 0;
                 if (split) {
                     float *ws = ws_ + (size_t)t * m * d.d_model;
                     rows.push_back(row_form(g, ws, ws_mstride_, gemm_partials(m, d.d_model, kz, n_act, tk)));

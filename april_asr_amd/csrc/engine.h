@@ -167,6 +167,7 @@ private:
     void run_sw_chain(int m, int T, bool dump_logits, const SwPlan &p);
     void launch_rowepi(GemmArgs fused_form, size_t ws_row0, hipStream_t st);
     bool gates_tile_rows(long rows) const;
+    bool ff1_tile_rows(long rows) const;
     void run_decproj(int n, const int *d_slots, const int *row_mask, const int *run_flag, int run_gen, float *out = nullptr);
     void build_dec_table();
     void run_chain(int m, bool dump_logits);     // advance + encoder + greedy rounds with arguments that depend on m only
