@@ -669,6 +669,14 @@ int aprilx_run_decide(AprilASRModel model, int n, int op, const float *logits, f
     model->m.engines[0]->debug_decide(n, op, logits, early_emit, (const int *)now_ms, round, state_io, (StepRecord *)records_out);
     return 0;
 }
+int aprilx_plan_gemm(int M, int N, int kz, int zcount, int tile_ok, int force, int32_t *out)
+{
+    if (!out || M <= 0 || N <= 0 || kz <= 0 || zcount <= 0) return -1;
+    out[0] = gemm_fullk(M, N, kz, force != 0, zcount, tile_ok) ? 1 : 0;
+    out[1] = gemm_partials(M, N, kz, zcount, tile_ok);
+    out[2] = gemm_tile_planned(M, N, kz, zcount) ? 1 : 0;
+    return 0;
+}
 int aprilx_run_fbank(AprilASRModel model, int n_frames, const int16_t *pcm_frames, float *out)
 {
     if (!model || model->m.engines.empty() || n_frames <= 0 || n_frames > model->m.engines[0]->ring_frames()) return -1;

@@ -739,7 +739,7 @@ static bool plan_fullk(int M, int N, int kz, TilePlan &t, bool force = false, in
 static int g_tile_pin_mt = env_int("APRIL_TILE_MT", 0), g_tile_pin_zs = env_int("APRIL_TILE_ZS", 0), g_tile_enable = -1;
 void gemm_tile_pin(int enable, int mt, int zs) { g_tile_enable = enable; g_tile_pin_mt = mt; g_tile_pin_zs = zs; }
 
-static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePlan &t, bool always = false, bool big_ok = false)
+static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePlan &t, bool always = false, bool big_ok = false, bool wide_ok = false)
 {
     static const int enabled = env_int("APRIL_GM_TILE", 1);
     static const int min_rows = env_int("APRIL_TILE_MIN_ROWS", 32);
@@ -779,6 +779,25 @@ static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePla
         }
     }
     t.mt = mt; t.nt = 4; t.zs = zs; t.mode = GM_TILE;
+    if (wide_ok && N % 128 == 0 && M >= 48 && pin_mt == 0) {
+        // fp16 projection / FFN down: 64 x 128 tiles, eight waves -- half the operand bytes per flop of 32 x 64; the cost model again,
+        // on those tiles
+        static const int wide = env_int("APRIL_TILE_WIDE", 0);      // measured: no gain (projection + FFN down 10.94 vs 11.02 ms per 10 feeds, more row-kernel work) -> off
+        if (wide) {
+            const long tw = (long)(N / 128) * ((M + 63) / 64) * zc;
+            int zw = kz;
+            if (!force_full && pin_zs == 0) {
+                long best = -1;
+                for (int z = kz; z >= 1; z >>= 1) {
+                    const long wgs = tw * (kz / z), per_cu = (wgs + 255) / 256;
+                    long cost = per_cu * (8L * z + 3) * 100;
+                    if (z < kz) cost += cost / 20 + 300;
+                    if (best < 0 || cost < best) { best = cost; zw = z; }
+                }
+            } else if (pin_zs > 0 && !force_full) zw = std::min(kz, pin_zs);
+            t.mt = 4; t.nt = 8; t.zs = zw;
+        }
+    }
     return true;
 }
 
@@ -787,7 +806,8 @@ bool gemm_tile_planned(int M, int N, int kz, int zcount) { TilePlan t; return pl
 bool gemm_fullk(int M, int N, int kz, bool force, int zcount, int tile_ok)
 {
     TilePlan t;
-    if (tile_ok && plan_tile(M, N, kz, zcount, force, t, tile_ok == 2)) return t.zs == kz;
+    // (tile_ok == 2 on a row-epilogue GEMM = the fp16 tile path: its wide tiles take part in the plan, here as in launch_gemm)
+    if (tile_ok && plan_tile(M, N, kz, zcount, force, t, tile_ok == 2, false, tile_ok == 2)) return t.zs == kz;
     return plan_fullk(M, N, kz, t, force);
 }
 
@@ -801,7 +821,8 @@ static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = fal
     TilePlan t;
     if (tile_ok && (epi == EPI_PARTIAL || epi == EPI_HR || epi == EPI_RESID_SSQ || epi == EPI_SLOT_STORE || epi == EPI_LSTM || epi == EPI_BIAS_DSWISH)) {
         // the caller asked gemm_fullk first: a row epilogue arrives only when that plan keeps all of K in the workgroup
-        if (plan_tile(M, N, kz, zcount_true, force_fullk || epi != EPI_PARTIAL, t, tile_ok == 2, (f16 || env_int("APRIL_TILE_BIG_F32", 0)) && tile_ok == 2 && (epi == EPI_LSTM || epi == EPI_BIAS_DSWISH))) return t;
+        if (plan_tile(M, N, kz, zcount_true, force_fullk || epi != EPI_PARTIAL, t, tile_ok == 2, (f16 || env_int("APRIL_TILE_BIG_F32", 0)) && tile_ok == 2 && (epi == EPI_LSTM || epi == EPI_BIAS_DSWISH),
+                      tile_ok == 2 && (epi == EPI_PARTIAL || epi == EPI_HR || epi == EPI_RESID_SSQ))) return t;
         if (tile_ok == 2) { fprintf(stderr, "libapril(mi355x): launch_gemm: no GM_TILE plan for an always-tile GEMM (M=%d N=%d kz=%d)\n", M, N, kz); abort(); }
     }
     if (epi != EPI_LSTM && epi != EPI_BIAS_DSWISH && epi != EPI_XPART && plan_fullk(M, N, kz, t, force_fullk, zcount)) return t;
@@ -916,7 +937,7 @@ void launch_gemm(const GemmArgs &g_in, hipStream_t s)
 {
     GemmArgs g = g_in;
     const TilePlan t = finalize_gemm(g);
-    if (t.mode == GM_TILE) { launch_gemm_tile(g, t.mt, nullptr, 0, s); return; }
+    if (t.mode == GM_TILE) { launch_gemm_tile(g, t.mt, t.nt, nullptr, 0, s); return; }
     const int mt = t.mt, nt = t.nt;
     bool ok = false;
     if (mt == 1) { if (nt == 4) ok = dispatch<1, 4>(g, s); else if (nt == 2) ok = dispatch<1, 2>(g, s); else ok = dispatch<1, 1>(g, s); }
@@ -977,7 +998,7 @@ void launch_gemm_z(const GemmArgs *staged, int n, const GemmArgs *dev_args, hipS
     const GemmArgs &g = staged[0];
     GemmArgs probe = g;
     const TilePlan t = finalize_gemm(probe);
-    if (t.mode == GM_TILE) { launch_gemm_tile(g, t.mt, dev_args, n, s); return; }
+    if (t.mode == GM_TILE) { launch_gemm_tile(g, t.mt, t.nt, dev_args, n, s); return; }
     const int mt = t.mt, nt = t.nt;
     bool ok = false;
     if (mt == 1) { if (nt == 4) ok = dispatch_z<1, 4>(g, dev_args, n, s); else if (nt == 2) ok = dispatch_z<1, 2>(g, dev_args, n, s); else ok = dispatch_z<1, 1>(g, dev_args, n, s); }

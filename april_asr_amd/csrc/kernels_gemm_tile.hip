@@ -49,6 +49,7 @@ constexpr int TILE_STAGES = APRIL_TILE_STAGES;
 
 // Tile shape: 16 MT rows x 16 NT columns per workgroup, NWM x NWN waves, each owning (MT / NWM) x (NT / NWN) MFMA tiles.
 //   <2, 4, 2, 2>, <4, 4, 2, 2>   32 / 64 rows x 64 columns, four waves (all epilogues, fp32 and fp16)
+//   <4, 8, 2, 4>                 64 x 128, eight waves (wave tile 32 x 32): the fp16 projection / FFN-down GEMMs (N = d_model)
 //   <8, 8, 2, 4>                 128 x 128, eight waves: twice the flops per operand byte -- the fp16 gates and FFN-up GEMMs, whose
 //                                k block is 64 SIMD cycles of MFMA against 8 KB of operands at 64 x 64 (bound by the CU's L2 -> LDS rate)
 template <int MT, int NT = 4, int NWM = 2, int NWN = 2, int NS_ = TILE_STAGES> struct TileGeom {
@@ -652,10 +653,15 @@ bool dispatch_tile(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream
 }  // namespace
 
 // launch of a GEMM whose plan (kernels_gemm.hip) chose GM_TILE: g.zs slabs per workgroup, tile rows 16 * mt
-void launch_gemm_tile(const GemmArgs &g, int mt, const GemmArgs *dev_args, int n, hipStream_t s)
+void launch_gemm_tile(const GemmArgs &g, int mt, int nt, const GemmArgs *dev_args, int n, hipStream_t s)
 {
     bool ok = false;
-    if (mt == 8) {                   // 128 x 128, eight waves: the fp16 gates / FFN-up GEMMs
+    if (mt == 4 && nt == 8) {        // 64 x 128, eight waves (wave tile 32 x 32): the fp16 N = d_model GEMMs (projection, FFN down)
+        if (g.wt == 1 && g.epi == EPI_PARTIAL) { launch_tile_one<4, EPI_PARTIAL, 1, 8, 2, 4>(g, dev_args, n, s); ok = true; }
+        else if (g.wt == 1 && g.epi == EPI_HR) { launch_tile_one<4, EPI_HR, 1, 8, 2, 4>(g, dev_args, n, s); ok = true; }
+        else if (g.wt == 1 && g.epi == EPI_RESID_SSQ) { launch_tile_one<4, EPI_RESID_SSQ, 1, 8, 2, 4>(g, dev_args, n, s); ok = true; }
+    }
+    else if (mt == 8) {                   // 128 x 128, eight waves: the fp16 gates / FFN-up GEMMs
         if (g.wt == 1 && g.epi == EPI_LSTM) { launch_tile_one<8, EPI_LSTM, 1, 8, 2, 4>(g, dev_args, n, s); ok = true; }
         else if (g.wt == 1 && g.epi == EPI_BIAS_DSWISH) { launch_tile_one<8, EPI_BIAS_DSWISH, 1, 8, 2, 4>(g, dev_args, n, s); ok = true; }
         else if (g.wt == 0 && g.epi == EPI_LSTM) { launch_tile_one<8, EPI_LSTM, 0, 8, 2, 4>(g, dev_args, n, s); ok = true; }
@@ -664,7 +670,7 @@ void launch_gemm_tile(const GemmArgs &g, int mt, const GemmArgs *dev_args, int n
     else if (g.wt == 1) { if (mt == 4) ok = dispatch_tile<4, 1>(g, dev_args, n, s); else if (mt == 2) ok = dispatch_tile<2, 1>(g, dev_args, n, s); }
     else if (mt == 4) ok = dispatch_tile<4, 0>(g, dev_args, n, s);
     else if (mt == 2) ok = dispatch_tile<2, 0>(g, dev_args, n, s);
-    if (!ok) { fprintf(stderr, "libapril(mi355x): launch_gemm_tile: no kernel for epi %d tile rows %d\n", g.epi, 16 * mt); abort(); }
+    if (!ok) { fprintf(stderr, "libapril(mi355x): launch_gemm_tile: no kernel for epi %d tile %d x %d (wt %d)\n", g.epi, 16 * mt, 16 * nt, g.wt); abort(); }
 }
 
 }  // namespace aprilx

@@ -99,6 +99,13 @@ APRIL_EXPORT int aprilx_run_fbank(AprilASRModel model, int n_frames, const int16
 APRIL_EXPORT int aprilx_run_decide(AprilASRModel model, int n, int op, const float *logits, float early_emit, const int32_t *now_ms,
                                    int round, int32_t *state_io, void *records_out);
 
+/* The host-side plan of a row-epilogue GEMM out[M, N] = A[M, K] x W (K in `kz` slabs; `zcount` same-shape problems per launch;
+ * tile_ok 0 = round-2 schedules, 1 = GM_TILE by the occupancy rule, 2 = GM_TILE always (fp16 tile path); force = the caller
+ * needs the fused form): out[0] = 1 when the plan keeps all of K in the workgroup (row epilogue fused into the GEMM), out[1] =
+ * partial planes the split form writes (finished by the row kernel), out[2] = 1 when the occupancy rule picks GM_TILE.  No GPU
+ * needed; tests only (the engine and the kernels consult the same functions, so their decisions cannot diverge). */
+APRIL_EXPORT int aprilx_plan_gemm(int M, int N, int kz, int zcount, int tile_ok, int force, int32_t *out);
+
 /* ---- tracing / statistics ---------------------------------------------------------------*/
 /* every joiner evaluation of this session appends `vocab` floats to buf (tests only; chunk steps of a traced session are
    issued eagerly and waited for one by one) */
