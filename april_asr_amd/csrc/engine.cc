@@ -303,6 +303,7 @@ Engine::~Engine()
     if (dec_table_) (void)hipFree(dec_table_);
     if (p_lm_) (void)hipFree(p_lm_);
     if (eout_lm_) (void)hipFree(eout_lm_);
+    for (void *p : {(void *)wx_, (void *)y16_, (void *)xb16_, (void *)u16_, (void *)ff16_, (void *)h16_}) if (p) (void)hipFree(p);      // fp16 tile path
     for (void *p : {(void *)w_, (void *)wh_, (void *)h_, (void *)c_, (void *)ring_, (void *)eout_, (void *)dout_, (void *)gstate_, (void *)cls_, (void *)ws_, (void *)xin_,
                     (void *)a3_, (void *)y_, (void *)ssq_, (void *)xb_, (void *)u_, (void *)ff_, (void *)de_, (void *)logits_, (void *)rec_d_, (void *)counter_d_,
                     (void *)rec_off_d_, (void *)flags_d_, (void *)step_d_, (void *)active_d_, (void *)dirty_d_, (void *)dec_slots_d_,

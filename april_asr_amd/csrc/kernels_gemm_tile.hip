@@ -35,6 +35,7 @@
 #include "kernels.h"
 #include "device_utils.h"
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -626,11 +627,16 @@ void launch_tile_one(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStre
     const int zdiv = g.kz / g.zs;
     dim3 grid((unsigned)(g.N / G::BN), (unsigned)((g.M + G::BM - 1) / G::BM), (unsigned)(zdiv * std::max(1, n)));
     const size_t lds = tile_lds_bytes<G>(g);
-    static bool attr_set = false;                        // (per instantiation) dynamic LDS beyond 64 KB has to be announced
-    if (!attr_set) {
+    // dynamic LDS beyond 64 KB has to be announced, per instantiation AND per device (one engine per GPU, each with its own
+    // stepping thread: a bit per device id, set after the attribute calls)
+    static std::atomic<uint64_t> attr_devs{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tile_kernel<MT, EPI, WT, NT, NWM, NWN, NSB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tile_zkernel<MT, EPI, WT, NT, NWM, NWN, NSB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_devs.fetch_or(bit, std::memory_order_release);
     }
     if (dev_args) hipLaunchKernelGGL((gemm_tile_zkernel<MT, EPI, WT, NT, NWM, NWN, NSB>), grid, dim3(G::NTH), lds, s, dev_args, zdiv);
     else hipLaunchKernelGGL((gemm_tile_kernel<MT, EPI, WT, NT, NWM, NWN, NSB>), grid, dim3(G::NTH), lds, s, g);

@@ -403,7 +403,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_config5:
         model.close()
         model = None
-        config5 = config5_leg(args, A, SM, torch, np)
+        try:
+            config5 = config5_leg(args, A, SM, torch, np)
+        except Exception as e:                      # the headline line must not depend on this leg
+            config5 = {"error": repr(e)}
 
     # ---------------- CPU baseline: the oracle (plain-C port, 1 thread) on the host, bounded sample
     cpu = None
