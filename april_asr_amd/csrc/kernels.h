@@ -120,6 +120,10 @@ struct GemmArgs {
 void launch_gemm(const GemmArgs &g, hipStream_t s);
 // (internal) GM_TILE launch, called by launch_gemm / launch_gemm_z once the plan is made: tile 16 * mt rows x 16 * nt columns; dev_args != null: n z-batched problems
 void launch_gemm_tile(const GemmArgs &g, int mt, int nt, const GemmArgs *dev_args, int n, hipStream_t s);
+// (internal) the recurrent GEMMs of a long feed at <= 16 rows as weight streams (kernels_recur.hip): recur_form says whether g is
+// one of them (1 gates h-half + cell, 2 projection), launch_recur runs n same-shape problems (dev_args) or g itself (dev_args == null)
+int recur_form(const GemmArgs &g);
+void launch_recur(const GemmArgs &g, int form, const GemmArgs *dev_args, int n, hipStream_t s);
 // n independent GEMMs of ONE shape (same M, N, K, kz, epilogue; any pointers) in one launch.  stage_gemm_z finalizes the
 // argument blocks on the host; launch_gemm_z launches once they are in device memory at dev_args (in stream order).
 // Fused-epilogue forms only (EPI_LSTM, EPI_XPART, EPI_BIAS_DSWISH, and EPI_HR / EPI_RESID_SSQ where gemm_fullk says so).

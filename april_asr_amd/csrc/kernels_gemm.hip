@@ -936,6 +936,7 @@ static TilePlan finalize_gemm(GemmArgs &g)
 void launch_gemm(const GemmArgs &g_in, hipStream_t s)
 {
     GemmArgs g = g_in;
+    if (const int rf = recur_form(g)) { launch_recur(g, rf, nullptr, 1, s); return; }
     const TilePlan t = finalize_gemm(g);
     if (t.mode == GM_TILE) { launch_gemm_tile(g, t.mt, t.nt, nullptr, 0, s); return; }
     const int mt = t.mt, nt = t.nt;
@@ -996,6 +997,7 @@ void launch_gemm_z(const GemmArgs *staged, int n, const GemmArgs *dev_args, hipS
 {
     if (n <= 0) return;
     const GemmArgs &g = staged[0];
+    if (const int rf = recur_form(g)) { launch_recur(g, rf, dev_args, n, s); return; }      // (stage_gemm_z checked that the n problems have one shape)
     GemmArgs probe = g;
     const TilePlan t = finalize_gemm(probe);
     if (t.mode == GM_TILE) { launch_gemm_tile(g, t.mt, t.nt, dev_args, n, s); return; }
