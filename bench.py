@@ -396,7 +396,7 @@ def main():
                    "schedule": "layer-major wavefront: blocks of time steps, the same launch of all layers z-batched into one (Engine::run_lm_wavefront)",
                    "recurrent_weight_bytes_per_chunk": int(wbytes),
                    "frac_of_hbm_peak_if_restreamed": round(wbytes * nchunks / (b - a) / 1e9 / HBM_PEAK_GBS, 4),
-                   "note": "recurrent weights (gate h-half + projection, 10 MB per layer) are re-read every time step from the Infinity Cache (120 MB for 12 layers)"}
+                   "note": "recurrent weights (gate h-half + projection, 10 MB per layer = 120 MB for 12 layers) are re-read from HBM at every time step by two weight-stream launches (csrc/kernels_recur.hip); the streaming read rate of this GPU is 6.8 TB/s from 48 MB up (tools/bw_probe), the Infinity Cache adds nothing"}
 
     # ---------------- BASELINE configs[4]: larger encoder, 512 sessions, fp16 MFMA path (and the same model in fp32)
     config5 = None

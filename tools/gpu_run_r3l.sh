@@ -1,7 +1,11 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-export APRIL_LOG_LEVEL=${APRIL_LOG_LEVEL:-WARNING}
-timeout 600 python -m pytest tests/test_gpu_f16.py -q -x --timeout 400 -p no:cacheprovider 2>&1 | tail -3
-for big in 1 0; do APRIL_TILE_BIG=$big python bench.py --config5-only > gpurun_out/r3l_config5_big$big.json 2> gpurun_out/r3l.err; python -c "
-import json; d=json.load(open('gpurun_out/r3l_config5_big$big.json'))
-print('big=$big', 'f16', d['f16']['ms_per_step'], d['f16']['gates_gemm']['avg_launch_us'], d['f16']['gates_gemm']['class_ms'], 'f32', d['f32']['ms_per_step'], 'x', d['f16_speedup_vs_f32'])"; done
+# kernel trace of the long feed (eager launches: rocprofv3 crashes on the replayed search graphs)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out
+export APRIL_LOG_LEVEL=WARNING APRIL_NO_GRAPHS=1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/lmprof -o lm -- python $R/tools/lm_probe.py v0 60 > $R/gpurun_out/r3l_probe.log 2>&1
+echo "rc=$?"; tail -5 $R/gpurun_out/r3l_probe.log
+f=$(find /tmp/lmprof -name "*kernel_stats.csv" | head -1); cp $f $R/gpurun_out/r3l_lm_kernel_stats.csv
+t=$(find /tmp/lmprof -name "*kernel_trace.csv" | head -1)
+python $R/tools/concurrency_summary.py $t > $R/gpurun_out/r3l_lm_trace_summary.txt 2>&1
+head -40 $R/gpurun_out/r3l_lm_trace_summary.txt
