@@ -1053,7 +1053,6 @@ Engine::SwPlan &Engine::sw_plan(int m, int T)
     SwPlan &p = sw_plans_[key];
     const NetDims &d = L_.dims;
     const int L = d.n_layers;
-    const size_t S = (size_t)cfg_.max_slots;
     std::vector<GemmArgs> items;
     std::vector<RowArgs> rows;
     for (int W = 0; W <= T + L; ++W) {
@@ -1103,7 +1102,6 @@ void Engine::run_sw_chain(int m, int T, bool dump_logits, const SwPlan &p)
 {
     const NetDims &d = L_.dims;
     const int MB = cfg_.max_batch;
-    const int L = d.n_layers;
     AdvanceArgs a;
     a.host_ring = ring_h_; a.host_step_off = step_off_h_; a.host_rec_off = rec_off_h_; a.counter = counter_d_;
     a.dst = step_d_; a.dst_stride = MB; a.n_arrays = 4; a.len[0] = m; a.len[1] = a.len[2] = a.len[3] = m * T; a.rec_off = rec_off_d_;
