@@ -16,6 +16,7 @@
 // (tests/test_gpu_layer_major.py compares every logit).
 #include "kernels.h"
 #include "device_utils.h"
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -34,12 +35,12 @@ constexpr int RPLANE = 16 * RLD;
 
 // TB consecutive k blocks (compile time: the whole stream is straight-line code, every load counted exactly) starting at the
 // wave's operand bases ap / bp (uniform; 64 B resp. 1 KB per block) plus the lane's 32-bit byte offsets ao / bo: chains of c
-// blocks, each finished chain handed to done(chunk number within the wave, acc).  At most 16 blocks (2 x 16 KB per wave) are in
-// flight: all of them before the first MFMA when TB <= 16.
-template <int TB, class F>
+// blocks, each finished chain handed to done(chunk number within the wave, acc).  At most RMAX blocks (2 x RMAX KB per wave) are
+// in flight: all of them before the first MFMA when TB <= RMAX.
+template <int TB, int RMAX, class F>
 __device__ __forceinline__ void stream_chains(const char *ap, uint32_t ao, const char *bp, uint32_t bo, int c, F done)
 {
-    constexpr int R = TB < 16 ? TB : 16;
+    constexpr int R = TB < RMAX ? TB : RMAX;
     f32x4 a[R], b[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
@@ -71,98 +72,164 @@ __device__ __forceinline__ void plane_store(float *plane, int lane, const f32x4 
     for (int r = 0; r < 4; ++r) plane[(r0 + r) * RLD + col] = acc[r];
 }
 
-// ---- gates: a workgroup = two 16-column tiles (eight hidden units) x the two chunks of the recurrent half of K
-template <int TB>
-__device__ __forceinline__ void recur_gates_body(const GemmArgs &g)
+// the rows' BasicNorm scales (RowScale): threads 0..63 (row = t / 4) fetch eight sum-of-squares partials each before the weight
+// stream, park them in LDS after it; row_scale_sum adds a row's partials in column order (the order of row_scale())
+constexpr int MAX_GROUPS = 32;
+struct ScalePart { float v[MAX_GROUPS / 4]; };
+__device__ __forceinline__ void scale_fetch(const RowScale &rs, int M, ScalePart &sp)
 {
+    const int row = (int)threadIdx.x >> 2, q = threadIdx.x & 3;
+    const int m = row < M ? row : M - 1;
+#pragma unroll
+    for (int k = 0; k < MAX_GROUPS / 4; ++k) { const int j = q * (MAX_GROUPS / 4) + k; sp.v[k] = gload<float>(rs.ssq + (size_t)m * rs.groups + (j < rs.groups ? j : rs.groups - 1)); }
+}
+__device__ __forceinline__ void scale_park(float *part, const ScalePart &sp)
+{
+    const int row = (int)threadIdx.x >> 2, q = threadIdx.x & 3;
+#pragma unroll
+    for (int k = 0; k < MAX_GROUPS / 4; ++k) part[row * (MAX_GROUPS + 1) + q * (MAX_GROUPS / 4) + k] = sp.v[k];
+}
+__device__ __forceinline__ float row_scale_sum(const float *part, int row, const RowScale &rs)
+{
+    float t = 0.0f;
+    for (int j = 0; j < rs.groups; ++j) t += part[row * (MAX_GROUPS + 1) + j];
+    return __builtin_amdgcn_rsqf(t * rs.inv_n + rs.eps);
+}
+
+// ---- the fused-epilogue GEMMs whose K is one slab (kz = 1, four chunks), four waves per workgroup:
+//   CF_GATES_H  gates, recurrent half (wave_mask 0b1100, p_add): 2 tiles x chunks 2, 3;  ((P + c2) + c3) + bias, LSTM cell
+//   CF_XPART    gates, input half (wave_mask 0b0011, EPI_XPART): 2 tiles x chunks 0, 1;  P = (c0 + c1) (* row scale)
+//   CF_GATES    the one-launch gates GEMM of a chunk step:        1 tile x chunks 0..3;  (((c0 + c1) * scale + c2) + c3) + bias, cell
+//   CF_DSWISH   feed-forward up (EPI_BIAS_DSWISH):                1 tile x chunks 0..3;  y = (((c0 + c1) + c2) + c3) + bias, y sigma(y - 1)
+enum { CF_GATES_H = 0, CF_XPART = 1, CF_GATES = 2, CF_DSWISH = 3 };
+
+template <int TB, int FORM>
+__device__ __forceinline__ void recur_cell_body(const GemmArgs &g)
+{
+    constexpr bool HALF = FORM == CF_GATES_H || FORM == CF_XPART;
+    constexpr bool CELL = FORM == CF_GATES_H || FORM == CF_GATES;
+    constexpr int TPW = HALF ? 2 : 1;                                      // column tiles per workgroup
     __shared__ __attribute__((aligned(16))) float red[4 * RPLANE];
+    __shared__ float part[16 * (MAX_GROUPS + 1)];
     if (g.run_flag && gload<int>(g.run_flag) != g.run_gen) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int KB = 4 * TB, c = TB;                                     // (checked on the host: K = 64 TB)
-    const int ct = blockIdx.x * 2 + (wave >> 1), half = wave & 1;         // this wave: chunk 2 + half of column tile ct
-    // epilogue operands of this thread's (row, unit), fetched before the stream (row -> slot -> previous cell value is a dependent pair)
+    const int wtile = HALF ? (wave >> 1) : 0;
+    const int chunk = FORM == CF_GATES_H ? 2 + (wave & 1) : (FORM == CF_XPART ? (wave & 1) : wave);
+    const int ct = blockIdx.x * TPW + wtile;
+    const bool scaled = (FORM == CF_XPART || FORM == CF_GATES) && g.x_scale.ssq != nullptr;
+    // epilogue operands of this thread's (tile, row, quad), fetched before the stream (row -> slot -> previous cell value is a dependent pair)
     const int et = threadIdx.x >> 6, erow = (threadIdx.x >> 2) & 15, eul = threadIdx.x & 3;
-    const bool e_on = threadIdx.x < 128, e_ok = e_on && erow < g.M;
-    const int en = (blockIdx.x * 2 + et) * 16 + eul * 4, eunit = en >> 2;
+    const bool e_on = (int)threadIdx.x < 64 * TPW, e_ok = e_on && erow < g.M;
+    const int en = (blockIdx.x * TPW + et) * 16 + eul * 4, eunit = en >> 2;
     const int em = erow < g.M ? erow : g.M - 1;
     float *cptr = nullptr;
     float cprev = 0.0f;
     f32x4 ebias = {0.f, 0.f, 0.f, 0.f}, xin = {0.f, 0.f, 0.f, 0.f};
+    ScalePart sp;
+    if (scaled && threadIdx.x < 64) scale_fetch(g.x_scale, g.M, sp);
     if (e_on) {
-        cptr = g.c_state + (size_t)gload<int>(g.slot_idx + em) * g.hidden + eunit;
-        ebias = gload<f32x4>(g.bias + en);
-        xin = gload<f32x4>(g.p_add + (size_t)em * g.ldp + en);
-        cprev = gload<float>(cptr);
+        if (CELL) {
+            cptr = g.c_state + (size_t)gload<int>(g.slot_idx + em) * g.hidden + eunit;
+            cprev = gload<float>(cptr);
+        }
+        if (FORM != CF_XPART) ebias = gload<f32x4>(g.bias + en);
+        if (FORM == CF_GATES_H) xin = gload<f32x4>(g.p_add + (size_t)em * g.ldp + en);
     }
+    // this wave's chunk: k range [chunk c 16, (chunk + 1) c 16) of the A row, which lies in K segment 0 or 1 as a whole
     int row = lane & 15;
     if (row >= g.M) row = g.M - 1;                                         // padding rows recompute the last row; never stored
-    const int slot = g.aidx1 ? gload<int>(g.aidx1 + row) : row;
+    const int koff = chunk * c * 16;
+    const bool seg1 = g.K1 > 0 && koff >= g.K0;                            // uniform
+    const int *aidx = seg1 ? g.aidx1 : g.aidx0;
+    const int arow = aidx ? gload<int>(aidx + row) : row;
     // (all operands are far below 4 GiB per array: 32-bit lane offsets)
-    const char *ap = reinterpret_cast<const char *>(g.a1) + (size_t)half * c * 64;
-    const uint32_t ao = (uint32_t)(((size_t)slot * g.lda1 + (lane >> 4) * 4) * sizeof(float));
-    const char *bp = reinterpret_cast<const char *>(g.wp) + ((size_t)ct * KB + (size_t)(2 + half) * c) * 1024;
+    const char *ap = reinterpret_cast<const char *>(seg1 ? g.a1 : g.a0) + (size_t)(seg1 ? koff - g.K0 : koff) * sizeof(float);
+    const uint32_t ao = (uint32_t)(((size_t)arow * (seg1 ? g.lda1 : g.lda0) + (lane >> 4) * 4) * sizeof(float));
+    const char *bp = reinterpret_cast<const char *>(g.wp) + ((size_t)ct * KB + (size_t)chunk * c) * 1024;
     float *mine = red + wave * RPLANE;
-    stream_chains<TB>(ap, ao, bp, (uint32_t)lane * 16u, c, [&](int, const f32x4 &acc) { plane_store(mine, lane, acc); });
+    stream_chains<TB, 16>(ap, ao, bp, (uint32_t)lane * 16u, c, [&](int, const f32x4 &acc) { plane_store(mine, lane, acc); });
+    if (scaled && threadIdx.x < 64) scale_park(part, sp);
     __syncthreads();
     if (e_on) {
         const int o = erow * RLD + eul * 4;
-        const f32x4 p2 = *reinterpret_cast<const f32x4 *>(red + (2 * et) * RPLANE + o), p3 = *reinterpret_cast<const f32x4 *>(red + (2 * et + 1) * RPLANE + o);
-        const f32x4 gt = ((xin + p2) + p3) + ebias;
-        const float c_new = fast_sigmoid(gt.y) * cprev + fast_sigmoid(gt.x) * fast_tanh(gt.z);
-        const float u = fast_sigmoid(gt.w) * fast_tanh(c_new);
-        if (e_ok) { gstore<float>(cptr, c_new); gstore<float>(g.out + (size_t)erow * g.ldo + eunit, u); }
+        const float *pl = red + (HALF ? 2 * et : 0) * RPLANE + o;           // the tile's planes, in chunk order
+        const f32x4 pa = *reinterpret_cast<const f32x4 *>(pl), pb = *reinterpret_cast<const f32x4 *>(pl + RPLANE);
+        if (FORM == CF_XPART) {
+            const f32x4 x = scaled ? (pa + pb) * row_scale_sum(part, erow, g.x_scale) : (pa + pb);
+            if (e_ok) gstore<f32x4>(g.out + (size_t)erow * g.ldo + en, x);
+        } else if (FORM == CF_DSWISH) {
+            const f32x4 y = (((pa + pb) + *reinterpret_cast<const f32x4 *>(pl + 2 * RPLANE)) + *reinterpret_cast<const f32x4 *>(pl + 3 * RPLANE)) + ebias;
+            f32x4 v;
+            v.x = y.x * fast_sigmoid(y.x - 1.0f); v.y = y.y * fast_sigmoid(y.y - 1.0f);
+            v.z = y.z * fast_sigmoid(y.z - 1.0f); v.w = y.w * fast_sigmoid(y.w - 1.0f);
+            if (e_ok) gstore<f32x4>(g.out + (size_t)erow * g.ldo + en, v);
+        } else {
+            f32x4 gt;
+            if (FORM == CF_GATES_H) gt = ((xin + pa) + pb) + ebias;
+            else {
+                const f32x4 p2 = *reinterpret_cast<const f32x4 *>(pl + 2 * RPLANE), p3 = *reinterpret_cast<const f32x4 *>(pl + 3 * RPLANE);
+                if (scaled) gt = (((pa + pb) * row_scale_sum(part, erow, g.x_scale) + p2) + p3) + ebias;
+                else gt = (((pa + pb) + p2) + p3) + ebias;
+            }
+            const float c_new = fast_sigmoid(gt.y) * cprev + fast_sigmoid(gt.x) * fast_tanh(gt.z);
+            const float u = fast_sigmoid(gt.w) * fast_tanh(c_new);
+            if (e_ok) { gstore<float>(cptr, c_new); gstore<float>(g.out + (size_t)erow * g.ldo + eunit, u); }
+        }
     }
 }
 
-// ---- projection: a workgroup = one 16-column tile, its 4 kz chunks dealt to the waves (consecutive chunks per wave)
-constexpr int WHR_MAX_PLANES = 32, WHR_MAX_GROUPS = 32;
+// ---- the row-epilogue GEMMs (all of K in the workgroup, 4 kz chunks per column tile dealt to the waves, consecutive chunks per wave):
+//   RF_HR         projection (EPI_HR): one 16-column tile, <= 8 waves;  h' = tree, state row, out = x * scale(x) + h'
+//   RF_RESID_SSQ  feed-forward down / embed linear (EPI_RESID_SSQ): two tiles = one 32-column sum-of-squares granule, <= 16 waves;
+//                 y = (resid +) tree + bias, out, ssq
+enum { RF_HR = 0, RF_RESID_SSQ = 1 };
 
-template <int TB>
-__device__ __forceinline__ void recur_whr_body(const GemmArgs &g)
+template <int TB, int FORM>
+__device__ __forceinline__ void recur_row_body(const GemmArgs &g)
 {
-    __shared__ __attribute__((aligned(16))) float red[WHR_MAX_PLANES * RPLANE];
-    __shared__ float part[16 * (WHR_MAX_GROUPS + 1)];
+    constexpr int NTILE = FORM == RF_RESID_SSQ ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) float dyn[];           // [chains][RPLANE] planes, then the scale partials
     if (g.run_flag && gload<int>(g.run_flag) != g.run_gen) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = (int)(blockDim.x >> 6);
-    const int KB = g.K >> 4, nch = 4 * g.kz, c = KB / nch, cpw = nch / nw;      // (checked on the host: cpw * c == TB)
-    const int ct = blockIdx.x;
-    // epilogue operands (threads 0..63: row = t / 4, quad = t % 4): slot, residual quad, the row's sum-of-squares partials
-    const int erow = (int)threadIdx.x >> 2, eq = threadIdx.x & 3;
-    const bool e_on = threadIdx.x < 64, e_ok = e_on && erow < g.M;
+    const int KB = g.K >> 4, nch = 4 * g.kz, c = KB / nch, cpw = NTILE * nch / nw;      // (checked on the host: cpw * c == TB)
+    float *red = dyn, *part = dyn + (size_t)NTILE * nch * RPLANE;
+    const int first = wave * cpw;                                         // this wave's chains: tile first / nch, chunks first % nch ..
+    const int ct = blockIdx.x * NTILE + first / nch, kb0 = (first % nch) * c;
+    // epilogue operands.  RF_HR: threads 0..63 = (row, quad).  RF_RESID_SSQ: threads 0..127 = (row, 8 quads of the 32-column granule)
+    const int erow = FORM == RF_HR ? (int)threadIdx.x >> 2 : (int)threadIdx.x >> 3, eq = FORM == RF_HR ? (threadIdx.x & 3) : (threadIdx.x & 7);
+    const bool e_on = (int)threadIdx.x < 64 * NTILE, e_ok = e_on && erow < g.M;
     const int em = erow < g.M ? erow : g.M - 1;
-    const int en = ct * 16 + eq * 4;
+    const int en = blockIdx.x * NTILE * 16 + eq * 4;
     int eslot = 0;
-    f32x4 eres = {0.f, 0.f, 0.f, 0.f};
-    float sp[WHR_MAX_GROUPS / 4];                                        // partials eq * 8 .. eq * 8 + 7 of the row (its four threads share them through LDS)
-    const int G = g.r_scale.groups;
+    f32x4 eres = {0.f, 0.f, 0.f, 0.f}, ebias = {0.f, 0.f, 0.f, 0.f};
+    ScalePart sp;
+    if (FORM == RF_HR && threadIdx.x < 64) scale_fetch(g.r_scale, g.M, sp);
     if (e_on) {
-        eslot = g.slot_idx ? gload<int>(g.slot_idx + em) : em;
-        eres = gload<f32x4>(g.resid + (size_t)em * g.ldr + en);
-#pragma unroll
-        for (int k = 0; k < WHR_MAX_GROUPS / 4; ++k) { const int j = eq * (WHR_MAX_GROUPS / 4) + k; sp[k] = gload<float>(g.r_scale.ssq + (size_t)em * G + (j < G ? j : G - 1)); }
+        if (FORM == RF_HR) eslot = g.slot_idx ? gload<int>(g.slot_idx + em) : em;
+        if (FORM == RF_HR || g.resid) eres = gload<f32x4>(g.resid + (size_t)em * g.ldr + en);
+        if (FORM == RF_RESID_SSQ) ebias = gload<f32x4>(g.bias + en);
     }
     int row = lane & 15;
     if (row >= g.M) row = g.M - 1;
     const int arow = g.aidx0 ? gload<int>(g.aidx0 + row) : row;
-    const int kb0 = wave * cpw * c;
     const char *ap = reinterpret_cast<const char *>(g.a0) + (size_t)kb0 * 64;
     const uint32_t ao = (uint32_t)(((size_t)arow * g.lda0 + (lane >> 4) * 4) * sizeof(float));
     const char *bp = reinterpret_cast<const char *>(g.wp) + ((size_t)ct * KB + kb0) * 1024;
-    float *mine = red + (size_t)wave * cpw * RPLANE;
-    stream_chains<TB>(ap, ao, bp, (uint32_t)lane * 16u, c, [&](int q, const f32x4 &acc) { plane_store(mine + q * RPLANE, lane, acc); });
-    if (e_on) {
-#pragma unroll
-        for (int k = 0; k < WHR_MAX_GROUPS / 4; ++k) part[erow * (WHR_MAX_GROUPS + 1) + eq * (WHR_MAX_GROUPS / 4) + k] = sp[k];
-    }
+    float *mine = red + (size_t)first * RPLANE;
+    // (these workgroups run at four waves per SIMD, 128 registers per lane: at most twelve blocks in flight, eight when the ring wraps)
+    stream_chains<TB, (FORM == RF_RESID_SSQ || TB > 12) ? 8 : 16>(ap, ao, bp, (uint32_t)lane * 16u, c, [&](int q, const f32x4 &acc) { plane_store(mine + q * RPLANE, lane, acc); });
+    if (FORM == RF_HR && threadIdx.x < 64) scale_park(part, sp);
     __syncthreads();
     if (e_on) {
-        const int o = erow * RLD + eq * 4;
+        const int tile = FORM == RF_HR ? 0 : eq >> 2;
+        const int o = erow * RLD + (eq & 3) * 4;
         // slab sums ((c0 + c1) + c2) + c3, then the balanced tree in slab order
         auto slab = [&](int z) {
-            const float *p = red + (size_t)(4 * z) * RPLANE + o;
+            const float *p = red + (size_t)(tile * nch + 4 * z) * RPLANE + o;
             return ((*reinterpret_cast<const f32x4 *>(p) + *reinterpret_cast<const f32x4 *>(p + RPLANE)) + *reinterpret_cast<const f32x4 *>(p + 2 * RPLANE)) + *reinterpret_cast<const f32x4 *>(p + 3 * RPLANE);
         };
         f32x4 v;
@@ -170,37 +237,46 @@ __device__ __forceinline__ void recur_whr_body(const GemmArgs &g)
         else if (g.kz == 4) v = (slab(0) + slab(1)) + (slab(2) + slab(3));
         else if (g.kz == 2) v = slab(0) + slab(1);
         else v = slab(0);
-        float t = 0.0f;                                                   // the row's BasicNorm scale, partials added in column order (row_scale())
-        for (int j = 0; j < G; ++j) t += part[erow * (WHR_MAX_GROUPS + 1) + j];
-        const float rs = __builtin_amdgcn_rsqf(t * g.r_scale.inv_n + g.r_scale.eps);
-        if (e_ok) {
-            gstore<f32x4>(g.state + (size_t)eslot * g.ld_state + en, v);
-            gstore<f32x4>(g.out + (size_t)erow * g.ldo + en, eres * rs + v);
+        if (FORM == RF_HR) {
+            const float rs = row_scale_sum(part, erow, g.r_scale);
+            if (e_ok) {
+                gstore<f32x4>(g.state + (size_t)eslot * g.ld_state + en, v);
+                gstore<f32x4>(g.out + (size_t)erow * g.ldo + en, eres * rs + v);
+            }
+        } else {
+            f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (e_ok) {
+                y = v + ebias;
+                if (g.resid) y = eres + y;
+                gstore<f32x4>(g.out + (size_t)erow * g.ldo + en, y);
+            }
+            const float ss = granule_ssq(y);                             // all lanes of waves 0 and 1 take part in the shuffles
+            if (e_ok && eq == 0) gstore<float>(g.ssq_out + (size_t)erow * (g.N / SSQ_COLS) + en / SSQ_COLS, ss);
         }
     }
 }
 
-template <int TB> __global__ __launch_bounds__(256, TB <= 16 ? 3 : 2) void recur_gates_kernel(GemmArgs g) { recur_gates_body<TB>(g); }
-template <int TB> __global__ __launch_bounds__(256, TB <= 16 ? 3 : 2) void recur_gates_zkernel(const GemmArgs *__restrict__ zargs) { const GemmArgs g = zargs[blockIdx.y]; recur_gates_body<TB>(g); }
-template <int TB> __global__ __launch_bounds__(512, 4) void recur_whr_kernel(GemmArgs g) { recur_whr_body<TB>(g); }
-template <int TB> __global__ __launch_bounds__(512, 4) void recur_whr_zkernel(const GemmArgs *__restrict__ zargs) { const GemmArgs g = zargs[blockIdx.y]; recur_whr_body<TB>(g); }
+template <int TB, int FORM> __global__ __launch_bounds__(256, TB <= 16 ? 3 : 2) void recur_cell_kernel(GemmArgs g) { recur_cell_body<TB, FORM>(g); }
+template <int TB, int FORM> __global__ __launch_bounds__(256, TB <= 16 ? 3 : 2) void recur_cell_zkernel(const GemmArgs *__restrict__ zargs) { const GemmArgs g = zargs[blockIdx.y]; recur_cell_body<TB, FORM>(g); }
+template <int TB, int FORM> __global__ __launch_bounds__(FORM == RF_HR ? 512 : 1024, 4) void recur_row_kernel(GemmArgs g) { recur_row_body<TB, FORM>(g); }
+template <int TB, int FORM> __global__ __launch_bounds__(FORM == RF_HR ? 512 : 1024, 4) void recur_row_zkernel(const GemmArgs *__restrict__ zargs) { const GemmArgs g = zargs[blockIdx.y]; recur_row_body<TB, FORM>(g); }
 
-// blocks per wave that have a kernel: gates = k blocks per chunk (K / 64), projection = K / 16 / waves
-#define APRIL_RECUR_GATES_TB(X) X(1) X(2) X(3) X(4) X(6) X(8) X(12) X(16) X(24)
-#define APRIL_RECUR_WHR_TB(X) X(1) X(2) X(3) X(4) X(5) X(6) X(8) X(10) X(12)
-bool gates_tb_ok(int tb) {
+// blocks per wave that have a kernel: cell forms = k blocks per chunk (K / 64), row forms = chunks per wave x blocks per chunk
+#define APRIL_RECUR_CELL_TB(X) X(1) X(2) X(3) X(4) X(6) X(8) X(12) X(16) X(24)
+#define APRIL_RECUR_ROW_TB(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(10) X(12) X(16) X(24)
+bool cell_tb_ok(int tb) {
 #define X(n) if (tb == n) return true;
-    APRIL_RECUR_GATES_TB(X)
+    APRIL_RECUR_CELL_TB(X)
 #undef X
     return false;
 }
-bool whr_tb_ok(int tb) {
+bool row_tb_ok(int tb) {
 #define X(n) if (tb == n) return true;
-    APRIL_RECUR_WHR_TB(X)
+    APRIL_RECUR_ROW_TB(X)
 #undef X
     return false;
 }
-int whr_waves(const GemmArgs &g) { const int nch = 4 * g.kz; return nch < 8 ? nch : 8; }
+int row_waves(const GemmArgs &g, int ntile) { const int chains = 4 * g.kz * ntile, cap = ntile == 2 ? 16 : 8; return chains < cap ? chains : cap; }
 
 int recur_enabled()
 {
@@ -208,42 +284,85 @@ int recur_enabled()
     return v;
 }
 
+template <int FORM>
+void launch_cell(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s)
+{
+    constexpr int TPW = (FORM == CF_GATES_H || FORM == CF_XPART) ? 2 : 1;
+    const dim3 grid((unsigned)(g.N / (16 * TPW)), (unsigned)(dev_args ? n : 1), 1);
+    switch (g.K / 64) {
+#define X(tb) case tb: if (dev_args) hipLaunchKernelGGL((recur_cell_zkernel<tb, FORM>), grid, dim3(256), 0, s, dev_args); else hipLaunchKernelGGL((recur_cell_kernel<tb, FORM>), grid, dim3(256), 0, s, g); return;
+    APRIL_RECUR_CELL_TB(X)
+#undef X
+    }
+    fprintf(stderr, "libapril(mi355x): launch_recur: no cell kernel for K = %d\n", g.K);
+    abort();
+}
+
+template <int FORM>
+void launch_row(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s)
+{
+    constexpr int NTILE = FORM == RF_RESID_SSQ ? 2 : 1;
+    const int nw = row_waves(g, NTILE), chains = 4 * g.kz * NTILE;
+    const dim3 grid((unsigned)(g.N / (16 * NTILE)), (unsigned)(dev_args ? n : 1), 1);
+    const size_t lds = ((size_t)chains * RPLANE + 16 * (MAX_GROUPS + 1)) * sizeof(float);
+    switch (g.K / 16 / (4 * g.kz) * (chains / nw)) {
+#define X(tb) case tb: { \
+        if (lds > 64 * 1024) {      /* dynamic LDS beyond 64 KB has to be announced, per instantiation and device */ \
+            static std::atomic<uint64_t> attr_devs{0}; \
+            int dev = 0; (void)hipGetDevice(&dev); \
+            const uint64_t bit = 1ull << (dev & 63); \
+            if (!(attr_devs.load(std::memory_order_acquire) & bit)) { \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&recur_row_kernel<tb, FORM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&recur_row_zkernel<tb, FORM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                attr_devs.fetch_or(bit, std::memory_order_release); \
+            } \
+        } \
+        if (dev_args) hipLaunchKernelGGL((recur_row_zkernel<tb, FORM>), grid, dim3(64 * nw), lds, s, dev_args); \
+        else hipLaunchKernelGGL((recur_row_kernel<tb, FORM>), grid, dim3(64 * nw), lds, s, g); \
+        return; }
+    APRIL_RECUR_ROW_TB(X)
+#undef X
+    }
+    fprintf(stderr, "libapril(mi355x): launch_recur: no row kernel for K = %d, kz = %d\n", g.K, g.kz);
+    abort();
+}
+
 }  // namespace
 
-// 1 = gates form, 2 = projection form, 0 = not one of the two (the general kernels take it)
+// which stream kernel takes g (0: none, the general kernels do)
+enum { RECUR_GATES_H = 1, RECUR_HR = 2, RECUR_GATES = 3, RECUR_XPART = 4, RECUR_DSWISH = 5, RECUR_RESID_SSQ = 6 };
+
 int recur_form(const GemmArgs &g)
 {
-    if (!recur_enabled() || g.wt != 0 || g.a_op != AOP_NONE || g.M < 1 || g.M > 16 || g.K % 64 != 0) return 0;
+    if (!recur_enabled() || g.wt != 0 || g.a_op != AOP_NONE || g.M < 1 || g.M > 16 || g.K % 64 != 0 || g.out16 || g.state16) return 0;
     const int KB = g.K / 16;
-    if (g.epi == EPI_LSTM && g.wave_mask == 0xC && g.p_add && g.kz == 1 && g.K0 * 2 == g.K && g.K1 == g.K0 && g.N % 32 == 0 && KB % 4 == 0 && gates_tb_ok(KB / 4) && !g.x_scale.ssq && g.out && !g.out16)
-        return 1;
-    if (g.epi == EPI_HR && g.wave_mask == 0xF && g.K1 == 0 && (g.kz == 1 || g.kz == 2 || g.kz == 4 || g.kz == 8) && KB % (4 * g.kz) == 0 && g.N % 16 == 0 &&
-        whr_tb_ok(KB / whr_waves(g)) && g.r_scale.ssq && g.r_scale.groups <= WHR_MAX_GROUPS && !g.out16 && !g.state16)
-        return 2;
+    const bool kz_ok = g.kz == 1 || g.kz == 2 || g.kz == 4 || g.kz == 8;
+    const bool halves = g.kz == 1 && g.K0 * 2 == g.K && g.K1 == g.K0 && cell_tb_ok(KB / 4);      // gates: [x | h], one slab
+    const bool xs_ok = !g.x_scale.ssq || g.x_scale.groups <= MAX_GROUPS;
+    if (g.epi == EPI_LSTM && halves && g.out && g.N % 32 == 0) {
+        if (g.wave_mask == 0xC && g.p_add && !g.x_scale.ssq) return RECUR_GATES_H;
+        if (g.wave_mask == 0xF && !g.p_add && xs_ok) return RECUR_GATES;
+    }
+    if (g.epi == EPI_XPART && halves && g.wave_mask == 0x3 && !g.p_add && xs_ok && g.N % 32 == 0) return RECUR_XPART;
+    if (g.epi == EPI_BIAS_DSWISH && g.wave_mask == 0xF && g.kz == 1 && g.K1 == 0 && cell_tb_ok(KB / 4) && g.out && g.N % 16 == 0) return RECUR_DSWISH;
+    if (g.wave_mask != 0xF || g.K1 != 0 || !kz_ok || KB % (4 * g.kz) != 0) return 0;
+    if (g.epi == EPI_HR && g.N % 16 == 0 && g.r_scale.ssq && g.r_scale.groups <= MAX_GROUPS && row_tb_ok(KB / row_waves(g, 1))) return RECUR_HR;
+    if (g.epi == EPI_RESID_SSQ && g.N % 32 == 0 && g.ssq_out && row_tb_ok(2 * KB / row_waves(g, 2))) return RECUR_RESID_SSQ;
     return 0;
 }
 
 // n problems of one shape (dev_args: their argument blocks in device memory) or one problem by value (dev_args == null)
 void launch_recur(const GemmArgs &g, int form, const GemmArgs *dev_args, int n, hipStream_t s)
 {
-    const int KB = g.K / 16;
-    if (form == 1) {
-        const dim3 grid((unsigned)(g.N / 32), (unsigned)(dev_args ? n : 1), 1);
-        switch (KB / 4) {
-#define X(tb) case tb: if (dev_args) hipLaunchKernelGGL(recur_gates_zkernel<tb>, grid, dim3(256), 0, s, dev_args); else hipLaunchKernelGGL(recur_gates_kernel<tb>, grid, dim3(256), 0, s, g); return;
-        APRIL_RECUR_GATES_TB(X)
-#undef X
-        }
-    } else {
-        const int nw = whr_waves(g);
-        const dim3 grid((unsigned)(g.N / 16), (unsigned)(dev_args ? n : 1), 1);
-        switch (KB / nw) {
-#define X(tb) case tb: if (dev_args) hipLaunchKernelGGL(recur_whr_zkernel<tb>, grid, dim3(64 * nw), 0, s, dev_args); else hipLaunchKernelGGL(recur_whr_kernel<tb>, grid, dim3(64 * nw), 0, s, g); return;
-        APRIL_RECUR_WHR_TB(X)
-#undef X
-        }
+    switch (form) {
+    case RECUR_GATES_H: launch_cell<CF_GATES_H>(g, dev_args, n, s); return;
+    case RECUR_GATES: launch_cell<CF_GATES>(g, dev_args, n, s); return;
+    case RECUR_XPART: launch_cell<CF_XPART>(g, dev_args, n, s); return;
+    case RECUR_DSWISH: launch_cell<CF_DSWISH>(g, dev_args, n, s); return;
+    case RECUR_HR: launch_row<RF_HR>(g, dev_args, n, s); return;
+    case RECUR_RESID_SSQ: launch_row<RF_RESID_SSQ>(g, dev_args, n, s); return;
     }
-    fprintf(stderr, "libapril(mi355x): launch_recur: no kernel for form %d, K = %d, kz = %d\n", form, g.K, g.kz);
+    fprintf(stderr, "libapril(mi355x): launch_recur: unknown form %d\n", form);
     abort();
 }
 
