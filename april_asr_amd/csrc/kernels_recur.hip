@@ -1,19 +1,20 @@
-// The two GEMMs of a recurrent time step of a LONG FEED at a handful of rows (one session handing over a file: M = 1), as
-// weight streams.  Reference path: the per-chunk encoder call of src/april_session.c:431-476 run on a whole recording; here the
-// layer-major schedule (engine.cc, Engine::run_lm_wavefront) leaves two launches per time step whose cost is the layers'
-// recurrent weights read once -- 96 MB of gate weights (h half) and 24 MB of projection weights at aprilv0 size, twelve layers
-// per launch:
-//   gates  EPI_LSTM, wave_mask 0b1100, p_add:  ((P + c2) + c3) + bias, LSTM cell           (P = the input half, EPI_XPART)
-//   whr    EPI_HR, all of K in the workgroup:   h' = u x Whr, state row, x + h'
-// The general kernels (kernels_gemm.hip) run them as 16 x 16 / 16 x 32 tiles with half of the waves idle and 6 KB of weights
-// in flight per wave: 20.9 + 9.3 us per time step at twelve layers, against 14.9 + 3.6 us for the same bytes at the streaming
-// rate of this GPU (tools/bw_probe: 6.8 TB/s from 48 MB up; the Infinity Cache adds nothing).  Here every wave owns whole
-// chunks of one 16-column tile and has its whole k range in flight before its first MFMA.
+// The layer GEMMs at a handful of rows (M <= 16: one session handing over a file, or a few sessions streaming) as WEIGHT STREAMS.
+// Reference path: the per-chunk encoder call of src/april_session.c:431-476.  At these sizes a GEMM is its weight matrix read once
+// (the recurrent pair of a long feed's time step: 96 MB of gate weights + 24 MB of projection weights for twelve layers per launch),
+// and the general kernels (kernels_gemm.hip) run them as a few dozen 16 x 16 / 16 x 32 tiles with 6 KB of weights in flight per
+// wave -- 20.9 + 9.3 us per time step of a long feed against 14.9 + 3.6 us for the same bytes at the streaming rate of this GPU
+// (tools/bw_probe: 6.8 TB/s from 48 MB up; the Infinity Cache adds nothing), 12.8 us for the 4 MB FFN-down GEMM of one session.
+// Here every wave owns whole CHUNKS (the unit of the canonical summation) of one 16-column tile and has its whole k range in
+// flight before its first MFMA.  Six forms:
+//   cell forms (kz = 1, four waves)   gates recurrent half + LSTM cell (long feed, p_add), gates input half (long feed, EPI_XPART),
+//                                     the one-launch gates GEMM + cell (streaming), FFN up + DoubleSwish
+//   row forms (all of K, <= 16 waves) projection (EPI_HR), FFN down / bias + residual + sums of squares (EPI_RESID_SSQ)
 //
 // Arithmetic: the chains are those of gemm_body -- a chunk is ONE in-order chain of v_mfma_f32_16x16x4_f32 over its k blocks
 // (k step j of a block = element j of the lane's operand quads), chunks meet as ((c0 + c1) + c2) + c3, slabs in the balanced
-// pairwise tree -- so the results are bit-identical to the general kernels and to the streaming schedule
-// (tests/test_gpu_layer_major.py compares every logit).
+// pairwise tree, epilogues term by term -- so the results are bit-identical to the general kernels at any batch size and to the
+// layer-major schedule (tests/test_gpu_recur_kernels.py runs the same sessions with these kernels off and on; the batch-invariance
+// and layer-major == streaming tests of tests/test_gpu_parity.py cross the same boundary).
 #include "kernels.h"
 #include "device_utils.h"
 #include <atomic>

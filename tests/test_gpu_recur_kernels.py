@@ -1,7 +1,7 @@
-"""The recurrent GEMMs of a long feed (gate h-half + LSTM cell, projection) at <= 16 rows run as weight streams
-(csrc/kernels_recur.hip) and as general GEMM tiles above; both must produce the same bits.  Two processes run the same sessions
-with the stream kernels off and on; every logit and every callback must be identical.  The four models cover the kernels' forms:
-1 / 2 / 5 / 6 / 8 / 12 / 16 / 24 k blocks per wave, kz = 1, 2 and 8, the 16-block ring wrapping (larger encoder)."""
+"""The layer GEMMs at <= 16 rows (the recurrent pair and the block stages of a long feed, every layer GEMM of a few streaming
+sessions) run as weight streams (csrc/kernels_recur.hip: six forms) and as general GEMM tiles above; both must produce the same
+bits.  Two processes run the same sessions with the stream kernels off and on; every logit and every callback must be identical.
+The four models cover the kernels' shapes: 1 ... 24 k blocks per wave, kz = 1, 2 and 8, the block ring wrapping (larger encoder)."""
 import os
 import subprocess
 import sys
