@@ -36,32 +36,32 @@ constexpr int RPLANE = 16 * RLD;
 
 // TB consecutive k blocks (compile time: the whole stream is straight-line code, every load counted exactly) starting at the
 // wave's operand bases ap / bp (uniform; 64 B resp. 1 KB per block) plus the lane's 32-bit byte offsets ao / bo: chains of c
-// blocks, each finished chain handed to done(chunk number within the wave, acc).  At most RMAX blocks (2 x RMAX KB per wave) are
-// in flight: all of them before the first MFMA when TB <= RMAX.
-template <int TB, int RMAX, class F>
+// blocks, each finished chain handed to done(chunk number within the wave, acc).  RB weight blocks and RA activation blocks are
+// in flight (rings; all of the stream before the first MFMA when TB <= both).  RA < RB where registers are short: the weights
+// come from HBM, the activation rows from L2, so the late half of the activation ring costs an L2 round trip, not an HBM one.
+template <int TB, int RB_, int RA_, class F>
 __device__ __forceinline__ void stream_chains(const char *ap, uint32_t ao, const char *bp, uint32_t bo, int c, F done)
 {
-    constexpr int R = TB < RMAX ? TB : RMAX;
-    f32x4 a[R], b[R];
+    constexpr int RB = TB < RB_ ? TB : RB_, RA = TB < RA_ ? TB : RA_;
+    static_assert(RA <= RB, "the activation ring is the shorter one");
+    f32x4 a[RA], b[RB];
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-        a[i] = gload<f32x4>(ap + (size_t)i * 64 + ao);
+    for (int i = 0; i < RB; ++i) {
+        if (i < RA) a[i] = gload<f32x4>(ap + (size_t)i * 64 + ao);
         b[i] = gload_nt<f32x4>(bp + (size_t)i * 1024 + bo);
     }
-    __builtin_amdgcn_sched_barrier(0);              // (left alone, the scheduler sinks each load to its MFMAs: four blocks in flight instead of R)
+    __builtin_amdgcn_sched_barrier(0);              // (left alone, the scheduler sinks each load to its MFMAs: four blocks in flight instead of the ring)
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     int in_chunk = 0, chunk = 0;
 #pragma unroll
     for (int i = 0; i < TB; ++i) {
-        const int s = i % R;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].x, b[s].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].y, b[s].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].z, b[s].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s].w, b[s].w, acc, 0, 0, 0);
-        if (i + R < TB) {
-            a[s] = gload<f32x4>(ap + (size_t)(i + R) * 64 + ao);
-            b[s] = gload_nt<f32x4>(bp + (size_t)(i + R) * 1024 + bo);
-        }
+        const int sa = i % RA, sb = i % RB;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sa].x, b[sb].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sa].y, b[sb].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sa].z, b[sb].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sa].w, b[sb].w, acc, 0, 0, 0);
+        if (i + RA < TB) a[sa] = gload<f32x4>(ap + (size_t)(i + RA) * 64 + ao);
+        if (i + RB < TB) b[sb] = gload_nt<f32x4>(bp + (size_t)(i + RB) * 1024 + bo);
         if (++in_chunk == c) { done(chunk, acc); ++chunk; in_chunk = 0; acc = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
 }
@@ -150,7 +150,7 @@ __device__ __forceinline__ void recur_cell_body(const GemmArgs &g)
     const uint32_t ao = (uint32_t)(((size_t)arow * (seg1 ? g.lda1 : g.lda0) + (lane >> 4) * 4) * sizeof(float));
     const char *bp = reinterpret_cast<const char *>(g.wp) + ((size_t)ct * KB + (size_t)chunk * c) * 1024;
     float *mine = red + wave * RPLANE;
-    stream_chains<TB, 16>(ap, ao, bp, (uint32_t)lane * 16u, c, [&](int, const f32x4 &acc) { plane_store(mine, lane, acc); });
+    stream_chains<TB, 16, 16>(ap, ao, bp, (uint32_t)lane * 16u, c, [&](int, const f32x4 &acc) { plane_store(mine, lane, acc); });
     if (scaled && threadIdx.x < 64) scale_park(part, sp);
     __syncthreads();
     if (e_on) {
@@ -221,8 +221,8 @@ __device__ __forceinline__ void recur_row_body(const GemmArgs &g)
     const uint32_t ao = (uint32_t)(((size_t)arow * g.lda0 + (lane >> 4) * 4) * sizeof(float));
     const char *bp = reinterpret_cast<const char *>(g.wp) + ((size_t)ct * KB + kb0) * 1024;
     float *mine = red + (size_t)first * RPLANE;
-    // (these workgroups run at four waves per SIMD, 128 registers per lane: at most twelve blocks in flight, eight when the ring wraps)
-    stream_chains<TB, (FORM == RF_RESID_SSQ || TB > 12) ? 8 : 16>(ap, ao, bp, (uint32_t)lane * 16u, c, [&](int q, const f32x4 &acc) { plane_store(mine + q * RPLANE, lane, acc); });
+    // (these workgroups run at four waves per SIMD, 128 registers per lane: sixteen weight blocks and eight activation blocks in flight, twelve and eight where the ring wraps)
+    stream_chains<TB, ((TB > 16 || (FORM == RF_HR && TB > 12)) ? 12 : 16), (FORM == RF_RESID_SSQ || TB > 12) ? 8 : 16>(ap, ao, bp, (uint32_t)lane * 16u, c, [&](int q, const f32x4 &acc) { plane_store(mine + q * RPLANE, lane, acc); });
     if (FORM == RF_HR && threadIdx.x < 64) scale_park(part, sp);
     __syncthreads();
     if (e_on) {
