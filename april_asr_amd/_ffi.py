@@ -57,7 +57,7 @@ EXPORTED_ENGINE_SYMBOLS = [
     "aprilx_model_dims", "aprilx_model_token", "aprilx_model_blob_size", "aprilx_model_export_blob",
     "aprilx_model_from_blob", "aprilx_model_save_blob", "aprilx_model_save_blob_f16", "aprilx_model_load_blob",
     "aprilx_broadcast_get_id", "aprilx_model_broadcast", "aprilx_model_load_info", "aprilx_feed_many", "aprilx_flush_many", "aprilx_session_drain",
-    "aprilx_run_encoder", "aprilx_run_decoder", "aprilx_run_joiner", "aprilx_run_fbank", "aprilx_run_decide", "aprilx_plan_gemm",
+    "aprilx_run_encoder", "aprilx_run_decoder", "aprilx_run_joiner", "aprilx_run_fbank", "aprilx_run_decide", "aprilx_plan_gemm", "aprilx_stream_form",
     "aprilx_session_trace_logits", "aprilx_session_chunks", "aprilx_session_context", "aprilx_model_stats", "aprilx_model_profile",
     "aprilx_greedy_create", "aprilx_greedy_step", "aprilx_greedy_finish", "aprilx_greedy_free", "aprilx_probe_file", "aprilx_model_load_host", "aprilx_model_fbank_tables", "aprilx_counting_handler",
 ]
@@ -106,6 +106,7 @@ def lib():
     L.aprilx_run_joiner.argtypes = [vp, C.c_int, vp, vp, vp]; L.aprilx_run_joiner.restype = C.c_int
     L.aprilx_run_fbank.argtypes = [vp, C.c_int, vp, vp]; L.aprilx_run_fbank.restype = C.c_int
     L.aprilx_plan_gemm.argtypes = [C.c_int] * 6 + [vp]; L.aprilx_plan_gemm.restype = C.c_int
+    L.aprilx_stream_form.argtypes = [C.c_int] * 6; L.aprilx_stream_form.restype = C.c_int
     L.aprilx_run_decide.argtypes = [vp, C.c_int, C.c_int, vp, C.c_float, vp, C.c_int, vp, vp]; L.aprilx_run_decide.restype = C.c_int
     L.aprilx_session_trace_logits.argtypes = [vp, vp, sz, C.POINTER(sz)]; L.aprilx_session_trace_logits.restype = None
     L.aprilx_session_chunks.argtypes = [vp]; L.aprilx_session_chunks.restype = C.c_uint64

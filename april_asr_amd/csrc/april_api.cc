@@ -677,6 +677,24 @@ int aprilx_plan_gemm(int M, int N, int kz, int zcount, int tile_ok, int force, i
     out[2] = gemm_tile_planned(M, N, kz, zcount) ? 1 : 0;
     return 0;
 }
+int aprilx_stream_form(int kind, int M, int N, int K, int kz, int groups)
+{
+    if (kind < 0 || kind > 5 || M <= 0 || N <= 0 || K <= 0 || kz <= 0) return -1;
+    static float dummy[4];
+    static int idummy[4];
+    GemmArgs g;                                       // only which pointers are set matters to recur_form
+    g.M = M; g.N = N; g.K = K; g.kz = kz; g.wp = dummy; g.out = dummy; g.bias = dummy; g.a0 = dummy; g.K0 = K;
+    RowScale rs; rs.ssq = dummy; rs.groups = groups; rs.inv_n = 1.0f;
+    switch (kind) {
+    case 0: g.epi = EPI_LSTM; g.K0 = K / 2; g.K1 = K / 2; g.a1 = dummy; g.x_scale = rs; g.c_state = dummy; g.slot_idx = idummy; break;
+    case 1: g.epi = EPI_LSTM; g.K0 = K / 2; g.K1 = K / 2; g.a1 = dummy; g.wave_mask = 0xC; g.p_add = dummy; g.c_state = dummy; g.slot_idx = idummy; break;
+    case 2: g.epi = EPI_XPART; g.K0 = K / 2; g.K1 = K / 2; g.a1 = dummy; g.wave_mask = 0x3; g.x_scale = rs; break;
+    case 3: g.epi = EPI_BIAS_DSWISH; break;
+    case 4: g.epi = EPI_HR; g.r_scale = rs; g.state = dummy; g.resid = dummy; g.slot_idx = idummy; break;
+    default: g.epi = EPI_RESID_SSQ; g.resid = dummy; g.ssq_out = dummy; break;
+    }
+    return recur_form(g);
+}
 int aprilx_run_fbank(AprilASRModel model, int n_frames, const int16_t *pcm_frames, float *out)
 {
     if (!model || model->m.engines.empty() || n_frames <= 0 || n_frames > model->m.engines[0]->ring_frames()) return -1;

@@ -106,6 +106,12 @@ APRIL_EXPORT int aprilx_run_decide(AprilASRModel model, int n, int op, const flo
  * needed; tests only (the engine and the kernels consult the same functions, so their decisions cannot diverge). */
 APRIL_EXPORT int aprilx_plan_gemm(int M, int N, int kz, int zcount, int tile_ok, int force, int32_t *out);
 
+/* Which weight-stream kernel (csrc/kernels_recur.hip; layer GEMMs at <= 16 rows) takes a layer GEMM of this shape: kind 0 = the
+ * one-launch gates GEMM of a chunk step, 1 = its recurrent half (long feeds), 2 = its input half (long feeds), 3 = FFN up,
+ * 4 = LSTM projection, 5 = FFN down; K in `kz` slabs, `groups` sum-of-squares partials per row.  Returns 0 when the general GEMM
+ * kernels run it, else the form number (3, 1, 4, 5, 2, 6 for the six kinds), -1 on bad arguments.  No GPU needed; tests only. */
+APRIL_EXPORT int aprilx_stream_form(int kind, int M, int N, int K, int kz, int groups);
+
 /* ---- tracing / statistics ---------------------------------------------------------------*/
 /* every joiner evaluation of this session appends `vocab` floats to buf (tests only; chunk steps of a traced session are
    issued eagerly and waited for one by one) */

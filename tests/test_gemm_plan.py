@@ -43,3 +43,34 @@ def test_always_tile_plans_every_batch_size(built):
         fused, planes, _ = plan(M, 768, 2, 1, 2, 0)
         assert (fused == 1) == (planes == 1) or fused == 0
     assert plan(1, 512, 8, 1, 2, 0)[0] == 0 and plan(1, 512, 8, 1, 2, 0)[1] == 8
+
+
+def stream_form(kind, M, N, K, kz, groups):
+    return int(_ffi.lib().aprilx_stream_form(kind, M, N, K, kz, groups))
+
+
+def pick_kz(K, N):
+    """csrc/engine.cc pick_kz (K slabs of a row-epilogue GEMM)"""
+    kz = max(1, min(256 // max(1, N // 16), 8))
+    while kz > 1 and ((K // 16) // kz < 4 or (K // 16) % (4 * kz) != 0):
+        kz >>= 1
+    return kz
+
+
+def test_stream_kernels_take_every_layer_gemm_up_to_16_rows(built):
+    """csrc/kernels_recur.hip: at <= 16 rows all six layer-GEMM forms of the four test models run as weight streams (so that
+    tests/test_gpu_recur_kernels.py compares what it says it compares), above 16 rows none does."""
+    from april_asr_amd import synth_model as SM
+    for dims in (SM.TINY_DIMS, SM.MEDIUM_DIMS, SM.APRILV0_DIMS, SM.LARGE_DIMS):
+        d, h, f = dims["d_model"], dims["hidden"], dims["ffn"]
+        G = d // 32
+        shapes = [(0, 4 * h, 2 * d, 1, 3), (1, 4 * h, 2 * d, 1, 1), (2, 4 * h, 2 * d, 1, 4), (3, f, d, 1, 5),
+                  (4, d, h, pick_kz(h, d), 2), (5, d, f, pick_kz(f, d), 6)]
+        for kind, N, K, kz, want in shapes:
+            for M in (1, 2, 7, 10, 16):
+                assert stream_form(kind, M, N, K, kz, G) == want, (dims["d_model"], kind, M)
+            for M in (17, 64, 256):
+                assert stream_form(kind, M, N, K, kz, G) == 0, (dims["d_model"], kind, M)
+    # shapes without a kernel fall back: K not a multiple of 64, more than 32 sum-of-squares partials per row
+    assert stream_form(3, 1, 2048, 544, 1, 16) == 0
+    assert stream_form(4, 1, 2048, 1024, 4, 64) == 0
