@@ -151,11 +151,12 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     const size_t S = (size_t)cfg_.max_slots, MB = (size_t)cfg_.max_batch;
     // Feature ring per session.  The reference keeps segment_size * 32 frames (src/fbank.c:147); a session that is fed faster
     // than real time (a whole file in one call) is processed a ring's worth of chunks at a time, and the offline wavefront
-    // (run_lm_wavefront) needs many more blocks of time steps than layers to fill: 2048 frames = ~20 s of audio per pass,
-    // 640 KB per slot (2.7 GB at 4096 slots, 1 % of this GPU's memory).  Results do not depend on the ring size.
+    // (run_lm_wavefront) needs many more blocks of time steps than layers to fill: 8192 frames = ~80 s of audio per pass
+    // (a minute of audio in one call is ONE wavefront: 65.7 ms against 68.8 ms in three passes of a 2048-frame ring),
+    // 2.6 MB per slot (10.7 GB at 4096 slots, 3.7 % of this GPU's memory).  Results do not depend on the ring size.
     {
         const char *e = getenv("APRIL_RING_FRAMES");
-        ring_frames_ = std::max(P_.segment_size * 32, e && *e ? atoi(e) : 2048);
+        ring_frames_ = std::max(P_.segment_size * 32, e && *e ? atoi(e) : 8192);
     }
     h_ = dmalloc<float>((size_t)d.n_layers * S * d.d_model);
     c_ = dmalloc<float>((size_t)d.n_layers * S * d.hidden);
