@@ -1,6 +1,7 @@
 // See engine.h.
 #include "engine.h"
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -873,11 +874,25 @@ void Engine::lm_stage_proj(int m, int t0, int t1, hipStream_t st)
     }
 }
 
-static int lm_block_steps()
+// Time steps per block of the long-feed wavefront (run_lm_wavefront).  A macro step costs its block's recurrent launches (2 per
+// time step, whatever the number of active layers) plus ~80 us of block stages (input halves, feed-forward, front end: weight
+// streams that do not depend on the block length), and the wavefront runs NB + L + 1 macro steps, L + 1 of them fill / drain:
+// (T / blk + L + 1) (c_step blk + c_block) is smallest near blk = sqrt(T c_block / ((L + 1) c_step)) ~ 0.75 sqrt(T) at aprilv0
+// size.  Measured, 60 s in one call (T = 1498): blk 10 / 16 / 20 / 24 / 32 -> 65.5 / 61.6 / 61.2 / 60.6 / 60.2 ms.
+// APRIL_LM_BLOCK pins it.  Results do not depend on the block length (same chains in the same order).
+static int lm_block_env()
 {
-    static const int v = std::max(1, getenv("APRIL_LM_BLOCK") ? atoi(getenv("APRIL_LM_BLOCK")) : 10);
+    static const int v = getenv("APRIL_LM_BLOCK") ? std::max(1, atoi(getenv("APRIL_LM_BLOCK"))) : 0;
     return v;
 }
+static int lm_block_steps(int T)
+{
+    if (lm_block_env() > 0) return lm_block_env();
+    const int b = (int)(0.75 * std::sqrt((double)std::max(1, T)) + 0.5);
+    return std::max(6, std::min(32, b));
+}
+// (feeds up to this many chunks run as one layer-major chain, captured as a graph: too few blocks for a wavefront to fill)
+static int lm_wavefront_min_chunks() { return lm_block_env() > 0 ? lm_block_env() : 10; }
 
 static bool lm_wavefront_on()
 {
@@ -916,7 +931,7 @@ void Engine::run_lm_wavefront(int m, int T, bool dump_logits)
     const NetDims &d = L_.dims;
     const int MB = cfg_.max_batch;
     const int L = d.n_layers;
-    const int blk = lm_block_steps();
+    const int blk = lm_block_steps(T);
     const int NB = (T + blk - 1) / blk;
     AdvanceArgs a;
     a.host_ring = ring_h_; a.host_step_off = step_off_h_; a.host_rec_off = rec_off_h_; a.counter = counter_d_;
@@ -1174,7 +1189,7 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
         run_sw_chain(m, T, logits_out != nullptr, p);
         kernels_per_step_ = (launch_count_ + 1 + T - 1) / T;          // per chunk
     } else {
-    const bool wavefront = lm_wavefront_on() && !profiling_ && T > lm_block_steps() &&
+    const bool wavefront = lm_wavefront_on() && !profiling_ && T > lm_wavefront_min_chunks() &&
                            gemm_fullk(m, d.d_model, kz_hr_, true, 1, tile_ok()) && gemm_fullk(m, d.d_model, kz_ff2_, true, 1, tile_ok());
     if (wavefront) {                 // long feed: all layers of a wavefront per launch (run_lm_wavefront)
         std::lock_guard<std::mutex> cg(capture_mu_);
