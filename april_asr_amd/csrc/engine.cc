@@ -161,7 +161,17 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     }
     h_ = dmalloc<float>((size_t)d.n_layers * S * d.d_model);
     c_ = dmalloc<float>((size_t)d.n_layers * S * d.hidden);
-    ring_ = dmalloc<float>(S * ring_frames_ * d.mel);
+    if (!(getenv("APRIL_RING_FRAMES") && *getenv("APRIL_RING_FRAMES"))) {
+        // the default ring is sized for this GPU's 288 GB; on a device that cannot spare it a quarter of it serves as well (more passes per long feed)
+        float *p = nullptr;
+        if (hipMalloc((void **)&p, S * ring_frames_ * d.mel * sizeof(float)) == hipSuccess) ring_ = p;
+        else {
+            (void)hipGetLastError();
+            ring_frames_ = std::max(P_.segment_size * 32, 2048);
+            LOGW("engine: no room for %zu MB of feature rings, falling back to %d frames per session", S * 8192 * d.mel * sizeof(float) >> 20, ring_frames_);
+        }
+    }
+    if (!ring_) ring_ = dmalloc<float>(S * ring_frames_ * d.mel);
     eout_ = dmalloc<float>(S * d.joiner);
     dout_ = dmalloc<float>(S * d.joiner);
     gstate_ = dmalloc<GreedyState>(S);
