@@ -351,5 +351,21 @@ class SessionGroup:
         ptrs, cnts = self._plan[step]
         self._L.aprilx_feed_many(len(self.sessions), self._handles, ptrs, cnts)
 
+    def feed_planned_pipelined(self, step: int, depth: int = 2):
+        """Queue feed `step` of the plan and return once at most depth - 1 feeds per session are still open (depth 2: the
+        library launches this feed behind the previous one and overlaps its host work with the GPU).  Call drain() at the end."""
+        ptrs, cnts = self._plan[step]
+        self._L.aprilx_feed_many_pipelined(len(self.sessions), self._handles, ptrs, cnts, depth)
+
+    def feed_pipelined(self, pcm_list: Sequence[np.ndarray], depth: int = 2):
+        keep = [np.ascontiguousarray(p, np.int16) for p in pcm_list]
+        for i, a in enumerate(keep):
+            self._ptrs[i] = a.ctypes.data
+            self._counts[i] = a.size
+        self._L.aprilx_feed_many_pipelined(len(keep), self._handles, self._ptrs, self._counts, depth)      # (samples are copied inside)
+
+    def drain(self):
+        self._L.aprilx_drain_many(len(self.sessions), self._handles)
+
     def flush(self):
         self._L.aprilx_flush_many(len(self.sessions), self._handles)

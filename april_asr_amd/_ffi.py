@@ -56,7 +56,7 @@ EXPORTED_REFERENCE_SYMBOLS = [
 EXPORTED_ENGINE_SYMBOLS = [
     "aprilx_model_dims", "aprilx_model_token", "aprilx_model_blob_size", "aprilx_model_export_blob",
     "aprilx_model_from_blob", "aprilx_model_save_blob", "aprilx_model_save_blob_f16", "aprilx_model_load_blob",
-    "aprilx_broadcast_get_id", "aprilx_model_broadcast", "aprilx_model_load_info", "aprilx_feed_many", "aprilx_flush_many", "aprilx_session_drain",
+    "aprilx_broadcast_get_id", "aprilx_model_broadcast", "aprilx_model_load_info", "aprilx_feed_many", "aprilx_flush_many", "aprilx_session_drain", "aprilx_feed_many_pipelined", "aprilx_drain_many",
     "aprilx_run_encoder", "aprilx_run_decoder", "aprilx_run_joiner", "aprilx_run_fbank", "aprilx_run_decide", "aprilx_plan_gemm", "aprilx_stream_form",
     "aprilx_session_trace_logits", "aprilx_session_chunks", "aprilx_session_context", "aprilx_model_stats", "aprilx_model_profile",
     "aprilx_greedy_create", "aprilx_greedy_step", "aprilx_greedy_finish", "aprilx_greedy_free", "aprilx_probe_file", "aprilx_model_load_host", "aprilx_model_fbank_tables", "aprilx_counting_handler",
@@ -101,6 +101,8 @@ def lib():
     L.aprilx_feed_many.argtypes = [sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz)]; L.aprilx_feed_many.restype = None
     L.aprilx_flush_many.argtypes = [sz, C.POINTER(vp)]; L.aprilx_flush_many.restype = None
     L.aprilx_session_drain.argtypes = [vp]; L.aprilx_session_drain.restype = None
+    L.aprilx_feed_many_pipelined.argtypes = [sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.c_int]; L.aprilx_feed_many_pipelined.restype = None
+    L.aprilx_drain_many.argtypes = [sz, C.POINTER(vp)]; L.aprilx_drain_many.restype = None
     L.aprilx_run_encoder.argtypes = [vp, C.c_int] + [vp] * 6; L.aprilx_run_encoder.restype = C.c_int
     L.aprilx_run_decoder.argtypes = [vp, C.c_int, vp, vp]; L.aprilx_run_decoder.restype = C.c_int
     L.aprilx_run_joiner.argtypes = [vp, C.c_int, vp, vp, vp]; L.aprilx_run_joiner.restype = C.c_int

@@ -629,6 +629,38 @@ void aprilx_feed_many(size_t n, AprilASRSession *sessions, const short *const *p
     for (size_t i = 0; i < n; ++i) if (sessions[i]->s.sync_mode) sessions[i]->s.sched->deliver_sync_events(&sessions[i]->s);
 }
 
+void aprilx_feed_many_pipelined(size_t n, AprilASRSession *sessions, const short *const *pcm16, const size_t *short_counts, int depth)
+{
+    if (n == 0) return;
+    if (depth < 1) depth = 1;
+    std::vector<Scheduler *> scheds;
+    for (size_t i = 0; i < n; ++i) { Scheduler *sc = sessions[i]->s.sched; if (std::find(scheds.begin(), scheds.end(), sc) == scheds.end()) scheds.push_back(sc); }
+    std::vector<std::vector<Session *>> groups(scheds.size());
+    std::vector<std::vector<const short *>> gp(scheds.size());
+    std::vector<std::vector<size_t>> gc(scheds.size());
+    for (size_t i = 0; i < n; ++i) {
+        size_t k = (size_t)(std::find(scheds.begin(), scheds.end(), sessions[i]->s.sched) - scheds.begin());
+        groups[k].push_back(&sessions[i]->s); gp[k].push_back(pcm16[i]); gc[k].push_back(short_counts[i]);
+    }
+    // the samples are copied into the sessions' queues (the caller may reuse its buffers at once), every GPU first, then the wait
+    for (size_t k = 0; k < scheds.size(); ++k) scheds[k]->submit((int)groups[k].size(), groups[k].data(), gp[k].data(), gc[k].data(), false, false, /*borrow=*/false);
+    for (size_t k = 0; k < scheds.size(); ++k) scheds[k]->wait_backlog(groups[k].data(), (int)groups[k].size(), (uint64_t)(depth - 1));
+    for (size_t i = 0; i < n; ++i) if (sessions[i]->s.sync_mode) sessions[i]->s.sched->deliver_sync_events(&sessions[i]->s);
+}
+
+void aprilx_drain_many(size_t n, AprilASRSession *sessions)
+{
+    if (n == 0) return;
+    std::vector<Scheduler *> scheds;
+    for (size_t i = 0; i < n; ++i) { Scheduler *sc = sessions[i]->s.sched; if (std::find(scheds.begin(), scheds.end(), sc) == scheds.end()) scheds.push_back(sc); }
+    for (Scheduler *sc : scheds) {
+        std::vector<Session *> g;
+        for (size_t i = 0; i < n; ++i) if (sessions[i]->s.sched == sc) g.push_back(&sessions[i]->s);
+        sc->wait_backlog(g.data(), (int)g.size(), 0);
+    }
+    for (size_t i = 0; i < n; ++i) if (sessions[i]->s.sync_mode) sessions[i]->s.sched->deliver_sync_events(&sessions[i]->s);
+}
+
 void aprilx_flush_many(size_t n, AprilASRSession *sessions)
 {
     for (size_t i = 0; i < n; ++i) { Session *s = &sessions[i]->s; s->sched->submit(1, &s, nullptr, nullptr, true, false); }

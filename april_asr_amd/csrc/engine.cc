@@ -222,9 +222,12 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     logits_ = dmalloc<float>(3 * MB * d.vocab);
     logits_h_ = hmalloc<float>(3 * MB * d.vocab);
     // step bookkeeping
-    ring_cap_ = std::max<size_t>((size_t)1 << 20, 3 * MB * 8 + 2 * S); ring_h_ = hmalloc<int>(ring_cap_);
-    step_cap_ = 1 << 14; step_off_h_ = hmalloc<int>((size_t)step_cap_); rec_off_h_ = hmalloc<int>((size_t)step_cap_);
-    rec_cap_ = std::max<size_t>((size_t)1 << 20, 3 * MB * 8); rec_d_ = dmalloc<StepRecord>(rec_cap_); rec_h_ = hmalloc<StepRecord>(rec_cap_);
+    // (two flights may be in the air -- the one the GPU runs and the one the host enqueues behind it -- so every per-flight
+    // ring exists twice: flight parity p owns [p * cap, (p + 1) * cap) of the index blocks, step tables and records)
+    ring_cap_ = std::max<size_t>((size_t)1 << 20, 3 * MB * 8 + 2 * S); ring_h_ = hmalloc<int>(2 * ring_cap_);
+    step_cap_ = 1 << 14; step_off_h_ = hmalloc<int>((size_t)2 * step_cap_); rec_off_h_ = hmalloc<int>((size_t)2 * step_cap_);
+    rec_cap_ = std::max<size_t>((size_t)1 << 20, 3 * MB * 8); rec_d_ = dmalloc<StepRecord>(2 * rec_cap_); rec_h_ = hmalloc<StepRecord>(2 * rec_cap_);
+    for (int i = 0; i < 2; ++i) HIP_CHECK(hipEventCreateWithFlags(&flight_done_[i], hipEventDisableTiming));
     counter_d_ = dmalloc<int>(1); rec_off_d_ = dmalloc<int>(1); flags_d_ = dmalloc<int>(8);
     step_d_ = dmalloc<int>(4 * MB); active_d_ = dmalloc<int>(MB); dirty_d_ = dmalloc<int>(MB);
     dec_slots_d_ = dmalloc<int>(std::max(S, MB));
@@ -324,6 +327,7 @@ Engine::~Engine()
     for (void *p : {(void *)ring_h_, (void *)step_off_h_, (void *)rec_off_h_, (void *)rec_h_, (void *)logits_h_, (void *)hs_desc_[0], (void *)hs_desc_[1], (void *)hs_pcm_[0], (void *)hs_pcm_[1]})
         if (p) (void)hipHostFree(p);
     for (int b = 0; b < 2; ++b) if (fb_done_[b]) (void)hipEventDestroy(fb_done_[b]);
+    for (int b = 0; b < 2; ++b) if (flight_done_[b]) (void)hipEventDestroy(flight_done_[b]);
     for (void *p : table_allocs_) (void)hipFree(p);
     (void)hipStreamDestroy(stream_);
 }
@@ -1240,18 +1244,23 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
 }
 
 
+// Flights alternate between the two halves of the per-flight rings, so that the host can enqueue flight k + 1 while the GPU
+// still runs flight k and the records of flight k are still being read (Scheduler::loop).  The device step counter starts at
+// the half's first step index: the step tables are indexed by it, so the launch chains (graphs) do not depend on the parity.
 void Engine::begin_flight()
 {
     HIP_CHECK(hipSetDevice(cfg_.device));
-    ring_pos_ = 0; rec_pos_ = 0; steps_ = 0;
+    flight_parity_ = next_parity_; next_parity_ ^= 1;
+    ring_base_ = (size_t)flight_parity_ * ring_cap_; rec_base_ = (size_t)flight_parity_ * rec_cap_; step_base_ = flight_parity_ * step_cap_;
+    ring_pos_ = ring_base_; rec_pos_ = rec_base_; steps_ = step_base_;
     std::lock_guard<std::mutex> cg(capture_mu_);
-    HIP_CHECK(hipMemsetAsync(counter_d_, 0, 4, stream_));
+    HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)counter_d_, step_base_, 1, stream_));
 }
 
 bool Engine::flight_has_room(int rows, int nsteps) const
 {
     // + max_slots: decoder refreshes stage their slot lists in the same index ring
-    return steps_ + nsteps <= step_cap_ && ring_pos_ + (size_t)3 * rows + (size_t)cfg_.max_slots <= ring_cap_ && rec_pos_ + (size_t)3 * rows <= rec_cap_;
+    return steps_ + nsteps <= step_base_ + step_cap_ && ring_pos_ + (size_t)3 * rows + (size_t)cfg_.max_slots <= ring_base_ + ring_cap_ && rec_pos_ + (size_t)3 * rows <= rec_base_ + rec_cap_;
 }
 
 int Engine::step(int m, const int *slots, const int *ring_tails, const int *now_ms, float *logits_out)
@@ -1309,7 +1318,7 @@ void Engine::decode_rows(int n, const int *slots, int op)
     std::lock_guard<std::mutex> cg(capture_mu_);
     for (int o = 0; o < n; o += MB) {
         const int m = std::min(MB, n - o);
-        if (ring_pos_ + (size_t)m > ring_cap_) { LOGE("engine: index ring exhausted"); abort(); }
+        if (ring_pos_ + (size_t)m > ring_base_ + ring_cap_) { LOGE("engine: index ring exhausted"); abort(); }
         int *blk = ring_h_ + ring_pos_;                  // staged in the flight's pinned ring: never rewritten before the copy ran
         memcpy(blk, slots + o, (size_t)m * 4);
         ring_pos_ += (size_t)m;
@@ -1320,12 +1329,31 @@ void Engine::decode_rows(int n, const int *slots, int op)
     }
 }
 
-void Engine::end_flight()
+int Engine::close_flight()
 {
     HIP_CHECK(hipSetDevice(cfg_.device));
-    if (rec_pos_) HIP_CHECK(hipMemcpyAsync(rec_h_, rec_d_, rec_pos_ * sizeof(StepRecord), hipMemcpyDeviceToHost, stream_));
-    sync();
+    std::lock_guard<std::mutex> cg(capture_mu_);
+    if (rec_pos_ > rec_base_) HIP_CHECK(hipMemcpyAsync(rec_h_ + rec_base_, rec_d_ + rec_base_, (rec_pos_ - rec_base_) * sizeof(StepRecord), hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipEventRecord(flight_done_[flight_parity_], stream_));
+    return flight_parity_;
 }
+
+bool Engine::flight_done(int parity)
+{
+    const hipError_t e = hipEventQuery(flight_done_[parity]);
+    if (e == hipSuccess) return true;
+    if (e != hipErrorNotReady) HIP_CHECK(e);
+    (void)hipGetLastError();
+    return false;
+}
+
+void Engine::wait_flight(int parity)
+{
+    HIP_CHECK(hipSetDevice(cfg_.device));
+    HIP_CHECK(hipEventSynchronize(flight_done_[parity]));
+}
+
+void Engine::end_flight() { wait_flight(close_flight()); if (profiling_) sync(); }
 
 // ---------------------------------------------------------------- debug / parity entry points
 // The debug calls borrow slots 0..n-1; give them back reset (what a new session expects).

@@ -109,7 +109,15 @@ public:
     int lm_max_rows() const { return cfg_.max_batch; }
     // decoder output refresh for listed slots from the context held on the device; op 1 = end-of-flush reset first
     void decode_rows(int n, const int *slots, int op);
-    void end_flight();                          // records -> host, wait
+    // end of a flight in two halves, so that the next flight can be enqueued before this one has run: close_flight() queues
+    // the record copy and an event and returns the flight's parity (0 / 1); wait_flight(parity) blocks until the GPU has
+    // passed that event, flight_done() polls it.  At most TWO flights are open at any time (begin_flight() reuses the parity
+    // of the flight before the previous one: its records must have been read by then).
+    int close_flight();
+    bool flight_done(int parity);
+    void wait_flight(int parity);
+    void end_flight();                          // close + wait (records -> host)
+    bool profiling() const { return profiling_; }
     const StepRecord *records(int step_index) const { return rec_h_ + rec_off_h_[step_index]; }   // [3][m], valid after end_flight()
     void sync();
 
@@ -203,9 +211,11 @@ private:
     float *logits_ = nullptr;                  // [3][max_batch][vocab] (traced steps, debug_joiner)
     float *p_lm_ = nullptr, *eout_lm_ = nullptr;   // layer-major: input half of the gates [rows][4 hidden], encoder outputs [rows][joiner] (allocated on first use)
     // step bookkeeping: pinned host rings (read by the advance kernel) + device mirrors
-    int *ring_h_ = nullptr; size_t ring_cap_ = 0, ring_pos_ = 0;      // index blocks
+    int *ring_h_ = nullptr; size_t ring_cap_ = 0, ring_pos_ = 0;      // index blocks (capacities are per flight parity)
     int *step_off_h_ = nullptr, *rec_off_h_ = nullptr; int step_cap_ = 0, steps_ = 0;
     StepRecord *rec_d_ = nullptr, *rec_h_ = nullptr; size_t rec_cap_ = 0, rec_pos_ = 0;
+    int flight_parity_ = 0, next_parity_ = 0; size_t ring_base_ = 0, rec_base_ = 0; int step_base_ = 0;
+    hipEvent_t flight_done_[2] = {nullptr, nullptr};
     int *counter_d_ = nullptr, *step_d_ = nullptr, *active_d_ = nullptr, *dirty_d_ = nullptr, *rec_off_d_ = nullptr, *flags_d_ = nullptr;
     int *dec_slots_d_ = nullptr;
     float *logits_h_ = nullptr;

@@ -244,6 +244,7 @@ Scheduler::Scheduler(Model *m, Engine *e) : model_(m), eng_(e), pool_(host_helpe
     lm_min_chunks_ = env_us("APRIL_LM_MIN_CHUNKS", 8);
     wave_min_chunks_ = env_us("APRIL_WAVE_MIN_CHUNKS", 2);
     wave_max_chunks_ = std::max(1, env_us("APRIL_WAVE_MAX_CHUNKS", 7));
+    pipeline_depth_ = std::max(1, std::min(2, env_us("APRIL_PIPELINE", 2)));
     thread_ = std::thread([this] { loop(); });
 }
 
@@ -360,11 +361,167 @@ void Scheduler::wait_idle_many(Session *const *ss, int n)
     });
 }
 
+void Scheduler::wait_backlog(Session *const *ss, int n, uint64_t max_open)
+{
+    auto ok = [&] {
+        for (int i = 0; i < n; ++i) { const Session *s = ss[i]; if (!s->closing && s->submitted - s->completed > max_open) return false; }
+        return true;
+    };
+    for (;;) {
+        uint64_t seen;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (ok()) return;
+            seen = done_seq_.load(std::memory_order_acquire);      // under the lock, as in submit()
+        }
+        spin_for_done(seen);
+        if (done_seq_.load(std::memory_order_acquire) != seen) continue;
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return ok() || done_seq_.load(std::memory_order_acquire) != seen; });
+    }
+}
+
 void Scheduler::deliver_sync_events(Session *s)
 {
     std::vector<Event> ev;
     { std::lock_guard<std::mutex> g(mu_); ev.swap(s->done_events); }
     for (auto &e : ev) s->handler(s->userdata, (AprilResultType)e.type, e.tokens.size(), e.tokens.empty() ? nullptr : e.tokens.data());
+}
+
+// One stepping thread, TWO flights in the air.  A flight is launched (frames cut, chunk steps enqueued, record copy + event
+// queued: launch_flight) without waiting for the GPU; it is completed (wait for its event, replay the records through the
+// search state machine, deliver the callbacks, release the callers: complete_flight) AFTER the next flight has been launched
+// whenever work for that next flight is already queued -- asynchronous sessions, pipelined group feeds
+// (aprilx_feed_many_pipelined), or simply other clients' sessions.  The host part of flight k + 1 (framing, PCM staging, index
+// blocks, launch) then runs under the GPU time of flight k instead of between two flights (measured at 256 sessions: 170 us of
+// GPU idle time per 100 ms feed, profiles/r04a_b256_timeline.txt).  A caller that blocks on its own feed (aas_feed_pcm16 of a
+// synchronous session, aprilx_feed_many) sees the same thing as before: its tickets complete when its flight does.
+bool Scheduler::collect(std::vector<Session *> &work, std::vector<uint64_t> &taken, bool block, uint64_t &work_seen)
+{
+    work.clear(); taken.clear();
+    if (block && spin_step_us_ > 0) {           // a feed usually follows the previous one within microseconds: poll before sleeping
+        const auto t0 = std::chrono::steady_clock::now();
+        while (work_seq_.load(std::memory_order_acquire) == work_seen) {
+            for (int i = 0; i < 64; ++i) cpu_relax();
+            if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_step_us_) break;
+        }
+    }
+    Lap lap;
+    std::unique_lock<std::mutex> lk(mu_);
+    auto have = [&] {
+        for (Session *s : sessions_) if (!s->closing && (s->fed || s->flush_requested)) return true;
+        return false;
+    };
+    if (block) cv_work_.wait(lk, [&] { return stop_ || have(); });
+    work_seen = work_seq_.load(std::memory_order_acquire);
+    if (stop_) return false;
+    lap();
+    for (Session *s : sessions_) {
+        if (s->closing || (!s->fed && !s->flush_requested)) continue;
+        s->busy = true;
+        s->inflight += 1;
+        if (s->borrow_cnt) {
+            if (s->inbox.empty() && !s->fb.ext) { s->fb.ext = s->borrow_ptr; s->fb.ext_cnt = s->borrow_cnt; }   // read in place during this tick
+            else { s->fb.absorb_ext(); s->fb.fifo.insert(s->fb.fifo.end(), s->borrow_ptr, s->borrow_ptr + s->borrow_cnt); }   // something queued behind it: keep the order
+            s->borrow_ptr = nullptr; s->borrow_cnt = 0;
+        }
+        if (!s->inbox.empty()) { s->fb.absorb_ext(); s->fb.fifo.insert(s->fb.fifo.end(), s->inbox.begin(), s->inbox.end()); s->inbox.clear(); }
+        if (s->fed) s->was_flushed = false;                               // april_session.c:510
+        s->fed = false;
+        if (s->flush_requested) {                                           // :547-552
+            s->flush_requested = false;
+            if (!s->was_flushed && s->flush_phase == 0) { s->was_flushed = true; s->flush_phase = 1; }
+        }
+        work.push_back(s);
+        taken.push_back(s->submitted);
+    }
+    // lent PCM: the caller is blocked until `completed` moves, so its buffer is read in place while the flight is launched (a
+    // lent buffer is only accepted when nothing is queued in front of it, so the order of samples is kept)
+    tick_.host_ms[0] += lap();
+    return !work.empty();
+}
+
+// Everything of a tick that does not need the GPU's answers.  Returns the flight (parity -1: nothing reached the GPU).
+// final == false: the flight's rings filled up; the same sessions continue in the next flight (loop() keeps `work`).
+Scheduler::Flight Scheduler::launch_flight(const std::vector<Session *> &work_in, const std::vector<uint64_t> &taken)
+{
+    Flight f;
+    f.work = work_in; f.taken = taken; f.t0 = std::chrono::steady_clock::now();
+    std::vector<Session *> &work = f.work;
+    f.mark.resize(work.size()); f.chunks0.resize(work.size());
+    for (size_t i = 0; i < work.size(); ++i) { f.mark[i] = (uint32_t)work[i]->replay.size(); f.chunks0[i] = work[i]->chunks; }
+    std::vector<Session *> ready;
+    eng_->begin_flight();
+    bool more = false;
+    for (;;) {
+        bool progressed = false;
+        cut_frames(work, progressed);
+        ready.clear();
+        for (Session *s : work) if (s->fb.chunk_ready()) ready.push_back(s);
+        if (!ready.empty()) {
+            if (!step_chunks(ready)) { more = true; break; }          // rings full: land this flight, continue in the next
+            progressed = true;
+        }
+        if (!progressed) break;
+    }
+    Lap lap;
+    f.parity = eng_->close_flight();
+    f.final = !more;
+    for (size_t i = 0; i < work.size(); ++i) f.mark[i] = (uint32_t)work[i]->replay.size() - f.mark[i];      // items this flight appended
+    // lent buffers go back to their callers when the tick completes; they are not read after this point (the samples are in
+    // pinned staging): keep what framing has not consumed yet
+    if (f.final) pool_.run(work.size(), 64, [&](size_t i) { work[i]->fb.settle(); });
+    f.chunks1.resize(work.size());
+    for (size_t i = 0; i < work.size(); ++i) f.chunks1[i] = work[i]->chunks;
+    tick_.host_ms[3] += lap();
+    tick_.flights++;
+    return f;
+}
+
+void Scheduler::complete_flight(Flight &f)
+{
+    Lap lap;
+    eng_->wait_flight(f.parity);
+    tick_.host_ms[4] += lap();
+    replay(f);
+    tick_.host_ms[5] += lap();
+    std::vector<Session *> &work = f.work;
+    {   // reference src/april_session.c:456-462: EMA of (processing time x 1.1) / audio time per chunk.  All sessions of a
+        // flight are stepped together, so a chunk's processing time is the flight's wall time over the chunks the session advanced
+        const double tick_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f.t0).count();
+        const double stride_ms = (double)(model_->host.params.segment_step * model_->host.params.frame_shift_ms);
+        for (size_t i = 0; i < work.size(); ++i) {
+            Session *s = work[i];
+            const uint64_t n = f.chunks1[i] - f.chunks0[i];
+            if (!n) continue;
+            double v = s->speed_needed.load(std::memory_order_relaxed);
+            for (uint64_t k = 0; k < n; ++k) v = (v * 9.0 + (tick_ms / (double)n) * 1.1 / stride_ms) / 10.0;
+            s->speed_needed.store(v, std::memory_order_relaxed);
+        }
+    }
+    // async sessions: deliver on this (library) thread, outside the lock
+    for (Session *s : work) if (!s->sync_mode) {
+        for (auto &e : s->events) s->handler(s->userdata, (AprilResultType)e.type, e.tokens.size(), e.tokens.empty() ? nullptr : e.tokens.data());
+        s->events.clear();
+    }
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        for (size_t i = 0; i < work.size(); ++i) {
+            Session *s = work[i];
+            if (s->sync_mode) { for (auto &e : s->events) s->done_events.push_back(std::move(e)); s->events.clear(); }
+            if (f.final) {
+                if (f.taken[i] > s->completed) s->completed = f.taken[i];
+                s->inflight -= 1;
+                s->busy = s->inflight > 0;
+            }
+        }
+        if (f.final) tick_.ticks++;
+        tick_.host_ms[7] += lap();
+        stats_.add(tick_);
+        tick_ = SchedStats();
+    }
+    done_seq_.fetch_add(1, std::memory_order_release);
+    cv_done_.notify_all();
 }
 
 void Scheduler::loop()
@@ -374,84 +531,43 @@ void Scheduler::loop()
     std::vector<Session *> work;
     std::vector<uint64_t> taken;
     uint64_t work_seen = 0;
+    bool have_pending = false, have_next = false, cont = false;
+    Flight pending, next;
     for (;;) {
-        work.clear(); taken.clear();
-        Lap lap;
-        if (spin_step_us_ > 0) {           // a feed usually follows the previous one within microseconds: poll before sleeping
-            const auto t0 = std::chrono::steady_clock::now();
-            while (work_seq_.load(std::memory_order_acquire) == work_seen) {
-                for (int i = 0; i < 64; ++i) cpu_relax();
-                if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_step_us_) break;
+        // ---- launch: the continuation of a tick whose flight filled the rings first, else whatever has been queued
+        if (!have_next) {
+            bool go = cont;
+            if (!go) {
+                go = collect(work, taken, /*block=*/!have_pending, work_seen);
+                if (!go && !have_pending) { std::lock_guard<std::mutex> g(mu_); if (stop_) return; }
+            }
+            if (go) {
+                next = launch_flight(work, taken);
+                have_next = true;
+                cont = !next.final;
             }
         }
-        {
-            std::unique_lock<std::mutex> lk(mu_);
-            cv_work_.wait(lk, [&] {
-                if (stop_) return true;
-                for (Session *s : sessions_) if (!s->closing && (s->fed || s->flush_requested)) return true;
-                return false;
-            });
-            if (stop_) return;
-            work_seen = work_seq_.load(std::memory_order_acquire);
-            lap();
-            for (Session *s : sessions_) {
-                if (s->closing || (!s->fed && !s->flush_requested)) continue;
-                s->busy = true;
-                if (s->borrow_cnt) {
-                    if (s->inbox.empty() && !s->fb.ext) { s->fb.ext = s->borrow_ptr; s->fb.ext_cnt = s->borrow_cnt; }   // read in place during this tick
-                    else { s->fb.absorb_ext(); s->fb.fifo.insert(s->fb.fifo.end(), s->borrow_ptr, s->borrow_ptr + s->borrow_cnt); }   // something queued behind it: keep the order
-                    s->borrow_ptr = nullptr; s->borrow_cnt = 0;
+        // ---- complete the older flight: at once when a younger one is already behind it on the stream (or nothing can be
+        // overlapped: profiling runs account every launch to the flight that issued it), else as soon as the GPU is through
+        // with it -- while watching for new work that could still be launched behind it
+        if (have_pending) {
+            bool done = have_next || pipeline_depth_ < 2 || eng_->profiling();
+            if (!done) {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (;;) {
+                    if (eng_->flight_done(pending.parity)) { done = true; break; }
+                    if (work_seq_.load(std::memory_order_acquire) != work_seen) break;                 // something was queued: try to launch it first
+                    for (int i = 0; i < 32; ++i) cpu_relax();
+                    if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_wait_us_) { done = true; break; }   // long flight: sleep on it
                 }
-                if (!s->inbox.empty()) { s->fb.absorb_ext(); s->fb.fifo.insert(s->fb.fifo.end(), s->inbox.begin(), s->inbox.end()); s->inbox.clear(); }
-                if (s->fed) s->was_flushed = false;                               // april_session.c:510
-                s->fed = false;
-                if (s->flush_requested) {                                           // :547-552
-                    s->flush_requested = false;
-                    if (!s->was_flushed && s->flush_phase == 0) { s->was_flushed = true; s->flush_phase = 1; }
-                }
-                work.push_back(s);
-                taken.push_back(s->submitted);
             }
+            if (done) { complete_flight(pending); have_pending = false; }
         }
-        // lent PCM: the caller is blocked until `completed` moves, so its buffer is read in place during this tick (a lent
-        // buffer is only accepted when nothing is queued in front of it, so the order of samples is kept)
-        tick_.host_ms[0] += lap();
-        for (Session *s : work) s->chunks_at_tick_start = s->chunks;
-        const auto t_tick = std::chrono::steady_clock::now();
-        process(work);
-        lap();
-        {   // reference src/april_session.c:456-462: EMA of (processing time x 1.1) / audio time per chunk.  All sessions of a
-            // tick are stepped together, so a chunk's processing time is the tick's wall time over the chunks the session advanced
-            const double tick_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tick).count();
-            const double stride_ms = (double)(model_->host.params.segment_step * model_->host.params.frame_shift_ms);
-            for (Session *s : work) {
-                const uint64_t n = s->chunks - s->chunks_at_tick_start;
-                if (!n) continue;
-                double v = s->speed_needed.load(std::memory_order_relaxed);
-                for (uint64_t i = 0; i < n; ++i) v = (v * 9.0 + (tick_ms / (double)n) * 1.1 / stride_ms) / 10.0;
-                s->speed_needed.store(v, std::memory_order_relaxed);
-            }
+        if (!have_pending && have_next) {
+            pending = std::move(next); next = Flight(); have_next = false; have_pending = true;
+            // nothing to overlap with: finish it right away when pipelining is off
+            if (pipeline_depth_ < 2 || eng_->profiling()) { complete_flight(pending); have_pending = false; }
         }
-        // async sessions: deliver on this (library) thread, outside the lock
-        for (Session *s : work) if (!s->sync_mode) {
-            for (auto &e : s->events) s->handler(s->userdata, (AprilResultType)e.type, e.tokens.size(), e.tokens.empty() ? nullptr : e.tokens.data());
-            s->events.clear();
-        }
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            for (size_t i = 0; i < work.size(); ++i) {
-                Session *s = work[i];
-                if (s->sync_mode) { for (auto &e : s->events) s->done_events.push_back(std::move(e)); s->events.clear(); }
-                s->completed = taken[i];
-                s->busy = false;
-            }
-            tick_.ticks++;
-            tick_.host_ms[7] += lap();
-            stats_.add(tick_);
-            tick_ = SchedStats();
-        }
-        done_seq_.fetch_add(1, std::memory_order_release);
-        cv_done_.notify_all();
     }
 }
 
@@ -461,15 +577,24 @@ void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
     desc_.clear(); pcm_parts_.clear();
     size_t staged = 0;
     std::vector<Session *> finishers;
+    // FbankFrameDesc::pcm_off is a 32-bit sample offset into ONE staging buffer: a pass stages at most `stage_limit` samples
+    // (default 2^30; 1640 sessions x a full 8192-frame ring of backlog would pass 2^31) and carries the rest to the next pass
+    // of process()'s loop.  APRIL_STAGE_LIMIT_SAMPLES exists for the test that crosses the limit with small numbers.
+    static const size_t stage_limit = [] {
+        const char *v = getenv("APRIL_STAGE_LIMIT_SAMPLES");
+        const long n = v && *v ? atol(v) : (1L << 30);
+        return (size_t)std::min(1L << 30, std::max(1L << 12, n));
+    }();
     for (Session *s : work) {
         FrameBook &fb = s->fb;
         // new real frames: frame k covers stream samples [k*shift, k*shift + padded)  (fbank.c:195-236)
         if (fb.can_cut()) {
+            if (staged + (size_t)fb.padded > stage_limit) { progressed = true; continue; }      // next pass
             const size_t base = staged;
             const size_t first = fb.fifo_pos;
             int cut = 0;
             // (up to a ring's worth per pass: a long feed then yields ~70 chunks per session at once for the layer-major step)
-            while (fb.can_cut() && cut < fb.ring_frames) {
+            while (fb.can_cut() && cut < fb.ring_frames && base + (size_t)cut * fb.shift + (size_t)fb.padded <= stage_limit) {
                 FbankFrameDesc d; d.slot = s->slot; d.ring_row = fb.head; d.pcm_off = (int)(base + (size_t)cut * fb.shift);
                 desc_.push_back(d);
                 fb.head = (fb.head + 1) % fb.ring_frames;
@@ -681,10 +806,14 @@ bool Scheduler::step_chunks(std::vector<Session *> &ready)
 
 // After the flight: per session, in the order things happened, feed the device's per-round records to the search state
 // machine (which builds the callbacks) and check that it takes the same decisions the device took.
-void Scheduler::replay(std::vector<Session *> &work)
+void Scheduler::replay(Flight &f)
 {
-    for (Session *s : work) {
-        for (const Session::Replay &it : s->replay) {
+    for (size_t w = 0; w < f.work.size(); ++w) {
+        Session *s = f.work[w];
+        // the first mark[w] items of the session's list are this flight's (flights complete in the order they were launched)
+        const size_t n = f.mark[w];
+        for (size_t q = 0; q < n; ++q) {
+            const Session::Replay &it = s->replay[q];
             if (it.kind == 1) { s->greedy.finish_flush(s->events); s->greedy.ctx_dirty = false; continue; }
             const StepRecord *recs = eng_->records(it.step);
             for (int r = 0; r < 3; ++r) {                               // april_session.c:449-454
@@ -702,36 +831,8 @@ void Scheduler::replay(std::vector<Session *> &work)
                 if (blank) break;
             }
         }
-        s->replay.clear();
+        s->replay.erase(s->replay.begin(), s->replay.begin() + (long)n);
     }
-}
-
-void Scheduler::process(std::vector<Session *> &work)
-{
-    std::vector<Session *> ready;
-    bool done = false;
-    while (!done) {
-        eng_->begin_flight();
-        for (;;) {
-            bool progressed = false;
-            cut_frames(work, progressed);
-            ready.clear();
-            for (Session *s : work) if (s->fb.chunk_ready()) ready.push_back(s);
-            if (!ready.empty()) {
-                if (!step_chunks(ready)) break;                       // rings full: land this flight, continue in the next
-                progressed = true;
-            }
-            if (!progressed) { done = true; break; }
-        }
-        Lap lap;
-        eng_->end_flight();
-        tick_.host_ms[4] += lap();
-        tick_.flights++;
-        replay(work);
-        tick_.host_ms[5] += lap();
-    }
-    // lent buffers go back to their callers when this tick completes: keep what framing has not consumed yet
-    pool_.run(work.size(), 64, [&](size_t i) { work[i]->fb.settle(); });
 }
 
 }  // namespace aprilx

@@ -17,6 +17,7 @@
 //               callbacks are replayed from the records.
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -111,7 +112,8 @@ struct Session {
     size_t borrow_cnt = 0;                    //   copied once, by the stepping thread, outside the lock
     bool fed = false;                         // a feed arrived since the last collection (even an empty one)
     bool flush_requested = false;
-    bool busy = false;                        // owned by the stepping thread right now
+    bool busy = false;                        // owned by the stepping thread right now (inflight > 0)
+    int inflight = 0;                         // ticks of this session that have been collected and not completed yet (<= 2)
     bool closing = false;
     uint64_t submitted = 0, completed = 0;    // work tickets
     std::vector<Event> done_events;           // sync sessions: events waiting for the caller thread
@@ -122,7 +124,7 @@ struct Session {
     bool dout_ready = false;
     bool compact_pending = false;
     struct Replay { int step; int row; int rows; uint32_t now_ms; int kind; int chunk; };   // kind 0: chunk `chunk` of step (3 rounds of records), 1: end of flush
-    std::vector<Replay> replay;               // what the flight in progress did for this session, in order
+    std::vector<Replay> replay;               // what the open flights did for this session, in order (a flight consumes its own items from the front)
     std::atomic<double> speed_needed{1.0};    // reference src/april_session.c:79,456-462 (EMA of processing time / audio time x 1.1);
                                               // written by the stepping thread, read by aas_realtime_get_speedup from any thread
     uint64_t chunks_at_tick_start = 0;
@@ -161,17 +163,32 @@ public:
     void deliver_sync_events(Session *s);          // caller-thread delivery for sync sessions
     void wait_idle(Session *s);                    // everything queued so far has been processed
     void wait_idle_many(Session *const *ss, int n);
+    // until every listed session has at most `max_open` feeds that were submitted and not completed yet (pipelined group feeds)
+    void wait_backlog(Session *const *ss, int n, uint64_t max_open);
     SchedStats stats();
     Engine *engine() { return eng_; }
     bool on_loop_thread() const { return std::this_thread::get_id() == loop_tid_; }
 
 private:
+    // one launched flight: the sessions it serves, their tickets, and how many replay items / chunks it added per session
+    struct Flight {
+        int parity = -1;                                     // the engine's flight id (Engine::close_flight)
+        bool final = true;                                   // false: the rings filled up, the same tick continues in the next flight
+        std::vector<Session *> work;
+        std::vector<uint64_t> taken;
+        std::vector<uint32_t> mark;
+        std::vector<uint64_t> chunks0, chunks1;
+        std::chrono::steady_clock::time_point t0;
+    };
     void loop();
-    void process(std::vector<Session *> &work);
+    bool collect(std::vector<Session *> &work, std::vector<uint64_t> &taken, bool block, uint64_t &work_seen);
+    Flight launch_flight(const std::vector<Session *> &work, const std::vector<uint64_t> &taken);
+    void complete_flight(Flight &f);
     void cut_frames(std::vector<Session *> &work, bool &progressed);
     bool step_chunks(std::vector<Session *> &ready);     // false: the flight's rings are full, (some) work is left for the next flight
     bool step_layer_major(std::vector<Session *> &group, int T, int mode = 0);
-    void replay(std::vector<Session *> &work);
+    void replay(Flight &f);
+    int pipeline_depth_ = 2;                             // APRIL_PIPELINE: 2 = launch the next flight before completing the current one, 1 = one flight at a time
 
     Model *model_;
     Engine *eng_;

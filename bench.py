@@ -40,7 +40,7 @@ def config5_leg(args, A, SM, torch, np):
     if not os.path.exists(lpath):
         SM.write_model(lpath, SM.LARGE_DIMS)
     nb5, wu5, ts5 = 512, 6, 20
-    config5 = {"sessions": nb5, "dims": "large (16 layers, d_model 768, cell 1536, ffn 3072; synthetic seeded weights)", "feed_ms": 100, "steps": ts5}
+    config5 = {"sessions": nb5, "dims": "large (16 layers, d_model 768, cell 1536, ffn 3072; synthetic seeded weights)", "feed_ms": 100, "steps": ts5, "ingest": getattr(args, "ingest", "pipelined")}
     prev = os.environ.get("APRIL_PRECISION")
     for prec in ("f16", "f32"):
         os.environ["APRIL_PRECISION"] = prec
@@ -49,11 +49,15 @@ def config5_leg(args, A, SM, torch, np):
         g5 = A.SessionGroup(s5)
         pp = [SM.lcg_pcm16(step_samples * (wu5 + ts5), seed=12345 + 40_000_000 + i) for i in range(nb5)]
         g5.plan(pp, step_samples)
+        pipelined = getattr(args, "ingest", "pipelined") != "lockstep"
+        feed5 = g5.feed_planned_pipelined if pipelined else g5.feed_planned
         for s in range(wu5):
-            g5.feed_planned(s)
+            feed5(s)
+        g5.drain()
         torch.cuda.synchronize(); a = time.perf_counter()
         for s in range(wu5, wu5 + ts5):
-            g5.feed_planned(s)
+            feed5(s)
+        g5.drain()
         torch.cuda.synchronize(); b = time.perf_counter()
         ms = (b - a) / ts5 * 1e3
         leg = {"ms_per_step": round(ms, 3), "rtf": round(ms / 100.0, 5), "audio_s_per_s": round(nb5 * 0.1 / (ms * 1e-3), 1), "params": int(m5.dims.param_count)}
@@ -111,6 +115,11 @@ def main():
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] leg (larger encoder, 512 sessions, fp16 MFMA path vs fp32)")
     ap.add_argument("--precision", choices=["f32", "f16"], default="f32",
                     help="f16 = opt-in fp16-operand mode (BASELINE configs[4]); the headline metric is quoted on f32")
+    ap.add_argument("--ingest", choices=["pipelined", "lockstep"], default="pipelined",
+                    help="how the 100 ms feeds reach the library: pipelined = aprilx_feed_many_pipelined depth 2 (the call for feed k + 1 "
+                         "returns when feed k is complete: the library prepares and launches a feed while the GPU works on the previous one, as "
+                         "with continuously streaming clients); lockstep = aprilx_feed_many (one blocking call per feed).  The other mode is "
+                         "measured too and reported next to the headline")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend for the weight broadcast; gloo (host tensors, ranks may share a GPU) exists to "
                          "exercise the multi-process path on a one-GPU box")
@@ -248,16 +257,21 @@ def main():
 
     step_wall = []                           # per-step wall time of the timed steps (p50/p99 latency of one 100 ms feed of all sessions)
 
-    def run_steps(group, pcms, s0, s1, record=None):
+    def run_steps(group, pcms, s0, s1, record=None, ingest=None):
+        """feeds s0 .. s1-1 of the plan; returns with every feed processed and every callback delivered"""
+        ingest = ingest or args.ingest
         if s0 == 0:
             group.plan(pcms, step_samples)       # pointer arrays built outside the timed region
+        feed = group.feed_planned if ingest == "lockstep" else group.feed_planned_pipelined
         for s in range(s0, s1):
             if record is None:
-                group.feed_planned(s)
+                feed(s)
             else:
                 a = time.perf_counter()
-                group.feed_planned(s)
+                feed(s)
                 record.append(time.perf_counter() - a)
+        if ingest != "lockstep":
+            group.drain()
 
     run_steps(grp, pcm, 0, args.warmup)
     barrier()
@@ -296,6 +310,26 @@ def main():
                   "what": "%d further 100 ms feeds of the same %d sessions per GPU after the timed region (max over ranks for the mean, rank 0 for the percentiles)" % (nst, B)}
         del more_s
         st = model.stats()
+    # the other ingest mode on the same sessions, same number of steps (never `value`)
+    other = "lockstep" if args.ingest == "pipelined" else "pipelined"
+    more_o = pcm_for(B, args.steps + 4, 40_000_000 + rank * B)
+    run_steps(grp, more_o, 0, 4, ingest=other)
+    barrier()
+    a = time.perf_counter()
+    ow = []
+    run_steps(grp, more_o, 4, args.steps + 4, ow, ingest=other)
+    barrier()
+    el_o = time.perf_counter() - a
+    if world > 1:
+        tt = torch.tensor([el_o], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el_o = float(tt.item())
+    other_ingest = {"ingest": other, "steps": args.steps, "ms_per_step": round(el_o / args.steps * 1e3, 3), "rtf": round(el_o / (args.steps * 0.1), 5),
+                    "p50": round(float(np.percentile(ow, 50)) * 1e3, 3), "what": "the same sessions, %d further feeds through %s" % (
+                        args.steps, "aprilx_feed_many (one blocking call per 100 ms feed: nothing of the next feed can start before the previous one has been delivered)"
+                        if other == "lockstep" else "aprilx_feed_many_pipelined depth 2")}
+    del more_o
+    st = model.stats()
     audio_per_session = args.steps * step_samples / 16000.0
     value = world * B * audio_per_session / elapsed
     rtf = elapsed / audio_per_session
@@ -481,7 +515,11 @@ def main():
             "config": {"workload": "aprilv0_en-us dims (synthetic seeded weights), %d concurrent streaming sessions per GPU, "
                                    "100 ms PCM16 feeds via aprilx_feed_many (BASELINE configs[2]; configs[3] at 8 GPUs)" % B,
                        "sessions_per_gpu": B, "feed_ms": 100, "params": int(d.param_count), "parallelism": "sessions sharded, dp%d" % world},
-            "rtf": round(rtf, 5), "sessions_total": world * B, "steady": steady, "config5_f16": config5,
+            "rtf": round(rtf, 5), "sessions_total": world * B,
+            "ingest": {"mode": args.ingest, "what": "aprilx_feed_many_pipelined, depth 2: feed k + 1 is queued (samples copied) while feed k is on the GPU, every callback "
+                                                     "of the K timed feeds is delivered inside the timed region (drain before the closing barrier)"
+                       if args.ingest == "pipelined" else "aprilx_feed_many: one blocking call per feed"},
+            "other_ingest": other_ingest, "steady": steady, "config5_f16": config5,
             "rccl_fallback": rccl_fallback, "rccl_libs_mapped": sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln}),
             "step_latency_ms": {"p50": round(float(np.percentile(step_wall, 50)) * 1e3, 3), "p99": round(float(np.percentile(step_wall, 99)) * 1e3, 3),
                                 "max": round(max(step_wall) * 1e3, 3), "series": [round(x * 1e3, 2) for x in step_wall[:200]], "what": "wall time of one aprilx_feed_many call (100 ms of audio for every session, callbacks delivered), rank 0"},

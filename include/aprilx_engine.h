@@ -75,6 +75,15 @@ APRIL_EXPORT void aprilx_feed_many(size_t n, AprilASRSession *sessions, const sh
 APRIL_EXPORT void aprilx_flush_many(size_t n, AprilASRSession *sessions);
 /* block until an asynchronous session has consumed everything queued so far */
 APRIL_EXPORT void aprilx_session_drain(AprilASRSession session);
+/* Pipelined group feed: queue one feed for each of the n sessions (the samples are COPIED, as for an asynchronous session,
+ * reference src/april_session.c:479-500), then block only until every session has at most `depth - 1` feeds that are
+ * queued or in progress.  depth = 2 is double buffering: the call for feed k + 1 returns when feed k is complete, so the
+ * library prepares and launches feed k + 1 while the GPU still works on feed k.  depth = 1 waits for this very feed
+ * (aprilx_feed_many without lending the buffers).  Results arrive in feed order: handlers of synchronous sessions run on the
+ * calling thread before the call returns (for the feeds that have completed by then), those of asynchronous sessions on the
+ * library thread.  aprilx_drain_many waits for everything queued and delivers what is left.                              */
+APRIL_EXPORT void aprilx_feed_many_pipelined(size_t n, AprilASRSession *sessions, const short *const *pcm16, const size_t *short_counts, int depth);
+APRIL_EXPORT void aprilx_drain_many(size_t n, AprilASRSession *sessions);
 
 /* ---- direct network evaluation (parity tests) -------------------------------------------
  * Same tensors as the three ORT Run calls, with a leading batch of n independent sessions:

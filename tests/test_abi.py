@@ -30,7 +30,9 @@ def test_every_declared_symbol_is_exported(built):
 
 def test_only_the_abi_is_exported(built):
     out = subprocess.check_output(["nm", "-D", "--defined-only", _ffi.LIB_PATH]).decode()
-    names = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    # every defined dynamic symbol of any kind (code, data, weak, vague-linkage: the HIP kernel handle objects used to leak
+    # out as D / V symbols; csrc/exports.map keeps them local)
+    names = {l.split()[-1] for l in out.splitlines() if len(l.split()) >= 3}
     assert names == set(_ffi.EXPORTED_REFERENCE_SYMBOLS) | set(_ffi.EXPORTED_ENGINE_SYMBOLS), names
 
 

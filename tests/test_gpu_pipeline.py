@@ -1,0 +1,65 @@
+"""The stepping thread keeps two flights in the air (csrc/session.cc Scheduler::loop): flight k + 1 is launched before flight k
+is completed whenever its work is already queued.  Which feeds share a flight, and whether a caller lent its buffers or had them
+copied, must not change a single callback: the same sessions are streamed in separate processes through the lock-step group feed
+(aprilx_feed_many), the pipelined group feed at depth 1 and 2 (aprilx_feed_many_pipelined), as asynchronous sessions, and with
+pipelining switched off in the library (APRIL_PIPELINE=1); every token, log-probability (bit for bit), flag and time must agree.
+Also here: the bound on the samples staged per pass (FbankFrameDesc::pcm_off is 32 bits) crossed with small numbers."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(path, nsess, steps, mode, feed=1600, flush=1, **env):
+    e = dict(os.environ, APRIL_MAX_SESSIONS="512", APRIL_MAX_BATCH="2048")
+    e.update({k: str(v) for k, v in env.items()})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "stream_worker.py"), path, str(nsess), str(steps), mode, str(feed), str(flush)],
+                       env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("DIGEST")][-1].split()
+    return dict(digest=line[1], chunks=int(line[2]), mismatch=int(line[3]), calls=int(line[4]), tokens=int(line[5]), flights=int(line[6]))
+
+
+def test_ingest_modes_give_the_same_callbacks(built, medium_model):
+    path = medium_model["path"]
+    ref = run(path, 24, 12, "sync")
+    assert ref["chunks"] > 0 and ref["calls"] > 0 and ref["mismatch"] == 0
+    for mode, env in (("pipe2", {}), ("pipe1", {}), ("async", {}), ("pipe2", {"APRIL_PIPELINE": 1}), ("sync", {"APRIL_PIPELINE": 1}), ("pipe2", {"APRIL_NO_GRAPHS": 1})):
+        got = run(path, 24, 12, mode, **env)
+        assert got["mismatch"] == 0 and got["chunks"] == ref["chunks"], (mode, env, got)
+        assert got["digest"] == ref["digest"], "callbacks differ in mode %s %r" % (mode, env)
+
+
+def test_pipelined_feeds_at_aprilv0_dims(built, v0_model):
+    path = v0_model["path"]
+    a = run(path, 64, 8, "sync")
+    b = run(path, 64, 8, "pipe2")
+    assert a["mismatch"] == 0 and b["mismatch"] == 0 and a["chunks"] == b["chunks"] > 0
+    assert a["digest"] == b["digest"]
+    assert b["flights"] >= 8
+
+
+def test_irregular_feeds_pipelined(built, medium_model):
+    """feeds that are not a whole number of frames (1234 samples): chunk counts per flight vary (0..1 chunk), flights with
+    nothing to do for some sessions"""
+    path = medium_model["path"]
+    a = run(path, 5, 40, "sync", feed=1234)
+    b = run(path, 5, 40, "pipe2", feed=1234)
+    c = run(path, 5, 40, "async", feed=1234)
+    assert a["mismatch"] == b["mismatch"] == c["mismatch"] == 0 and a["chunks"] == b["chunks"] == c["chunks"] > 0
+    assert a["digest"] == b["digest"] == c["digest"]
+
+
+def test_staged_samples_per_pass_are_bounded(built, medium_model):
+    """3 s per session in ONE feed, 6 sessions = 288 000 samples; with the limit at 20 000 samples a pass stages one session's
+    worth of frames at most and the rest waits for the next pass -- the callbacks are those of the unbounded run"""
+    path = medium_model["path"]
+    a = run(path, 6, 1, "sync", feed=48000)
+    b = run(path, 6, 1, "sync", feed=48000, APRIL_STAGE_LIMIT_SAMPLES=20000)
+    c = run(path, 6, 1, "pipe2", feed=48000, APRIL_STAGE_LIMIT_SAMPLES=20000)
+    assert a["mismatch"] == b["mismatch"] == c["mismatch"] == 0 and a["chunks"] == b["chunks"] == c["chunks"] > 0
+    assert a["digest"] == b["digest"] == c["digest"]
