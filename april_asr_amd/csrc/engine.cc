@@ -143,6 +143,14 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
 {
     HIP_CHECK(hipSetDevice(cfg_.device));
     HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&f_stream_, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&s_stream_, hipStreamNonBlocking));
+    search_stream_ = stream_;
+    for (int i = 0; i < 32; ++i) { hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); join_ev_.push_back(e); }
+    {
+        const char *e = getenv("APRIL_SPLIT_STREAMS");
+        split_streams_ = e && *e ? std::max(0, std::min(2, atoi(e))) : 2;
+    }
     const NetDims &d = L_.dims;
     w_ = dmalloc<float>(L_.total);
     if (blob_device) HIP_CHECK(hipMemcpy(w_, blob_device, L_.total * 4, hipMemcpyDeviceToDevice));
@@ -199,7 +207,8 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
         f16_tile_ = want && d.d_model % 128 == 0 && d.hidden % 128 == 0 && d.ffn % 128 == 0 && d.hidden % 16 == 0;
         if (f16_tile_) {
             kzx_hr_ = pick_kz(d.hidden, d.d_model, 32); kzx_ff2_ = pick_kz(d.ffn, d.d_model, 32);
-            y16_ = dmalloc<uint16_t>(MB * d.d_model); xb16_ = dmalloc<uint16_t>(MB * d.d_model);
+            for (int p = 0; p < 2; ++p) y16_buf_[p] = dmalloc<uint16_t>(MB * d.d_model);
+            y16_ = y16_buf_[0]; xb16_ = dmalloc<uint16_t>(MB * d.d_model);
             u16_ = dmalloc<uint16_t>(MB * d.hidden); ff16_ = dmalloc<uint16_t>(MB * d.ffn);
             h16_ = dmalloc<uint16_t>((size_t)d.n_layers * S * d.d_model);
             HIP_CHECK(hipMemset(h16_, 0, (size_t)d.n_layers * S * d.d_model * 2));
@@ -212,8 +221,12 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     xin_ = dmalloc<float>(MB * d.embed_in);
     a3_ = dmalloc<float>(MB * d.f_out * L_.k3);
     HIP_CHECK(hipMemset(a3_, 0, MB * d.f_out * L_.k3 * 4));      // padded k columns (if any) stay zero
-    y_ = dmalloc<float>(MB * d.d_model);
-    ssq_ = dmalloc<float>(MB * (d.d_model / SSQ_COLS));
+    // buffers that the front end / index fetch of flight k + 1 writes while flight k's layers or search still read them exist
+    // once per flight parity (begin_flight() selects): encoder rows y + their sums of squares, the step's index arrays, the
+    // round flags, the record offset, the batched encoder outputs (eout_lm_, allocated on first use)
+    for (int p = 0; p < 2; ++p) { y_buf_[p] = dmalloc<float>(MB * d.d_model); ssq_buf_[p] = dmalloc<float>(MB * (d.d_model / SSQ_COLS)); }
+    y_ = y_buf_[0]; ssq_ = ssq_buf_[0];
+    ws_fe_ = dmalloc<float>((size_t)kz_embed_ * d.d_model * MB);      // the front end's own split-K planes (embed at small batches)
     xb_ = dmalloc<float>(MB * d.d_model);
     u_ = dmalloc<float>(MB * d.hidden);
     ff_ = dmalloc<float>(MB * d.ffn);
@@ -228,10 +241,15 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     step_cap_ = 1 << 14; step_off_h_ = hmalloc<int>((size_t)2 * step_cap_); rec_off_h_ = hmalloc<int>((size_t)2 * step_cap_);
     rec_cap_ = std::max<size_t>((size_t)1 << 20, 3 * MB * 8); rec_d_ = dmalloc<StepRecord>(2 * rec_cap_); rec_h_ = hmalloc<StepRecord>(2 * rec_cap_);
     for (int i = 0; i < 2; ++i) HIP_CHECK(hipEventCreateWithFlags(&flight_done_[i], hipEventDisableTiming));
-    counter_d_ = dmalloc<int>(1); rec_off_d_ = dmalloc<int>(1); flags_d_ = dmalloc<int>(8);
-    step_d_ = dmalloc<int>(4 * MB); active_d_ = dmalloc<int>(MB); dirty_d_ = dmalloc<int>(MB);
+    counter_d_ = dmalloc<int>(1);
+    for (int p = 0; p < 2; ++p) {
+        rec_off_buf_[p] = dmalloc<int>(1); flags_buf_[p] = dmalloc<int>(8); step_buf_[p] = dmalloc<int>(4 * MB);
+        HIP_CHECK(hipMemset(rec_off_buf_[p], 0, 4)); HIP_CHECK(hipMemset(flags_buf_[p], 0, 32));
+    }
+    rec_off_d_ = rec_off_buf_[0]; flags_d_ = flags_buf_[0]; step_d_ = step_buf_[0];
+    active_d_ = dmalloc<int>(MB); dirty_d_ = dmalloc<int>(MB);
     dec_slots_d_ = dmalloc<int>(std::max(S, MB));
-    HIP_CHECK(hipMemset(counter_d_, 0, 4)); HIP_CHECK(hipMemset(rec_off_d_, 0, 4)); HIP_CHECK(hipMemset(flags_d_, 0, 32));
+    HIP_CHECK(hipMemset(counter_d_, 0, 4));
 
     upload_tables(ft);
     use_graphs_ = !(getenv("APRIL_NO_GRAPHS") && atoi(getenv("APRIL_NO_GRAPHS")));
@@ -303,12 +321,13 @@ void Engine::build_dec_table()
 Engine::~Engine()
 {
     (void)hipSetDevice(cfg_.device);
-    (void)hipStreamSynchronize(stream_);
+    (void)hipStreamSynchronize(f_stream_); (void)hipStreamSynchronize(stream_); (void)hipStreamSynchronize(s_stream_);
+    for (hipEvent_t e : join_ev_) (void)hipEventDestroy(e);
     for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &g : step_graphs_) (void)hipGraphExecDestroy(g.second);
     for (auto &g : lm_graphs_) (void)hipGraphExecDestroy(g.second);
     for (auto &g : lm_search_graphs_) (void)hipGraphExecDestroy(g.second);
-    for (auto &p : sw_plans_) { if (p.second.graph) (void)hipGraphExecDestroy(p.second.graph); if (p.second.dev) (void)hipFree(p.second.dev); if (p.second.rdev) (void)hipFree(p.second.rdev); }
+    for (auto &p : sw_plans_) { if (p.second.graph) (void)hipGraphExecDestroy(p.second.graph); for (hipGraphExec_t x : p.second.g3) if (x) (void)hipGraphExecDestroy(x); if (p.second.dev) (void)hipFree(p.second.dev); if (p.second.rdev) (void)hipFree(p.second.rdev); }
     if (lm_stream_) { (void)hipStreamSynchronize(lm_stream_); (void)hipStreamDestroy(lm_stream_); }
     for (hipEvent_t e : lm_events_) (void)hipEventDestroy(e);
     if (zargs_h_) { (void)hipHostFree(zargs_h_); (void)hipFree(zargs_d_); }
@@ -317,11 +336,13 @@ Engine::~Engine()
     if (ws_g_) (void)hipFree(ws_g_);
     if (dec_table_) (void)hipFree(dec_table_);
     if (p_lm_) (void)hipFree(p_lm_);
-    if (eout_lm_) (void)hipFree(eout_lm_);
-    for (void *p : {(void *)wx_, (void *)y16_, (void *)xb16_, (void *)u16_, (void *)ff16_, (void *)h16_}) if (p) (void)hipFree(p);      // fp16 tile path
+    for (int p = 0; p < 2; ++p)
+        for (void *q : {(void *)eout_lm_buf_[p], (void *)y16_buf_[p], (void *)y_buf_[p], (void *)ssq_buf_[p], (void *)rec_off_buf_[p], (void *)flags_buf_[p], (void *)step_buf_[p]}) if (q) (void)hipFree(q);
+    if (ws_fe_) (void)hipFree(ws_fe_);
+    for (void *p : {(void *)wx_, (void *)xb16_, (void *)u16_, (void *)ff16_, (void *)h16_}) if (p) (void)hipFree(p);      // fp16 tile path
     for (void *p : {(void *)w_, (void *)wh_, (void *)h_, (void *)c_, (void *)ring_, (void *)eout_, (void *)dout_, (void *)gstate_, (void *)cls_, (void *)ws_, (void *)xin_,
-                    (void *)a3_, (void *)y_, (void *)ssq_, (void *)xb_, (void *)u_, (void *)ff_, (void *)de_, (void *)logits_, (void *)rec_d_, (void *)counter_d_,
-                    (void *)rec_off_d_, (void *)flags_d_, (void *)step_d_, (void *)active_d_, (void *)dirty_d_, (void *)dec_slots_d_,
+                    (void *)a3_, (void *)xb_, (void *)u_, (void *)ff_, (void *)de_, (void *)logits_, (void *)rec_d_, (void *)counter_d_,
+                    (void *)active_d_, (void *)dirty_d_, (void *)dec_slots_d_,
                     (void *)ds_desc_[0], (void *)ds_desc_[1], (void *)ds_pcm_[0], (void *)ds_pcm_[1]})
         if (p) (void)hipFree(p);
     for (void *p : {(void *)ring_h_, (void *)step_off_h_, (void *)rec_off_h_, (void *)rec_h_, (void *)logits_h_, (void *)hs_desc_[0], (void *)hs_desc_[1], (void *)hs_pcm_[0], (void *)hs_pcm_[1]})
@@ -329,7 +350,7 @@ Engine::~Engine()
     for (int b = 0; b < 2; ++b) if (fb_done_[b]) (void)hipEventDestroy(fb_done_[b]);
     for (int b = 0; b < 2; ++b) if (flight_done_[b]) (void)hipEventDestroy(flight_done_[b]);
     for (void *p : table_allocs_) (void)hipFree(p);
-    (void)hipStreamDestroy(stream_);
+    (void)hipStreamDestroy(stream_); (void)hipStreamDestroy(f_stream_); (void)hipStreamDestroy(s_stream_);
 }
 
 void Engine::upload_tables(const FbankHostTables &ft)
@@ -382,7 +403,35 @@ void Engine::free_slot(int slot)
     --live_;
 }
 
-void Engine::sync() { HIP_CHECK(hipStreamSynchronize(stream_)); if (profiling_) collect_timing(); }
+void Engine::sync()
+{
+    HIP_CHECK(hipStreamSynchronize(f_stream_)); HIP_CHECK(hipStreamSynchronize(stream_)); HIP_CHECK(hipStreamSynchronize(s_stream_));
+    f_unseen_by_m_ = s_unseen_by_m_ = m_unseen_by_f_ = m_unseen_by_s_ = false;
+    if (profiling_) collect_timing();
+}
+
+// ---------------------------------------------------------------- streams
+// Three in-order streams.  stream_ (M) carries the layer chain and every launch of the general paths; f_stream_ (F) the PCM
+// upload and the fbank kernel of every flight and, for a feed that runs as a split wavefront (lm_step mode 1), its index fetch
+// and conv / embed front end; s_stream_ (S) the search of such a feed.  Inside one flight FE -> layers -> search are chained by
+// events; ACROSS flights the front end of flight k + 1 and the search of flight k run beside the layers of flights k / k + 1
+// (they share no buffer: see the per-parity buffers in the constructor).  The general paths (chunk-by-chunk steps, long feeds,
+// decoder refreshes, traced steps) stay on M and first wait for whatever F and S still have in the air; a split feed after
+// general work makes F and S wait for M the same way.  The flags say which stream has work the other has not waited for yet.
+void Engine::join(hipStream_t waiter, hipStream_t src)
+{
+    hipEvent_t e = join_ev_[join_pos_++ % join_ev_.size()];
+    HIP_CHECK(hipEventRecord(e, src));
+    HIP_CHECK(hipStreamWaitEvent(waiter, e, 0));
+}
+
+void Engine::general_prologue()
+{
+    if (f_unseen_by_m_) { join(stream_, f_stream_); f_unseen_by_m_ = false; }
+    if (s_unseen_by_m_) { join(stream_, s_stream_); s_unseen_by_m_ = false; }
+    m_unseen_by_f_ = m_unseen_by_s_ = true;
+    flight_tail_s_ = false;
+}
 
 // ---------------------------------------------------------------- profiling
 void Engine::set_profiling(bool on) { sync(); profiling_ = on; }
@@ -448,13 +497,18 @@ void Engine::fbank(int n_frames, const FbankFrameDesc *desc, const std::pair<con
         size_t off = 0;
         for (size_t i = 0; i < n_parts; ++i) { memcpy(hs_pcm_[b] + off, parts[i].first, parts[i].second * sizeof(int16_t)); off += parts[i].second; }
     }
-    HIP_CHECK(hipMemcpyAsync(ds_pcm_[b], hs_pcm_[b], doff + (size_t)n_frames * sizeof(FbankFrameDesc), hipMemcpyHostToDevice, stream_));
+    std::lock_guard<std::mutex> cg(capture_mu_);
+    if (m_unseen_by_f_) { join(f_stream_, stream_); m_unseen_by_f_ = false; }      // (general-path work may still read ring rows this call overwrites)
+    HIP_CHECK(hipMemcpyAsync(ds_pcm_[b], hs_pcm_[b], doff + (size_t)n_frames * sizeof(FbankFrameDesc), hipMemcpyHostToDevice, f_stream_));
     FbankArgs a;
     a.t = ft_; a.pcm = ds_pcm_[b]; a.desc = reinterpret_cast<const FbankFrameDesc *>(reinterpret_cast<const char *>(ds_pcm_[b]) + doff); a.n_frames = n_frames; a.ring = ring_; a.ring_frames = ring_frames_; a.pad_value = pad_value_;
-    timed_begin(T_FBANK);
-    launch_fbank(a, stream_);
-    timed_end(T_FBANK);
-    HIP_CHECK(hipEventRecord(fb_done_[b], stream_));       // no host wait here: the encoder launches queue right behind
+    if (profiling_) {        // (the per-class hipEvents live on M: a profiled fbank runs there, behind its upload)
+        join(stream_, f_stream_);
+        timed_begin(T_FBANK); launch_fbank(a, stream_); timed_end(T_FBANK);
+        join(f_stream_, stream_);
+    } else launch_fbank(a, f_stream_);
+    HIP_CHECK(hipEventRecord(fb_done_[b], f_stream_));       // no host wait here: the encoder launches queue right behind
+    f_unseen_by_m_ = true;
 }
 
 // ---------------------------------------------------------------- encoder
@@ -582,14 +636,14 @@ void Engine::run_decproj(int n, const int *d_slots, const int *row_mask, const i
     g.M = n; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_; g.tile_ok = tile_ok(); g.run_flag = run_flag; g.run_gen = run_gen;
     if (gemm_fullk(n, d.joiner, kz_proj_, false, 1, tile_ok())) {
         g.epi = EPI_SLOT_STORE; g.bias = w_ + L_.b_decproj; g.out = out; g.ldo = d.joiner; g.slot_idx = d_slots; g.row_mask = row_mask;
-        timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
+        timed_begin(T_DEC); launch_gemm(g, search_stream_); timed_end(T_DEC);
         return;
     }
     g.epi = EPI_PARTIAL; g.out = ws_g_; g.m_stride = ws_mstride_;
-    timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
+    timed_begin(T_DEC); launch_gemm(g, search_stream_); timed_end(T_DEC);
     RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_g_; r.parts = gemm_partials(n, d.joiner, kz_proj_, 1, tile_ok()); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = n;
     r.bias = w_ + L_.b_decproj; r.out = out; r.ldo = d.joiner; r.slot_idx = d_slots; r.row_mask = row_mask; r.run_flag = run_flag; r.run_gen = run_gen;
-    timed_begin(T_DEC); launch_row(r, stream_); timed_end(T_DEC);
+    timed_begin(T_DEC); launch_row(r, search_stream_); timed_end(T_DEC);
 }
 
 // The reference's loop "joiner -> process_logits, up to three times, early-emit 1,0,0" (src/april_session.c:449-454)
@@ -616,7 +670,7 @@ void Engine::run_greedy_rounds(int n, const GreedyIo &io)
             else { g.a0 = eout_; g.aidx0 = d_slots; }
             lin(g, L_.w_out); g.M = n; g.N = L_.vocab_pad; g.K = d.joiner; g.kz = kz_out_; g.epi = EPI_PARTIAL; g.out = ws_g_; g.m_stride = ws_mstride_;
             if (round > 0) { g.run_flag = flags_d_ + round; g.run_gen = gen; }
-            timed_begin(T_DEC); launch_gemm(g, stream_); timed_end(T_DEC);
+            timed_begin(T_DEC); launch_gemm(g, search_stream_); timed_end(T_DEC);
         }
         DecideArgs a;
         a.ws = ws_g_; a.parts = gemm_partials(n, L_.vocab_pad, kz_out_); a.m_stride = ws_mstride_; a.N = L_.vocab_pad; a.M = n; a.n_valid = d.vocab;
@@ -626,7 +680,7 @@ void Engine::run_greedy_rounds(int n, const GreedyIo &io)
         a.logits_dump = io.dump ? io.dump + (size_t)round * n * d.vocab : nullptr;
         a.dec = dec_params(); a.de_out = dec_table_ ? nullptr : de_; a.ld_de = d.d_model;
         a.run_flags = flags_d_; a.rerun_flags = flags_d_ + 4;
-        timed_begin(T_DEC); launch_decide(a, stream_); timed_end(T_DEC);
+        timed_begin(T_DEC); launch_decide(a, search_stream_); timed_end(T_DEC);
         if (!dec_table_) run_decproj(n, d_slots, dirty_d_, flags_d_ + 4 + round, gen);
     }
 }
@@ -635,7 +689,7 @@ void Engine::run_chain(int m, bool dump_logits)
 {
     const int MB = cfg_.max_batch;
     AdvanceArgs a;
-    a.host_ring = ring_h_; a.host_step_off = step_off_h_; a.host_rec_off = rec_off_h_; a.counter = counter_d_;
+    a.host_ring = ring_h_; a.host_step_off = step_off_h_; a.host_rec_off = rec_off_h_; a.counter = counter_d_; a.index_mask = 2 * step_cap_ - 1;
     a.dst = step_d_; a.dst_stride = MB; a.n_arrays = 3; a.len[0] = a.len[1] = a.len[2] = m; a.rec_off = rec_off_d_;
     a.flags = flags_d_; a.n_flags = 8;
     launch_advance(a, stream_);
@@ -653,7 +707,7 @@ void Engine::run_chain(int m, bool dump_logits)
 // layer(l, b) needs layer(l - 1, b) (its input rows) and layer(l, b - 1) (the recurrent state): stages of different layers
 // on different blocks are independent: their launches are z-batched into one (see run_lm_wavefront).  Work buffers are row-partitioned,
 // so concurrent stages never share a byte.
-void Engine::lm_stage_embed(int m, int t0, int t1, hipStream_t st)
+void Engine::lm_stage_embed(int m, int t0, int t1, hipStream_t st, bool own_ws)
 {
     const NetDims &d = L_.dims;
     const int MB = cfg_.max_batch;
@@ -673,13 +727,14 @@ void Engine::lm_stage_embed(int m, int t0, int t1, hipStream_t st)
         g.M = rows * d.f_out; g.N = d.conv_ch[2]; g.K = L_.k3; g.kz = 1; g.epi = EPI_BIAS_DSWISH; g.out = xin_ + r0 * d.embed_in; g.ldo = d.conv_ch[2]; g.bias = w_ + L_.conv_b[2];
         timed_begin(T_CONV); launch_gemm(g, st); timed_end(T_CONV);
     }
-    lm_resid_ssq(xin_ + r0 * d.embed_in, d.embed_in, L_.w_embed, kz_embed_, w_ + L_.b_embed, nullptr, r0, rows, st);
+    lm_resid_ssq(xin_ + r0 * d.embed_in, d.embed_in, L_.w_embed, kz_embed_, w_ + L_.b_embed, nullptr, r0, rows, st, own_ws ? ws_fe_ : ws_);
     if (f16_tile_) launch_cvt_f16(y_ + r0 * d.d_model, y16_ + r0 * d.d_model, (size_t)rows * d.d_model, st);      // layer 0 reads binary16 rows
 }
 
 // y[r0 .. r0 + rows) = A x W + bias (+ residual) with sums of squares; fused where the tiles own all of K
-void Engine::lm_resid_ssq(const float *a, int K, size_t w_off, int kz, const float *bias, const float *resid, size_t r0, int rows, hipStream_t st)
+void Engine::lm_resid_ssq(const float *a, int K, size_t w_off, int kz, const float *bias, const float *resid, size_t r0, int rows, hipStream_t st, float *ws)
 {
+    if (!ws) ws = ws_;
     const NetDims &d = L_.dims;
     const int G = d.d_model / SSQ_COLS;
     GemmArgs g; g.a0 = a; g.lda0 = K; g.K0 = K; lin(g, w_off);
@@ -690,9 +745,9 @@ void Engine::lm_resid_ssq(const float *a, int K, size_t w_off, int kz, const flo
         timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
         return;
     }
-    g.epi = EPI_PARTIAL; g.out = ws_ + r0 * d.d_model; g.m_stride = ws_mstride_;
+    g.epi = EPI_PARTIAL; g.out = ws + r0 * d.d_model; g.m_stride = ws_mstride_;
     timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
-    RowArgs r; r.mode = ROW_RESID_SSQ; r.ws = ws_ + r0 * d.d_model; r.parts = gemm_partials(rows, d.d_model, kz, 1, tile_ok()); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = rows;
+    RowArgs r; r.mode = ROW_RESID_SSQ; r.ws = ws + r0 * d.d_model; r.parts = gemm_partials(rows, d.d_model, kz, 1, tile_ok()); r.m_stride = ws_mstride_; r.N = d.d_model; r.M = rows;
     r.bias = bias; r.resid = resid; r.ldr = d.d_model; r.out = yo; r.ldo = d.d_model; r.ssq_out = so;
     timed_begin(T_ROW); launch_row(r, st); timed_end(T_ROW);
 }
@@ -920,7 +975,7 @@ void Engine::run_lm_chain(int m, int T, bool dump_logits)
     const int MB = cfg_.max_batch;
     const int L = d.n_layers;
     AdvanceArgs a;
-    a.host_ring = ring_h_; a.host_step_off = step_off_h_; a.host_rec_off = rec_off_h_; a.counter = counter_d_;
+    a.host_ring = ring_h_; a.host_step_off = step_off_h_; a.host_rec_off = rec_off_h_; a.counter = counter_d_; a.index_mask = 2 * step_cap_ - 1;
     a.dst = step_d_; a.dst_stride = MB; a.n_arrays = 4; a.len[0] = m; a.len[1] = a.len[2] = a.len[3] = m * T; a.rec_off = rec_off_d_;
     a.flags = flags_d_; a.n_flags = 8;
     launch_advance(a, stream_);
@@ -948,7 +1003,7 @@ void Engine::run_lm_wavefront(int m, int T, bool dump_logits)
     const int blk = lm_block_steps(T);
     const int NB = (T + blk - 1) / blk;
     AdvanceArgs a;
-    a.host_ring = ring_h_; a.host_step_off = step_off_h_; a.host_rec_off = rec_off_h_; a.counter = counter_d_;
+    a.host_ring = ring_h_; a.host_step_off = step_off_h_; a.host_rec_off = rec_off_h_; a.counter = counter_d_; a.index_mask = 2 * step_cap_ - 1;
     a.dst = step_d_; a.dst_stride = MB; a.n_arrays = 4; a.len[0] = m; a.len[1] = a.len[2] = a.len[3] = m * T; a.rec_off = rec_off_d_;
     a.flags = flags_d_; a.n_flags = 8;
     launch_advance(a, stream_);
@@ -1045,7 +1100,7 @@ void Engine::run_lm_wavefront(int m, int T, bool dump_logits)
                 }
             };
             if (!use_graphs_ || dump_logits) { search(); continue; }
-            const std::pair<int, int> key(m, len);
+            const std::pair<int, int> key(m * 2 + flight_parity_, len);      // (round flags and encoder outputs are per flight parity)
             auto it = lm_search_graphs_.find(key);
             if (it == lm_search_graphs_.end()) {
                 if (lm_search_graphs_.size() >= 64) { HIP_CHECK(hipStreamSynchronize(stream_)); /* execs launched earlier in this flight may still run */ for (auto &g : lm_search_graphs_) (void)hipGraphExecDestroy(g.second); lm_search_graphs_.clear(); }
@@ -1079,12 +1134,12 @@ void Engine::run_lm_wavefront(int m, int T, bool dump_logits)
 // The argument blocks depend on (m, T) only: built once per shape, kept in device memory, and the whole chain is one graph.
 Engine::SwPlan &Engine::sw_plan(int m, int T)
 {
-    const std::pair<int, int> key(m, T);
+    const std::pair<int, int> key(m, T * 2 + flight_parity_);      // (the argument blocks point into the parity's buffers)
     auto it = sw_plans_.find(key);
     if (it != sw_plans_.end()) return it->second;
     if (sw_plans_.size() >= 64) {
-        HIP_CHECK(hipStreamSynchronize(stream_));
-        for (auto &p : sw_plans_) { if (p.second.graph) (void)hipGraphExecDestroy(p.second.graph); if (p.second.dev) (void)hipFree(p.second.dev); if (p.second.rdev) (void)hipFree(p.second.rdev); }
+        sync();
+        for (auto &p : sw_plans_) { if (p.second.graph) (void)hipGraphExecDestroy(p.second.graph); for (hipGraphExec_t x : p.second.g3) if (x) (void)hipGraphExecDestroy(x); if (p.second.dev) (void)hipFree(p.second.dev); if (p.second.rdev) (void)hipFree(p.second.rdev); }
         sw_plans_.clear();
     }
     SwPlan &p = sw_plans_[key];
@@ -1135,27 +1190,36 @@ Engine::SwPlan &Engine::sw_plan(int m, int T)
     return p;
 }
 
-void Engine::run_sw_chain(int m, int T, bool dump_logits, const SwPlan &p)
+// part 0: index fetch + front end (stream fe), 1: the layer wavefront + encoder_proj (stream ly), 2: the searches (stream sr);
+// parts < 0: all three in order on one stream
+void Engine::run_sw_chain(int m, int T, bool dump_logits, const SwPlan &p, int part, hipStream_t st)
 {
     const NetDims &d = L_.dims;
     const int MB = cfg_.max_batch;
-    AdvanceArgs a;
-    a.host_ring = ring_h_; a.host_step_off = step_off_h_; a.host_rec_off = rec_off_h_; a.counter = counter_d_;
-    a.dst = step_d_; a.dst_stride = MB; a.n_arrays = 4; a.len[0] = m; a.len[1] = a.len[2] = a.len[3] = m * T; a.rec_off = rec_off_d_;
-    a.flags = flags_d_; a.n_flags = 8;
-    launch_advance(a, stream_);
-    // Front end and encoder_proj do not take part in the wavefront: one launch chain each over all T x m rows (as in the
-    // layer-major step), before the first and after the last macro step; the searches follow in time order.
-    // (Measured and dropped: front end / encoder_proj / search on a second captured stream beside the layer launches, forked
-    // and joined by events inside the capture -- works, gains nothing: the graph executor does not overlap the branches.)
-    lm_stage_embed(m, 0, T, stream_);
-    static const int cls_of[4] = {T_GATES, T_GEMM_OTHER, T_GEMM_OTHER, T_GEMM_OTHER};
-    for (const SwPlan::Batch &b : p.batches) {      // macro steps in order; inside one: gates, projection, FFN up, FFN down of the active layers
-        timed_begin(cls_of[b.kind]); launch_gemm_z(p.host.data() + b.off, b.n, p.dev + b.off, stream_); timed_end(cls_of[b.kind]);
-        if (b.rn > 0) { timed_begin(T_ROW); launch_row_z(p.rhost.data() + b.roff, b.rn, p.rdev + b.roff, stream_); timed_end(T_ROW); }
+    if (part < 0 || part == 0) {
+        AdvanceArgs a;
+        a.host_ring = ring_h_; a.host_step_off = step_off_h_; a.host_rec_off = rec_off_h_; a.counter = counter_d_; a.index_mask = 2 * step_cap_ - 1;
+        a.dst = step_d_; a.dst_stride = MB; a.n_arrays = 4; a.len[0] = m; a.len[1] = a.len[2] = a.len[3] = m * T; a.rec_off = rec_off_d_;
+        a.flags = flags_d_; a.n_flags = 8;
+        launch_advance(a, st);
+        // Front end and encoder_proj do not take part in the wavefront: one launch chain each over all T x m rows (as in the
+        // layer-major step), before the first and after the last macro step; the searches follow in time order.
+        lm_stage_embed(m, 0, T, st, part == 0);
     }
-    lm_stage_proj(m, 0, T, stream_);
-    for (int t = 0; t < T; ++t) run_greedy_rounds(m, dump_logits, t, eout_lm_ + (size_t)t * m * d.joiner);
+    if (part < 0 || part == 1) {
+        static const int cls_of[4] = {T_GATES, T_GEMM_OTHER, T_GEMM_OTHER, T_GEMM_OTHER};
+        for (const SwPlan::Batch &b : p.batches) {      // macro steps in order; inside one: gates, projection, FFN up, FFN down of the active layers
+            timed_begin(cls_of[b.kind]); launch_gemm_z(p.host.data() + b.off, b.n, p.dev + b.off, st); timed_end(cls_of[b.kind]);
+            if (b.rn > 0) { timed_begin(T_ROW); launch_row_z(p.rhost.data() + b.roff, b.rn, p.rdev + b.roff, st); timed_end(T_ROW); }
+        }
+        lm_stage_proj(m, 0, T, st);
+    }
+    if (part < 0 || part == 2) {
+        hipStream_t keep = search_stream_;
+        search_stream_ = st;
+        for (int t = 0; t < T; ++t) run_greedy_rounds(m, dump_logits, t, eout_lm_ + (size_t)t * m * d.joiner);
+        search_stream_ = keep;
+    }
 }
 
 int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const int *now_ms, float *logits_out, int mode)
@@ -1166,7 +1230,8 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
     const NetDims &d = L_.dims;
     if (!p_lm_) {
         p_lm_ = dmalloc<float>((size_t)cfg_.max_batch * 4 * d.hidden);
-        eout_lm_ = dmalloc<float>((size_t)cfg_.max_batch * d.joiner);
+        for (int p = 0; p < 2; ++p) eout_lm_buf_[p] = dmalloc<float>((size_t)cfg_.max_batch * d.joiner);
+        eout_lm_ = eout_lm_buf_[flight_parity_];
     }
     if (!lm_stream_) {               // the wavefront's stream, events and block bookkeeping (created outside any stream capture)
         HIP_CHECK(hipStreamCreateWithFlags(&lm_stream_, hipStreamNonBlocking));
@@ -1174,7 +1239,7 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
         for (int i = 0; i < 3; ++i) HIP_CHECK(hipEventCreateWithFlags(&zargs_done_[i], hipEventDisableTiming));
         lm_now_d_ = dmalloc<int>((size_t)cfg_.max_batch); lm_rows_d_ = dmalloc<int>((size_t)cfg_.max_batch); lm_rec_off_d_ = dmalloc<int>(1);
     }
-    const int k = steps_++;
+    const int k = next_step_index();
     int *blk = ring_h_ + ring_pos_;
     memcpy(blk, slots, (size_t)m * 4);
     memcpy(blk + m, ring_tails, (size_t)rows * 4);
@@ -1182,16 +1247,48 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
     for (int t = 0; t < T; ++t) memcpy(blk + m + 2 * rows + (size_t)t * m, slots, (size_t)m * 4);
     step_off_h_[k] = (int)ring_pos_; rec_off_h_[k] = (int)rec_pos_;
     ring_pos_ += (size_t)m + 3 * (size_t)rows; rec_pos_ += (size_t)3 * rows;
+    std::lock_guard<std::mutex> cg(capture_mu_);
     if (mode == 1) {                 // the chunk steps of one feed as a wavefront over the layers (run_sw_chain)
-        std::lock_guard<std::mutex> cg(capture_mu_);
         SwPlan &p = sw_plan(m, T);
-        // a shape is captured into a graph the SECOND time it is seen: capturing costs a few milliseconds, which a batch shape
-        // that occurs once (sessions joining and leaving) never earns back; its launches go out one by one (~0.25 ms of host time)
-        if (use_graphs_ && !profiling_ && !logits_out && (p.graph || ++p.uses >= 2)) {
+        // a shape is captured into graphs the SECOND time it is seen (by either flight parity): capturing costs a few
+        // milliseconds, which a batch shape that occurs once (sessions joining and leaving) never earns back; its launches go
+        // out one by one (~0.25 ms of host time)
+        int &uses = sw_uses_[std::make_pair(m, T)];
+        const bool graphs = use_graphs_ && !profiling_ && !logits_out && (p.graph || p.g3[0] || ++uses >= 2);
+        if (graphs && split_streams_ > 0) {
+            // split feed: front end on F, layers on M, search on S, chained by events inside the feed; across feeds the three
+            // parts of neighbouring flights overlap (see "streams" above).  split_streams_ == 1 keeps the front end on M.
+            hipStream_t fe = split_streams_ >= 2 ? f_stream_ : stream_;
+            if (!p.g3[0]) {
+                hipStream_t on[3] = {fe, stream_, s_stream_};
+                for (int part = 0; part < 3; ++part) {
+                    hipGraph_t graph = nullptr;
+                    HIP_CHECK(hipStreamBeginCapture(on[part], hipStreamCaptureModeThreadLocal));
+                    run_sw_chain(m, T, false, p, part, on[part]);
+                    HIP_CHECK(hipStreamEndCapture(on[part], &graph));
+                    HIP_CHECK(hipGraphInstantiate(&p.g3[part], graph, nullptr, nullptr, 0));
+                    HIP_CHECK(hipGraphDestroy(graph));
+                }
+            }
+            if (fe == f_stream_) {
+                if (m_unseen_by_f_) { join(f_stream_, stream_); m_unseen_by_f_ = false; }
+            } else if (f_unseen_by_m_) { join(stream_, f_stream_); f_unseen_by_m_ = false; }       // (the fbank launch of this flight)
+            if (m_unseen_by_s_) { join(s_stream_, stream_); m_unseen_by_s_ = false; }
+            HIP_CHECK(hipGraphLaunch(p.g3[0], fe));
+            if (fe == f_stream_) { join(stream_, f_stream_); f_unseen_by_m_ = false; }
+            HIP_CHECK(hipGraphLaunch(p.g3[1], stream_));
+            join(s_stream_, stream_);
+            HIP_CHECK(hipGraphLaunch(p.g3[2], s_stream_));
+            s_unseen_by_m_ = true; flight_tail_s_ = true;
+            if (fe != f_stream_) m_unseen_by_f_ = true;          // (front-end kernels on M read ring rows: the next fbank waits for them)
+            return k;
+        }
+        general_prologue();
+        if (graphs) {
             if (!p.graph) {
                 hipGraph_t graph = nullptr;
                 HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-                run_sw_chain(m, T, false, p);
+                run_sw_chain(m, T, false, p, -1, stream_);
                 HIP_CHECK(hipStreamEndCapture(stream_, &graph));
                 HIP_CHECK(hipGraphInstantiate(&p.graph, graph, nullptr, nullptr, 0));
                 HIP_CHECK(hipGraphDestroy(graph));
@@ -1200,39 +1297,36 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
             return k;
         }
         launch_count_ = 0;
-        run_sw_chain(m, T, logits_out != nullptr, p);
+        run_sw_chain(m, T, logits_out != nullptr, p, -1, stream_);
         kernels_per_step_ = (launch_count_ + 1 + T - 1) / T;          // per chunk
     } else {
-    const bool wavefront = lm_wavefront_on() && !profiling_ && T > lm_wavefront_min_chunks() &&
-                           gemm_fullk(m, d.d_model, kz_hr_, true, 1, tile_ok()) && gemm_fullk(m, d.d_model, kz_ff2_, true, 1, tile_ok());
-    if (wavefront) {                 // long feed: all layers of a wavefront per launch (run_lm_wavefront)
-        std::lock_guard<std::mutex> cg(capture_mu_);
-        run_lm_wavefront(m, T, logits_out != nullptr);
-        if (!logits_out) return k;
-    } else if (use_graphs_ && !profiling_ && !logits_out) {
-        const std::pair<int, int> key(m, T);
-        auto it = lm_graphs_.find(key);
-        if (it == lm_graphs_.end()) {
-            if (lm_graphs_.size() >= 16) { HIP_CHECK(hipStreamSynchronize(stream_)); for (auto &g : lm_graphs_) (void)hipGraphExecDestroy(g.second); lm_graphs_.clear(); }
-            hipGraph_t graph = nullptr;
-            hipGraphExec_t exec = nullptr;
-            std::lock_guard<std::mutex> cg(capture_mu_);
-            HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-            run_lm_chain(m, T, false);
-            HIP_CHECK(hipStreamEndCapture(stream_, &graph));
-            HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-            HIP_CHECK(hipGraphDestroy(graph));
-            it = lm_graphs_.emplace(key, exec).first;
+        general_prologue();
+        const bool wavefront = lm_wavefront_on() && !profiling_ && T > lm_wavefront_min_chunks() &&
+                               gemm_fullk(m, d.d_model, kz_hr_, true, 1, tile_ok()) && gemm_fullk(m, d.d_model, kz_ff2_, true, 1, tile_ok());
+        if (wavefront) {                 // long feed: all layers of a wavefront per launch (run_lm_wavefront)
+            run_lm_wavefront(m, T, logits_out != nullptr);
+            if (!logits_out) return k;
+        } else if (use_graphs_ && !profiling_ && !logits_out) {
+            const std::pair<int, int> key(m * 2 + flight_parity_, T);
+            auto it = lm_graphs_.find(key);
+            if (it == lm_graphs_.end()) {
+                if (lm_graphs_.size() >= 32) { sync(); for (auto &g : lm_graphs_) (void)hipGraphExecDestroy(g.second); lm_graphs_.clear(); }
+                hipGraph_t graph = nullptr;
+                hipGraphExec_t exec = nullptr;
+                HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+                run_lm_chain(m, T, false);
+                HIP_CHECK(hipStreamEndCapture(stream_, &graph));
+                HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                HIP_CHECK(hipGraphDestroy(graph));
+                it = lm_graphs_.emplace(key, exec).first;
+            }
+            HIP_CHECK(hipGraphLaunch(it->second, stream_));
+            return k;
+        } else {
+            launch_count_ = 0;
+            run_lm_chain(m, T, logits_out != nullptr);
+            kernels_per_step_ = launch_count_ + 1;
         }
-        std::lock_guard<std::mutex> cg(capture_mu_);
-        HIP_CHECK(hipGraphLaunch(it->second, stream_));
-        return k;
-    } else {
-        std::lock_guard<std::mutex> cg(capture_mu_);
-        launch_count_ = 0;
-        run_lm_chain(m, T, logits_out != nullptr);
-        kernels_per_step_ = launch_count_ + 1;
-    }
     }
     if (logits_out) {
         HIP_CHECK(hipMemcpyAsync(logits_h_, logits_, (size_t)3 * rows * d.vocab * 4, hipMemcpyDeviceToHost, stream_));
@@ -1250,54 +1344,54 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
 void Engine::begin_flight()
 {
     HIP_CHECK(hipSetDevice(cfg_.device));
-    flight_parity_ = next_parity_; next_parity_ ^= 1;
-    ring_base_ = (size_t)flight_parity_ * ring_cap_; rec_base_ = (size_t)flight_parity_ * rec_cap_; step_base_ = flight_parity_ * step_cap_;
-    ring_pos_ = ring_base_; rec_pos_ = rec_base_; steps_ = step_base_;
-    std::lock_guard<std::mutex> cg(capture_mu_);
-    HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)counter_d_, step_base_, 1, stream_));
+    const int p = flight_parity_ = next_parity_; next_parity_ ^= 1;
+    ring_base_ = (size_t)p * ring_cap_; rec_base_ = (size_t)p * rec_cap_;
+    ring_pos_ = ring_base_; rec_pos_ = rec_base_; flight_steps_ = 0;
+    // the flight's own copies of what the next flight's front end overwrites while this flight's layers / search still read it
+    y_ = y_buf_[p]; ssq_ = ssq_buf_[p]; y16_ = y16_buf_[p]; step_d_ = step_buf_[p]; flags_d_ = flags_buf_[p]; rec_off_d_ = rec_off_buf_[p]; eout_lm_ = eout_lm_buf_[p];
+    flight_tail_s_ = false;
 }
 
 bool Engine::flight_has_room(int rows, int nsteps) const
 {
     // + max_slots: decoder refreshes stage their slot lists in the same index ring
-    return steps_ + nsteps <= step_base_ + step_cap_ && ring_pos_ + (size_t)3 * rows + (size_t)cfg_.max_slots <= ring_base_ + ring_cap_ && rec_pos_ + (size_t)3 * rows <= rec_base_ + rec_cap_;
+    return flight_steps_ + nsteps <= step_cap_ && ring_pos_ + (size_t)3 * rows + (size_t)cfg_.max_slots <= ring_base_ + ring_cap_ && rec_pos_ + (size_t)3 * rows <= rec_base_ + rec_cap_;
 }
 
 int Engine::step(int m, const int *slots, const int *ring_tails, const int *now_ms, float *logits_out)
 {
     if (m <= 0 || m > cfg_.max_batch || !flight_has_room(m, 1)) { LOGE("engine: step of %d rows does not fit (max batch %d)", m, cfg_.max_batch); abort(); }
-    const int k = steps_++;
+    const int k = next_step_index();
     int *blk = ring_h_ + ring_pos_;
     memcpy(blk, slots, (size_t)m * 4); memcpy(blk + m, ring_tails, (size_t)m * 4); memcpy(blk + 2 * m, now_ms, (size_t)m * 4);
     step_off_h_[k] = (int)ring_pos_; rec_off_h_[k] = (int)rec_pos_;
     ring_pos_ += (size_t)3 * m; rec_pos_ += (size_t)3 * m;
-    // The whole per-chunk chain (index fetch + 58 kernels) is replayed from a hipGraph captured once per batch size:
-    // at small batches the chain is launch-bound on the host (~3.5 us per launch), the replay is not.  Kernel arguments
-    // depend only on m; the step's indices and its record offset reach the kernels through the device step counter.
-    if (use_graphs_ && !profiling_ && !logits_out && (step_graphs_.count(m) || ++step_seen_[m] >= 2)) {      // (captured at the second use, see lm_step)
-        auto it = step_graphs_.find(m);
+    // The whole per-chunk chain (index fetch + 58 kernels) is replayed from a hipGraph captured once per batch size (and flight
+    // parity: the parity selects buffers): at small batches the chain is launch-bound on the host (~3.5 us per launch), the
+    // replay is not.  Kernel arguments depend only on m; the step's indices and its record offset reach the kernels through
+    // the device step counter.
+    std::lock_guard<std::mutex> cg(capture_mu_);               // aas_free on another thread resets slots through this stream
+    general_prologue();
+    const int gkey = m * 2 + flight_parity_;
+    if (use_graphs_ && !profiling_ && !logits_out && (step_graphs_.count(gkey) || ++step_seen_[m] >= 2)) {      // (captured at the second use, see lm_step)
+        auto it = step_graphs_.find(gkey);
         if (it == step_graphs_.end()) {
-            if (step_graphs_.size() >= 128) { HIP_CHECK(hipStreamSynchronize(stream_)); for (auto &g : step_graphs_) (void)hipGraphExecDestroy(g.second); step_graphs_.clear(); step_seen_.clear(); }
+            if (step_graphs_.size() >= 256) { sync(); for (auto &g : step_graphs_) (void)hipGraphExecDestroy(g.second); step_graphs_.clear(); step_seen_.clear(); }
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
-            std::lock_guard<std::mutex> cg(capture_mu_);       // aas_free on another thread resets slots through this stream
             HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
             run_chain(m, false);
             HIP_CHECK(hipStreamEndCapture(stream_, &graph));
             HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
             HIP_CHECK(hipGraphDestroy(graph));
-            it = step_graphs_.emplace(m, exec).first;
+            it = step_graphs_.emplace(gkey, exec).first;
         }
-        std::lock_guard<std::mutex> cg(capture_mu_);
         HIP_CHECK(hipGraphLaunch(it->second, stream_));
         return k;
     }
-    {
-        std::lock_guard<std::mutex> cg(capture_mu_);
-        launch_count_ = 0;
-        run_chain(m, logits_out != nullptr);
-        kernels_per_step_ = launch_count_ + 1;        // + the index fetch
-    }
+    launch_count_ = 0;
+    run_chain(m, logits_out != nullptr);
+    kernels_per_step_ = launch_count_ + 1;        // + the index fetch
     if (logits_out) {
         const NetDims &d = L_.dims;
         HIP_CHECK(hipMemcpyAsync(logits_h_, logits_, (size_t)3 * m * d.vocab * 4, hipMemcpyDeviceToHost, stream_));
@@ -1316,6 +1410,7 @@ void Engine::decode_rows(int n, const int *slots, int op)
     const NetDims &d = L_.dims;
     const int MB = cfg_.max_batch;
     std::lock_guard<std::mutex> cg(capture_mu_);
+    general_prologue();
     for (int o = 0; o < n; o += MB) {
         const int m = std::min(MB, n - o);
         if (ring_pos_ + (size_t)m > ring_base_ + ring_cap_) { LOGE("engine: index ring exhausted"); abort(); }
@@ -1333,8 +1428,16 @@ int Engine::close_flight()
 {
     HIP_CHECK(hipSetDevice(cfg_.device));
     std::lock_guard<std::mutex> cg(capture_mu_);
-    if (rec_pos_ > rec_base_) HIP_CHECK(hipMemcpyAsync(rec_h_ + rec_base_, rec_d_ + rec_base_, (rec_pos_ - rec_base_) * sizeof(StepRecord), hipMemcpyDeviceToHost, stream_));
-    HIP_CHECK(hipEventRecord(flight_done_[flight_parity_], stream_));
+    // where the flight ends: on S when its last step was a split feed (layers on M, search on S: the record copy must not sit
+    // in M's order, where it would hold the next flight's layers back until this search is through), else on M
+    hipStream_t tail = s_stream_;
+    if (!(flight_tail_s_ && s_unseen_by_m_)) {
+        tail = stream_;
+        if (f_unseen_by_m_) { join(stream_, f_stream_); f_unseen_by_m_ = false; }
+        if (s_unseen_by_m_) { join(stream_, s_stream_); s_unseen_by_m_ = false; }
+    }
+    if (rec_pos_ > rec_base_) HIP_CHECK(hipMemcpyAsync(rec_h_ + rec_base_, rec_d_ + rec_base_, (rec_pos_ - rec_base_) * sizeof(StepRecord), hipMemcpyDeviceToHost, tail));
+    HIP_CHECK(hipEventRecord(flight_done_[flight_parity_], tail));
     return flight_parity_;
 }
 

@@ -143,10 +143,10 @@ private:
     void upload_tables(const FbankHostTables &ft);
     void zero_slots(int n);
     void run_encoder_rows(int n, const int *d_slots, const int *d_tails, const float *x_direct);
-    void lm_stage_embed(int m, int t0, int t1, hipStream_t st);
+    void lm_stage_embed(int m, int t0, int t1, hipStream_t st, bool own_ws = false);
     void lm_stage_layer(int l, int m, int t0, int t1, hipStream_t st);
     void lm_stage_proj(int m, int t0, int t1, hipStream_t st);
-    void lm_resid_ssq(const float *a, int K, size_t w_off, int kz, const float *bias, const float *resid, size_t r0, int rows, hipStream_t st);
+    void lm_resid_ssq(const float *a, int K, size_t w_off, int kz, const float *bias, const float *resid, size_t r0, int rows, hipStream_t st, float *ws = nullptr);
     GemmArgs lm_args_xpart(int l, int m, int t0, int t1) const;
     GemmArgs lm_args_gates(int l, int m, int t) const;
     GemmArgs sw_args_gates(int l, int m, int t) const;
@@ -169,10 +169,14 @@ private:
     struct SwPlan {                          // argument blocks + launch list of run_sw_chain for one (m, T), and its captured graph
         struct Batch { size_t off; int n, macro, kind; size_t roff; int rn; };      // rn > 0: the GEMMs write partial planes, rn row problems finish them
         std::vector<GemmArgs> host; GemmArgs *dev = nullptr; std::vector<Batch> batches; hipGraphExec_t graph = nullptr; int uses = 0;
+        hipGraphExec_t g3[3] = {nullptr, nullptr, nullptr};                      // split feed: front end / layers / search, one graph per stream
         std::vector<RowArgs> rhost; RowArgs *rdev = nullptr;
     };
     SwPlan &sw_plan(int m, int T);
-    void run_sw_chain(int m, int T, bool dump_logits, const SwPlan &p);
+    void run_sw_chain(int m, int T, bool dump_logits, const SwPlan &p, int part, hipStream_t st);
+    void join(hipStream_t waiter, hipStream_t src);
+    void general_prologue();
+    int next_step_index() { ++flight_steps_; return (int)(step_seq_++ & (uint64_t)(2 * step_cap_ - 1)); }
     void launch_rowepi(GemmArgs fused_form, size_t ws_row0, hipStream_t st);
     bool gates_tile_rows(long rows) const;
     bool ff1_tile_rows(long rows) const;
@@ -212,10 +216,20 @@ private:
     float *p_lm_ = nullptr, *eout_lm_ = nullptr;   // layer-major: input half of the gates [rows][4 hidden], encoder outputs [rows][joiner] (allocated on first use)
     // step bookkeeping: pinned host rings (read by the advance kernel) + device mirrors
     int *ring_h_ = nullptr; size_t ring_cap_ = 0, ring_pos_ = 0;      // index blocks (capacities are per flight parity)
-    int *step_off_h_ = nullptr, *rec_off_h_ = nullptr; int step_cap_ = 0, steps_ = 0;
+    int *step_off_h_ = nullptr, *rec_off_h_ = nullptr; int step_cap_ = 0;
     StepRecord *rec_d_ = nullptr, *rec_h_ = nullptr; size_t rec_cap_ = 0, rec_pos_ = 0;
-    int flight_parity_ = 0, next_parity_ = 0; size_t ring_base_ = 0, rec_base_ = 0; int step_base_ = 0;
+    int flight_parity_ = 0, next_parity_ = 0; size_t ring_base_ = 0, rec_base_ = 0; int flight_steps_ = 0;
+    uint64_t step_seq_ = 0;                    // steps enqueued since the engine started = the device's step counter (advance_kernel)
     hipEvent_t flight_done_[2] = {nullptr, nullptr};
+    // streams (engine.cc "streams"): front end / search beside the layer chain, the per-parity buffers that make it safe
+    hipStream_t f_stream_ = nullptr, s_stream_ = nullptr, search_stream_ = nullptr;
+    std::vector<hipEvent_t> join_ev_; size_t join_pos_ = 0;
+    bool f_unseen_by_m_ = false, s_unseen_by_m_ = false, m_unseen_by_f_ = false, m_unseen_by_s_ = false, flight_tail_s_ = false;
+    int split_streams_ = 2;                    // APRIL_SPLIT_STREAMS: 0 = one stream, 1 = search on S, 2 = search on S + front end on F
+    float *y_buf_[2] = {nullptr, nullptr}, *ssq_buf_[2] = {nullptr, nullptr}, *eout_lm_buf_[2] = {nullptr, nullptr}, *ws_fe_ = nullptr;
+    uint16_t *y16_buf_[2] = {nullptr, nullptr};
+    int *step_buf_[2] = {nullptr, nullptr}, *flags_buf_[2] = {nullptr, nullptr}, *rec_off_buf_[2] = {nullptr, nullptr};
+    std::map<std::pair<int, int>, int> sw_uses_;
     int *counter_d_ = nullptr, *step_d_ = nullptr, *active_d_ = nullptr, *dirty_d_ = nullptr, *rec_off_d_ = nullptr, *flags_d_ = nullptr;
     int *dec_slots_d_ = nullptr;
     float *logits_h_ = nullptr;

@@ -240,7 +240,8 @@ struct AdvanceArgs {
     const int *host_ring = nullptr;        // pinned, device-readable
     const int *host_step_off = nullptr;    // pinned: [step] -> offset of the step's block in host_ring
     const int *host_rec_off = nullptr;     // pinned: [step] -> offset of the step's records in the record ring
-    int *counter = nullptr;                // device: next step
+    int *counter = nullptr;                // device: next step (runs on for the life of the engine; table index = counter & index_mask)
+    int index_mask = 0x7fffffff;
     int *dst = nullptr; int dst_stride = 0;   // device: [n_arrays][dst_stride]
     int n_arrays = 3; int len[4] = {0, 0, 0, 0};
     int *rec_off = nullptr;                // device: record offset of the current step

@@ -263,14 +263,14 @@ __global__ __launch_bounds__(1024) void advance_kernel(AdvanceArgs a)
     __shared__ int s_k;
     if (threadIdx.x == 0) s_k = a.counter[0];
     __syncthreads();
-    const int k = s_k;
+    const int kc = s_k, k = kc & a.index_mask;
     const int *src = a.host_ring + a.host_step_off[k];          // pinned host memory, read once per step
     for (int arr = 0; arr < a.n_arrays; ++arr) {
         for (int i = threadIdx.x; i < a.len[arr]; i += 1024) a.dst[arr * a.dst_stride + i] = src[i];
         src += a.len[arr];
     }
     if (threadIdx.x < a.n_flags) a.flags[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { a.rec_off[0] = a.host_rec_off[k]; a.counter[0] = k + 1; }
+    if (threadIdx.x == 0) { a.rec_off[0] = a.host_rec_off[k]; a.counter[0] = (kc + 1) & 0x7fffffff; }
 }
 
 void launch_advance(const AdvanceArgs &a, hipStream_t s)
