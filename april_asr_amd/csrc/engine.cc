@@ -142,9 +142,24 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     : cfg_(cfg), L_(layout), P_(params)
 {
     HIP_CHECK(hipSetDevice(cfg_.device));
-    HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-    HIP_CHECK(hipStreamCreateWithFlags(&f_stream_, hipStreamNonBlocking));
-    HIP_CHECK(hipStreamCreateWithFlags(&s_stream_, hipStreamNonBlocking));
+    {
+        // APRIL_STREAM_PRIO (measurement): 1 = the layer stream at the device's highest priority, front end and search at the lowest;
+        // 2 = the other way round; 0 = all at the default priority
+        const char *e = getenv("APRIL_STREAM_PRIO");
+        const int mode = e && *e ? atoi(e) : 0;
+        int least = 0, greatest = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        if (mode == 0 || least == greatest) {
+            HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+            HIP_CHECK(hipStreamCreateWithFlags(&f_stream_, hipStreamNonBlocking));
+            HIP_CHECK(hipStreamCreateWithFlags(&s_stream_, hipStreamNonBlocking));
+        } else {
+            const int pm = mode == 1 ? greatest : least, po = mode == 1 ? least : greatest;
+            HIP_CHECK(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, pm));
+            HIP_CHECK(hipStreamCreateWithPriority(&f_stream_, hipStreamNonBlocking, po));
+            HIP_CHECK(hipStreamCreateWithPriority(&s_stream_, hipStreamNonBlocking, po));
+        }
+    }
     search_stream_ = stream_;
     for (int i = 0; i < 32; ++i) { hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); join_ev_.push_back(e); }
     {
@@ -227,6 +242,7 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     for (int p = 0; p < 2; ++p) { y_buf_[p] = dmalloc<float>(MB * d.d_model); ssq_buf_[p] = dmalloc<float>(MB * (d.d_model / SSQ_COLS)); }
     y_ = y_buf_[0]; ssq_ = ssq_buf_[0];
     ws_fe_ = dmalloc<float>((size_t)kz_embed_ * d.d_model * MB);      // the front end's own split-K planes (embed at small batches)
+    ws_sr_ = dmalloc<float>((size_t)std::max(kz_proj_ * d.joiner, d.d_model) * MB);      // encoder_proj's, when it runs on the search stream
     xb_ = dmalloc<float>(MB * d.d_model);
     u_ = dmalloc<float>(MB * d.hidden);
     ff_ = dmalloc<float>(MB * d.ffn);
@@ -339,6 +355,7 @@ Engine::~Engine()
     for (int p = 0; p < 2; ++p)
         for (void *q : {(void *)eout_lm_buf_[p], (void *)y16_buf_[p], (void *)y_buf_[p], (void *)ssq_buf_[p], (void *)rec_off_buf_[p], (void *)flags_buf_[p], (void *)step_buf_[p]}) if (q) (void)hipFree(q);
     if (ws_fe_) (void)hipFree(ws_fe_);
+    if (ws_sr_) (void)hipFree(ws_sr_);
     for (void *p : {(void *)wx_, (void *)xb16_, (void *)u16_, (void *)ff16_, (void *)h16_}) if (p) (void)hipFree(p);      // fp16 tile path
     for (void *p : {(void *)w_, (void *)wh_, (void *)h_, (void *)c_, (void *)ring_, (void *)eout_, (void *)dout_, (void *)gstate_, (void *)cls_, (void *)ws_, (void *)xin_,
                     (void *)a3_, (void *)xb_, (void *)u_, (void *)ff_, (void *)de_, (void *)logits_, (void *)rec_d_, (void *)counter_d_,
@@ -920,8 +937,9 @@ void Engine::lm_stage_layer(int l, int m, int t0, int t1, hipStream_t st)
     lm_resid_ssq(ff_ + b0 * d.ffn, d.ffn, o.wff2, kz_ff2_, w_ + o.bff2, xb_ + b0 * d.d_model, b0, brows, st);
 }
 
-void Engine::lm_stage_proj(int m, int t0, int t1, hipStream_t st)
+void Engine::lm_stage_proj(int m, int t0, int t1, hipStream_t st, float *ws)
 {
+    if (!ws) ws = ws_;
     const NetDims &d = L_.dims;
     const int G = d.d_model / SSQ_COLS;
     const size_t b0 = (size_t)t0 * m;
@@ -935,9 +953,9 @@ void Engine::lm_stage_proj(int m, int t0, int t1, hipStream_t st)
         g.epi = EPI_SLOT_STORE; g.bias = w_ + L_.b_encproj; g.out = eo; g.ldo = d.joiner; g.x_scale = ys;
         timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
     } else {
-        g.epi = EPI_PARTIAL; g.out = ws_ + b0 * d.d_model; g.m_stride = ws_mstride_;     // (joiner width == a d_model-wide slice or less: see the constructor's workspace size)
+        g.epi = EPI_PARTIAL; g.out = ws + b0 * d.d_model; g.m_stride = ws_mstride_;     // (joiner width == a d_model-wide slice or less: see the constructor's workspace size)
         timed_begin(T_GEMM_OTHER); launch_gemm(g, st); timed_end(T_GEMM_OTHER);
-        RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws_ + b0 * d.d_model; r.parts = gemm_partials(brows, d.joiner, kz_proj_, 1, tile_ok()); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = brows;
+        RowArgs r; r.mode = ROW_SLOT_STORE; r.ws = ws + b0 * d.d_model; r.parts = gemm_partials(brows, d.joiner, kz_proj_, 1, tile_ok()); r.m_stride = ws_mstride_; r.N = d.joiner; r.M = brows;
         r.bias = w_ + L_.b_encproj; r.out = eo; r.ldo = d.joiner; r.r_scale = ys;
         timed_begin(T_ROW); launch_row(r, st); timed_end(T_ROW);
     }
@@ -1212,9 +1230,12 @@ void Engine::run_sw_chain(int m, int T, bool dump_logits, const SwPlan &p, int p
             timed_begin(cls_of[b.kind]); launch_gemm_z(p.host.data() + b.off, b.n, p.dev + b.off, st); timed_end(cls_of[b.kind]);
             if (b.rn > 0) { timed_begin(T_ROW); launch_row_z(p.rhost.data() + b.roff, b.rn, p.rdev + b.roff, st); timed_end(T_ROW); }
         }
-        lm_stage_proj(m, 0, T, st);
+        if (part < 0) lm_stage_proj(m, 0, T, st);
     }
     if (part < 0 || part == 2) {
+        // (split feed: encoder_proj feeds only the search, so it leaves the layer stream with it; its split-K planes, if any, go to
+        // a workspace of its own: ws_ belongs to the layers of the next flight by then)
+        if (part == 2) lm_stage_proj(m, 0, T, st, ws_sr_);
         hipStream_t keep = search_stream_;
         search_stream_ = st;
         for (int t = 0; t < T; ++t) run_greedy_rounds(m, dump_logits, t, eout_lm_ + (size_t)t * m * d.joiner);
@@ -1255,7 +1276,7 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
         // out one by one (~0.25 ms of host time)
         int &uses = sw_uses_[std::make_pair(m, T)];
         const bool graphs = use_graphs_ && !profiling_ && !logits_out && (p.graph || p.g3[0] || ++uses >= 2);
-        if (graphs && split_streams_ > 0) {
+        if (graphs && split_streams_ > 0 && overlap_hint_) {
             // split feed: front end on F, layers on M, search on S, chained by events inside the feed; across feeds the three
             // parts of neighbouring flights overlap (see "streams" above).  split_streams_ == 1 keeps the front end on M.
             hipStream_t fe = split_streams_ >= 2 ? f_stream_ : stream_;

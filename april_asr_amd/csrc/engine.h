@@ -118,6 +118,9 @@ public:
     void wait_flight(int parity);
     void end_flight();                          // close + wait (records -> host)
     bool profiling() const { return profiling_; }
+    // the scheduler's hint for the flight being launched: another flight is in the air (or follows at once), so a feed is worth
+    // splitting over the three streams; a lone flight runs on one stream (the events between the streams cost it ~50 us)
+    void set_overlap_hint(bool on) { overlap_hint_ = on; }
     const StepRecord *records(int step_index) const { return rec_h_ + rec_off_h_[step_index]; }   // [3][m], valid after end_flight()
     void sync();
 
@@ -145,7 +148,7 @@ private:
     void run_encoder_rows(int n, const int *d_slots, const int *d_tails, const float *x_direct);
     void lm_stage_embed(int m, int t0, int t1, hipStream_t st, bool own_ws = false);
     void lm_stage_layer(int l, int m, int t0, int t1, hipStream_t st);
-    void lm_stage_proj(int m, int t0, int t1, hipStream_t st);
+    void lm_stage_proj(int m, int t0, int t1, hipStream_t st, float *ws = nullptr);
     void lm_resid_ssq(const float *a, int K, size_t w_off, int kz, const float *bias, const float *resid, size_t r0, int rows, hipStream_t st, float *ws = nullptr);
     GemmArgs lm_args_xpart(int l, int m, int t0, int t1) const;
     GemmArgs lm_args_gates(int l, int m, int t) const;
@@ -225,8 +228,9 @@ private:
     hipStream_t f_stream_ = nullptr, s_stream_ = nullptr, search_stream_ = nullptr;
     std::vector<hipEvent_t> join_ev_; size_t join_pos_ = 0;
     bool f_unseen_by_m_ = false, s_unseen_by_m_ = false, m_unseen_by_f_ = false, m_unseen_by_s_ = false, flight_tail_s_ = false;
+    bool overlap_hint_ = false;
     int split_streams_ = 2;                    // APRIL_SPLIT_STREAMS: 0 = one stream, 1 = search on S, 2 = search on S + front end on F
-    float *y_buf_[2] = {nullptr, nullptr}, *ssq_buf_[2] = {nullptr, nullptr}, *eout_lm_buf_[2] = {nullptr, nullptr}, *ws_fe_ = nullptr;
+    float *y_buf_[2] = {nullptr, nullptr}, *ssq_buf_[2] = {nullptr, nullptr}, *eout_lm_buf_[2] = {nullptr, nullptr}, *ws_fe_ = nullptr, *ws_sr_ = nullptr;
     uint16_t *y16_buf_[2] = {nullptr, nullptr};
     int *step_buf_[2] = {nullptr, nullptr}, *flags_buf_[2] = {nullptr, nullptr}, *rec_off_buf_[2] = {nullptr, nullptr};
     std::map<std::pair<int, int>, int> sw_uses_;

@@ -542,6 +542,11 @@ void Scheduler::loop()
                 if (!go && !have_pending) { std::lock_guard<std::mutex> g(mu_); if (stop_) return; }
             }
             if (go) {
+                // a flight launched behind one that is still in the air overlaps with it (and, with steady pipelined feeding, the
+                // one after it will be launched behind this one): worth its three streams.  `split_sticky_` keeps the choice for
+                // a few flights so that a flight that happened to find the GPU idle does not flip the launch path back and forth
+                if (have_pending) split_sticky_ = 8; else if (split_sticky_ > 0) --split_sticky_;
+                eng_->set_overlap_hint(pipeline_depth_ >= 2 && split_sticky_ > 0);
                 next = launch_flight(work, taken);
                 have_next = true;
                 cont = !next.final;

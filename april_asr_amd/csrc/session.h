@@ -188,6 +188,7 @@ private:
     bool step_chunks(std::vector<Session *> &ready);     // false: the flight's rings are full, (some) work is left for the next flight
     bool step_layer_major(std::vector<Session *> &group, int T, int mode = 0);
     void replay(Flight &f);
+    int split_sticky_ = 0;
     int pipeline_depth_ = 2;                             // APRIL_PIPELINE: 2 = launch the next flight before completing the current one, 1 = one flight at a time
 
     Model *model_;
