@@ -288,6 +288,16 @@ class Session:
     def chunks(self) -> int:
         return int(self._L.aprilx_session_chunks(self._handle))
 
+    def frames(self) -> np.ndarray:
+        """every log-mel row the session's feature ring has received so far (real frames and flush padding), [rows][mel];
+        parity tests of the online fbank"""
+        total = int(self._L.aprilx_session_read_frames(self._handle, 0, 0, None))
+        out = np.zeros((total, self.model.dims.mel), np.float32)
+        if total:
+            got = int(self._L.aprilx_session_read_frames(self._handle, 0, total, out.ctypes.data))
+            assert got == total
+        return out
+
     def contexts(self):
         """(host context [2], device search state [ctx0, ctx1, last token, last emission ms]) -- derived independently, must agree"""
         h = np.zeros(2, np.int32); d = np.zeros(4, np.int32)

@@ -50,7 +50,12 @@ bool broadcast_local(Model &m)
 {
     std::vector<Engine *> peers;            // one engine per distinct device, root first
     std::vector<int> devs;
-    for (Engine *e : m.engines) if (std::find(devs.begin(), devs.end(), e->device()) == devs.end()) { devs.push_back(e->device()); peers.push_back(e); }
+    // APRIL_FAULT_RCCL (fault injection, tests): 1 = every engine counts as a broadcast peer even when it shares a device with
+    // another one, so that on a ONE-GPU box (APRIL_GPU_DEVICES=0,0) RCCL is asked for a communicator over duplicate devices
+    // and genuinely fails -> the failure / fallback / clean-up paths below run; 2 = the broadcast to peer 1 reports an error
+    // inside the open group (needs two real devices) -> the abort path
+    const int fault = env_int("APRIL_FAULT_RCCL", 0);
+    for (Engine *e : m.engines) if (fault == 1 || std::find(devs.begin(), devs.end(), e->device()) == devs.end()) { devs.push_back(e->device()); peers.push_back(e); }
     const size_t count = m.layout.total;
     if (devs.size() > 1) {
         // Every exit path destroys the communicators; an RCCL failure is loud, fails the load under APRIL_STRICT_RCCL=1 and
@@ -66,13 +71,26 @@ bool broadcast_local(Model &m)
             bool ok = true;
             for (size_t i = 0; i < peers.size() && ok; ++i) {
                 HIP_CHECK(hipSetDevice(devs[i]));
-                const ncclResult_t r = ncclBroadcast(peers[0]->weights_device(), peers[i]->weights_mut(), count, ncclFloat, 0, comms[i], peers[i]->stream());
+                const ncclResult_t r = (fault == 2 && i == 1) ? ncclInternalError
+                    : ncclBroadcast(peers[0]->weights_device(), peers[i]->weights_mut(), count, ncclFloat, 0, comms[i], peers[i]->stream());
                 if (r != ncclSuccess) { LOGE("RCCL: ncclBroadcast (device %d) failed: %s", devs[i], ncclGetErrorString(r)); ok = false; }
             }
-            const ncclResult_t ge = ncclGroupEnd();          // (always closes the group that was opened)
-            if (ge != ncclSuccess) { LOGE("RCCL: ncclGroupEnd failed: %s", ncclGetErrorString(ge)); ok = false; }
+            if (!ok) {
+                // some ranks have joined the collective, the others never will: closing the group would launch a broadcast that
+                // waits for them forever (and the stream synchronisation below with it).  Abort the communicators instead --
+                // that also releases whatever the group has queued -- and leave the streams alone.
+                for (ncclComm_t &c : comms) if (c) { (void)ncclCommAbort(c); c = nullptr; }
+                (void)ncclGroupEnd();
+                return false;
+            }
+            const ncclResult_t ge = ncclGroupEnd();
+            if (ge != ncclSuccess) {
+                LOGE("RCCL: ncclGroupEnd failed: %s", ncclGetErrorString(ge));
+                for (ncclComm_t &c : comms) if (c) { (void)ncclCommAbort(c); c = nullptr; }
+                return false;
+            }
             for (size_t i = 0; i < peers.size(); ++i) { HIP_CHECK(hipSetDevice(devs[i])); HIP_CHECK(hipStreamSynchronize(peers[i]->stream())); }
-            return ok;
+            return true;
         };
         const bool used = rccl_path();
         for (ncclComm_t c : comms) if (c) (void)ncclCommDestroy(c);
@@ -85,7 +103,8 @@ bool broadcast_local(Model &m)
             const double t2 = now_ms();
             for (size_t i = 1; i < peers.size(); ++i) {
                 HIP_CHECK(hipSetDevice(devs[i]));
-                HIP_CHECK(hipMemcpyPeer(peers[i]->weights_mut(), devs[i], peers[0]->weights_device(), devs[0], count * 4));
+                if (devs[i] == devs[0]) HIP_CHECK(hipMemcpy(peers[i]->weights_mut(), peers[0]->weights_device(), count * 4, hipMemcpyDeviceToDevice));
+                else HIP_CHECK(hipMemcpyPeer(peers[i]->weights_mut(), devs[i], peers[0]->weights_device(), devs[0], count * 4));
             }
             m.load.broadcast_ms = now_ms() - t2; m.load.comm_init_ms = 0;
             m.load.broadcast_bytes = count * 4; m.load.ranks = (int)devs.size(); m.load.used_rccl = 0;
@@ -742,6 +761,24 @@ void aprilx_session_trace_logits(AprilASRSession session, float *buf, size_t cap
 }
 
 uint64_t aprilx_session_chunks(AprilASRSession session) { return session->s.chunks; }
+
+uint64_t aprilx_session_read_frames(AprilASRSession session, uint64_t first, int n, float *out)
+{
+    Session *s = &session->s;
+    s->sched->wait_idle(s);
+    const uint64_t total = s->fb.rows_written;
+    if (out && n > 0) {
+        const int R = s->eng->ring_frames();
+        if (first + (uint64_t)n > total || total - first > (uint64_t)R) return total;      // not written yet / already overwritten
+        int done = 0;
+        while (done < n) {          // (the ring may wrap inside the range)
+            const int row = (int)((first + (uint64_t)done) % (uint64_t)R), cnt = std::min(n - done, R - row);
+            s->eng->read_ring(s->slot, row, cnt, out + (size_t)done * s->eng->dims().mel);
+            done += cnt;
+        }
+    }
+    return total;
+}
 
 void aprilx_session_context(AprilASRSession session, int32_t *host_ctx, int32_t *device_state)
 {

@@ -185,13 +185,28 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     h_ = dmalloc<float>((size_t)d.n_layers * S * d.d_model);
     c_ = dmalloc<float>((size_t)d.n_layers * S * d.hidden);
     if (!(getenv("APRIL_RING_FRAMES") && *getenv("APRIL_RING_FRAMES"))) {
-        // the default ring is sized for this GPU's 288 GB; on a device that cannot spare it a quarter of it serves as well (more passes per long feed)
+        // the default ring is sized for this GPU's 288 GB (10.7 GB at 4096 slots); where that is more than a quarter of what the
+        // device has free right now -- several models / lanes / ranks on one device, a smaller GPU -- the ring shrinks (more
+        // passes per long feed, same results), so that the allocations that FOLLOW it (state, work buffers, fp16 copies,
+        // decoder table) still fit: those abort the process when they fail
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
+            const size_t per_frame = S * (size_t)d.mel * sizeof(float);
+            const size_t fit = (free_b / 4) / per_frame;
+            if (fit < (size_t)ring_frames_) {
+                const int shrunk = std::max(P_.segment_size * 32, (int)std::min<size_t>(fit, 8192) / 64 * 64);
+                LOGW("engine: %zu MB of feature rings (%d frames x %zu slots) exceed a quarter of the %zu MB free on device %d: %d frames per session",
+                     per_frame * (size_t)ring_frames_ >> 20, ring_frames_, S, free_b >> 20, cfg_.device, shrunk);
+                ring_frames_ = shrunk;
+            }
+        } else (void)hipGetLastError();
         float *p = nullptr;
         if (hipMalloc((void **)&p, S * ring_frames_ * d.mel * sizeof(float)) == hipSuccess) ring_ = p;
         else {
             (void)hipGetLastError();
+            const size_t asked = S * (size_t)ring_frames_ * d.mel * sizeof(float);
             ring_frames_ = std::max(P_.segment_size * 32, 2048);
-            LOGW("engine: no room for %zu MB of feature rings, falling back to %d frames per session", S * 8192 * d.mel * sizeof(float) >> 20, ring_frames_);
+            LOGW("engine: no room for %zu MB of feature rings, falling back to %d frames per session", asked >> 20, ring_frames_);
         }
     }
     if (!ring_) ring_ = dmalloc<float>(S * ring_frames_ * d.mel);

@@ -603,6 +603,7 @@ void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
                 FbankFrameDesc d; d.slot = s->slot; d.ring_row = fb.head; d.pcm_off = (int)(base + (size_t)cut * fb.shift);
                 desc_.push_back(d);
                 fb.head = (fb.head + 1) % fb.ring_frames;
+                fb.rows_written += 1;
                 fb.avail += 1;
                 fb.avail_shadow = fb.avail;                       // fbank.c:300
                 fb.fifo_pos += (size_t)fb.shift;
@@ -626,6 +627,7 @@ void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
                     FbankFrameDesc d; d.slot = s->slot; d.ring_row = fb.head; d.pcm_off = -1;
                     desc_.push_back(d);
                     fb.head = (fb.head + 1) % fb.ring_frames;
+                    fb.rows_written += 1;
                     fb.avail += 1;                                // padding does not touch the shadow counter
                 }
             } else {

@@ -79,6 +79,7 @@ struct FrameBook {
     int shift = 0, padded = 0, seg_count = 0, seg_step = 0, ring_frames = 0;
     int head = 0, tail = 0;
     long avail = 0, avail_shadow = 0;
+    uint64_t rows_written = 0;      // ring rows written since the session started (real frames + flush padding)
     std::vector<int16_t> fifo;      // samples not yet fully consumed by framing
     size_t fifo_pos = 0;            // start of the next frame inside the stream  fifo ++ ext  (may point into ext)
     // A caller that blocks until its feed is processed LENDS its buffer: the samples are staged for the GPU straight from

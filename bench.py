@@ -416,6 +416,7 @@ def main():
             st_a = model.stats()
             torch.cuda.synchronize(); a = time.perf_counter()
             gg.feed([p60])
+            gg.flush()                            # RTF = feed + flush: the 28 flush chunks and the final callbacks are inside
             torch.cuda.synchronize(); b = time.perf_counter()
             st_b = model.stats()
             for s_ in ss:
@@ -423,7 +424,7 @@ def main():
         nchunks = int(st_b.chunks - st_a.chunks)
         # per chunk the weights that cannot be shared across time are the recurrent half of the gates and the projection
         wbytes = d.n_layers * (d.d_model * 4 * d.hidden + d.hidden * d.d_model) * 4
-        offline = {"audio_s": secs, "wall_ms": round((b - a) * 1e3, 2), "rtf": round((b - a) / secs, 6), "chunks": nchunks,
+        offline = {"audio_s": secs, "includes_flush": True, "wall_ms": round((b - a) * 1e3, 2), "rtf": round((b - a) / secs, 6), "chunks": nchunks,
                    "us_per_chunk": round((b - a) * 1e6 / max(1, nchunks), 2), "layer_major_chunks": int(st_b.lm_chunks - st_a.lm_chunks),
                    "streaming_100ms_rtf_same_session": sweep.get("1") if sweep else None,
                    "speedup_vs_streaming": round(sweep["1"] / ((b - a) / secs), 2) if sweep and sweep.get("1") else None,
@@ -437,9 +438,15 @@ def main():
     if rank == 0 and world == 1 and not args.no_config5:
         model.close()
         model = None
+        # in a process of its own: the native library reports a failed device allocation or a missing kernel plan with abort(),
+        # which an `except` cannot catch -- the headline line must not depend on this leg
+        import subprocess
         try:
-            config5 = config5_leg(args, A, SM, torch, np)
-        except Exception as e:                      # the headline line must not depend on this leg
+            r5 = subprocess.run([sys.executable, os.path.abspath(__file__), "--config5-only", "--ingest", args.ingest, "--profile-steps", str(args.profile_steps)],
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True)
+            lines5 = [ln for ln in r5.stdout.splitlines() if ln.startswith("{")]
+            config5 = json.loads(lines5[-1]) if lines5 else {"error": "configs[4] leg exited with code %d: %s" % (r5.returncode, r5.stderr[-400:])}
+        except Exception as e:
             config5 = {"error": repr(e)}
 
     # ---------------- CPU baseline: the oracle (plain-C port, 1 thread) on the host, bounded sample
@@ -481,7 +488,12 @@ def main():
         # scaled on a CPU host: its ORT sessions run intra=inter=1, april_model.c:54-55)
         import subprocess
         import sys
-        k = max(1, min(int(os.environ.get("BENCH_CPU_PROCS", "32")), (os.cpu_count() or 1)))
+        # one process per host CPU, bounded by memory: a worker holds the parsed model (~1.2 GB at aprilv0 size)
+        try:
+            avail_gb = [int(ln.split()[1]) for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")][0] / 1048576.0
+        except Exception:
+            avail_gb = 64.0
+        k = max(1, min(int(os.environ.get("BENCH_CPU_PROCS", str(os.cpu_count() or 1))), (os.cpu_count() or 1), int(avail_gb / 2.5)))
         start = os.path.join(tempfile.gettempdir(), "bench_cpu_start_%d" % os.getpid())
         if os.path.exists(start):
             os.remove(start)
@@ -492,7 +504,7 @@ def main():
                 assert pr.stdout.readline().startswith("ready")
             open(start, "w").close()
             times = [float(pr.stdout.readline().split()[1]) for pr in procs]
-            cpu["all_cores"] = {"value": round(k * 6.0 / max(times), 3), "unit": "audio_seconds_per_second", "cores": k,
+            cpu["all_cores"] = {"value": round(k * 6.0 / max(times), 3), "unit": "audio_seconds_per_second", "cores": k, "host_cpus": os.cpu_count(),
                                 "sample": "%d processes x (1 session, 1 thread, 6 s of audio) started together; slowest %.2f s, fastest %.2f s" % (k, max(times), min(times))}
         except Exception as e:                          # the single-core figure above stands on its own
             cpu["all_cores"] = {"error": repr(e)}

@@ -126,6 +126,11 @@ APRIL_EXPORT int aprilx_stream_form(int kind, int M, int N, int K, int kz, int g
    issued eagerly and waited for one by one) */
 APRIL_EXPORT void aprilx_session_trace_logits(AprilASRSession session, float *buf, size_t cap_floats, size_t *used_floats);
 APRIL_EXPORT uint64_t aprilx_session_chunks(AprilASRSession session);
+/* parity tests of the online fbank (reference src/fbank.c:174-349): copies log-mel rows [first, first + n) of everything the
+ * session's feature ring has received so far -- real frames and flush padding, in the order the reference's ring sees them --
+ * into out[n][mel] (when they are still in the ring) and returns the number of rows written so far.  Waits for the session
+ * to be idle.  Chunk j of the session is rows [j * segment_step, j * segment_step + segment_size).                        */
+APRIL_EXPORT uint64_t aprilx_session_read_frames(AprilASRSession session, uint64_t first, int n, float *out);
 /* The token context as the host's result state machine holds it (host_ctx[2]) and the search state the device keeps for the
    session's slot (device_state[4]: context[0], context[1], last active token or -1, time of the last emission in ms).  The two
    contexts are derived independently from the same joiner results (reference context tensor, src/april_session.c:181-196)

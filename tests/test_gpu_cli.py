@@ -53,6 +53,35 @@ def test_main_cli_matches_oracle(tiny_model, tmp_path, container):
     s.close(); om.close()
 
 
+def test_main_cli_aprilv0_10s_wav(v0_model, tmp_path):
+    """BASELINE configs[0] at its own size: an aprilv0-dimension model, one session, a 10 s 16 kHz mono PCM16 WAV file through
+    the ./main-style program (only include/april_api.h and the 12 reference symbols); the printed lines are the oracle's
+    transcript of the same samples."""
+    from oracle import orc_py as O
+    exe = str(tmp_path / "main")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "examples", "main.cpp"), "-I", os.path.join(ROOT, "include"),
+                           "-L", os.path.join(ROOT, "april_asr_amd"), "-laprilasr", "-Wl,-rpath," + os.path.join(ROOT, "april_asr_amd"), "-o", exe])
+    pcm = np.concatenate([speech_like_pcm(4.0, seed=21, silence=(1.5, 1.9)), np.zeros(16000 * 3, np.int16), speech_like_pcm(3.0, seed=22)])
+    assert pcm.size == 160000
+    path = str(tmp_path / "ten_seconds.wav")
+    data = pcm.tobytes()
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16)
+                + b"data" + struct.pack("<I", len(data)))
+        f.write(data)
+    out = subprocess.run([exe, path, v0_model["path"]], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()
+    got = out.stdout.decode().split("\n")[:-1]
+    om = O.Model(v0_model["path"])
+    s = O.Session(om)
+    for o in range(0, pcm.size, 1600):
+        s.feed(pcm[o:o + 1600])
+    s.flush()
+    want = render(s.events, om.token)
+    assert got == want and len(got) > 3 and any(l.startswith("@ ") for l in got)
+    s.close(); om.close()
+
+
 def _stamp(ms):
     """hh:mm:ss,mmm as the reference's example_srt.cpp computes it (units peeled off while the remainder EXCEEDS a unit)."""
     out = []

@@ -640,6 +640,24 @@ def test_session_60s_aprilv0(gpu_v0, orc_v0):
     assert np.abs(lg0 - lg1).max() < 1e-3, np.abs(lg0 - lg1).max()
     assert_same_transcript(want, got)
     assert {t for t, _ in got} >= {1, 2, 4}
+    # the same minute handed over in ONE aas_feed_pcm16 call + flush (the path bench.py's offline_single_session_60s times:
+    # one pass of the layer-major wavefront at aprilv0 dims, block length 29, 8192-frame ring): every logit and every callback
+    # against the oracle, and bit for bit against the 100 ms feeds
+    got1, lg2, n2 = run_gpu(gpu_v0, pcm, pcm.size)
+    assert n2 == n0 and lg2.shape == lg0.shape
+    assert np.abs(lg0 - lg2).max() < 1e-3, np.abs(lg0 - lg2).max()
+    assert_same_transcript(want, got1)
+    assert np.array_equal(lg1.view(np.uint32), lg2.view(np.uint32)), "one 60 s feed differs from 100 ms feeds"
+    assert got1 == got
+    # ... and untraced (captured graphs, the wavefront's own search graphs): the callbacks again
+    import april_asr_amd as A
+    ev = []
+    s = A.Session(gpu_v0, lambda t, toks: ev.append((t, toks)), raw_events=True)
+    lm0 = gpu_v0.stats().lm_chunks
+    s.feed_pcm16(pcm); s.flush()
+    assert s.chunks() == n0 and ev == got
+    assert gpu_v0.stats().lm_chunks - lm0 >= 1400, "the one-call minute did not take the layer-major path"
+    s.close()
 
 
 def test_odd_dimensions_model(medium_model):
