@@ -623,7 +623,23 @@ void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
         switch (s->flush_phase) {
         case 1: case 3:
             if (fb.flush_allowed()) {
-                while (fb.avail < fb.seg_count) {
+                // The reference drains with "pad the ring up to one segment, pull it, ask again" (src/fbank.c:308-325 under
+                // src/april_session.c:552-560) until the shadow counter says stop.  Every round pads exactly what the pull before it
+                // consumed and lowers the shadow counter by one segment step, so the number of rounds is known now: all their
+                // padding rows go out in this pass and the rounds' chunks are stepped TOGETHER (one wavefront instead of one
+                // single-chunk step per round: the 28 flush chunks of a session cost 2 steps instead of 28).  Same rows in the same
+                // ring places, same counters afterwards.
+                long av = fb.avail, sh = fb.avail_shadow;
+                const long floor_sh = -(long)(fb.seg_count * 3);
+                const long room = (long)fb.ring_frames - fb.avail;
+                long pad = 0;
+                while (sh >= floor_sh) {
+                    const long need = av < fb.seg_count ? fb.seg_count - av : 0;
+                    if (pad + need > room) break;                 // (never with the default ring; a tiny test ring takes the rest next pass)
+                    pad += need; av += need;
+                    av -= fb.seg_step; sh -= fb.seg_step;
+                }
+                for (long i = 0; i < pad; ++i) {
                     FbankFrameDesc d; d.slot = s->slot; d.ring_row = fb.head; d.pcm_off = -1;
                     desc_.push_back(d);
                     fb.head = (fb.head + 1) % fb.ring_frames;
