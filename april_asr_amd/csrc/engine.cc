@@ -410,6 +410,7 @@ void Engine::upload_tables(const FbankHostTables &ft)
 int Engine::alloc_slot()
 {
     std::lock_guard<std::mutex> g(slot_mu_);
+    if (free_.empty() && !zero_pending_.empty()) zero_pending_slots();
     if (free_.empty()) return -1;
     const int s = free_.back();
     free_.pop_back();
@@ -417,22 +418,37 @@ int Engine::alloc_slot()
     return s;
 }
 
-void Engine::free_slot(int slot)
+// (slot_mu_ held) reset every slot that was freed since the last call: up to 64 slots per launch instead of one launch per
+// aas_free -- tearing down 2048 sessions cost 2048 launches (4.3 ms of the stream, profiles/r03_b2048_kernel_stats.csv)
+void Engine::zero_pending_slots()
 {
-    // reset the slot so the next owner starts from the reference's calloc'd tensors (april_session.c:40-58) and a
-    // [blank, blank] context: ONE kernel, stream-ordered ahead of any later use of the slot.
+    if (zero_pending_.empty()) return;
     // Teardown-tolerant: sessions may be freed while the process is exiting and the HIP runtime is already gone.
     if (hipSetDevice(cfg_.device) == hipSuccess) {
         std::lock_guard<std::mutex> cg(capture_mu_);           // never enqueue into a stream that is being captured (step())
         const NetDims &d = L_.dims;
-        ZeroSlotArgs z;
-        z.h = h_; z.c = c_; z.n_layers = d.n_layers; z.slots = (size_t)cfg_.max_slots; z.d_model = d.d_model; z.hidden = d.hidden;
-        z.eout = eout_; z.dout = dout_; z.joiner = d.joiner; z.state = gstate_; z.blank = P_.blank_id; z.slot = slot; z.h16 = h16_;
-        launch_zero_slot(z, stream_);
+        for (size_t o = 0; o < zero_pending_.size(); o += 64) {
+            ZeroSlotArgs z;
+            z.h = h_; z.c = c_; z.n_layers = d.n_layers; z.slots = (size_t)cfg_.max_slots; z.d_model = d.d_model; z.hidden = d.hidden;
+            z.eout = eout_; z.dout = dout_; z.joiner = d.joiner; z.state = gstate_; z.blank = P_.blank_id; z.h16 = h16_;
+            z.n_list = (int)std::min<size_t>(64, zero_pending_.size() - o);
+            for (int i = 0; i < z.n_list; ++i) z.list[i] = zero_pending_[o + (size_t)i];
+            launch_zero_slot(z, stream_);
+        }
     }
+    for (int s : zero_pending_) free_.push_back(s);
+    zero_pending_.clear();
+}
+
+void Engine::free_slot(int slot)
+{
+    // the slot goes back to the free list once it has been reset to the reference's calloc'd tensors (april_session.c:40-58)
+    // and a [blank, blank] context -- in a batch: when 256 freed slots have gathered, when the free list runs dry, or before
+    // the next flight is launched (begin_flight), stream-ordered ahead of any later use of the slot
     std::lock_guard<std::mutex> g(slot_mu_);
-    free_.push_back(slot);
+    zero_pending_.push_back(slot);
     --live_;
+    if (zero_pending_.size() >= 256) zero_pending_slots();
 }
 
 void Engine::sync()
@@ -1291,7 +1307,10 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
         // out one by one (~0.25 ms of host time)
         int &uses = sw_uses_[std::make_pair(m, T)];
         const bool graphs = use_graphs_ && !profiling_ && !logits_out && (p.graph || p.g3[0] || ++uses >= 2);
-        if (graphs && split_streams_ > 0 && overlap_hint_) {
+        // (only the FIRST step of a flight: the per-parity buffers keep neighbouring FLIGHTS apart, a second step of the same
+        // flight -- a flush runs several -- would have its index fetch and front end overwrite what the first step's layers and
+        // search still read; it takes the one-stream path, behind everything the first step put on F and S)
+        if (graphs && split_streams_ > 0 && overlap_hint_ && flight_steps_ == 1) {
             // split feed: front end on F, layers on M, search on S, chained by events inside the feed; across feeds the three
             // parts of neighbouring flights overlap (see "streams" above).  split_streams_ == 1 keeps the front end on M.
             hipStream_t fe = split_streams_ >= 2 ? f_stream_ : stream_;
@@ -1386,6 +1405,7 @@ void Engine::begin_flight()
     // the flight's own copies of what the next flight's front end overwrites while this flight's layers / search still read it
     y_ = y_buf_[p]; ssq_ = ssq_buf_[p]; y16_ = y16_buf_[p]; step_d_ = step_buf_[p]; flags_d_ = flags_buf_[p]; rec_off_d_ = rec_off_buf_[p]; eout_lm_ = eout_lm_buf_[p];
     flight_tail_s_ = false;
+    { std::lock_guard<std::mutex> g(slot_mu_); zero_pending_slots(); }
 }
 
 bool Engine::flight_has_room(int rows, int nsteps) const

@@ -248,7 +248,8 @@ private:
     std::vector<void *> table_allocs_;
     float pad_value_ = 0;
     // slots
-    std::vector<int> free_;
+    std::vector<int> free_, zero_pending_;     // free slots (reset), freed slots waiting for their reset launch
+    void zero_pending_slots();
     int live_ = 0;
     std::mutex slot_mu_;
     std::mutex capture_mu_;                    // held while stream_ is being captured into a graph, and by other threads' enqueues

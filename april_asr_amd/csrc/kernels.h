@@ -256,6 +256,7 @@ struct ZeroSlotArgs {
     GreedyState *state = nullptr; int blank = 0;
     int slot = 0;
     void *h16 = nullptr;                   // fp16 tile engines: the binary16 copy of h, zeroed too
+    int n_list = 0; int list[64] = {0};    // n_list > 0: the listed slots in ONE launch (grid.y), `slot` unused
 };
 void launch_zero_slot(const ZeroSlotArgs &a, hipStream_t s);
 

@@ -281,7 +281,7 @@ void launch_advance(const AdvanceArgs &a, hipStream_t s)
 __global__ __launch_bounds__(256) void zero_slot_kernel(ZeroSlotArgs a)
 {
     const int l = blockIdx.x;                        // one workgroup per layer, the last one also resets the per-slot rows
-    const size_t s = (size_t)a.slot;
+    const size_t s = (size_t)(a.n_list > 0 ? a.list[blockIdx.y] : a.slot);
     if (l < a.n_layers) {
         float *h = a.h + ((size_t)l * a.slots + s) * a.d_model, *c = a.c + ((size_t)l * a.slots + s) * a.hidden;
         for (int i = threadIdx.x; i < a.d_model; i += 256) h[i] = 0.0f;
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void zero_slot_kernel(ZeroSlotArgs a)
 
 void launch_zero_slot(const ZeroSlotArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(zero_slot_kernel, dim3((unsigned)a.n_layers + 1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(zero_slot_kernel, dim3((unsigned)a.n_layers + 1, (unsigned)std::max(1, a.n_list)), dim3(256), 0, s, a);
 }
 
 __global__ __launch_bounds__(256) void block_setup_kernel(BlockSetupArgs a)

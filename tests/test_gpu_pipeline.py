@@ -63,3 +63,15 @@ def test_staged_samples_per_pass_are_bounded(built, medium_model):
     c = run(path, 6, 1, "pipe2", feed=48000, APRIL_STAGE_LIMIT_SAMPLES=20000)
     assert a["mismatch"] == b["mismatch"] == c["mismatch"] == 0 and a["chunks"] == b["chunks"] == c["chunks"] > 0
     assert a["digest"] == b["digest"] == c["digest"]
+
+
+def test_flights_with_several_steps_pipelined(built, medium_model):
+    """0.5 s per feed with the layer-major path switched off: every flight holds TWO feed wavefronts (7 + 5 chunks).  Only the
+    first step of a flight may use the three streams -- the second one shares the flight's buffers with it (this is what a
+    flush of many sessions looks like on an fp16 engine: tests/test_gpu_f16.py caught it at 512 sessions)"""
+    path = medium_model["path"]
+    a = run(path, 16, 6, "sync", feed=8000)
+    b = run(path, 16, 6, "pipe2", feed=8000, APRIL_LM_MIN_CHUNKS=0)
+    c = run(path, 16, 6, "async", feed=8000, APRIL_LM_MIN_CHUNKS=0)
+    assert a["mismatch"] == b["mismatch"] == c["mismatch"] == 0 and a["chunks"] == b["chunks"] == c["chunks"] > 0
+    assert a["digest"] == b["digest"] == c["digest"]
