@@ -1239,6 +1239,35 @@ Engine::SwPlan &Engine::sw_plan(int m, int T)
     return p;
 }
 
+// Measurement (APRIL_CHAIN_STREAMS=1): the layer part of a split feed as T per-chunk chains on T streams instead of z-batched
+// wavefront launches on one.  Chunk t's chain is G -> P -> U -> D layer after layer on the rows of chunk t (one 256-row problem per
+// launch); the only coupling is the recurrent state: G(l, t) waits for P(l, t - 1) by an event.  Same kernels, same arguments,
+// same chains as the z-batched launches (row-partitioned work buffers), so the results are bit-identical; what changes is
+// that the chains' launches overlap each other's ramp, prologue and epilogue.  Eager launches (events cross the streams).
+void Engine::run_sw_layers_chains(int m, int T)
+{
+    const NetDims &d = L_.dims;
+    const int L = d.n_layers;
+    while ((int)chain_streams_.size() < T - 1) { hipStream_t s; HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); chain_streams_.push_back(s); }
+    while (chain_ev_.size() < (size_t)L * (size_t)T) { hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); chain_ev_.push_back(e); }
+    auto st = [&](int t) { return t == 0 ? stream_ : chain_streams_[(size_t)t - 1]; };
+    for (int t = 1; t < T; ++t) join(st(t), stream_);                    // behind the front end (and the flight before)
+    for (int W = 1; W <= T + L - 1; ++W) {                               // issue in wavefront order so that no stream runs dry on the host's account
+        for (int l = 0; l < L; ++l) {
+            const int t = W - 1 - l;
+            if (t < 0 || t >= T) continue;
+            hipStream_t s = st(t);
+            if (t > 0) HIP_CHECK(hipStreamWaitEvent(s, chain_ev_[(size_t)l * T + (size_t)t - 1], 0));
+            launch_gemm(sw_args_gates(l, m, t), s);
+            launch_rowepi(lm_args_whr(l, m, t), (size_t)t * m, s);          // (fused, or planes + row kernel: the planner's choice for one problem)
+            if (t + 1 < T) HIP_CHECK(hipEventRecord(chain_ev_[(size_t)l * T + (size_t)t], s));
+            launch_gemm(lm_args_ff1(l, m, t, t + 1), s);
+            launch_rowepi(lm_args_ff2(l, m, t, t + 1), (size_t)t * m, s);
+        }
+    }
+    for (int t = 1; t < T; ++t) join(stream_, st(t));
+}
+
 // part 0: index fetch + front end (stream fe), 1: the layer wavefront + encoder_proj (stream ly), 2: the searches (stream sr);
 // parts < 0: all three in order on one stream
 void Engine::run_sw_chain(int m, int T, bool dump_logits, const SwPlan &p, int part, hipStream_t st)
@@ -1331,7 +1360,9 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
             if (m_unseen_by_s_) { join(s_stream_, stream_); m_unseen_by_s_ = false; }
             HIP_CHECK(hipGraphLaunch(p.g3[0], fe));
             if (fe == f_stream_) { join(stream_, f_stream_); f_unseen_by_m_ = false; }
-            HIP_CHECK(hipGraphLaunch(p.g3[1], stream_));
+            static const bool chains = getenv("APRIL_CHAIN_STREAMS") && atoi(getenv("APRIL_CHAIN_STREAMS")) != 0;
+            if (chains && cfg_.precision == 0) run_sw_layers_chains(m, T);
+            else HIP_CHECK(hipGraphLaunch(p.g3[1], stream_));
             join(s_stream_, stream_);
             HIP_CHECK(hipGraphLaunch(p.g3[2], s_stream_));
             s_unseen_by_m_ = true; flight_tail_s_ = true;

@@ -177,6 +177,8 @@ private:
     };
     SwPlan &sw_plan(int m, int T);
     void run_sw_chain(int m, int T, bool dump_logits, const SwPlan &p, int part, hipStream_t st);
+    void run_sw_layers_chains(int m, int T);
+    std::vector<hipStream_t> chain_streams_; std::vector<hipEvent_t> chain_ev_;
     void join(hipStream_t waiter, hipStream_t src);
     void general_prologue();
     int next_step_index() { ++flight_steps_; return (int)(step_seq_++ & (uint64_t)(2 * step_cap_ - 1)); }
