@@ -50,7 +50,7 @@ template <> struct WQuad<1> { using type = h4; };
 // outputs per workgroup a wave has two accumulator tiles, i.e. chains of four DEPENDENT MFMAs back to back, which issue at
 // half rate (measured: 520 cycles per k-block instead of 256); a second wave on the same SIMD fills the gaps.
 template <int MT, int NT, int EPI, int AOP, int WT, int MODE, int ASM, int NW = 4>
-__device__ __forceinline__ void gemm_body(const GemmArgs &g, const int zg, const unsigned wg_linear)
+__device__ __forceinline__ void gemm_body(const GemmArgs &g, const int zg, const unsigned wg_linear, const int bx, const int by, const bool one_m_block)
 {
     using Cfg = TileCfg<MT, NT, NW>;
     constexpr int NTH = NW * 64;
@@ -82,8 +82,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int zg, const
 #endif
     // XCD-aware mapping: consecutive blockIdx.x land on different XCDs, so keep the
     // M-blocks that share one weight column on the same XCD (same x mod 8).
-    const int nt0 = blockIdx.x * NT;
-    const int m0 = blockIdx.y * Cfg::BM;
+    const int nt0 = bx * NT;
+    const int m0 = by * Cfg::BM;
     // zg (GM_SLAB): this workgroup owns slabs [zg*zs, (zg+1)*zs)
     if (g.skew > 0) {
         // Two workgroups share a CU.  Dispatched together they run in lock-step: both stream MFMAs (halving each
@@ -188,7 +188,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int zg, const
         aoff1[mt] = g.K1 > 0 ? (uint32_t)(((size_t)r1v[mt] * g.lda1 + kq * 4) * sizeof(float)) : 0u;
     }
     const uint32_t boff = (uint32_t)lane * sizeof(BQ);
-    const bool stream_once = gridDim.y == 1;   // weights read by exactly one workgroup: bypass-friendly loads
+    const bool stream_once = one_m_block;      // weights read by exactly one workgroup: bypass-friendly loads
 
     // pairwise (balanced-tree) slab accumulation (GM_SLAB): level b holds the sum of 2^b consecutive slabs.  A workgroup
     // that owns zs = 2^t slabs needs t levels; the 64x64 tile is capped at zs = 4 (2 levels, 32 registers) so that it stays
@@ -688,7 +688,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int zg, const
 template <int MT, int NT, int EPI, int AOP, int WT, int MODE, int ASM, int NW = 4>
 __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kernel(GemmArgs g)
 {
-    gemm_body<MT, NT, EPI, AOP, WT, MODE, ASM, NW>(g, (int)blockIdx.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+    gemm_body<MT, NT, EPI, AOP, WT, MODE, ASM, NW>(g, (int)blockIdx.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), (int)blockIdx.x, (int)blockIdx.y, gridDim.y == 1);
 }
 
 // The same GEMM for `gridDim.z / zdiv` INDEPENDENT problems of one shape in one launch: blockIdx.z / zdiv selects the argument
@@ -703,7 +703,35 @@ __global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_zkern
     // are generic to the compiler -- flat_load / flat_store instead of global_load with an SGPR base -- and neither assumptions
     // nor address-space round trips change that; measured against the by-value kernel at one problem per launch: no difference.)
     const GemmArgs g = zargs[zl];
-    gemm_body<MT, NT, EPI, AOP, WT, MODE, ASM, 4>(g, (int)blockIdx.z - zl * zdiv, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+    gemm_body<MT, NT, EPI, AOP, WT, MODE, ASM, 4>(g, (int)blockIdx.z - zl * zdiv, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), (int)blockIdx.x, (int)blockIdx.y, gridDim.y == 1);
+}
+
+// Balanced form of the z-batched launch for tile counts that are not a whole number of rounds (three 256-row gate problems =
+// 768 tiles on 512 resident workgroups): `slots` workgroups walk the tile list with that stride, tile id = x + gx (y + gy z),
+// so a CU's two resident workgroups get three tiles between them (slot s takes s and s + slots: the same x, i.e. the same
+// XCD and weight column stripe, as in the plain launch).  The plain launch leaves the placement of the last 256 workgroups to
+// the dispatcher: they land wherever a slot frees first, some CUs take two of them and the launch waits for those (measured
+// 58 us or 70 us per launch, at random; profiles/r04e_b256_streams_under_rocprof.txt).  Same body, same arguments per tile.
+template <int MT, int NT, int EPI, int AOP, int WT, int MODE, int ASM>
+__global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_zkernel_walk(const GemmArgs *__restrict__ zargs, int zdiv, int gx, int gy, int ntiles)
+{
+    // (at most two tiles per workgroup, as two straight-line copies of the body: a loop around it costs 20 registers, which
+    // takes the hand-scheduled 64 x 64 tile over 256 and the kernel down to one workgroup per CU)
+    {
+        const int tile = (int)blockIdx.x;
+        const int bx = tile % gx, r = tile / gx, by = r % gy, bz = r / gy;
+        const int zl = bz / zdiv;
+        const GemmArgs g = zargs[zl];
+        gemm_body<MT, NT, EPI, AOP, WT, MODE, ASM, 4>(g, bz - zl * zdiv, (unsigned)tile, bx, by, gy == 1);
+    }
+    const int tile = (int)blockIdx.x + (int)gridDim.x;
+    if (tile < ntiles) {
+        __syncthreads();                                         // the first tile's epilogue is done with the LDS planes
+        const int bx = tile % gx, r = tile / gx, by = r % gy, bz = r / gy;
+        const int zl = bz / zdiv;
+        const GemmArgs g = zargs[zl];
+        gemm_body<MT, NT, EPI, AOP, WT, MODE, ASM, 4>(g, bz - zl * zdiv, (unsigned)tile, bx, by, gy == 1);
+    }
 }
 
 // ---------------------------------------------------------------- host side
@@ -959,7 +987,19 @@ static void launch_one_z(const GemmArgs &g, const GemmArgs *dev_args, int n, hip
     constexpr bool HAS_ASM = MODE == GM_SLAB && MT == 4 && (NT == 4 || NT == 2) && AOP == AOP_NONE && (EPI == EPI_LSTM || EPI == EPI_BIAS_DSWISH);
     if (g.wt == 1) { hipLaunchKernelGGL((gemm_f32_zkernel<MT, NT, EPI, AOP, 1, MODE, 0>), grid, dim3(256), lds, s, dev_args, zdiv); return; }
     if constexpr (HAS_ASM) {
-        if (g.asm_loop && g.debug != 1) { hipLaunchKernelGGL((gemm_f32_zkernel<MT, NT, EPI, AOP, 0, MODE, 1>), grid, dim3(256), lds, s, dev_args, zdiv); return; }
+        if (g.asm_loop && g.debug != 1) {
+            if constexpr (EPI == EPI_LSTM && MT == 4 && NT == 4) {
+                // APRIL_GEMM_WALK (1): 512 walking workgroups when the launch is more than one round of the chip's 512 resident
+                // 64 x 64 gate workgroups but not a whole number of rounds
+                static const int walk = env_int("APRIL_GEMM_WALK", 1);
+                const long ntiles = (long)grid.x * grid.y * grid.z;
+                if (walk && ntiles > 512 && ntiles < 1024) {
+                    hipLaunchKernelGGL((gemm_f32_zkernel_walk<MT, NT, EPI, AOP, 0, MODE, 1>), dim3(512), dim3(256), lds, s, dev_args, zdiv, (int)grid.x, (int)grid.y, (int)ntiles);
+                    return;
+                }
+            }
+            hipLaunchKernelGGL((gemm_f32_zkernel<MT, NT, EPI, AOP, 0, MODE, 1>), grid, dim3(256), lds, s, dev_args, zdiv); return;
+        }
     }
     hipLaunchKernelGGL((gemm_f32_zkernel<MT, NT, EPI, AOP, 0, MODE, 0>), grid, dim3(256), lds, s, dev_args, zdiv);
 }
