@@ -1,5 +1,6 @@
 // See engine.h.
 #include "engine.h"
+#include <array>
 #include <algorithm>
 #include <cmath>
 #include <chrono>
@@ -353,6 +354,11 @@ Engine::~Engine()
 {
     (void)hipSetDevice(cfg_.device);
     (void)hipStreamSynchronize(f_stream_); (void)hipStreamSynchronize(stream_); (void)hipStreamSynchronize(s_stream_);
+    dump_stream_trace();
+    for (StreamTrace &t : trace_) for (hipEvent_t e : t.ev) if (e) (void)hipEventDestroy(e);
+    if (trace_base_) (void)hipEventDestroy(trace_base_);
+    for (hipStream_t cs : chain_streams_) (void)hipStreamDestroy(cs);
+    for (hipEvent_t e : chain_ev_) (void)hipEventDestroy(e);
     for (hipEvent_t e : join_ev_) (void)hipEventDestroy(e);
     for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &g : step_graphs_) (void)hipGraphExecDestroy(g.second);
@@ -466,6 +472,46 @@ void Engine::sync()
 // (they share no buffer: see the per-parity buffers in the constructor).  The general paths (chunk-by-chunk steps, long feeds,
 // decoder refreshes, traced steps) stay on M and first wait for whatever F and S still have in the air; a split feed after
 // general work makes F and S wait for M the same way.  The flags say which stream has work the other has not waited for yet.
+// APRIL_STREAM_TRACE=<file> (measurement): hipEvent time stamps around the three parts of every split feed -- front end on F,
+// layers on M, search on S -- written as one line per feed when the engine is destroyed: the evidence that neighbouring feeds'
+// parts overlap (rocprofv3's kernel trace serialises the queues, so it cannot show it).
+Engine::StreamTrace *Engine::trace_slot()
+{
+    static const char *path = getenv("APRIL_STREAM_TRACE");
+    if (!path || !*path) return nullptr;
+    if (!trace_base_) { HIP_CHECK(hipEventCreate(&trace_base_)); HIP_CHECK(hipEventRecord(trace_base_, stream_)); }
+    if (trace_.size() >= 4096) return nullptr;
+    trace_.emplace_back();
+    StreamTrace &t = trace_.back();
+    for (hipEvent_t &e : t.ev) HIP_CHECK(hipEventCreate(&e));
+    return &t;
+}
+
+void Engine::dump_stream_trace()
+{
+    const char *path = getenv("APRIL_STREAM_TRACE");
+    if (!path || !*path || trace_.empty()) return;
+    FILE *f = fopen(path, "w");
+    if (!f) return;
+    fprintf(f, "# one line per split feed; times in us since the first split feed; FE = index fetch + conv + embed on stream F, LY = layer wavefront on M, SR = encoder_proj + search on S\n");
+    fprintf(f, "# feed sessions chunks  FE_start FE_end  LY_start LY_end  SR_start SR_end   overlap: FE inside the previous feed's LY window? SR inside the next feed's LY window?\n");
+    std::vector<std::array<float, 6>> ts;
+    for (StreamTrace &t : trace_) {
+        std::array<float, 6> a{};
+        bool ok = t.used;
+        for (int i = 0; i < 6 && ok; ++i) ok = hipEventElapsedTime(&a[(size_t)i], trace_base_, t.ev[i]) == hipSuccess;
+        if (ok) ts.push_back(a); else (void)hipGetLastError();
+    }
+    for (size_t i = 0; i < ts.size(); ++i) {
+        const auto &a = ts[i];
+        const bool fe_in_prev = i > 0 && a[0] * 1e3f < ts[i - 1][3] * 1e3f && a[1] * 1e3f > ts[i - 1][2] * 1e3f;
+        const bool sr_in_next = i + 1 < ts.size() && a[5] > ts[i + 1][2] && a[4] < ts[i + 1][3];
+        fprintf(f, "%4zu %5d %2d  %10.1f %10.1f  %10.1f %10.1f  %10.1f %10.1f   %s %s\n", i, trace_[i].m, trace_[i].T, a[0] * 1e3, a[1] * 1e3, a[2] * 1e3, a[3] * 1e3, a[4] * 1e3, a[5] * 1e3,
+                fe_in_prev ? "FE<prevLY" : "-", sr_in_next ? "SR<nextLY" : "-");
+    }
+    fclose(f);
+}
+
 void Engine::join(hipStream_t waiter, hipStream_t src)
 {
     hipEvent_t e = join_ev_[join_pos_++ % join_ev_.size()];
@@ -1358,13 +1404,20 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
                 if (m_unseen_by_f_) { join(f_stream_, stream_); m_unseen_by_f_ = false; }
             } else if (f_unseen_by_m_) { join(stream_, f_stream_); f_unseen_by_m_ = false; }       // (the fbank launch of this flight)
             if (m_unseen_by_s_) { join(s_stream_, stream_); m_unseen_by_s_ = false; }
+            StreamTrace *tr = trace_slot();
+            if (tr) HIP_CHECK(hipEventRecord(tr->ev[0], fe));
             HIP_CHECK(hipGraphLaunch(p.g3[0], fe));
+            if (tr) HIP_CHECK(hipEventRecord(tr->ev[1], fe));
             if (fe == f_stream_) { join(stream_, f_stream_); f_unseen_by_m_ = false; }
+            if (tr) HIP_CHECK(hipEventRecord(tr->ev[2], stream_));
             static const bool chains = getenv("APRIL_CHAIN_STREAMS") && atoi(getenv("APRIL_CHAIN_STREAMS")) != 0;
             if (chains && cfg_.precision == 0) run_sw_layers_chains(m, T);
             else HIP_CHECK(hipGraphLaunch(p.g3[1], stream_));
+            if (tr) HIP_CHECK(hipEventRecord(tr->ev[3], stream_));
             join(s_stream_, stream_);
+            if (tr) HIP_CHECK(hipEventRecord(tr->ev[4], s_stream_));
             HIP_CHECK(hipGraphLaunch(p.g3[2], s_stream_));
+            if (tr) { HIP_CHECK(hipEventRecord(tr->ev[5], s_stream_)); tr->m = m; tr->T = T; tr->used = true; }
             s_unseen_by_m_ = true; flight_tail_s_ = true;
             if (fe != f_stream_) m_unseen_by_f_ = true;          // (front-end kernels on M read ring rows: the next fbank waits for them)
             return k;

@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <deque>
 #include <array>
 #include <functional>
 #include <map>
@@ -179,6 +180,10 @@ private:
     void run_sw_chain(int m, int T, bool dump_logits, const SwPlan &p, int part, hipStream_t st);
     void run_sw_layers_chains(int m, int T);
     std::vector<hipStream_t> chain_streams_; std::vector<hipEvent_t> chain_ev_;
+    struct StreamTrace { hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; int m = 0, T = 0; bool used = false; };
+    std::deque<StreamTrace> trace_; hipEvent_t trace_base_ = nullptr;
+    StreamTrace *trace_slot();
+    void dump_stream_trace();
     void join(hipStream_t waiter, hipStream_t src);
     void general_prologue();
     int next_step_index() { ++flight_steps_; return (int)(step_seq_++ & (uint64_t)(2 * step_cap_ - 1)); }
