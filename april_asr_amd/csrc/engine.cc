@@ -1594,9 +1594,10 @@ void Engine::wait_flight(int parity)
 {
     HIP_CHECK(hipSetDevice(cfg_.device));
     HIP_CHECK(hipEventSynchronize(flight_done_[parity]));
+    if (profiling_) sync();            // (profiled flights are completed one by one: every launch's event pair has run, collect them)
 }
 
-void Engine::end_flight() { wait_flight(close_flight()); if (profiling_) sync(); }
+void Engine::end_flight() { wait_flight(close_flight()); }
 
 // ---------------------------------------------------------------- debug / parity entry points
 // The debug calls borrow slots 0..n-1; give them back reset (what a new session expects).

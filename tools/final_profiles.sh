@@ -2,23 +2,24 @@
 # Round-end measurement set (run on the GPU box through gpurun): per-kernel stats + inter-kernel gap summaries at 256, 1 and
 # 2048 sessions (graph replay: --profile-steps 0 keeps the captured graphs in use), the configs[4] leg (fp16 tile path vs fp32),
 # PMC passes at 256 sessions (separate passes, kernel-trace only), the default bench line.  Outputs land in gpurun_out/ and are
-# copied into profiles/ by hand.
-tag=${1:-r03}
+# copied into profiles/ by hand.  (rocprofv3's kernel trace serialises the queues, so the traced runs use the lock-step ingest: one
+# stream's worth of kernels per feed; the overlap of the three streams is shown by APRIL_STREAM_TRACE instead.)
+tag=${1:-r04}
 cd $GRAFT_REPO_ROOT
 export APRIL_LOG_LEVEL=${APRIL_LOG_LEVEL:-WARNING}
-bash tools/trace_pass.sh ${tag}_b256 --steps 10 --warmup 4 --no-sweep --no-cpu-baseline --no-config5 --steady-steps 0 --profile-steps 0
-bash tools/trace_pass.sh ${tag}_b1 --sessions 1 --steps 20 --warmup 5 --no-sweep --no-cpu-baseline --no-config5 --steady-steps 0 --profile-steps 0
-bash tools/trace_pass.sh ${tag}_b2048 --sessions 2048 --steps 8 --warmup 4 --no-sweep --no-cpu-baseline --no-config5 --steady-steps 0 --profile-steps 0
+bash tools/trace_pass.sh ${tag}_b256 --ingest lockstep --steps 10 --warmup 4 --no-sweep --no-cpu-baseline --no-config5 --steady-steps 0 --profile-steps 0
+bash tools/trace_pass.sh ${tag}_b1 --ingest lockstep --sessions 1 --steps 20 --warmup 5 --no-sweep --no-cpu-baseline --no-config5 --steady-steps 0 --profile-steps 0
+bash tools/trace_pass.sh ${tag}_b2048 --ingest lockstep --sessions 2048 --steps 8 --warmup 4 --no-sweep --no-cpu-baseline --no-config5 --steady-steps 0 --profile-steps 0
 bash tools/trace_pass.sh ${tag}_config5 --config5-only --profile-steps 0
 for b in b256 b1 b2048 config5; do
   f=$(ls /tmp/trace/${tag}_$b/*kernel_trace.csv 2>/dev/null | head -1)
   [ -n "$f" ] && python tools/gap_summary.py "$f" > gpurun_out/${tag}_${b}_gap_summary.txt
 done
-bash tools/pmc_pass.sh ${tag}_b256 --steps 4 --warmup 2 --no-sweep --no-cpu-baseline --no-config5 --steady-steps 0 --profile-steps 1
+bash tools/pmc_pass.sh ${tag}_b256 --ingest lockstep --steps 4 --warmup 2 --no-sweep --no-cpu-baseline --no-config5 --steady-steps 0 --profile-steps 1
 timeout 600 python bench.py > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err
 tail -c 2500 gpurun_out/${tag}_bench_default.json
 cat gpurun_out/${tag}_b256_gap_summary.txt gpurun_out/${tag}_b2048_gap_summary.txt gpurun_out/${tag}_config5_gap_summary.txt
 head -14 gpurun_out/${tag}_b256_kernel_stats.csv | cut -c1-150
 head -10 gpurun_out/${tag}_b2048_kernel_stats.csv | cut -c1-150
-grep -E "gemm_f32_zkernel<4, 4, 1" gpurun_out/pmc_${tag}_b256_summary.txt | cut -c1-400
+grep -E "gemm_f32_zkernel(_walk)?<4, 4, 1" gpurun_out/pmc_${tag}_b256_summary.txt | cut -c1-400
 ls -la gpurun_out | wc -l
