@@ -250,7 +250,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int zg, const
 #ifndef APRIL_DEPTH1
 #define APRIL_DEPTH1 6
 #endif
-    constexpr int DEPTH = FULLK ? ((MT == 1) ? APRIL_FULLK_DEPTH1 : (MT == 2 ? 4 : 3)) : ((MT == 1) ? APRIL_DEPTH1 : (MT == 2 ? 3 : APRIL_DEPTH4));
+#ifndef APRIL_FULLK_DEPTH2
+#define APRIL_FULLK_DEPTH2 4
+#endif
+    constexpr int DEPTH = FULLK ? ((MT == 1) ? APRIL_FULLK_DEPTH1 : (MT == 2 ? APRIL_FULLK_DEPTH2 : 3)) : ((MT == 1) ? APRIL_DEPTH1 : (MT == 2 ? 3 : APRIL_DEPTH4));
     f32x4 a_st[DEPTH][MT];
     BQ b_st[DEPTH][NT];
     int ld_base = first_kb, ld_off = 0, ld_cnt = 0;
