@@ -789,7 +789,14 @@ static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePla
         // fp16 gates / FFN up: 128 x 128 tiles (eight waves) once they give most CUs a workgroup -- twice the flops per operand byte
         static const int big = env_int("APRIL_TILE_BIG", 1), big_tiles = env_int("APRIL_TILE_BIG_TILES", 192), big_min_n = env_int("APRIL_TILE_BIG_MIN_N", 0);
         const long tiles8 = (long)(N / 128) * ((M + 127) / 128) * zc;
-        if (big && tiles8 >= big_tiles && N >= big_min_n) { t.mt = 8; t.nt = 8; t.zs = 1; t.mode = GM_TILE; return true; }
+        if (big && tiles8 >= big_tiles && N >= big_min_n) {
+            t.mt = 8; t.nt = 8; t.zs = 1; t.mode = GM_TILE;
+            // APRIL_TILE_BIG_NT=12 (measurement): 128 x 192 tiles where N divides -- fewer, fatter workgroups: two 512-row problems of
+            // the larger encoder's gates are 256 tiles = one per CU (128 x 128: 384 tiles = one and a half rounds of one workgroup per CU)
+            static const int big_nt = env_int("APRIL_TILE_BIG_NT", 8);
+            if (big_nt == 12 && N % 192 == 0) t.nt = 12;
+            return true;
+        }
     }
     int zs = kz;
     if (pin_zs > 0) { if (!force_full) zs = std::min(kz, pin_zs); }

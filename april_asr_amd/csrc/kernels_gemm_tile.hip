@@ -622,7 +622,7 @@ void launch_tile_one(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStre
 #ifndef APRIL_TILE_STAGES_F16
 #define APRIL_TILE_STAGES_F16 4
 #endif
-    constexpr int NSB = WT ? APRIL_TILE_STAGES_F16 : TILE_STAGES;
+    constexpr int NSB = (WT && NT <= 8) ? APRIL_TILE_STAGES_F16 : TILE_STAGES;      // (128 x 192 tiles: 40 KB per stage, three stages fit the LDS)
     using G = TileGeom<MT, NT, NWM, NWN, NSB>;
     const int zdiv = g.kz / g.zs;
     dim3 grid((unsigned)(g.N / G::BN), (unsigned)((g.M + G::BM - 1) / G::BM), (unsigned)(zdiv * std::max(1, n)));
@@ -666,6 +666,10 @@ void launch_gemm_tile(const GemmArgs &g, int mt, int nt, const GemmArgs *dev_arg
         if (g.wt == 1 && g.epi == EPI_PARTIAL) { launch_tile_one<4, EPI_PARTIAL, 1, 8, 2, 4>(g, dev_args, n, s); ok = true; }
         else if (g.wt == 1 && g.epi == EPI_HR) { launch_tile_one<4, EPI_HR, 1, 8, 2, 4>(g, dev_args, n, s); ok = true; }
         else if (g.wt == 1 && g.epi == EPI_RESID_SSQ) { launch_tile_one<4, EPI_RESID_SSQ, 1, 8, 2, 4>(g, dev_args, n, s); ok = true; }
+    }
+    else if (mt == 8 && nt == 12) {       // 128 x 192, eight waves (wave tile 64 x 48): 77 flop per operand byte; N a multiple of 192
+        if (g.wt == 1 && g.epi == EPI_LSTM) { launch_tile_one<8, EPI_LSTM, 1, 12, 2, 4>(g, dev_args, n, s); ok = true; }
+        else if (g.wt == 1 && g.epi == EPI_BIAS_DSWISH) { launch_tile_one<8, EPI_BIAS_DSWISH, 1, 12, 2, 4>(g, dev_args, n, s); ok = true; }
     }
     else if (mt == 8) {                   // 128 x 128, eight waves: the fp16 gates / FFN-up GEMMs
         if (g.wt == 1 && g.epi == EPI_LSTM) { launch_tile_one<8, EPI_LSTM, 1, 8, 2, 4>(g, dev_args, n, s); ok = true; }
