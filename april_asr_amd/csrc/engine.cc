@@ -859,6 +859,10 @@ GemmArgs Engine::lm_args_xpart(int l, int m, int t0, int t1) const
     g.a1 = g.a0; g.lda1 = d.d_model; g.K1 = d.d_model;          // never read (wave_mask)
     lin(g, o.wg); g.M = (t1 - t0) * m; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_XPART; g.wave_mask = 0x3;
     g.out = p_lm_ + b0 * 4 * d.hidden; g.ldo = 4 * d.hidden;
+    if (f16_tile_) {                  // binary16 operands (y16), P stays fp32
+        g.a0 = reinterpret_cast<const float *>(y16_ + b0 * d.d_model); g.a1 = g.a0;
+        lin16(g, o.wg);
+    }
     return g;
 }
 
@@ -873,6 +877,10 @@ GemmArgs Engine::lm_args_gates(int l, int m, int t) const
     lin(g, o.wg); g.M = m; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_LSTM; g.wave_mask = 0xC;
     g.p_add = p_lm_ + r0 * 4 * d.hidden; g.ldp = 4 * d.hidden;
     g.out = u_ + r0 * d.hidden; g.ldo = d.hidden; g.bias = w_ + o.bg; g.c_state = c_ + (size_t)l * S * d.hidden; g.slot_idx = step_d_; g.hidden = d.hidden;
+    if (f16_tile_) {                  // [never read | h16(slot)], u leaves as binary16 only
+        g.a0 = reinterpret_cast<const float *>(y16_ + r0 * d.d_model); g.a1 = reinterpret_cast<const float *>(h16_ + (size_t)l * S * d.d_model);
+        lin16(g, o.wg); g.out = nullptr; g.out16 = u16_ + r0 * d.hidden;
+    }
     return g;
 }
 
@@ -994,6 +1002,15 @@ void Engine::lm_stage_layer(int l, int m, int t0, int t1, hipStream_t st)
     const size_t b0 = (size_t)t0 * m;
     const int brows = (t1 - t0) * m;
     timed_begin(T_GATES); launch_gemm(lm_args_xpart(l, m, t0, t1), st); timed_end(T_GATES);
+    if (f16_tile_) {                  // fp16 tile engines: the same stage on the tile kernels (row epilogues fused or planes + row kernel, the planner's choice)
+        for (int t = t0; t < t1; ++t) {
+            timed_begin(T_GATES); launch_gemm(lm_args_gates(l, m, t), st); timed_end(T_GATES);
+            launch_rowepi(lm_args_whr(l, m, t), (size_t)t * m, st);
+        }
+        timed_begin(T_GEMM_OTHER); launch_gemm(lm_args_ff1(l, m, t0, t1), st); timed_end(T_GEMM_OTHER);
+        launch_rowepi(lm_args_ff2(l, m, t0, t1), b0, st);
+        return;
+    }
     for (int t = t0; t < t1; ++t) {
         const size_t r0 = (size_t)t * m;
         timed_begin(T_GATES); launch_gemm(lm_args_gates(l, m, t), st); timed_end(T_GATES);
@@ -1440,8 +1457,9 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
         kernels_per_step_ = (launch_count_ + 1 + T - 1) / T;          // per chunk
     } else {
         general_prologue();
+        const int tk = f16_tile_ ? 2 : tile_ok();
         const bool wavefront = lm_wavefront_on() && !profiling_ && T > lm_wavefront_min_chunks() &&
-                               gemm_fullk(m, d.d_model, kz_hr_, true, 1, tile_ok()) && gemm_fullk(m, d.d_model, kz_ff2_, true, 1, tile_ok());
+                               gemm_fullk(m, d.d_model, kz_hr(), true, 1, tk) && gemm_fullk(m, d.d_model, kz_ff2(), true, 1, tk);
         if (wavefront) {                 // long feed: all layers of a wavefront per launch (run_lm_wavefront)
             run_lm_wavefront(m, T, logits_out != nullptr);
             if (!logits_out) return k;

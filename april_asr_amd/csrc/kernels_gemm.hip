@@ -857,9 +857,9 @@ static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = fal
     // 5 = 64x32 tiles for split-K GEMMs at M > 32
     static const int tune = env_int("APRIL_GEMM_TUNE", 0);
     TilePlan t;
-    if (tile_ok && (epi == EPI_PARTIAL || epi == EPI_HR || epi == EPI_RESID_SSQ || epi == EPI_SLOT_STORE || epi == EPI_LSTM || epi == EPI_BIAS_DSWISH)) {
+    if (tile_ok && (epi == EPI_PARTIAL || epi == EPI_HR || epi == EPI_RESID_SSQ || epi == EPI_SLOT_STORE || epi == EPI_LSTM || epi == EPI_BIAS_DSWISH || (epi == EPI_XPART && tile_ok == 2))) {
         // the caller asked gemm_fullk first: a row epilogue arrives only when that plan keeps all of K in the workgroup
-        if (plan_tile(M, N, kz, zcount_true, force_fullk || epi != EPI_PARTIAL, t, tile_ok == 2, (f16 || env_int("APRIL_TILE_BIG_F32", 0)) && tile_ok == 2 && (epi == EPI_LSTM || epi == EPI_BIAS_DSWISH),
+        if (plan_tile(M, N, kz, zcount_true, force_fullk || epi != EPI_PARTIAL, t, tile_ok == 2, (f16 || env_int("APRIL_TILE_BIG_F32", 0)) && tile_ok == 2 && (epi == EPI_LSTM || epi == EPI_BIAS_DSWISH || epi == EPI_XPART),
                       tile_ok == 2 && (epi == EPI_PARTIAL || epi == EPI_HR || epi == EPI_RESID_SSQ))) return t;
         if (tile_ok == 2) { fprintf(stderr, "libapril(mi355x): launch_gemm: no GM_TILE plan for an always-tile GEMM (M=%d N=%d kz=%d)\n", M, N, kz); abort(); }
     }
@@ -953,7 +953,9 @@ static TilePlan finalize_gemm(GemmArgs &g)
     const bool is_slab_epi = g.epi == EPI_LSTM || g.epi == EPI_BIAS_DSWISH || g.epi == EPI_XPART;
     // GM_TILE eligibility: planner-rule GEMMs (tile_ok 1) are the fp32 row-epilogue / partial GEMMs over one A segment; always-tile
     // GEMMs (tile_ok 2, fp16 tile engines) may also carry two segments and the LSTM / DoubleSwish epilogues
-    const bool plain = g.a_op == AOP_NONE && g.wave_mask == 0xF && g.N % 64 == 0 && !g.p_add;
+    // (the fp16 tile kernels also have the layer-major halves of the gate GEMM: wave_mask 0x3 + EPI_XPART, 0xC + p_add + EPI_LSTM)
+    const bool lm_half = g.tile_ok == 2 && g.wt == 1 && ((g.epi == EPI_XPART && g.wave_mask == 0x3 && !g.p_add) || (g.epi == EPI_LSTM && g.wave_mask == 0xC && g.p_add));
+    const bool plain = g.a_op == AOP_NONE && g.N % 64 == 0 && ((g.wave_mask == 0xF && !g.p_add) || lm_half);
     const int tile_ok = !plain ? 0 : (g.tile_ok == 2 ? 2 : ((g.tile_ok == 1 && g.K1 == 0 && g.wt == 0 && g.epi != EPI_LSTM && g.epi != EPI_BIAS_DSWISH) ? 1 : 0));
     if (g.tile_ok == 2 && !tile_ok) { fprintf(stderr, "libapril(mi355x): launch_gemm: always-tile GEMM with a prologue / wave mask / odd N\n"); abort(); }
     const TilePlan t = plan_tiles(g.M, g.N, g.kz, g.epi, g.force_fullk != 0, (z_tiles == 1 || (z_tiles == 2 && is_slab_epi) || (z_tiles == 3 && !is_slab_epi)) ? zc : 1, tile_ok, zc, g.wt == 1);

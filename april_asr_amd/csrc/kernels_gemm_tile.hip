@@ -82,7 +82,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
     constexpr int BM = G::BM, MTW = G::MTW, NTW = G::NTW, NTH = G::NTH, LDR = G::LDR, TILE_BN = G::BN;
     constexpr int KBLK = WT ? 32 : 16, AE = WT ? 2 : 4;          // k per k block, bytes per activation element
     constexpr bool ROW_EPI = EPI == EPI_HR || EPI == EPI_RESID_SSQ || EPI == EPI_SLOT_STORE;
-    static_assert(ROW_EPI || EPI == EPI_PARTIAL || EPI == EPI_LSTM || EPI == EPI_BIAS_DSWISH, "no GM_TILE form of this epilogue");
+    static_assert(ROW_EPI || EPI == EPI_PARTIAL || EPI == EPI_LSTM || EPI == EPI_BIAS_DSWISH || EPI == EPI_XPART, "no GM_TILE form of this epilogue");
     extern __shared__ __attribute__((aligned(1024))) float red[];
     char *lds = reinterpret_cast<char *>(red);
 
@@ -103,14 +103,18 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
     const int m0 = blockIdx.y * BM;
     const int KB = g.K / KBLK;
     const int c = KB / (4 * g.kz);                       // k blocks per chunk
-    const int T = 4 * c * g.zs;                          // k blocks of this workgroup (even)
-    const int first_kb = zg * T;
+    // layer-major split of the gate GEMM (kernels.h, wave_mask; kz = 1, K0 = K1 = K / 2): 0x3 = the input half alone (chunks 0, 1:
+    // EPI_XPART writes P = (c0 + c1) * scale), 0xC = the recurrent half alone on top of P (chunks 2, 3: ((P + c2) + c3) + bias).
+    // The K-split kernels hand those halves to wave pairs; here the workgroup simply walks half of the k blocks.
+    const bool half_x = (EPI == EPI_XPART || EPI == EPI_LSTM) && g.wave_mask == 0x3, half_h = EPI == EPI_LSTM && g.wave_mask == 0xC;
+    const int T = (half_x || half_h) ? 2 * c : 4 * c * g.zs;      // k blocks of this workgroup (even)
+    const int first_kb = half_h ? 2 * c : zg * T;
     const int nstage = T >> 1;
 
     // ---- BasicNorm scales of the tile's rows (EPI_HR: residual; EPI_SLOT_STORE: the whole sum), as in gemm_body: the partials
     // make one trip from global memory at kernel start and are added up after the K loop
     const RowScale &rsc = EPI == EPI_HR ? g.r_scale : g.x_scale;
-    const bool NEED_SCL = (EPI == EPI_HR || EPI == EPI_SLOT_STORE || EPI == EPI_LSTM) && rsc.ssq != nullptr;
+    const bool NEED_SCL = (EPI == EPI_HR || EPI == EPI_SLOT_STORE || EPI == EPI_LSTM || EPI == EPI_XPART) && rsc.ssq != nullptr;
     float *scl = red + G::LDS_MAIN / 4;
     float stg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int TPR = NTH / BM;
@@ -268,6 +272,21 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
     int top = 0;
     while ((1 << top) < g.zs) ++top;
     int chunk_i = 0, slab_done = 0, in_chunk = 0;
+    if (EPI == EPI_LSTM && half_h && g.p_add) {
+        // the slab starts as P (this lane's accumulator elements of the tile, fetched now, used at the first chunk end): S = P,
+        // then S + c2, then S + c3 -- the canonical ((P + c2) + c3)
+        chunk_i = 2;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int row = m0 + (wm * MTW + mt) * 16 + (lane >> 4) * 4 + r;
+                    if (row >= g.M) row = g.M - 1;
+                    S[mt][nt][r] = g.p_add[(size_t)row * g.ldp + n0 + (wn * NTW + nt) * 16 + (lane & 15)];
+                }
+    }
     // EPI_LSTM with x_scale: x = y * scale(y) entered the GEMM as y, the first two chunks are exactly the y half of K (kz = 1,
     // K0 = K / 2, checked on the host): ((c0 + c1) * scale + c2) + c3, the scale of this lane's accumulator rows held in registers
     float xrs[MTW][4];
@@ -275,11 +294,11 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) xrs[mt][r] = 1.0f;
-    const bool fold_scale = EPI == EPI_LSTM && NEED_SCL;
+    const bool fold_scale = (EPI == EPI_LSTM || EPI == EPI_XPART) && NEED_SCL;
     auto chunk_end = [&]() {
         if (chunk_i == 0) { APRIL_TILE_EACH(S[mt][nt] = acc[mt][nt]) }
         else { APRIL_TILE_EACH(S[mt][nt] = S[mt][nt] + acc[mt][nt]) }
-        if (EPI == EPI_LSTM && fold_scale && chunk_i == 1) {
+        if ((EPI == EPI_LSTM || EPI == EPI_XPART) && fold_scale && chunk_i == 1) {
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -341,7 +360,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
         constexpr int NS = G::NS;
 #pragma unroll
         for (int i = 0; i < NS - 1; ++i) if (i < nstage) issue(i);
-        if (EPI == EPI_LSTM && fold_scale) {
+        if ((EPI == EPI_LSTM || EPI == EPI_XPART) && fold_scale) {
             // the scales are needed INSIDE the loop (after the second chunk): reduce them now, behind the first DMA stages (the
             // compiler settles every outstanding memory operation here, which the first stage needs anyway)
             compute_scl();
@@ -490,6 +509,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
     tr_t = __builtin_amdgcn_s_memtime();
 #endif
 
+    if (EPI == EPI_XPART) { APRIL_TILE_EACH(res[mt][nt] = S[mt][nt]) }      // (c0 + c1) * scale: half a slab, by design
     // ---- the workgroup's sums -> LDS plane (each wave owns its columns; no cross-wave addition) -> 4-column quads per thread
     __syncthreads();                                       // the last stage has been read by every wave
 #pragma unroll
@@ -507,9 +527,16 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
         v[i] = q < NQ ? *reinterpret_cast<const f32x4 *>(red + (q / QROW) * LDR + (q % QROW) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    if (NEED_SCL && EPI != EPI_LSTM) compute_scl();
+    if (NEED_SCL && EPI != EPI_LSTM && EPI != EPI_XPART) compute_scl();
 
-    if (EPI == EPI_PARTIAL) {
+    if (EPI == EPI_XPART) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * NTH;
+            const int m = m0 + q / QROW;
+            if (q < NQ && m < g.M) *reinterpret_cast<f32x4 *>(g.out + (size_t)m * g.ldo + n0 + (q % QROW) * 4) = v[i];
+        }
+    } else if (EPI == EPI_PARTIAL) {
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
             const int q = threadIdx.x + i * NTH;
@@ -610,7 +637,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void gemm_t
 
 template <class G> size_t tile_lds_bytes(const GemmArgs &g)
 {
-    const int sg = g.epi == EPI_HR ? g.r_scale.groups : ((g.epi == EPI_SLOT_STORE || g.epi == EPI_LSTM) && g.x_scale.ssq ? g.x_scale.groups : 0);
+    const int sg = g.epi == EPI_HR ? g.r_scale.groups : ((g.epi == EPI_SLOT_STORE || g.epi == EPI_LSTM || g.epi == EPI_XPART) && g.x_scale.ssq ? g.x_scale.groups : 0);
     return (size_t)G::LDS_MAIN + (size_t)(G::BM + (sg ? G::BM * (sg + 1) : 0)) * sizeof(float);
 }
 
@@ -652,6 +679,7 @@ bool dispatch_tile(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream
     case EPI_SLOT_STORE: launch_tile_one<MT, EPI_SLOT_STORE, WT>(g, dev_args, n, s); return true;
     case EPI_LSTM: launch_tile_one<MT, EPI_LSTM, WT>(g, dev_args, n, s); return true;
     case EPI_BIAS_DSWISH: launch_tile_one<MT, EPI_BIAS_DSWISH, WT>(g, dev_args, n, s); return true;
+    case EPI_XPART: if constexpr (WT == 1) { launch_tile_one<MT, EPI_XPART, WT>(g, dev_args, n, s); return true; } else return false;
     default: return false;
     }
 }
@@ -674,6 +702,7 @@ void launch_gemm_tile(const GemmArgs &g, int mt, int nt, const GemmArgs *dev_arg
     else if (mt == 8) {                   // 128 x 128, eight waves: the fp16 gates / FFN-up GEMMs
         if (g.wt == 1 && g.epi == EPI_LSTM) { launch_tile_one<8, EPI_LSTM, 1, 8, 2, 4>(g, dev_args, n, s); ok = true; }
         else if (g.wt == 1 && g.epi == EPI_BIAS_DSWISH) { launch_tile_one<8, EPI_BIAS_DSWISH, 1, 8, 2, 4>(g, dev_args, n, s); ok = true; }
+        else if (g.wt == 1 && g.epi == EPI_XPART) { launch_tile_one<8, EPI_XPART, 1, 8, 2, 4>(g, dev_args, n, s); ok = true; }
         else if (g.wt == 0 && g.epi == EPI_LSTM) { launch_tile_one<8, EPI_LSTM, 0, 8, 2, 4>(g, dev_args, n, s); ok = true; }
         else if (g.wt == 0 && g.epi == EPI_BIAS_DSWISH) { launch_tile_one<8, EPI_BIAS_DSWISH, 0, 8, 2, 4>(g, dev_args, n, s); ok = true; }
     }

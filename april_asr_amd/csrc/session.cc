@@ -756,8 +756,10 @@ bool Scheduler::step_chunks(std::vector<Session *> &ready)
     // sessions with a long backlog (a whole file fed at once) go layer-major, in groups that fit the work buffers
     std::vector<Session *> one, lm;
     auto waiting = [](const Session *s) { return (int)((s->fb.avail - s->fb.seg_count) / s->fb.seg_step + 1); };
-    // (fp16 tile engines have no layer-major form: a long feed runs as successive feed wavefronts of up to wave_max_chunks_ chunks)
-    const bool lm_ok = lm_min_chunks_ > 0 && lm_min_chunks_ <= MB && !eng_->f16_tile();
+    // (fp16 tile engines: layer-major since round 4 -- the tile kernels have the two halves of the gate GEMM; APRIL_F16_LM=0 falls back
+    // to successive feed wavefronts of up to wave_max_chunks_ chunks)
+    static const bool f16_lm = !(getenv("APRIL_F16_LM") && atoi(getenv("APRIL_F16_LM")) == 0);
+    const bool lm_ok = lm_min_chunks_ > 0 && lm_min_chunks_ <= MB && (!eng_->f16_tile() || f16_lm);
     for (Session *s : ready) ((lm_ok && waiting(s) >= lm_min_chunks_) ? lm : one).push_back(s);
     if (!lm.empty()) {
         const int per = std::max(1, MB / lm_min_chunks_);

@@ -182,3 +182,52 @@ def test_f16_cache_file_gives_the_same_model(tiny_model, tmp_path):
     e1, l1, _ = run_gpu(m1, pcm, 1600)
     assert e0 == e1 and np.array_equal(l0, l1)
     m0.close(); m1.close()
+
+
+@pytest.mark.parametrize("secs,chunk", [(0.5, 8000), (3.0, 48000), (3.0, 7000)])
+def test_f16_layer_major_equals_streaming(f16_models, secs, chunk):
+    """fp16 tile engines step long feeds layer-major too (round 4: the tile kernels have the two halves of the gate GEMM --
+    wave_mask 0x3 + EPI_XPART over all chunks at once, 0xC + p_add per time step): the same chains in the same order, so every
+    logit and callback equals the 100 ms feeds bit for bit.  0.5 s = the sequential layer-major chain (12 chunks), 3 s = the
+    wavefront over blocks of time steps (74 chunks), 7000-sample feeds = a mix of both per call."""
+    gm, _ = f16_models["v0"]
+    assert gm.dims.precision == 1
+    pcm = speech_like_pcm(secs, seed=77, silence=(0.2 * secs, 0.3 * secs))
+    lm0 = gm.stats().lm_chunks
+    ev_a, lg_a, n_a = run_gpu(gm, pcm, 1600)
+    assert gm.stats().lm_chunks - lm0 < 40              # (the flush rounds of the 100 ms run may be stepped together)
+    lm1 = gm.stats().lm_chunks
+    ev_b, lg_b, n_b = run_gpu(gm, pcm, chunk)
+    assert gm.stats().lm_chunks - lm1 >= 10, "the long feeds did not take the layer-major path"
+    assert n_a == n_b and lg_a.shape == lg_b.shape
+    assert np.array_equal(lg_a.view(np.uint32), lg_b.view(np.uint32)), np.abs(lg_a - lg_b).max()
+    assert ev_a == ev_b
+    # untraced (graphs / the wavefront's z-batched launches): callbacks again
+    import april_asr_amd as A
+    ev = []
+    s = A.Session(gm, lambda t, toks: ev.append((t, toks)), raw_events=True)
+    for i in range(0, pcm.size, chunk):
+        s.feed_pcm16(pcm[i:i + chunk])
+    s.flush()
+    assert ev == ev_a
+    s.close()
+
+
+def test_f16_layer_major_many_sessions(f16_models):
+    """24 sessions x 2 s in one group feed on the fp16 engine (layer-major, 24 rows per time step) == each session alone"""
+    import april_asr_amd as A
+    from oracle import orc_py as O
+    gm, _ = f16_models["v0"]
+    n = 24
+    pcms = [O.lcg_pcm16_fast(32000, seed=640 + i) for i in range(n)]
+    evs = [[] for _ in range(n)]
+    ss = [A.Session(gm, (lambda k: (lambda t, toks: evs[k].append((t, toks))))(i), raw_events=True) for i in range(n)]
+    g = A.SessionGroup(ss)
+    g.feed(pcms)
+    g.flush()
+    assert gm.stats().replay_mismatch == 0
+    for i in (0, 7, 23):
+        ev1, _, _ = run_gpu(gm, pcms[i], 1600)
+        assert ev1 == evs[i], i
+    for s in ss:
+        s.close()
