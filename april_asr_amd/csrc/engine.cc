@@ -1393,30 +1393,53 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
     ring_pos_ += (size_t)m + 3 * (size_t)rows; rec_pos_ += (size_t)3 * rows;
     std::lock_guard<std::mutex> cg(capture_mu_);
     if (mode == 1) {                 // the chunk steps of one feed as a wavefront over the layers (run_sw_chain)
-        SwPlan &p = sw_plan(m, T);
         // a shape is captured into graphs the SECOND time it is seen (by either flight parity): capturing costs a few
         // milliseconds, which a batch shape that occurs once (sessions joining and leaving) never earns back; its launches go
-        // out one by one (~0.25 ms of host time)
+        // out one by one (~0.25 ms of host time).  When it is captured, it is captured for BOTH parities: which parity a shape
+        // meets depends on the history of flights (feeds alternate between 2 and 3 chunks, parities alternate too, and one merged
+        // or empty flight flips the pairing), and a capture in the middle of a stream is a 3 ms hiccup.
+        const int par = flight_parity_;
+        sw_plan(m, T);
+        SwPlan *pp = &sw_plans_.find(std::make_pair(m, T * 2 + par))->second;
         int &uses = sw_uses_[std::make_pair(m, T)];
-        const bool graphs = use_graphs_ && !profiling_ && !logits_out && (p.graph || p.g3[0] || ++uses >= 2);
-        // (only the FIRST step of a flight: the per-parity buffers keep neighbouring FLIGHTS apart, a second step of the same
+        const bool graphs = use_graphs_ && !profiling_ && !logits_out && (pp->graph || pp->g3[0] || ++uses >= 2);
+        // (split: only the FIRST step of a flight: the per-parity buffers keep neighbouring FLIGHTS apart, a second step of the same
         // flight -- a flush runs several -- would have its index fetch and front end overwrite what the first step's layers and
         // search still read; it takes the one-stream path, behind everything the first step put on F and S)
-        if (graphs && split_streams_ > 0 && overlap_hint_ && flight_steps_ == 1) {
-            // split feed: front end on F, layers on M, search on S, chained by events inside the feed; across feeds the three
-            // parts of neighbouring flights overlap (see "streams" above).  split_streams_ == 1 keeps the front end on M.
-            hipStream_t fe = split_streams_ >= 2 ? f_stream_ : stream_;
-            if (!p.g3[0]) {
-                hipStream_t on[3] = {fe, stream_, s_stream_};
-                for (int part = 0; part < 3; ++part) {
+        const bool split = graphs && split_streams_ > 0 && overlap_hint_ && flight_steps_ == 1;
+        hipStream_t fe = split_streams_ >= 2 ? f_stream_ : stream_;
+        if (graphs && (split ? !pp->g3[0] : !pp->graph)) {
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const int q = k2 == 0 ? 1 - par : par;          // the other parity first, this one last (the member pointers end where they were)
+                select_parity(q);
+                SwPlan &pl = sw_plan(m, T);
+                if (split) {
+                    if (pl.g3[0]) continue;
+                    hipStream_t on[3] = {fe, stream_, s_stream_};
+                    for (int part = 0; part < 3; ++part) {
+                        hipGraph_t graph = nullptr;
+                        HIP_CHECK(hipStreamBeginCapture(on[part], hipStreamCaptureModeThreadLocal));
+                        run_sw_chain(m, T, false, pl, part, on[part]);
+                        HIP_CHECK(hipStreamEndCapture(on[part], &graph));
+                        HIP_CHECK(hipGraphInstantiate(&pl.g3[part], graph, nullptr, nullptr, 0));
+                        HIP_CHECK(hipGraphDestroy(graph));
+                    }
+                } else {
+                    if (pl.graph) continue;
                     hipGraph_t graph = nullptr;
-                    HIP_CHECK(hipStreamBeginCapture(on[part], hipStreamCaptureModeThreadLocal));
-                    run_sw_chain(m, T, false, p, part, on[part]);
-                    HIP_CHECK(hipStreamEndCapture(on[part], &graph));
-                    HIP_CHECK(hipGraphInstantiate(&p.g3[part], graph, nullptr, nullptr, 0));
+                    HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+                    run_sw_chain(m, T, false, pl, -1, stream_);
+                    HIP_CHECK(hipStreamEndCapture(stream_, &graph));
+                    HIP_CHECK(hipGraphInstantiate(&pl.graph, graph, nullptr, nullptr, 0));
                     HIP_CHECK(hipGraphDestroy(graph));
                 }
             }
+            pp = &sw_plans_.find(std::make_pair(m, T * 2 + par))->second;      // (a plan-cache eviction in between would have moved it)
+        }
+        SwPlan &p = *pp;
+        if (split) {
+            // split feed: front end on F, layers on M, search on S, chained by events inside the feed; across feeds the three
+            // parts of neighbouring flights overlap (see "streams" above).  split_streams_ == 1 keeps the front end on M.
             if (fe == f_stream_) {
                 if (m_unseen_by_f_) { join(f_stream_, stream_); m_unseen_by_f_ = false; }
             } else if (f_unseen_by_m_) { join(stream_, f_stream_); f_unseen_by_m_ = false; }       // (the fbank launch of this flight)
@@ -1441,14 +1464,6 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
         }
         general_prologue();
         if (graphs) {
-            if (!p.graph) {
-                hipGraph_t graph = nullptr;
-                HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-                run_sw_chain(m, T, false, p, -1, stream_);
-                HIP_CHECK(hipStreamEndCapture(stream_, &graph));
-                HIP_CHECK(hipGraphInstantiate(&p.graph, graph, nullptr, nullptr, 0));
-                HIP_CHECK(hipGraphDestroy(graph));
-            }
             HIP_CHECK(hipGraphLaunch(p.graph, stream_));
             return k;
         }
@@ -1498,14 +1513,20 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
 // Flights alternate between the two halves of the per-flight rings, so that the host can enqueue flight k + 1 while the GPU
 // still runs flight k and the records of flight k are still being read (Scheduler::loop).  The device step counter starts at
 // the half's first step index: the step tables are indexed by it, so the launch chains (graphs) do not depend on the parity.
+// the flight's own copies of what the next flight's front end overwrites while this flight's layers / search still read it
+void Engine::select_parity(int p)
+{
+    flight_parity_ = p;
+    y_ = y_buf_[p]; ssq_ = ssq_buf_[p]; y16_ = y16_buf_[p]; step_d_ = step_buf_[p]; flags_d_ = flags_buf_[p]; rec_off_d_ = rec_off_buf_[p]; eout_lm_ = eout_lm_buf_[p];
+}
+
 void Engine::begin_flight()
 {
     HIP_CHECK(hipSetDevice(cfg_.device));
     const int p = flight_parity_ = next_parity_; next_parity_ ^= 1;
     ring_base_ = (size_t)p * ring_cap_; rec_base_ = (size_t)p * rec_cap_;
     ring_pos_ = ring_base_; rec_pos_ = rec_base_; flight_steps_ = 0;
-    // the flight's own copies of what the next flight's front end overwrites while this flight's layers / search still read it
-    y_ = y_buf_[p]; ssq_ = ssq_buf_[p]; y16_ = y16_buf_[p]; step_d_ = step_buf_[p]; flags_d_ = flags_buf_[p]; rec_off_d_ = rec_off_buf_[p]; eout_lm_ = eout_lm_buf_[p];
+    select_parity(p);
     flight_tail_s_ = false;
     { std::lock_guard<std::mutex> g(slot_mu_); zero_pending_slots(); }
 }
@@ -1535,14 +1556,22 @@ int Engine::step(int m, const int *slots, const int *ring_tails, const int *now_
         auto it = step_graphs_.find(gkey);
         if (it == step_graphs_.end()) {
             if (step_graphs_.size() >= 256) { sync(); for (auto &g : step_graphs_) (void)hipGraphExecDestroy(g.second); step_graphs_.clear(); step_seen_.clear(); }
-            hipGraph_t graph = nullptr;
-            hipGraphExec_t exec = nullptr;
-            HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-            run_chain(m, false);
-            HIP_CHECK(hipStreamEndCapture(stream_, &graph));
-            HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-            HIP_CHECK(hipGraphDestroy(graph));
-            it = step_graphs_.emplace(gkey, exec).first;
+            const int par = flight_parity_;
+            for (int k2 = 0; k2 < 2; ++k2) {               // both parities at once (see lm_step), this flight's last
+                const int q = k2 == 0 ? 1 - par : par;
+                if (step_graphs_.count(m * 2 + q)) continue;
+                select_parity(q);
+                hipGraph_t graph = nullptr;
+                hipGraphExec_t exec = nullptr;
+                HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+                run_chain(m, false);
+                HIP_CHECK(hipStreamEndCapture(stream_, &graph));
+                HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                HIP_CHECK(hipGraphDestroy(graph));
+                step_graphs_.emplace(m * 2 + q, exec);
+            }
+            select_parity(par);
+            it = step_graphs_.find(gkey);
         }
         HIP_CHECK(hipGraphLaunch(it->second, stream_));
         return k;

@@ -184,6 +184,7 @@ private:
     std::deque<StreamTrace> trace_; hipEvent_t trace_base_ = nullptr;
     StreamTrace *trace_slot();
     void dump_stream_trace();
+    void select_parity(int p);
     void join(hipStream_t waiter, hipStream_t src);
     void general_prologue();
     int next_step_index() { ++flight_steps_; return (int)(step_seq_++ & (uint64_t)(2 * step_cap_ - 1)); }

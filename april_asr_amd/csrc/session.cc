@@ -239,7 +239,7 @@ static int env_us(const char *name, int def)
 
 Scheduler::Scheduler(Model *m, Engine *e) : model_(m), eng_(e), pool_(host_helpers())
 {
-    spin_step_us_ = env_us("APRIL_SPIN_STEP_US", 100);
+    spin_step_us_ = env_us("APRIL_SPIN_STEP_US", 1000);     // (1 ms: a client that pauses for a barrier or a sync between two feeds finds the thread awake; 100 us until round 3)
     spin_wait_us_ = env_us("APRIL_SPIN_WAIT_US", 3000);
     lm_min_chunks_ = env_us("APRIL_LM_MIN_CHUNKS", 8);
     wave_min_chunks_ = env_us("APRIL_WAVE_MIN_CHUNKS", 2);

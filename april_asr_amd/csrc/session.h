@@ -200,7 +200,7 @@ private:
     // spin-then-block on both sides of the hand-over (a condition-variable wake-up costs 30..60 us each way, which is 5 %
     // of a 2 ms step): submit() bumps work_seq_, the end of a tick bumps done_seq_
     std::atomic<uint64_t> work_seq_{0}, done_seq_{0};
-    int spin_step_us_ = 100, spin_wait_us_ = 3000;   // APRIL_SPIN_STEP_US / APRIL_SPIN_WAIT_US
+    int spin_step_us_ = 1000, spin_wait_us_ = 3000;   // APRIL_SPIN_STEP_US / APRIL_SPIN_WAIT_US
     int wave_min_chunks_ = 2, wave_max_chunks_ = 7;  // APRIL_WAVE_MIN_CHUNKS (0 = chunk steps one by one) / APRIL_WAVE_MAX_CHUNKS: chunk steps of one feed as a wavefront
     int lm_min_chunks_ = 8;                          // APRIL_LM_MIN_CHUNKS: sessions with at least this many chunks waiting take the layer-major path (0 = never)
     void spin_for_done(uint64_t seen);

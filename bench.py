@@ -121,6 +121,9 @@ def main():
                          "returns when feed k is complete: the library prepares and launches a feed while the GPU works on the previous one, as "
                          "with continuously streaming clients); lockstep = aprilx_feed_many (one blocking call per feed).  The other mode is "
                          "measured too and reported next to the headline")
+    ap.add_argument("--pre-roll", type=int, default=30,
+                    help="untimed feeds BEFORE the W warm-up steps (set-up, like the model load): the launch chains of both feed shapes and "
+                         "both flight parities are captured and the GPU's clocks have ramped by the time the warm-up starts (reported as pre_roll_steps)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend for the weight broadcast; gloo (host tensors, ranks may share a GPU) exists to "
                          "exercise the multi-process path on a one-GPU box")
@@ -255,6 +258,13 @@ def main():
 
     sess, grp = make_group(B, rank * B)
     pcm = pcm_for(B, n_steps, rank * B)
+    if args.pre_roll > 0:                    # set-up: see --pre-roll
+        pre = pcm_for(B, args.pre_roll, 50_000_000 + rank * B)
+        grp.plan(pre, step_samples)
+        for s in range(args.pre_roll):
+            (grp.feed_planned if args.ingest == "lockstep" else grp.feed_planned_pipelined)(s)
+        grp.drain()
+        del pre
 
     step_wall = []                           # per-step wall time of the timed steps (p50/p99 latency of one 100 ms feed of all sessions)
 
@@ -526,7 +536,7 @@ def main():
             "config": {"workload": "aprilv0_en-us dims (synthetic seeded weights), %d concurrent streaming sessions per GPU, "
                                    "100 ms PCM16 feeds via aprilx_feed_many (BASELINE configs[2]; configs[3] at 8 GPUs)" % B,
                        "sessions_per_gpu": B, "feed_ms": 100, "params": int(d.param_count), "parallelism": "sessions sharded, dp%d" % world},
-            "rtf": round(rtf, 5), "sessions_total": world * B,
+            "rtf": round(rtf, 5), "sessions_total": world * B, "pre_roll_steps": args.pre_roll,
             "ingest": {"mode": args.ingest, "what": "aprilx_feed_many_pipelined, depth 2: feed k + 1 is queued (samples copied) while feed k is on the GPU, every callback "
                                                      "of the K timed feeds is delivered inside the timed region (drain before the closing barrier)"
                        if args.ingest == "pipelined" else "aprilx_feed_many: one blocking call per feed"},
