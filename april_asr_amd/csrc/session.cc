@@ -584,7 +584,7 @@ void Scheduler::cut_frames(std::vector<Session *> &work, bool &progressed)
     std::vector<Session *> finishers;
     // FbankFrameDesc::pcm_off is a 32-bit sample offset into ONE staging buffer: a pass stages at most `stage_limit` samples
     // (default 2^30; 1640 sessions x a full 8192-frame ring of backlog would pass 2^31) and carries the rest to the next pass
-    // of process()'s loop.  APRIL_STAGE_LIMIT_SAMPLES exists for the test that crosses the limit with small numbers.
+    // of launch_flight()'s loop.  APRIL_STAGE_LIMIT_SAMPLES exists for the test that crosses the limit with small numbers.
     static const size_t stage_limit = [] {
         const char *v = getenv("APRIL_STAGE_LIMIT_SAMPLES");
         const long n = v && *v ? atol(v) : (1L << 30);

@@ -128,7 +128,6 @@ struct Session {
     std::vector<Replay> replay;               // what the open flights did for this session, in order (a flight consumes its own items from the front)
     std::atomic<double> speed_needed{1.0};    // reference src/april_session.c:79,456-462 (EMA of processing time / audio time x 1.1);
                                               // written by the stepping thread, read by aas_realtime_get_speedup from any thread
-    uint64_t chunks_at_tick_start = 0;
     bool was_flushed = false;
     int flush_phase = 0;                      // 0 none, 1 pad-drain, 2 zeros, 3 pad-drain, 4 finish
     size_t now_ms = 0;

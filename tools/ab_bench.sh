@@ -1,4 +1,4 @@
-# usage: tools/r4_ab.sh tag "ENV1=.. ENV2=.." "ENV.." ...   -- the pipelined 256-session bench under each environment, alternating twice
+# usage: tools/ab_bench.sh tag "ENV1=.. ENV2=.." "ENV.." ...   -- the pipelined 256-session bench under each environment, alternating twice
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 export APRIL_LOG_LEVEL=WARNING
 tag=$1; shift

@@ -1,4 +1,4 @@
-# usage: tools/r4_f16.sh tag "ENV.." ...  -- the configs[4] leg (512 sessions, larger encoder, fp16 + fp32) under each environment
+# usage: tools/ab_config5.sh tag "ENV.." ...  -- the configs[4] leg (512 sessions, larger encoder, fp16 + fp32) under each environment
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 export APRIL_LOG_LEVEL=WARNING
 tag=$1; shift
