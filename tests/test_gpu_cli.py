@@ -123,3 +123,22 @@ def test_srt_cli_matches_oracle(v0_model, tmp_path):
             want += [str(cue), "%s --> %s" % (_stamp(ms), _stamp(end)), text, ""]
     got = out.stdout.decode().split("\n")[:-1]
     assert got == want and cue >= 3
+
+
+def test_serve_many_pipelined_equals_lockstep(v0_model, tmp_path):
+    """examples/serve_many.cpp: 48 streams from one thread through the engine ABI's group feeds; the pipelined feed (depth 2) and
+    the lock-step feed print the same per-stream results (callbacks, FINAL results, their tokens and the last FINAL text)."""
+    exe = str(tmp_path / "serve_many")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "examples", "serve_many.cpp"), "-I", os.path.join(ROOT, "include"),
+                           "-L", os.path.join(ROOT, "april_asr_amd"), "-laprilasr", "-Wl,-rpath," + os.path.join(ROOT, "april_asr_amd"), "-o", exe])
+    pcm = np.concatenate([speech_like_pcm(3.0, seed=31, silence=(1.0, 1.3)), np.zeros(16000 * 3, np.int16), speech_like_pcm(2.0, seed=32)])
+    path = str(tmp_path / "audio.raw")
+    pcm.tofile(path)
+    outs = []
+    for mode in ("pipelined", "lockstep"):
+        r = subprocess.run([exe, v0_model["path"], path, "48", mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
+                           env=dict(os.environ, APRIL_MAX_SESSIONS="256", APRIL_MAX_BATCH="1024"))
+        assert r.returncode == 0, r.stderr.decode()[-1000:]
+        outs.append(r.stdout.decode().splitlines())
+    assert len(outs[0]) == 48 and outs[0] == outs[1]
+    assert sum(int(l.split()[2]) for l in outs[0]) > 0, "no FINAL result in any stream"
