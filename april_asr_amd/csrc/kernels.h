@@ -45,10 +45,13 @@ enum GemmAOp { AOP_NONE = 0, AOP_TANH_ADD = 1 };
 //   - a GEMM over x (LSTM gates' input half, encoder_proj) runs over y and multiplies the finished partial sum by the row's
 //     scale in its epilogue (`x_scale`): scale * sum_k(y_k w_k), one rounding away from sum_k((scale y_k) w_k);
 //   - the residual x + h' reads y and multiplies (`r_scale`).
-enum GemmMode { GM_SLAB = 0, GM_FULLK = 1, GM_TILE = 2 };
+enum GemmMode { GM_SLAB = 0, GM_FULLK = 1, GM_TILE = 2, GM_KW = 3 };
 //     GM_TILE   (kernels_gemm_tile.hip) the four waves split the OUTPUT tile and share both operands through LDS; every wave
 //               folds chunk -> slab -> tree in registers over the workgroup's zs slabs.  zs == kz: row epilogue fused;
 //               zs < kz: kz / zs partial planes, finished by the row kernels exactly as for GM_SLAB.
+//     GM_KW     (kernels_gemm_kw.hip, round 5) the waves split K as in GM_FULLK (eight waves: one slab each at kz = 8), but every wave's
+//               activation rows arrive in full 128-byte lines through a wave-private LDS ring (no barrier in the K loop); 32 x 32 tiles.
+//               The N = d_model GEMMs (and FFN up) at a few hundred rows per launch.
 
 constexpr int SSQ_COLS = 32;       // columns per sum-of-squares partial (one granule = 8 consecutive 4-column quads)
 
@@ -120,6 +123,12 @@ struct GemmArgs {
 void launch_gemm(const GemmArgs &g, hipStream_t s);
 // (internal) GM_TILE launch, called by launch_gemm / launch_gemm_z once the plan is made: tile 16 * mt rows x 16 * nt columns; dev_args != null: n z-batched problems
 void launch_gemm_tile(const GemmArgs &g, int mt, int nt, const GemmArgs *dev_args, int n, hipStream_t s);
+// (internal) GM_KW launch (kernels_gemm_kw.hip): tile 16 * mt rows x 16 * nt columns, all of K in the workgroup; dev_args != null: n z-batched
+// problems.  gemm_kw_waves: 8 / 4 = the waves a GM_KW workgroup would use for this GEMM (operands, epilogue, chunk structure), 0 = not eligible
+int gemm_kw_waves(const GemmArgs &g);
+void launch_gemm_kw(const GemmArgs &g, int mt, int nt, const GemmArgs *dev_args, int n, hipStream_t s);
+// measurement only (tools/kw_bench): enable / ff1 (FFN up on GM_KW): -1 = environment default, 0 / 1 = off / on; mt = 0 (planner) or pinned tile rows / 16
+void gemm_kw_pin(int enable, int mt, int ff1);
 // (internal) the recurrent GEMMs of a long feed at <= 16 rows as weight streams (kernels_recur.hip): recur_form says whether g is
 // one of them (1 gates h-half + cell, 2 projection), launch_recur runs n same-shape problems (dev_args) or g itself (dev_args == null)
 int recur_form(const GemmArgs &g);

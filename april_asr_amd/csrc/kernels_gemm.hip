@@ -941,6 +941,34 @@ static bool dispatch(const GemmArgs &g, hipStream_t s)
     return false;
 }
 
+// GM_KW (kernels_gemm_kw.hip) takes over a fused full-K plan of the K-split kernels -- the row-epilogue GEMMs on 16..64 x 32
+// GM_FULLK / GM_SLAB tiles, and (APRIL_KW_FF1) the FFN-up GEMM on its hand-scheduled slab tiles -- when the operands allow it
+// (gemm_kw_waves) and the launch is a few hundred rows: below APRIL_KW_MIN_ROWS the launch is latency-bound either way, above
+// the GM_TILE threshold plan_tile has already taken it.  The decision never changes a caller-visible property of the plan (all
+// of K in the workgroup, row work in the epilogue), so gemm_fullk / gemm_partials need not know.
+static int g_kw_enable = -1, g_kw_pin_mt = 0, g_kw_ff1 = -1;
+void gemm_kw_pin(int enable, int mt, int ff1) { g_kw_enable = enable; g_kw_pin_mt = mt; g_kw_ff1 = ff1; }
+static void plan_kw(const GemmArgs &g, TilePlan &t, int zc)
+{
+    static const int enabled = env_int("APRIL_GM_KW", 1), min_rows = env_int("APRIL_KW_MIN_ROWS", 33), max_rows = env_int("APRIL_KW_MAX_ROWS", 1 << 30);
+    static const int ff1 = env_int("APRIL_KW_FF1", 0), env_mt = env_int("APRIL_KW_MT", 0);
+    if (!(g_kw_enable < 0 ? enabled : g_kw_enable) || t.mode == GM_TILE || t.zs != g.kz) return;
+    if (g.M < min_rows || g.M > max_rows) return;
+    if (g.epi == EPI_BIAS_DSWISH ? !(g_kw_ff1 < 0 ? ff1 : g_kw_ff1) : (g.epi != EPI_HR && g.epi != EPI_RESID_SSQ)) return;
+    const int nw = gemm_kw_waves(g);
+    if (!nw) return;
+    int mt = g_kw_pin_mt ? g_kw_pin_mt : env_mt;
+    const int nt = (g.epi == EPI_BIAS_DSWISH && g.N % 64 == 0) ? 4 : 2;
+    if (!mt) {
+        // 32-row tiles are the efficient ones (one memory instruction per four MFMAs; 16-row tiles: three per eight), 16-row tiles the
+        // finer grain: the launch takes ceil(tiles / 256 CUs) rounds, a 16-row round costs ~0.55 of a 32-row one (tools/kw_bench)
+        const long t32 = (long)(g.N / (16 * nt)) * ((g.M + 31) / 32) * zc, t16 = (long)(g.N / (16 * nt)) * ((g.M + 15) / 16) * zc;
+        mt = (nw == 8 && ((t16 + 255) / 256) * 55 < ((t32 + 255) / 256) * 100) ? 1 : 2;
+    }
+    if (nw == 4 && mt == 1) mt = 2;
+    t.mt = mt; t.nt = nt; t.zs = g.kz; t.mode = GM_KW;
+}
+
 // plan + checks + measurement knobs: everything launch_gemm decides on the host
 static TilePlan finalize_gemm(GemmArgs &g)
 {
@@ -958,7 +986,8 @@ static TilePlan finalize_gemm(GemmArgs &g)
     const bool plain = g.a_op == AOP_NONE && g.N % 64 == 0 && ((g.wave_mask == 0xF && !g.p_add) || lm_half);
     const int tile_ok = !plain ? 0 : (g.tile_ok == 2 ? 2 : ((g.tile_ok == 1 && g.K1 == 0 && g.wt == 0 && g.epi != EPI_LSTM && g.epi != EPI_BIAS_DSWISH) ? 1 : 0));
     if (g.tile_ok == 2 && !tile_ok) { fprintf(stderr, "libapril(mi355x): launch_gemm: always-tile GEMM with a prologue / wave mask / odd N\n"); abort(); }
-    const TilePlan t = plan_tiles(g.M, g.N, g.kz, g.epi, g.force_fullk != 0, (z_tiles == 1 || (z_tiles == 2 && is_slab_epi) || (z_tiles == 3 && !is_slab_epi)) ? zc : 1, tile_ok, zc, g.wt == 1);
+    TilePlan t = plan_tiles(g.M, g.N, g.kz, g.epi, g.force_fullk != 0, (z_tiles == 1 || (z_tiles == 2 && is_slab_epi) || (z_tiles == 3 && !is_slab_epi)) ? zc : 1, tile_ok, zc, g.wt == 1);
+    plan_kw(g, t, zc);
     const bool row_epi = g.epi == EPI_HR || g.epi == EPI_RESID_SSQ || g.epi == EPI_SLOT_STORE;
     if (row_epi && t.zs != g.kz) { fprintf(stderr, "libapril(mi355x): launch_gemm: row epilogue %d needs the full-K plan (M=%d N=%d kz=%d)\n", g.epi, g.M, g.N, g.kz); abort(); }
     g.zs = t.zs; g.mode = t.mode;
@@ -970,6 +999,8 @@ static TilePlan finalize_gemm(GemmArgs &g)
     //   workgroups per CU): 91.3 / 170.4   compiler loop, no skew: 56.5 / 100.7 / 180.2;  FFN-up [2048,512]x[512,2048]: 42.3 vs 45.7
     g.asm_loop = asm_loop != 0;
     g.skew = (long)(g.N / (16 * t.nt)) * ((g.M + 16 * t.mt - 1) / (16 * t.mt)) * (t.mode == GM_FULLK ? 1 : g.kz / g.zs) >= 512 ? skew : 0;   // two workgroups per CU
+    static const int kw_skew = env_int("APRIL_KW_SKEW", 8);      // GM_KW: start delay of the second half of a workgroup's waves, x 64 cycles (kernels_gemm_kw.hip)
+    if (t.mode == GM_KW) g.skew = kw_skew;
     return t;
 }
 
@@ -979,6 +1010,7 @@ void launch_gemm(const GemmArgs &g_in, hipStream_t s)
     if (const int rf = recur_form(g)) { launch_recur(g, rf, nullptr, 1, s); return; }
     const TilePlan t = finalize_gemm(g);
     if (t.mode == GM_TILE) { launch_gemm_tile(g, t.mt, t.nt, nullptr, 0, s); return; }
+    if (t.mode == GM_KW) { launch_gemm_kw(g, t.mt, t.nt, nullptr, 0, s); return; }
     const int mt = t.mt, nt = t.nt;
     bool ok = false;
     if (mt == 1) { if (nt == 4) ok = dispatch<1, 4>(g, s); else if (nt == 2) ok = dispatch<1, 2>(g, s); else ok = dispatch<1, 1>(g, s); }
@@ -1053,6 +1085,7 @@ void launch_gemm_z(const GemmArgs *staged, int n, const GemmArgs *dev_args, hipS
     GemmArgs probe = g;
     const TilePlan t = finalize_gemm(probe);
     if (t.mode == GM_TILE) { launch_gemm_tile(g, t.mt, t.nt, dev_args, n, s); return; }
+    if (t.mode == GM_KW) { launch_gemm_kw(g, t.mt, t.nt, dev_args, n, s); return; }
     const int mt = t.mt, nt = t.nt;
     bool ok = false;
     if (mt == 1) { if (nt == 4) ok = dispatch_z<1, 4>(g, dev_args, n, s); else if (nt == 2) ok = dispatch_z<1, 2>(g, dev_args, n, s); else ok = dispatch_z<1, 1>(g, dev_args, n, s); }
