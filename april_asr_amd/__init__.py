@@ -219,6 +219,16 @@ class Model:
         self._L.aprilx_model_stats(self._handle, device_index, C.byref(s))
         return s
 
+    def feed_latencies(self, device_index: int = 0, reset: bool = False) -> np.ndarray:
+        """hand-over -> delivery latency (ms) of the last completed ticks of one GPU's stepping thread, oldest first"""
+        n = int(self._L.aprilx_model_feed_latency(self._handle, device_index, None, 0, 0))
+        out = np.zeros(n, np.float64)
+        if n:
+            n = int(self._L.aprilx_model_feed_latency(self._handle, device_index, out.ctypes.data, n, 1 if reset else 0))
+        elif reset:
+            self._L.aprilx_model_feed_latency(self._handle, device_index, None, 0, 1)
+        return out[:n]
+
     def profile(self, enable: bool):
         self._L.aprilx_model_profile(self._handle, 1 if enable else 0)
 
@@ -295,7 +305,8 @@ class Session:
         out = np.zeros((total, self.model.dims.mel), np.float32)
         if total:
             got = int(self._L.aprilx_session_read_frames(self._handle, 0, total, out.ctypes.data))
-            assert got == total
+            if got != total:      # UINT64_MAX: the first rows have left the ring (more than ring_frames rows written)
+                raise RuntimeError("frames(): %d rows written, the feature ring no longer holds the first ones" % total)
         return out
 
     def contexts(self):

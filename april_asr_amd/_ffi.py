@@ -58,7 +58,7 @@ EXPORTED_ENGINE_SYMBOLS = [
     "aprilx_model_from_blob", "aprilx_model_save_blob", "aprilx_model_save_blob_f16", "aprilx_model_load_blob",
     "aprilx_broadcast_get_id", "aprilx_model_broadcast", "aprilx_model_load_info", "aprilx_feed_many", "aprilx_flush_many", "aprilx_session_drain", "aprilx_feed_many_pipelined", "aprilx_drain_many",
     "aprilx_run_encoder", "aprilx_run_decoder", "aprilx_run_joiner", "aprilx_run_fbank", "aprilx_run_decide", "aprilx_plan_gemm", "aprilx_stream_form",
-    "aprilx_session_trace_logits", "aprilx_session_chunks", "aprilx_session_read_frames", "aprilx_session_context", "aprilx_model_stats", "aprilx_model_profile",
+    "aprilx_session_trace_logits", "aprilx_session_chunks", "aprilx_session_read_frames", "aprilx_session_context", "aprilx_model_stats", "aprilx_model_profile", "aprilx_model_feed_latency",
     "aprilx_greedy_create", "aprilx_greedy_step", "aprilx_greedy_finish", "aprilx_greedy_free", "aprilx_probe_file", "aprilx_model_load_host", "aprilx_model_fbank_tables", "aprilx_counting_handler",
 ]
 
@@ -115,6 +115,7 @@ def lib():
     L.aprilx_session_read_frames.argtypes = [vp, C.c_uint64, C.c_int, C.c_void_p]; L.aprilx_session_read_frames.restype = C.c_uint64
     L.aprilx_session_context.argtypes = [vp, vp, vp]; L.aprilx_session_context.restype = None
     L.aprilx_model_stats.argtypes = [vp, C.c_int, C.POINTER(AprilxStats)]; L.aprilx_model_stats.restype = None
+    L.aprilx_model_feed_latency.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int]; L.aprilx_model_feed_latency.restype = C.c_int
     L.aprilx_model_profile.argtypes = [vp, C.c_int]; L.aprilx_model_profile.restype = None
     L.aprilx_greedy_create.argtypes = [vp, HANDLER, vp]; L.aprilx_greedy_create.restype = vp
     L.aprilx_greedy_step.argtypes = [vp, C.c_int32, C.c_float, C.c_float, C.c_float, sz, C.POINTER(C.c_int32)]

@@ -71,16 +71,19 @@ bool broadcast_local(Model &m)
             bool ok = true;
             for (size_t i = 0; i < peers.size() && ok; ++i) {
                 HIP_CHECK(hipSetDevice(devs[i]));
-                const ncclResult_t r = (fault == 2 && i == 1) ? ncclInternalError
-                    : ncclBroadcast(peers[0]->weights_device(), peers[i]->weights_mut(), count, ncclFloat, 0, comms[i], peers[i]->stream());
+                // (fault 2: the call itself is made with null buffers, so that RCCL's own argument check fails INSIDE the group and
+                // records the group error, as a real failure would)
+                const bool inject = fault == 2 && i == 1;
+                const ncclResult_t r = ncclBroadcast(inject ? nullptr : peers[0]->weights_device(), inject ? nullptr : peers[i]->weights_mut(), count, ncclFloat, 0, comms[i], peers[i]->stream());
                 if (r != ncclSuccess) { LOGE("RCCL: ncclBroadcast (device %d) failed: %s", devs[i], ncclGetErrorString(r)); ok = false; }
             }
             if (!ok) {
-                // some ranks have joined the collective, the others never will: closing the group would launch a broadcast that
-                // waits for them forever (and the stream synchronisation below with it).  Abort the communicators instead --
-                // that also releases whatever the group has queued -- and leave the streams alone.
-                for (ncclComm_t &c : comms) if (c) { (void)ncclCommAbort(c); c = nullptr; }
+                // some ranks have queued their part of the collective, the failing one has not.  A call that fails inside an open
+                // group records the error in the group: ncclGroupEnd then discards what was queued and returns that error instead
+                // of launching a broadcast that would wait for the missing rank.  So: close the group FIRST (the queued tasks
+                // still point at live communicators), THEN abort the communicators; the streams are left alone.
                 (void)ncclGroupEnd();
+                for (ncclComm_t &c : comms) if (c) { (void)ncclCommAbort(c); c = nullptr; }
                 return false;
             }
             const ncclResult_t ge = ncclGroupEnd();
@@ -769,7 +772,7 @@ uint64_t aprilx_session_read_frames(AprilASRSession session, uint64_t first, int
     const uint64_t total = s->fb.rows_written;
     if (out && n > 0) {
         const int R = s->eng->ring_frames();
-        if (first + (uint64_t)n > total || total - first > (uint64_t)R) return total;      // not written yet / already overwritten
+        if (first + (uint64_t)n > total || total - first > (uint64_t)R) return UINT64_MAX;      // not written yet / already overwritten: nothing copied
         int done = 0;
         while (done < n) {          // (the ring may wrap inside the range)
             const int row = (int)((first + (uint64_t)done) % (uint64_t)R), cnt = std::min(n - done, R - row);
@@ -803,6 +806,12 @@ void aprilx_model_stats(AprilASRModel model, int device_index, AprilxStats *out)
     Engine *e = model->m.engines[(size_t)device_index];
     out->kernels_per_step = (uint64_t)e->kernels_per_step();
     for (int i = 0; i < 6; ++i) { out->kernel_ms[i] = e->timing(i).ms; out->kernel_launches[i] = (uint64_t)e->timing(i).launches; }
+}
+
+int aprilx_model_feed_latency(AprilASRModel model, int device_index, double *out_ms, int cap, int reset)
+{
+    if (!model || device_index < 0 || device_index >= (int)model->m.scheds.size()) return 0;
+    return (int)model->m.scheds[(size_t)device_index]->latencies(out_ms, cap > 0 ? (size_t)cap : 0, reset != 0);
 }
 
 void aprilx_model_profile(AprilASRModel model, int enable)

@@ -457,9 +457,19 @@ void Engine::free_slot(int slot)
     if (zero_pending_.size() >= 256) zero_pending_slots();
 }
 
-void Engine::sync()
+// Waits for the three streams and touches nothing else: safe from any thread (the readers below are called by client threads
+// while the stepping thread keeps enqueueing).
+void Engine::sync_streams()
 {
     HIP_CHECK(hipStreamSynchronize(f_stream_)); HIP_CHECK(hipStreamSynchronize(stream_)); HIP_CHECK(hipStreamSynchronize(s_stream_));
+}
+
+// Stepping thread only (or under capture_mu_): everything enqueued so far is done, so no stream has work another one has not seen.
+// A client thread must NOT clear these flags -- between its stream waits and the store the stepping thread may have enqueued a new
+// fbank and set one; it uses sync_streams(), a stale "unseen" only costs a redundant event.
+void Engine::sync()
+{
+    sync_streams();
     f_unseen_by_m_ = s_unseen_by_m_ = m_unseen_by_f_ = m_unseen_by_s_ = false;
     if (profiling_) collect_timing();
 }
@@ -528,7 +538,7 @@ void Engine::general_prologue()
 }
 
 // ---------------------------------------------------------------- profiling
-void Engine::set_profiling(bool on) { sync(); profiling_ = on; }
+void Engine::set_profiling(bool on) { std::lock_guard<std::mutex> cg(capture_mu_); sync(); profiling_ = on; }
 void Engine::reset_timing() { for (auto &t : timing_) t = KernelTiming(); }
 void Engine::timed_begin(int cls)
 {
@@ -1524,6 +1534,10 @@ void Engine::begin_flight()
 {
     HIP_CHECK(hipSetDevice(cfg_.device));
     const int p = flight_parity_ = next_parity_; next_parity_ ^= 1;
+    // the buffers of this parity (index ring half, record ring half, y / ssq / step tables, eout_lm) were lent to the flight before the
+    // previous one: it must have completed -- the scheduler keeps at most two flights open and completes them in order, so the event
+    // is done long ago and this costs nothing; any other caller would silently overwrite an in-flight search
+    if (flight_open_[p]) { HIP_CHECK(hipEventSynchronize(flight_done_[p])); flight_open_[p] = false; }
     ring_base_ = (size_t)p * ring_cap_; rec_base_ = (size_t)p * rec_cap_;
     ring_pos_ = ring_base_; rec_pos_ = rec_base_; flight_steps_ = 0;
     select_parity(p);
@@ -1625,6 +1639,7 @@ int Engine::close_flight()
     }
     if (rec_pos_ > rec_base_) HIP_CHECK(hipMemcpyAsync(rec_h_ + rec_base_, rec_d_ + rec_base_, (rec_pos_ - rec_base_) * sizeof(StepRecord), hipMemcpyDeviceToHost, tail));
     HIP_CHECK(hipEventRecord(flight_done_[flight_parity_], tail));
+    flight_open_[flight_parity_] = true;
     return flight_parity_;
 }
 
@@ -1803,14 +1818,14 @@ void Engine::debug_fbank(int n_frames, const int16_t *pcm_frames, float *out)
 void Engine::read_greedy_state(int slot, GreedyState *out)
 {
     HIP_CHECK(hipSetDevice(cfg_.device));
-    sync();
+    sync_streams();
     HIP_CHECK(hipMemcpy(out, gstate_ + slot, sizeof(GreedyState), hipMemcpyDeviceToHost));
 }
 
 void Engine::read_ring(int slot, int row, int n_rows, float *out)
 {
     HIP_CHECK(hipSetDevice(cfg_.device));
-    sync();
+    sync_streams();
     const int nb = ft_.nbins;
     for (int i = 0; i < n_rows; ++i)
         HIP_CHECK(hipMemcpy(out + (size_t)i * nb, ring_ + ((size_t)slot * ring_frames_ + (row + i) % ring_frames_) * nb, (size_t)nb * 4, hipMemcpyDeviceToHost));

@@ -123,7 +123,8 @@ public:
     // splitting over the three streams; a lone flight runs on one stream (the events between the streams cost it ~50 us)
     void set_overlap_hint(bool on) { overlap_hint_ = on; }
     const StepRecord *records(int step_index) const { return rec_h_ + rec_off_h_[step_index]; }   // [3][m], valid after end_flight()
-    void sync();
+    void sync();                               // stepping thread (or under capture_mu_): waits for the three streams and clears the cross-stream dependency flags
+    void sync_streams();                       // any thread: waits for the three streams, nothing else
 
     // ---- debug / parity entry points (state passed explicitly, like the ORT tensors)
     void debug_encoder(int n, const float *x, const float *h, const float *c, float *eout, float *h2, float *c2);
@@ -232,6 +233,7 @@ private:
     int flight_parity_ = 0, next_parity_ = 0; size_t ring_base_ = 0, rec_base_ = 0; int flight_steps_ = 0;
     uint64_t step_seq_ = 0;                    // steps enqueued since the engine started = the device's step counter (advance_kernel)
     hipEvent_t flight_done_[2] = {nullptr, nullptr};
+    bool flight_open_[2] = {false, false};     // flight_done_[p] has been recorded and not yet waited for by begin_flight (wait_flight leaves it set: waiting twice is free)
     // streams (engine.cc "streams"): front end / search beside the layer chain, the per-parity buffers that make it safe
     hipStream_t f_stream_ = nullptr, s_stream_ = nullptr, search_stream_ = nullptr;
     std::vector<hipEvent_t> join_ev_; size_t join_pos_ = 0;

@@ -293,16 +293,29 @@ bool Scheduler::detach(Session *s)
 
 SchedStats Scheduler::stats() { std::lock_guard<std::mutex> g(mu_); return stats_; }
 
+size_t Scheduler::latencies(double *out, size_t cap, bool reset)
+{
+    std::lock_guard<std::mutex> g(mu_);
+    const size_t have = lat_ms_.size(), first = lat_n_ > kLatRing ? (size_t)(lat_n_ % kLatRing) : 0;
+    const size_t n = out ? std::min(have, cap) : 0;
+    for (size_t i = 0; i < n; ++i) out[i] = lat_ms_[(first + (have - n) + i) % have];      // the newest n, oldest first
+    const size_t ret = out ? n : have;
+    if (reset) { lat_ms_.clear(); lat_n_ = 0; }
+    return ret;
+}
+
 void Scheduler::submit(int n, Session *const *ss, const short *const *pcm, const size_t *counts, bool flush, bool wait, bool borrow)
 {
     std::vector<Session *> overflowed;
     std::vector<uint64_t> tickets((size_t)n, 0);
     uint64_t done_seen = 0;
+    const auto t_sub = std::chrono::steady_clock::now();
     {
         std::unique_lock<std::mutex> lk(mu_);
         for (int i = 0; i < n; ++i) {
             Session *s = ss[i];
             if (s->closing) continue;
+            if (!s->has_oldest) { s->oldest_submit = t_sub; s->has_oldest = true; }
             if (flush) s->flush_requested = true;
             else {
                 const size_t cnt = counts[i];
@@ -416,8 +429,10 @@ bool Scheduler::collect(std::vector<Session *> &work, std::vector<uint64_t> &tak
     work_seen = work_seq_.load(std::memory_order_acquire);
     if (stop_) return false;
     lap();
+    collect_has_sub_ = false;
     for (Session *s : sessions_) {
         if (s->closing || (!s->fed && !s->flush_requested)) continue;
+        if (s->has_oldest) { if (!collect_has_sub_ || s->oldest_submit < collect_t_sub_) collect_t_sub_ = s->oldest_submit; collect_has_sub_ = true; s->has_oldest = false; }
         s->busy = true;
         s->inflight += 1;
         if (s->borrow_cnt) {
@@ -447,6 +462,7 @@ Scheduler::Flight Scheduler::launch_flight(const std::vector<Session *> &work_in
 {
     Flight f;
     f.work = work_in; f.taken = taken; f.t0 = std::chrono::steady_clock::now();
+    f.t_sub = collect_t_sub_; f.has_sub = collect_has_sub_;      // (a follow-up flight of the same tick keeps the tick's hand-over time)
     std::vector<Session *> &work = f.work;
     f.mark.resize(work.size()); f.chunks0.resize(work.size());
     for (size_t i = 0; i < work.size(); ++i) { f.mark[i] = (uint32_t)work[i]->replay.size(); f.chunks0[i] = work[i]->chunks; }
@@ -487,8 +503,13 @@ void Scheduler::complete_flight(Flight &f)
     tick_.host_ms[5] += lap();
     std::vector<Session *> &work = f.work;
     {   // reference src/april_session.c:456-462: EMA of (processing time x 1.1) / audio time per chunk.  All sessions of a
-        // flight are stepped together, so a chunk's processing time is the flight's wall time over the chunks the session advanced
-        const double tick_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - f.t0).count();
+        // flight are stepped together, so a chunk's processing time is the flight's wall time over the chunks the session advanced.
+        // With two flights in the air a flight's wall time since its launch includes the time it queued behind the one before it:
+        // what it cost is the span since that one completed (the EMA read up to 2 x too high under steady pipelined load)
+        const auto now = std::chrono::steady_clock::now();
+        const auto from = (have_prev_done_ && prev_done_ > f.t0) ? prev_done_ : f.t0;
+        const double tick_ms = std::chrono::duration<double, std::milli>(now - from).count();
+        prev_done_ = now; have_prev_done_ = true;
         const double stride_ms = (double)(model_->host.params.segment_step * model_->host.params.frame_shift_ms);
         for (size_t i = 0; i < work.size(); ++i) {
             Session *s = work[i];
@@ -516,6 +537,11 @@ void Scheduler::complete_flight(Flight &f)
             }
         }
         if (f.final) tick_.ticks++;
+        if (f.final && f.has_sub) {
+            const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - f.t_sub).count();
+            if (lat_ms_.size() < kLatRing) lat_ms_.push_back(ms); else lat_ms_[(size_t)(lat_n_ % kLatRing)] = ms;
+            ++lat_n_;
+        }
         tick_.host_ms[7] += lap();
         stats_.add(tick_);
         tick_ = SchedStats();

@@ -117,6 +117,8 @@ struct Session {
     int inflight = 0;                         // ticks of this session that have been collected and not completed yet (<= 2)
     bool closing = false;
     uint64_t submitted = 0, completed = 0;    // work tickets
+    std::chrono::steady_clock::time_point oldest_submit;   // when the oldest work not yet collected by the stepping thread was handed over
+    bool has_oldest = false;
     std::vector<Event> done_events;           // sync sessions: events waiting for the caller thread
 
     // ---- owned by the stepping thread while busy
@@ -166,6 +168,9 @@ public:
     // until every listed session has at most `max_open` feeds that were submitted and not completed yet (pipelined group feeds)
     void wait_backlog(Session *const *ss, int n, uint64_t max_open);
     SchedStats stats();
+    // hand-over -> delivery latencies (ms) of the last completed ticks, oldest first: from the submit() that queued the oldest work a
+    // flight served to the moment its results were delivered (asynchronous handlers have run; synchronous callers have been released)
+    size_t latencies(double *out, size_t cap, bool reset);
     Engine *engine() { return eng_; }
     bool on_loop_thread() const { return std::this_thread::get_id() == loop_tid_; }
 
@@ -179,6 +184,8 @@ private:
         std::vector<uint32_t> mark;
         std::vector<uint64_t> chunks0, chunks1;
         std::chrono::steady_clock::time_point t0;
+        std::chrono::steady_clock::time_point t_sub;          // hand-over of the oldest work in the flight (submit() of any of its sessions)
+        bool has_sub = false;
     };
     void loop();
     bool collect(std::vector<Session *> &work, std::vector<uint64_t> &taken, bool block, uint64_t &work_seen);
@@ -200,6 +207,8 @@ private:
     // of a 2 ms step): submit() bumps work_seq_, the end of a tick bumps done_seq_
     std::atomic<uint64_t> work_seq_{0}, done_seq_{0};
     int spin_step_us_ = 1000, spin_wait_us_ = 3000;   // APRIL_SPIN_STEP_US / APRIL_SPIN_WAIT_US
+    std::chrono::steady_clock::time_point prev_done_;   // when the previous flight completed (stepping thread only): start of the next flight's own span
+    bool have_prev_done_ = false;
     int wave_min_chunks_ = 2, wave_max_chunks_ = 7;  // APRIL_WAVE_MIN_CHUNKS (0 = chunk steps one by one) / APRIL_WAVE_MAX_CHUNKS: chunk steps of one feed as a wavefront
     int lm_min_chunks_ = 8;                          // APRIL_LM_MIN_CHUNKS: sessions with at least this many chunks waiting take the layer-major path (0 = never)
     void spin_for_done(uint64_t seen);
@@ -208,6 +217,10 @@ private:
     std::thread thread_;
     SchedStats stats_;                             // guarded by mu_
     SchedStats tick_;                              // the stepping thread's own; merged into stats_ under mu_ at the end of a tick
+    std::vector<float> lat_ms_;                    // guarded by mu_: ring of the last kLatRing hand-over -> delivery latencies
+    uint64_t lat_n_ = 0;
+    static constexpr size_t kLatRing = 8192;
+    std::chrono::steady_clock::time_point collect_t_sub_; bool collect_has_sub_ = false;   // stepping thread: oldest hand-over among the work of the last collect()
     std::thread::id loop_tid_;
     // scratch reused across ticks
     std::vector<FbankFrameDesc> desc_;

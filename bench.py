@@ -286,11 +286,15 @@ def main():
 
     run_steps(grp, pcm, 0, args.warmup)
     barrier()
+    model.feed_latencies(reset=True)
     t0 = time.perf_counter()
     run_steps(grp, pcm, args.warmup, n_steps, step_wall)
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    # hand-over -> delivery latency of every tick of the timed region, stamped inside the library (aprilx_model_feed_latency): in
+    # pipelined mode the feed CALL returns as soon as the samples are queued, so its duration is not the latency of a feed
+    feed_lat = model.feed_latencies(reset=True)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -328,15 +332,19 @@ def main():
     barrier()
     a = time.perf_counter()
     ow = []
+    model.feed_latencies(reset=True)
     run_steps(grp, more_o, 4, args.steps + 4, ow, ingest=other)
     barrier()
     el_o = time.perf_counter() - a
+    lat_o = model.feed_latencies(reset=True)
     if world > 1:
         tt = torch.tensor([el_o], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el_o = float(tt.item())
     other_ingest = {"ingest": other, "steps": args.steps, "ms_per_step": round(el_o / args.steps * 1e3, 3), "rtf": round(el_o / (args.steps * 0.1), 5),
-                    "p50": round(float(np.percentile(ow, 50)) * 1e3, 3), "what": "the same sessions, %d further feeds through %s" % (
+                    "p50": round(float(np.percentile(ow, 50)) * 1e3, 3),
+                    "feed_latency_ms": None if lat_o.size == 0 else {"p50": round(float(np.percentile(lat_o, 50)), 3), "p99": round(float(np.percentile(lat_o, 99)), 3), "n": int(lat_o.size)},
+                    "what": "the same sessions, %d further feeds through %s" % (
                         args.steps, "aprilx_feed_many (one blocking call per 100 ms feed: nothing of the next feed can start before the previous one has been delivered)"
                         if other == "lockstep" else "aprilx_feed_many_pipelined depth 2")}
     del more_o
@@ -534,7 +542,8 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16" if d.precision == 1 else "f32", "data": "synthetic",
             "config": {"workload": "aprilv0_en-us dims (synthetic seeded weights), %d concurrent streaming sessions per GPU, "
-                                   "100 ms PCM16 feeds via aprilx_feed_many (BASELINE configs[2]; configs[3] at 8 GPUs)" % B,
+                                   "100 ms PCM16 feeds via %s (BASELINE configs[2]; configs[3] at 8 GPUs)" % (
+                                       B, "aprilx_feed_many_pipelined (depth 2)" if args.ingest == "pipelined" else "aprilx_feed_many (one blocking call per feed)"),
                        "sessions_per_gpu": B, "feed_ms": 100, "params": int(d.param_count), "parallelism": "sessions sharded, dp%d" % world},
             "rtf": round(rtf, 5), "sessions_total": world * B, "pre_roll_steps": args.pre_roll,
             "ingest": {"mode": args.ingest, "what": "aprilx_feed_many_pipelined, depth 2: feed k + 1 is queued (samples copied) while feed k is on the GPU, every callback "
@@ -542,8 +551,18 @@ def main():
                        if args.ingest == "pipelined" else "aprilx_feed_many: one blocking call per feed"},
             "other_ingest": other_ingest, "steady": steady, "config5_f16": config5,
             "rccl_fallback": rccl_fallback, "rccl_libs_mapped": sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln}),
-            "step_latency_ms": {"p50": round(float(np.percentile(step_wall, 50)) * 1e3, 3), "p99": round(float(np.percentile(step_wall, 99)) * 1e3, 3),
-                                "max": round(max(step_wall) * 1e3, 3), "series": [round(x * 1e3, 2) for x in step_wall[:200]], "what": "wall time of one aprilx_feed_many call (100 ms of audio for every session, callbacks delivered), rank 0"},
+            # the duration of the feed CALL: in lockstep mode that is the latency of a feed (the call returns with every callback
+            # delivered); in pipelined mode it is only the hand-over (the call returns when at most one earlier feed is still open)
+            ("step_latency_ms" if args.ingest == "lockstep" else "handover_ms"): {
+                "p50": round(float(np.percentile(step_wall, 50)) * 1e3, 3), "p99": round(float(np.percentile(step_wall, 99)) * 1e3, 3),
+                "max": round(max(step_wall) * 1e3, 3), "series": [round(x * 1e3, 2) for x in step_wall[:200]],
+                "what": ("wall time of one aprilx_feed_many call (100 ms of audio for every session, callbacks delivered), rank 0" if args.ingest == "lockstep" else
+                         "wall time of one aprilx_feed_many_pipelined call, rank 0: the hand-over of 100 ms of audio for every session (returns once at most one earlier feed is open); NOT a latency")},
+            "feed_latency_ms": None if feed_lat.size == 0 else {
+                "p50": round(float(np.percentile(feed_lat, 50)), 3), "p90": round(float(np.percentile(feed_lat, 90)), 3), "p99": round(float(np.percentile(feed_lat, 99)), 3),
+                "max": round(float(feed_lat.max()), 3), "n": int(feed_lat.size), "series": [round(float(x), 2) for x in feed_lat[:200]],
+                "what": "hand-over -> delivery, stamped inside the library (aprilx_model_feed_latency), rank 0: from the feed call that queued the oldest audio a flight "
+                        "served to the moment every callback of that flight had been delivered; with two flights in the air this includes the time queued behind the previous feed"},
             "max_sessions_per_gpu_rtf_le_0.1_tested": max_ok, "rtf_by_sessions_per_gpu": sweep,
             "callbacks": int(counts[0]), "tokens_in_callbacks": int(counts[5]), "model_load_s": round(load_s, 2), "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2), "weight_broadcast": bcast_info,
             "engine_steps": int(st.steps), "host_phase_ms_total": host_ms, "max_batch_seen": int(st.max_batch_seen),

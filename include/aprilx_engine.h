@@ -128,8 +128,9 @@ APRIL_EXPORT void aprilx_session_trace_logits(AprilASRSession session, float *bu
 APRIL_EXPORT uint64_t aprilx_session_chunks(AprilASRSession session);
 /* parity tests of the online fbank (reference src/fbank.c:174-349): copies log-mel rows [first, first + n) of everything the
  * session's feature ring has received so far -- real frames and flush padding, in the order the reference's ring sees them --
- * into out[n][mel] (when they are still in the ring) and returns the number of rows written so far.  Waits for the session
- * to be idle.  Chunk j of the session is rows [j * segment_step, j * segment_step + segment_size).                        */
+ * into out[n][mel] and returns the number of rows written so far; when the range is not (or no longer) in the ring nothing is
+ * copied and UINT64_MAX is returned.  n = 0 / out = NULL: only the count.  Waits for the session to be idle.  Chunk j of the
+ * session is rows [j * segment_step, j * segment_step + segment_size).                                                         */
 APRIL_EXPORT uint64_t aprilx_session_read_frames(AprilASRSession session, uint64_t first, int n, float *out);
 /* The token context as the host's result state machine holds it (host_ctx[2]) and the search state the device keeps for the
    session's slot (device_state[4]: context[0], context[1], last active token or -1, time of the last emission in ms).  The two
@@ -154,6 +155,13 @@ typedef struct AprilxStats {
     uint64_t wave_steps, wave_chunks;/* feeds whose 2..7 chunk steps ran as one wavefront over the layers, and the session-chunks they covered (included in steps / chunks) */
 } AprilxStats;
 APRIL_EXPORT void aprilx_model_stats(AprilASRModel model, int device_index, AprilxStats *out);
+/* Hand-over -> delivery latency of the last (up to 8192) completed ticks of one GPU's stepping thread, in ms, oldest first: from the
+ * feed call (aas_feed_pcm16 / aprilx_feed_many / aprilx_feed_many_pipelined / flush) that queued the oldest work a flight served to
+ * the moment that flight's results were delivered (asynchronous and pipelined sessions: their handlers have run; synchronous callers:
+ * released).  With the pipelined group feed the duration of the feed CALL is only the hand-over; this is the latency a client sees
+ * (reference: the time aas_feed_pcm16 blocks, src/april_session.c:479-538).  out_ms = NULL: returns the number available; reset != 0
+ * empties the ring afterwards.                                                                                                    */
+APRIL_EXPORT int aprilx_model_feed_latency(AprilASRModel model, int device_index, double *out_ms, int cap, int reset);
 /* bracket every launch with hipEvents on the engine's stream (measurement runs only) */
 APRIL_EXPORT void aprilx_model_profile(AprilASRModel model, int enable);
 

@@ -34,6 +34,7 @@ def main():
         else:
             grp.feed_planned_pipelined(k, 2 if mode == "async" else int(mode[4:]))
     grp.drain()
+    lat = m.feed_latencies(reset=True)          # hand-over -> delivery per tick (aprilx_model_feed_latency), before the flush
     if flush:
         grp.flush()
     h = hashlib.sha256()
@@ -43,6 +44,7 @@ def main():
         ntok += sum(len(t) for _, t in events[i])
     st = m.stats()
     print("DIGEST", h.hexdigest(), int(st.chunks), int(st.replay_mismatch), sum(len(e) for e in events), ntok, int(st.flights), flush=True)
+    print("LATENCY", lat.size, "%.4f" % (float(lat.min()) if lat.size else -1.0), "%.4f" % (float(lat.max()) if lat.size else -1.0), flush=True)
     for s in sess:
         s.close()
     m.close()

@@ -21,7 +21,9 @@ def run(path, nsess, steps, mode, feed=1600, flush=1, **env):
                        env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("DIGEST")][-1].split()
-    return dict(digest=line[1], chunks=int(line[2]), mismatch=int(line[3]), calls=int(line[4]), tokens=int(line[5]), flights=int(line[6]))
+    lat = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("LATENCY")][-1].split()
+    return dict(digest=line[1], chunks=int(line[2]), mismatch=int(line[3]), calls=int(line[4]), tokens=int(line[5]), flights=int(line[6]),
+                lat_n=int(lat[1]), lat_min=float(lat[2]), lat_max=float(lat[3]))
 
 
 def test_ingest_modes_give_the_same_callbacks(built, medium_model):
@@ -75,3 +77,13 @@ def test_flights_with_several_steps_pipelined(built, medium_model):
     c = run(path, 16, 6, "async", feed=8000, APRIL_LM_MIN_CHUNKS=0)
     assert a["mismatch"] == b["mismatch"] == c["mismatch"] == 0 and a["chunks"] == b["chunks"] == c["chunks"] > 0
     assert a["digest"] == b["digest"] == c["digest"]
+
+
+def test_feed_latency_is_stamped_inside_the_library(built, medium_model):
+    """aprilx_model_feed_latency: one hand-over -> delivery latency per completed tick.  Lock-step feeds: one tick per feed call;
+    pipelined feeds: feeds may share a tick, never more ticks than feeds; every latency is positive and far below a second here."""
+    path = medium_model["path"]
+    a = run(path, 8, 10, "sync", flush=0)
+    assert a["lat_n"] == 10 and 0.0 < a["lat_min"] <= a["lat_max"] < 2000.0, a
+    b = run(path, 8, 10, "pipe2", flush=0)
+    assert 1 <= b["lat_n"] <= 10 and 0.0 < b["lat_min"] <= b["lat_max"] < 2000.0, b
