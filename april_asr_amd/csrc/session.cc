@@ -468,7 +468,8 @@ Scheduler::Flight Scheduler::launch_flight(const std::vector<Session *> &work_in
     for (size_t i = 0; i < work.size(); ++i) { f.mark[i] = (uint32_t)work[i]->replay.size(); f.chunks0[i] = work[i]->chunks; }
     std::vector<Session *> ready;
     eng_->begin_flight();
-    bool more = false;
+    bool more = false, any = false;
+    const uint64_t steps0 = tick_.steps;
     for (;;) {
         bool progressed = false;
         cut_frames(work, progressed);
@@ -479,6 +480,13 @@ Scheduler::Flight Scheduler::launch_flight(const std::vector<Session *> &work_in
             progressed = true;
         }
         if (!progressed) break;
+        any = true;
+    }
+    if (more && !any && tick_.steps == steps0) {
+        // a step that does not fit an EMPTY flight will never fit: the engine's index / record rings must hold max_batch rows
+        // (engine.cc sizes them so); without this the stepping thread would open flight after flight forever
+        LOGE("scheduler: a chunk step does not fit an empty flight (index / record rings smaller than one step of max_batch rows)");
+        abort();
     }
     Lap lap;
     f.parity = eng_->close_flight();

@@ -1,0 +1,56 @@
+"""The host scheduler under sanitizers ("-fsanitize=thread,address on the host scheduler").
+
+tests/sched_harness/ builds the REAL host runtime -- csrc/session.cc (two flights in the air, spin waits, work / done sequence
+counters, lent buffers), csrc/april_api.cc (the C ABI), csrc/host_pool.h, the loader -- host-only against a fake engine
+(fake_engine.cc: asynchronous flight completion after a random delay, records visible only once a flight has completed, small
+rings, decisions by a copy of the product's own state machine) and drives it through the C ABI in the scenarios of
+test_gpu_pipeline.py / test_gpu_concurrency.py: lock-step, pipelined and asynchronous ingest with identical callbacks, eight client
+threads with their own sessions, session churn beside streaming sessions, frees from inside handlers, queue overflow, irregular and
+long feeds.  Once with -fsanitize=thread, once with -fsanitize=address,undefined; any report, inconsistency, replay mismatch or
+hang fails.  Reference threading contract: src/april_session.c:479-493,567-585, src/audio_provider.c:25-40."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "tests", "sched_harness", "build.sh")
+
+
+def _build(tmp, name, flags):
+    out = os.path.join(str(tmp), name)
+    r = subprocess.run(["bash", BUILD, flags, out], capture_output=True, timeout=900)
+    if r.returncode != 0 and b"sanitizer" in r.stderr.lower() and b"unsupported" in r.stderr.lower():
+        pytest.skip("toolchain without this sanitizer runtime")
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    return out
+
+
+def _run(exe, model, **env):
+    e = dict(os.environ, APRIL_LOG_LEVEL="NONE", TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1")
+    e.update({k: str(v) for k, v in env.items()})
+    r = subprocess.run([exe, model], env=e, capture_output=True, timeout=600)
+    out = r.stdout.decode() + r.stderr.decode()
+    assert "ThreadSanitizer" not in out and "AddressSanitizer" not in out and "runtime error" not in out, out[-4000:]
+    assert r.returncode == 0 and "HARNESS ok" in out, out[-4000:]
+    return out
+
+
+@pytest.fixture(scope="module")
+def harness_dir(tmp_path_factory):
+    return tmp_path_factory.mktemp("sched_harness")
+
+
+def test_scheduler_under_thread_sanitizer(harness_dir, tiny_model):
+    exe = _build(harness_dir, "harness_tsan", "-fsanitize=thread")
+    _run(exe, tiny_model["path"])
+    _run(exe, tiny_model["path"], FAKE_STEP_CAP=1)                      # every flight fills up: follow-up flights of one tick
+    _run(exe, tiny_model["path"], APRIL_PIPELINE=1)                     # one flight at a time
+    _run(exe, tiny_model["path"], FAKE_DELAY_US=0, FAKE_DELAY_US_MAX=5, FAKE_STEP_CAP=2)      # flights complete at once
+    _run(exe, tiny_model["path"], APRIL_SPIN_STEP_US=0, APRIL_SPIN_WAIT_US=0)                 # no spinning: every hand-over through the condition variables
+
+
+def test_scheduler_under_address_and_ub_sanitizers(harness_dir, tiny_model):
+    exe = _build(harness_dir, "harness_asan", "-fsanitize=address,undefined -fno-sanitize-recover=undefined")
+    _run(exe, tiny_model["path"])
+    _run(exe, tiny_model["path"], FAKE_STEP_CAP=1, APRIL_HOST_THREADS=8)
