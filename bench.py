@@ -411,15 +411,24 @@ def main():
     sweep = None
     if rank == 0 and world == 1 and not args.no_sweep:          # single-GPU runs only (the driver computes scaling from per-N values)
         sweep = {}
+        sweep_runs = {}
         for nb in (1, 16, 64, 1024, 2048, 2304, 2560, 2816, 3072):
             ss, gg = make_group(nb, 0)
             wu, ts = 6, 20                                     # (both feed shapes -- 2 and 3 chunks -- are captured during warm-up)
             pp = pcm_for(nb, wu + ts, 20_000_000)
             run_steps(gg, pp, 0, wu)
-            torch.cuda.synchronize(); a = time.perf_counter()
-            run_steps(gg, pp, wu, wu + ts)
-            torch.cuda.synchronize(); b = time.perf_counter()
-            sweep[str(nb)] = round((b - a) / (ts * 0.1), 5)
+            # three timed passes of 20 feeds on the same sessions (the same audio again: only the time matters here), the WORST one
+            # is the point's value -- a capacity claim must not rest on one lucky 20-step run
+            runs = []
+            for rep in range(3 if nb >= 1024 else 1):
+                if rep:
+                    run_steps(gg, pp, 0, wu)                   # (re-plan from the start of the buffer; untimed)
+                torch.cuda.synchronize(); a = time.perf_counter()
+                run_steps(gg, pp, wu, wu + ts)
+                torch.cuda.synchronize(); b = time.perf_counter()
+                runs.append(round((b - a) / (ts * 0.1), 5))
+            sweep[str(nb)] = max(runs)
+            sweep_runs[str(nb)] = runs
             for s in ss:
                 s.close()
         sweep[str(B)] = round(rtf, 5)
@@ -564,6 +573,7 @@ def main():
                 "what": "hand-over -> delivery, stamped inside the library (aprilx_model_feed_latency), rank 0: from the feed call that queued the oldest audio a flight "
                         "served to the moment every callback of that flight had been delivered; with two flights in the air this includes the time queued behind the previous feed"},
             "max_sessions_per_gpu_rtf_le_0.1_tested": max_ok, "rtf_by_sessions_per_gpu": sweep,
+            "rtf_sweep_runs": sweep_runs if sweep else None,      # every timed pass behind a sweep point (3 x 20 feeds from 1024 sessions up; the point is the worst)
             "callbacks": int(counts[0]), "tokens_in_callbacks": int(counts[5]), "model_load_s": round(load_s, 2), "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2), "weight_broadcast": bcast_info,
             "engine_steps": int(st.steps), "host_phase_ms_total": host_ms, "max_batch_seen": int(st.max_batch_seen),
             "kernels_per_chunk_step": int(sp.kernels_per_step) if roofline else None,

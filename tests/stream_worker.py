@@ -43,6 +43,9 @@ def main():
         h.update(repr(events[i]).encode())
         ntok += sum(len(t) for _, t in events[i])
     st = m.stats()
+    per_engine = [int(m.stats(i).chunks) for i in range(16)]          # (device_index beyond the model's engines reads zeros)
+    print("ENGINES", " ".join(str(c) for c in per_engine), flush=True)
+    st.chunks = sum(per_engine); st.replay_mismatch = sum(int(m.stats(i).replay_mismatch) for i in range(16)); st.flights = sum(int(m.stats(i).flights) for i in range(16))
     print("DIGEST", h.hexdigest(), int(st.chunks), int(st.replay_mismatch), sum(len(e) for e in events), ntok, int(st.flights), flush=True)
     print("LATENCY", lat.size, "%.4f" % (float(lat.min()) if lat.size else -1.0), "%.4f" % (float(lat.max()) if lat.size else -1.0), flush=True)
     for s in sess:

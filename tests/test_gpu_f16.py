@@ -73,6 +73,25 @@ def test_f16_networks_match_f16_oracle(f16_models, which):
         assert np.abs(lg[i] - l0.ravel()).max() < 2e-3
 
 
+# BASELINE.md config 5 ("logits tolerance vs fp32 oracle"): binary16 operands (11-bit significands) with fp32 accumulation over
+# K <= 3072 products and twelve to sixteen layers of recurrence leave every joiner logit within 5e-3 of the fp32 semantics on these
+# models (measured 1.3e-3 .. 1.7e-3; logit range ~ +-10); stated here, asserted unconditionally below at tiny, aprilv0 and configs[4] dimensions.
+F16_VS_F32_TOL = 5e-3
+
+
+def f32_distance(lg32, lg16):
+    """max |dlogit| between two per-round logit traces over the rounds both runs took with the SAME history: all rounds up to the first
+    one whose arg-max differs (after a flipped decision the token context differs and the traces are no longer comparable).
+    Returns (max error over that prefix incl. the flipping round, rounds compared, index of the first flip or None)."""
+    n = min(lg32.shape[0], lg16.shape[0])
+    am32, am16 = lg32[:n].argmax(1), lg16[:n].argmax(1)
+    diff = np.nonzero(am32 != am16)[0]
+    flip = int(diff[0]) if diff.size else (None if lg32.shape[0] == lg16.shape[0] else n)
+    upto = n if flip is None else min(n, flip + 1)
+    err = float(np.abs(lg32[:upto] - lg16[:upto]).max()) if upto else 0.0
+    return err, upto, flip
+
+
 def test_f16_batch_invariant_bitwise(f16_models):
     gm, _ = f16_models["tiny"]
     d = gm.dims
@@ -110,10 +129,11 @@ def test_f16_session_against_both_oracles(f16_models, which, secs, request):
         o32.close()
     finally:
         O.set_f16_linear(True)
-    if lg32.shape == lg1.shape:                               # same number of joiner rounds (no token flipped)
-        err32 = float(np.abs(lg32 - lg1).max())
-        print("fp16 mode vs fp32 oracle: max |dlogit| = %.4g (vs fp16-rounding oracle %.4g)" % (err32, err16))
-        assert err32 < 5e-2, err32
+    err32, rounds, flip = f32_distance(lg32, lg1)
+    print("fp16 mode vs fp32 oracle: max |dlogit| = %.4g over %d joiner rounds (vs fp16-rounding oracle %.4g); first decision flip: %s" % (
+        err32, rounds, err16, "none" if flip is None else "round %d" % flip))
+    assert err32 < F16_VS_F32_TOL, err32
+    assert flip is None, "fp16 operands flipped the decision of joiner round %d against the fp32 oracle" % flip
 
 
 def test_config5_f16_larger_encoder_512_sessions(large_model):
@@ -157,6 +177,14 @@ def test_config5_f16_larger_encoder_512_sessions(large_model):
         assert ev1 == evs[i], i
         if i == 0:
             assert lg1.shape == lg0.shape and np.abs(lg1 - lg0).max() < 5e-3, np.abs(lg1 - lg0).max()
+            # the same session against the fp32 semantics (the oracle without operand rounding), at the configs[4] dimensions
+            o32 = O.Model(large_model["path"])
+            _, lg32, _ = run_oracle(o32, pcms[0], 1600)
+            o32.close()
+            err32, rounds, flip = f32_distance(lg32, lg1)
+            print("configs[4] dims, fp16 mode vs fp32 oracle: max |dlogit| = %.4g over %d joiner rounds; first decision flip: %s" % (err32, rounds, "none" if flip is None else "round %d" % flip))
+            assert err32 < F16_VS_F32_TOL, err32
+            assert flip is None, "fp16 operands flipped the decision of joiner round %d against the fp32 oracle" % flip
     for s in sess:
         s.close()
     gm.close()

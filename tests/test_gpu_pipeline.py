@@ -22,8 +22,9 @@ def run(path, nsess, steps, mode, feed=1600, flush=1, **env):
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("DIGEST")][-1].split()
     lat = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("LATENCY")][-1].split()
+    eng = [int(x) for x in [ln for ln in r.stdout.decode().splitlines() if ln.startswith("ENGINES")][-1].split()[1:]]
     return dict(digest=line[1], chunks=int(line[2]), mismatch=int(line[3]), calls=int(line[4]), tokens=int(line[5]), flights=int(line[6]),
-                lat_n=int(lat[1]), lat_min=float(lat[2]), lat_max=float(lat[3]))
+                lat_n=int(lat[1]), lat_min=float(lat[2]), lat_max=float(lat[3]), engines=eng)
 
 
 def test_ingest_modes_give_the_same_callbacks(built, medium_model):
@@ -87,3 +88,18 @@ def test_feed_latency_is_stamped_inside_the_library(built, medium_model):
     assert a["lat_n"] == 10 and 0.0 < a["lat_min"] <= a["lat_max"] < 2000.0, a
     b = run(path, 8, 10, "pipe2", flush=0)
     assert 1 <= b["lat_n"] <= 10 and 0.0 < b["lat_min"] <= b["lat_max"] < 2000.0, b
+
+
+def test_eight_engines_on_one_device(built, medium_model, v0_model):
+    """The per-GPU sharding of BASELINE configs[3] on the one GPU a test box has: APRIL_GPU_DEVICES=0,0,0,0,0,0,0,0 builds eight
+    engines (weights copied device to device from the first), each with its own stepping thread and streams; least-loaded placement
+    (reference load site src/april_model.c:57-61 -> april_api.cc aas_create_session) deals the sessions out evenly, the eight
+    threads step concurrently, and every session produces exactly the callbacks it produces on a single engine."""
+    for path, nsess, steps in ((medium_model["path"], 64, 10), (v0_model["path"], 256, 4)):
+        one = run(path, nsess, steps, "pipe2")
+        eight = run(path, nsess, steps, "pipe2", APRIL_GPU_DEVICES="0,0,0,0,0,0,0,0", APRIL_MAX_SESSIONS=64)
+        assert one["mismatch"] == eight["mismatch"] == 0 and one["chunks"] == eight["chunks"] > 0
+        assert one["digest"] == eight["digest"], "callbacks differ between one engine and eight"
+        used = [c for c in eight["engines"] if c]
+        assert len(used) == 8 and len(set(used)) == 1, "sessions were not dealt evenly: chunks per engine %r" % eight["engines"]
+        assert [c for c in one["engines"] if c] == [one["chunks"]]
