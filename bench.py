@@ -116,6 +116,10 @@ def main():
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] leg (larger encoder, 512 sessions, fp16 MFMA path vs fp32)")
     ap.add_argument("--precision", choices=["f32", "f16"], default="f32",
                     help="f16 = opt-in fp16-operand mode (BASELINE configs[4]); the headline metric is quoted on f32")
+    ap.add_argument("--pipeline-depth", type=int, default=2,
+                    help="feeds per session the pipelined group feed keeps open (aprilx_feed_many_pipelined depth): 2 = one feed queued behind "
+                         "the one on the GPU (default, `value`); deeper queues let the stepping thread find two feeds queued and step them as one "
+                         "wavefront of ~5 chunks -- fewer, larger launches, one more feed of latency (measurement knob, named in the line)")
     ap.add_argument("--ingest", choices=["pipelined", "lockstep"], default="pipelined",
                     help="how the 100 ms feeds reach the library: pipelined = aprilx_feed_many_pipelined depth 2 (the call for feed k + 1 "
                          "returns when feed k is complete: the library prepares and launches a feed while the GPU works on the previous one, as "
@@ -262,7 +266,7 @@ def main():
         pre = pcm_for(B, args.pre_roll, 50_000_000 + rank * B)
         grp.plan(pre, step_samples)
         for s in range(args.pre_roll):
-            (grp.feed_planned if args.ingest == "lockstep" else grp.feed_planned_pipelined)(s)
+            (grp.feed_planned(s) if args.ingest == "lockstep" else grp.feed_planned_pipelined(s, args.pipeline_depth))
         grp.drain()
         del pre
 
@@ -273,7 +277,7 @@ def main():
         ingest = ingest or args.ingest
         if s0 == 0:
             group.plan(pcms, step_samples)       # pointer arrays built outside the timed region
-        feed = group.feed_planned if ingest == "lockstep" else group.feed_planned_pipelined
+        feed = group.feed_planned if ingest == "lockstep" else (lambda k: group.feed_planned_pipelined(k, args.pipeline_depth))
         for s in range(s0, s1):
             if record is None:
                 feed(s)
@@ -555,7 +559,7 @@ def main():
                                        B, "aprilx_feed_many_pipelined (depth 2)" if args.ingest == "pipelined" else "aprilx_feed_many (one blocking call per feed)"),
                        "sessions_per_gpu": B, "feed_ms": 100, "params": int(d.param_count), "parallelism": "sessions sharded, dp%d" % world},
             "rtf": round(rtf, 5), "sessions_total": world * B, "pre_roll_steps": args.pre_roll,
-            "ingest": {"mode": args.ingest, "what": "aprilx_feed_many_pipelined, depth 2: feed k + 1 is queued (samples copied) while feed k is on the GPU, every callback "
+            "ingest": {"mode": args.ingest, "depth": args.pipeline_depth if args.ingest == "pipelined" else 1, "what": "aprilx_feed_many_pipelined, depth 2 by default: feed k + 1 is queued (samples copied) while feed k is on the GPU, every callback "
                                                      "of the K timed feeds is delivered inside the timed region (drain before the closing barrier)"
                        if args.ingest == "pipelined" else "aprilx_feed_many: one blocking call per feed"},
             "other_ingest": other_ingest, "steady": steady, "config5_f16": config5,
