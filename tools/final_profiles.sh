@@ -4,7 +4,7 @@
 # PMC passes at 256 sessions (separate passes, kernel-trace only), the default bench line.  Outputs land in gpurun_out/ and are
 # copied into profiles/ by hand.  (rocprofv3's kernel trace serialises the queues, so the traced runs use the lock-step ingest: one
 # stream's worth of kernels per feed; the overlap of the three streams is shown by APRIL_STREAM_TRACE instead.)
-tag=${1:-r04}
+tag=${1:-r05}
 cd $GRAFT_REPO_ROOT
 export APRIL_LOG_LEVEL=${APRIL_LOG_LEVEL:-WARNING}
 bash tools/trace_pass.sh ${tag}_b256 --ingest lockstep --steps 10 --warmup 4 --no-sweep --no-cpu-baseline --no-config5 --steady-steps 0 --profile-steps 0
@@ -16,6 +16,11 @@ for b in b256 b1 b2048 config5; do
   [ -n "$f" ] && python tools/gap_summary.py "$f" > gpurun_out/${tag}_${b}_gap_summary.txt
 done
 bash tools/pmc_pass.sh ${tag}_b256 --ingest lockstep --steps 4 --warmup 2 --no-sweep --no-cpu-baseline --no-config5 --steady-steps 0 --profile-steps 1
+# the three streams of the default (pipelined) invocation: hipEvent stamps around the front end / layer / search parts of every split feed
+APRIL_STREAM_TRACE=/tmp/${tag}_stream.txt timeout 200 python bench.py --steps 30 --warmup 6 --no-sweep --no-cpu-baseline --no-config5 --steady-steps 0 > /dev/null 2>&1
+[ -f /tmp/${tag}_stream.txt ] && cp /tmp/${tag}_stream.txt gpurun_out/${tag}_stream_overlap_trace.txt
+timeout 120 tools/kw_bench 200 > gpurun_out/${tag}_kw_bench.txt 2>&1
+timeout 120 tools/vmem_mfma_probe > gpurun_out/${tag}_vmem_mfma_probe.txt 2>&1
 timeout 600 python bench.py > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err
 tail -c 2500 gpurun_out/${tag}_bench_default.json
 cat gpurun_out/${tag}_b256_gap_summary.txt gpurun_out/${tag}_b2048_gap_summary.txt gpurun_out/${tag}_config5_gap_summary.txt
