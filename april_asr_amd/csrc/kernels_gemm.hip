@@ -966,7 +966,7 @@ static void plan_kw(const GemmArgs &g, TilePlan &t, int zc)
         mt = (nw == 8 && ((t16 + 255) / 256) * 55 < ((t32 + 255) / 256) * 100) ? 1 : 2;
     }
     if (nw == 4 && mt == 1) mt = 2;
-    t.mt = mt; t.nt = nt; t.zs = g.kz; t.mode = GM_KW;
+    t.mt = mt; t.nt = (mt == 4 && nw == 8 && g.N % 64 == 0) ? 4 : nt; t.zs = g.kz; t.mode = GM_KW;      // (pinned 64-row tiles: 64 x 64, a wave tile of one memory instruction per eight MFMAs)
 }
 
 // plan + checks + measurement knobs: everything launch_gemm decides on the host

@@ -64,6 +64,7 @@ __device__ __forceinline__ void gemm_kw_body(const GemmArgs &g, const int bx, co
     static_assert(ROW_EPI || EPI == EPI_BIAS_DSWISH, "no GM_KW form of this epilogue");
     static_assert(NW == 4 || NW == 8, "four or eight waves");
     static_assert(CPW == 1 || CPW == 4, "a wave owns one chunk or one slab");
+    constexpr bool DB1 = MT * NT >= 16;                    // 64 x 64 wave tiles: the register-lean form of the K loop (below)
     extern __shared__ __attribute__((aligned(1024))) float red[];
     char *lds = reinterpret_cast<char *>(red);
 
@@ -150,10 +151,13 @@ __device__ __forceinline__ void gemm_kw_body(const GemmArgs &g, const int bx, co
     const char *bp = reinterpret_cast<const char *>(g.wp) + ((size_t)nt0 * KB + first_kb) * 1024;
     const size_t bstride = (size_t)KB * 1024;
     const uint32_t boff = (uint32_t)lane * 16u;
-    f32x4 be[D][NT], bo[D][NT];
+    // 64 x 64 wave tiles keep ONE stage of weights in registers (a k block is 64 MFMAs = 2 k cycles: the next block's weights, issued behind
+    // the block that frees their registers, have landed by then); smaller tiles a ring of D stages
+    constexpr int DB = DB1 ? 1 : D;
+    f32x4 be[DB][NT], bo[DB][NT];
 #ifdef APRIL_KW_ABLATE
 #pragma unroll
-    for (int t = 0; t < D; ++t)
+    for (int t = 0; t < DB; ++t)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) { be[t][nt] = f32x4{1.f, 1.f, 1.f, 1.f}; bo[t][nt] = be[t][nt]; }
 #endif
@@ -173,11 +177,13 @@ __device__ __forceinline__ void gemm_kw_body(const GemmArgs &g, const int bx, co
         bp += 1024;
     };
 
-    // ---- what the epilogue reads besides the sums: fetched before the K loop (as in gemm_body)
+    // ---- what the epilogue reads besides the sums: fetched before the K loop (as in gemm_body); the 64 x 64 wave tiles have no registers
+    // to park it in during the loop (accumulators + slab sums + a stage of weights = 224 of 256) and fetch it behind the loop instead
     constexpr int QROW = BN / 4, NQ = BM * QROW, QPT = (NQ + NTH - 1) / NTH;
     f32x4 e_bias[QPT], e_res[ROW_EPI ? QPT : 1];
     int e_slot[ROW_EPI ? QPT : 1];
     bool e_ok[QPT];
+    auto fetch_epilogue_operands = [&]() {
 #pragma unroll
     for (int i = 0; i < QPT; ++i) {
         const int q = threadIdx.x + i * NTH;
@@ -191,6 +197,8 @@ __device__ __forceinline__ void gemm_kw_body(const GemmArgs &g, const int bx, co
             e_res[i] = (EPI == EPI_HR || (EPI == EPI_RESID_SSQ && g.resid)) ? gload<f32x4>(g.resid + (size_t)m * g.ldr + qn) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
+    };
+    if constexpr (!DB1) fetch_epilogue_operands();
 
     // ---- fragment addresses inside a stage buffer: k block p, m tile mt: row 16 mt + mrow, segment (4 p + kq) ^ ((mrow >> 1) & 7)
     const int mrow = lane & 15, kq = lane >> 4;
@@ -215,9 +223,17 @@ __device__ __forceinline__ void gemm_kw_body(const GemmArgs &g, const int bx, co
     int chunk_i = 0, in_chunk = 0;
     auto fold = [&]() {                                   // a chunk chain is complete (CPW == 4: S = ((c0 + c1) + c2) + c3)
         if constexpr (CPW == 4) {
-            if (chunk_i == 0) { APRIL_KW_EACH(S[mt][nt] = acc[mt][nt]) }
-            else { APRIL_KW_EACH(S[mt][nt] = S[mt][nt] + acc[mt][nt]) }
-            APRIL_KW_EACH(acc[mt][nt] = (f32x4{0.f, 0.f, 0.f, 0.f}))
+            // one accumulator tile at a time (pinned): left alone, the scheduler computes all sums into fresh registers first, which at 64 x 64
+            // per wave (64 + 64 registers) overflows the file
+            const bool first = chunk_i == 0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    S[mt][nt] = first ? acc[mt][nt] : S[mt][nt] + acc[mt][nt];
+                    acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (MT * NT >= 16) __builtin_amdgcn_sched_barrier(0);
+                }
             ++chunk_i;
         }
     };
@@ -256,6 +272,54 @@ __device__ __forceinline__ void gemm_kw_body(const GemmArgs &g, const int bx, co
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) { a0[mt] = f32x4{1.f, 1.f, 1.f, 1.f}; a1[mt] = a0[mt]; }
 #endif
+    if constexpr (DB1) {
+        // one stage of weights in registers, two stages of activation rows in the ring (D == 2).  Issue order: DMA(0) DMA(1) Be(0) Bo(0) |
+        // iteration s: {DMA(s + 2), Be(s + 1)} behind the first k block, {Bo(s + 1)} behind the second; the explicit wait in between is for
+        // DMA(s + 1), younger than it: Be(s), Bo(s), DMA(s + 2), Be(s + 1) (the weights are register loads: the compiler's own counts)
+        static_assert(D == 2, "two ring stages");
+        if (g.debug != 1) {
+            issue_dma(0); issue_dma(1); load_b(be[0]); load_b(bo[0]);
+            wait_vm<G::NPIECE + 2 * NT>();                 // DMA(0) has landed
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(0, 0, a0);
+            stamp(1);
+            // m tile outermost: a block's fragment of m tile mt is dead after that tile's 16 MFMAs (k steps in order per accumulator, four
+            // accumulators in rotation), so the NEXT block's fragment is read into the same registers right behind them: one fragment set
+            auto mfma_mt = [&](int mt, const f32x4 (&b)[NT]) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
+            };
+            auto read_frag1 = [&](int slot, int p, int mt) { a0[mt] = *reinterpret_cast<const f32x4 *>(my + slot * G::STAGE_BYTES + a_rd[p] + mt * 2048); };
+            for (int s = 0; s < nstage; ++s) {
+                const int slot = s & 1;
+                const bool more_a = s + 2 < nstage, more_b = s + 1 < nstage;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    mfma_mt(mt, be[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_frag1(slot, 1, mt);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                wait_lgkm0();                              // both k blocks of the buffer are in registers
+                if (more_a) issue_dma(slot);
+                if (more_b) load_b(be[0]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    mfma_mt(mt, bo[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (mt == 0) { if (more_a) wait_vm<G::NPIECE + 3 * NT>(); else if (more_b) wait_vm<3 * NT>(); }      // DMA(s + 1) has landed
+                    read_frag1(slot ^ 1, 0, mt);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (more_b) load_b(bo[0]);
+                if constexpr (CPW == 4) { if (++in_chunk == cs) { in_chunk = 0; fold(); } }
+            }
+        }
+        fetch_epilogue_operands();
+    } else
     if (g.debug != 1) {
 #pragma unroll
         for (int t = 0; t < D; ++t) { issue_dma(t); load_b(be[t]); load_b(bo[t]); }
@@ -475,7 +539,7 @@ int gemm_kw_waves(const GemmArgs &g)
     else if (g.kz == 8 || g.kz == 2) nw = 8;               // one slab / one chunk per wave
     if (!nw) return 0;
     const int nstage = (4 * g.kz / nw) * c / 2;
-    if (nstage < 2 || nstage % 2 != 0) return 0;           // ring depth 2 (4 where nstage allows): whole rounds of the ring
+    if (nstage < 2 || nstage % 2 != 0) return 0;           // ring depth 2 (4 where nstage allows): whole rounds of the ring (the 64 x 64 form takes any nstage >= 2)
     return nw;
 }
 
@@ -488,7 +552,8 @@ void launch_gemm_kw(const GemmArgs &g, int mt, int nt, const GemmArgs *dev_args,
     const int nstage = nw ? (4 * g.kz / nw) * (g.K / 16 / (4 * g.kz)) / 2 : 0;
     if (nw == 8 && ring == 4 && nstage % 4 == 0 && mt == 2 && nt == 2) ok = dispatch_kw<2, 2, 8, 4>(g, dev_args, n, s);
     else if (nw == 8) {
-        if (mt == 2 && nt == 2) ok = dispatch_kw<2, 2, 8, 2>(g, dev_args, n, s);
+        if (mt == 4 && nt == 4) ok = dispatch_kw<4, 4, 8, 2>(g, dev_args, n, s);
+        else if (mt == 2 && nt == 2) ok = dispatch_kw<2, 2, 8, 2>(g, dev_args, n, s);
         else if (mt == 1 && nt == 2) ok = dispatch_kw<1, 2, 8, 2>(g, dev_args, n, s);
     } else if (nw == 4) {
         if (mt == 2 && nt == 4) ok = dispatch_kw<2, 4, 4, 2>(g, dev_args, n, s);

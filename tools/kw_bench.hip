@@ -44,9 +44,9 @@ static Problem make_problem(int M, int N, int K, int kz, int epi, unsigned seed)
     p.slots = dalloc<int>((size_t)M); CK(hipMemcpy(p.slots, perm.data(), (size_t)M * 4, hipMemcpyHostToDevice));
     return p;
 }
-static GemmArgs gemm_of(const Problem &p, int zcount)
+static GemmArgs gemm_of(const Problem &p, int zcount, int tile_ok = 0)
 {
-    GemmArgs g;
+    GemmArgs g; g.tile_ok = tile_ok;
     g.a0 = p.a; g.lda0 = p.K; g.K0 = p.K; g.wp = p.w; g.M = p.M; g.N = p.N; g.K = p.K; g.kz = p.kz; g.zcount = zcount;
     g.epi = p.epi; g.out = p.out; g.ldo = p.N; g.bias = p.bias;
     if (p.epi == EPI_HR) { g.state = p.state; g.ld_state = p.N; g.slot_idx = p.slots; g.resid = p.resid; g.ldr = p.N;
@@ -58,11 +58,11 @@ struct Chain {
     std::vector<GemmArgs> gh; GemmArgs *gd = nullptr; int n = 0;
     void run(hipStream_t s) const { if (n == 1) launch_gemm(gh[0], s); else launch_gemm_z(gh.data(), n, gd, s); }
 };
-static Chain make_chain(const std::vector<Problem> &ps)
+static Chain make_chain(const std::vector<Problem> &ps, int tile_ok = 0)
 {
     Chain c; c.n = (int)ps.size();
     std::vector<GemmArgs> items;
-    for (const Problem &p : ps) items.push_back(gemm_of(p, c.n));
+    for (const Problem &p : ps) items.push_back(gemm_of(p, c.n, tile_ok));
     if (c.n == 1) { c.gh = items; GemmArgs probe; stage_gemm_z(items.data(), 1, &probe); c.gh[0].mode = probe.mode; }      // (launch_gemm plans again; the mode is for the report)
     else {
         c.gh.resize(items.size()); stage_gemm_z(items.data(), c.n, c.gh.data());
@@ -129,6 +129,10 @@ int main(int argc, char **argv)
         {"proj 1024x2", 1024, 512, 1024, 8, EPI_HR, 2},
         {"ffdn 1024x2", 1024, 512, 2048, 8, EPI_RESID_SSQ, 2},
         {"ffdn 2048x2", 2048, 512, 2048, 8, EPI_RESID_SSQ, 2},
+        {"proj 2048x2", 2048, 512, 1024, 8, EPI_HR, 2},
+        {"ffdn 2300x2", 2300, 512, 2048, 8, EPI_RESID_SSQ, 2},          // ragged 64-row tiles
+        {"proj 2048x3", 2048, 512, 1024, 8, EPI_HR, 3},
+        {"ffdn 2048x3", 2048, 512, 2048, 8, EPI_RESID_SSQ, 3},
         {"proj  512x3 L", 512, 768, 1536, 2, EPI_HR, 3},                // larger encoder (configs[4] dims), fp32
         {"ffdn  512x3 L", 512, 768, 3072, 2, EPI_RESID_SSQ, 3},
         {"ffup  512x3 L", 512, 3072, 768, 1, EPI_BIAS_DSWISH, 3},
@@ -145,8 +149,21 @@ int main(int argc, char **argv)
         const std::vector<float> want = snapshot(ps);
         const double t_ref = time_chain(ref, s, iters);
         printf("%-13s M=%d N=%d K=%d kz=%d x%d | round-4 schedule (mode %d): %7.2f us (%.3f of peak)\n", sh.name, sh.M, sh.N, sh.K, sh.kz, sh.n, ref.gh[0].mode, t_ref, flops / (t_ref * 1e-6) / 157.3e12);
-        for (int mt : {0, 2, 1}) {
-            if (mt == 1 && sh.epi == EPI_BIAS_DSWISH) continue;
+        if (sh.epi != EPI_BIAS_DSWISH && gemm_tile_planned(sh.M, sh.N, sh.kz, sh.n) && gemm_fullk(sh.M, sh.N, sh.kz, true, sh.n, 1)) {
+            // GM_TILE with the row work fused, where the engine's planner would take it (for the crossover between the two)
+            gemm_kw_pin(0, 0, 0);
+            Chain ct = make_chain(ps, 1);
+            if (ct.gh[0].mode == GM_TILE) {
+                clear_outputs(ps); ct.run(s); CK(hipStreamSynchronize(s));
+                const std::vector<float> got = snapshot(ps);
+                size_t diff = 0; for (size_t i = 0; i < want.size(); ++i) if (memcmp(&want[i], &got[i], 4) != 0) ++diff;
+                const double t = time_chain(ct, s, iters);
+                printf("    GM_TILE (fused, planner) : %7.2f us (%.3f of peak, %.2fx)  %s\n", t, flops / (t * 1e-6) / 157.3e12, t_ref / t, diff ? "MISMATCH" : "bit-identical");
+                if (diff) ++bad;
+            }
+        }
+        for (int mt : {0, 2, 1, 4}) {
+            if ((mt == 1 || mt == 4) && sh.epi == EPI_BIAS_DSWISH) continue;
             gemm_kw_pin(1, mt, 1);
             Chain c = make_chain(ps);
             if (c.gh[0].mode != GM_KW) { printf("    (GM_KW not planned for this shape, mt pin %d)\n", mt); continue; }
