@@ -999,7 +999,7 @@ static TilePlan finalize_gemm(GemmArgs &g)
     //   workgroups per CU): 91.3 / 170.4   compiler loop, no skew: 56.5 / 100.7 / 180.2;  FFN-up [2048,512]x[512,2048]: 42.3 vs 45.7
     g.asm_loop = asm_loop != 0;
     g.skew = (long)(g.N / (16 * t.nt)) * ((g.M + 16 * t.mt - 1) / (16 * t.mt)) * (t.mode == GM_FULLK ? 1 : g.kz / g.zs) >= 512 ? skew : 0;   // two workgroups per CU
-    static const int kw_skew = env_int("APRIL_KW_SKEW", 8);      // GM_KW: start delay of the second half of a workgroup's waves, x 64 cycles (kernels_gemm_kw.hip)
+    static const int kw_skew = env_int("APRIL_KW_SKEW", 0);      // GM_KW: start delay of the second half of a workgroup's waves, x 64 cycles (measured: no effect; kernels_gemm_kw.hip)
     if (t.mode == GM_KW) g.skew = kw_skew;
     return t;
 }

@@ -263,10 +263,11 @@ __device__ __forceinline__ void gemm_kw_body(const GemmArgs &g, const int bx, co
     // B odd(t)}; iteration s issues LX(s + D) behind its first k block (the buffer of stage s has been read: lgkmcnt(0)) and
     // LY(s + D) behind its second, and waits for LX(s + 1) in between -- (D - 1) GSZ younger operations stay in flight (the tail
     // counts down; the weights are register loads, which the compiler's own counts cover).  Nothing here is shared between waves:
-    // no barrier.  The stage is [MFMA block][issue][MFMA block][issue] with the two issue halves about equal, and the second half of
-    // the waves starts one MFMA block late (g.skew x 64 cycles): the two waves of a SIMD then alternate -- one streams MFMAs while
-    // the other issues its memory operations -- instead of sharing the matrix pipe and then leaving it idle together (measured in
-    // lock-step: 7.0 k cycles per MFMA phase pair for 4.1 k of MFMA, 5.3 k cycles of issue per eight stages on top).
+    // no barrier.  The stage is [MFMA block][issue][MFMA block][issue] with the two issue halves about equal (FFN down, two problems:
+    // 17.0 -> 16.1 us against all issue behind the first block).  g.skew (APRIL_KW_SKEW, default 0) delays the second half of the waves
+    // by that many x 64 cycles at the start: measured 0 .. 14, no effect (profiles/r05_kw_phase_trace.txt) -- the two waves of a SIMD
+    // do not settle into alternating phases, and what a memory instruction costs beside MFMAs does not depend on which wave issues it
+    // (tools/vmem_mfma_probe); kept as a measurement knob.
     f32x4 a0[MT], a1[MT];
 #ifdef APRIL_KW_ABLATE
 #pragma unroll
