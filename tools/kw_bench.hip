@@ -19,7 +19,7 @@ using namespace aprilx;
 template <class T> static T *dalloc(size_t n) { T *p; CK(hipMalloc((void **)&p, n * sizeof(T))); return p; }
 
 struct Problem {
-    int M, N, K, kz, epi;
+    int M, N, K, kz, epi; bool a_indexed = false;      // a_indexed: the activation rows are reached through the row -> slot indirection (aidx0)
     float *a, *w, *bias, *resid, *ssq_in, *out, *state, *ssq_out;
     int *slots;
 };
@@ -47,7 +47,7 @@ static Problem make_problem(int M, int N, int K, int kz, int epi, unsigned seed)
 static GemmArgs gemm_of(const Problem &p, int zcount, int tile_ok = 0)
 {
     GemmArgs g; g.tile_ok = tile_ok;
-    g.a0 = p.a; g.lda0 = p.K; g.K0 = p.K; g.wp = p.w; g.M = p.M; g.N = p.N; g.K = p.K; g.kz = p.kz; g.zcount = zcount;
+    g.a0 = p.a; g.lda0 = p.K; g.K0 = p.K; g.aidx0 = p.a_indexed ? p.slots : nullptr; g.wp = p.w; g.M = p.M; g.N = p.N; g.K = p.K; g.kz = p.kz; g.zcount = zcount;
     g.epi = p.epi; g.out = p.out; g.ldo = p.N; g.bias = p.bias;
     if (p.epi == EPI_HR) { g.state = p.state; g.ld_state = p.N; g.slot_idx = p.slots; g.resid = p.resid; g.ldr = p.N;
                            g.r_scale.ssq = p.ssq_in; g.r_scale.groups = p.N / 32; g.r_scale.inv_n = 1.0f / p.N; g.r_scale.eps = 0.25f; g.bias = nullptr; g.force_fullk = 1; }
@@ -103,7 +103,7 @@ int main(int argc, char **argv)
     const int iters = argc > 1 ? atoi(argv[1]) : 200;
     const int only = argc > 2 ? atoi(argv[2]) : -1;
     hipStream_t s; CK(hipStreamCreate(&s));
-    struct Shape { const char *name; int M, N, K, kz, epi, n; };
+    struct Shape { const char *name; int M, N, K, kz, epi, n; bool idx = false; };
     const Shape shapes[] = {
         {"proj  256x1", 256, 512, 1024, 8, EPI_HR, 1},
         {"proj  256x2", 256, 512, 1024, 8, EPI_HR, 2},
@@ -116,6 +116,7 @@ int main(int argc, char **argv)
         {"ffup  256x3", 256, 2048, 512, 1, EPI_BIAS_DSWISH, 3},
         {"proj  250x2", 250, 512, 1024, 8, EPI_HR, 2},                  // ragged rows
         {"ffdn   40x2", 40, 512, 2048, 8, EPI_RESID_SSQ, 2},
+        {"proj  200x2 i", 200, 512, 1024, 8, EPI_HR, 2, true},          // activation rows through the slot indirection, ragged
         {"ffup   70x3", 70, 2048, 512, 1, EPI_BIAS_DSWISH, 3},
         {"proj   64x3", 64, 512, 1024, 8, EPI_HR, 3},
         {"ffdn   64x3", 64, 512, 2048, 8, EPI_RESID_SSQ, 3},
@@ -141,7 +142,7 @@ int main(int argc, char **argv)
     for (const Shape &sh : shapes) {
         if (only >= 0 && (&sh - shapes) != only) continue;
         std::vector<Problem> ps;
-        for (int i = 0; i < sh.n; ++i) ps.push_back(make_problem(sh.M, sh.N, sh.K, sh.kz, sh.epi, 1000u * (unsigned)(&sh - shapes) + 10u * (unsigned)i));
+        for (int i = 0; i < sh.n; ++i) { ps.push_back(make_problem(sh.M, sh.N, sh.K, sh.kz, sh.epi, 1000u * (unsigned)(&sh - shapes) + 10u * (unsigned)i)); ps.back().a_indexed = sh.idx; }
         const double flops = 2.0 * sh.M * sh.N * sh.K * sh.n;
         gemm_kw_pin(0, 0, 0);
         Chain ref = make_chain(ps);
