@@ -98,7 +98,7 @@ __device__ __forceinline__ void gemm_kw_body(const GemmArgs &g, const int bx, co
     float stg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int TPR = NTH / BM;
     const int ppt = (rsc.groups + TPR - 1) / TPR;
-    const bool staged = NEED_SCL && ppt <= 4;
+    const bool staged = NEED_SCL && ppt <= 4 && !(MT == 1 || MT * NT >= 16);      // (the register-lean forms fetch the partials behind the loop; NEED_SCL is EPI_HR only)
     const int srow = threadIdx.x / TPR, sj0 = (threadIdx.x % TPR) * ppt;
     if (NEED_SCL && staged) {
         int r = m0 + srow;
@@ -198,7 +198,10 @@ __device__ __forceinline__ void gemm_kw_body(const GemmArgs &g, const int bx, co
         }
     }
     };
-    if constexpr (!DB1) fetch_epilogue_operands();
+    // (16-row projection tiles: 80 registers = six waves per SIMD = three workgroups per CU, so that the 768 workgroups of a three-problem
+    // launch are ONE round: 17.7 -> 14.7 us; FFN down, twice the K, is operand-issue bound and LOSES with the third workgroup: 22.5 -> 24.5 us)
+    constexpr bool LATE_EPI = DB1 || (MT == 1 && EPI == EPI_HR);
+    if constexpr (!LATE_EPI) fetch_epilogue_operands();
 
     // ---- fragment addresses inside a stage buffer: k block p, m tile mt: row 16 mt + mrow, segment (4 p + kq) ^ ((mrow >> 1) & 7)
     const int mrow = lane & 15, kq = lane >> 4;
@@ -319,7 +322,6 @@ __device__ __forceinline__ void gemm_kw_body(const GemmArgs &g, const int bx, co
                 if constexpr (CPW == 4) { if (++in_chunk == cs) { in_chunk = 0; fold(); } }
             }
         }
-        fetch_epilogue_operands();
     } else
     if (g.debug != 1) {
 #pragma unroll
@@ -371,6 +373,7 @@ __device__ __forceinline__ void gemm_kw_body(const GemmArgs &g, const int bx, co
             stage(1, false, [] {});
         }
     }
+    if constexpr (LATE_EPI) fetch_epilogue_operands();
     stamp(2);
 #ifdef APRIL_GEMM_TRACE
     if (g.trace && lane == 0 && (wave == 0 || wave == 4)) {      // phase sums of wave 0 and of wave 4 (the younger wave of the same SIMD, as a rule)
@@ -471,16 +474,17 @@ __device__ __forceinline__ void gemm_kw_body(const GemmArgs &g, const int bx, co
 #undef APRIL_KW_EACH
 }
 
-// waves per SIMD the register budget must allow: one eight-wave workgroup per CU (the 128 registers of two spill inside the K loop), three four-wave ones
+// waves per SIMD the register budget must allow: one eight-wave workgroup per CU (the 128 registers of two spill inside the K loop) -- three for the
+// 16-row projection tiles --, three four-wave ones
 template <int MT, int NT, int NW, int EPI, int D, int CPW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void gemm_kw_kernel(GemmArgs g)
+__global__ __launch_bounds__(64 * NW, NW == 8 ? ((MT == 1 && EPI == EPI_HR) ? 6 : 2) : 3) void gemm_kw_kernel(GemmArgs g)
 {
     gemm_kw_body<MT, NT, NW, EPI, D, CPW>(g, (int)blockIdx.x, (int)blockIdx.y, blockIdx.x + gridDim.x * blockIdx.y);
 }
 
 // n independent same-shape problems in one launch (see gemm_f32_zkernel): blockIdx.z picks the argument block
 template <int MT, int NT, int NW, int EPI, int D, int CPW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void gemm_kw_zkernel(const GemmArgs *__restrict__ zargs)
+__global__ __launch_bounds__(64 * NW, NW == 8 ? ((MT == 1 && EPI == EPI_HR) ? 6 : 2) : 3) void gemm_kw_zkernel(const GemmArgs *__restrict__ zargs)
 {
     const GemmArgs g = zargs[blockIdx.z];
     gemm_kw_body<MT, NT, NW, EPI, D, CPW>(g, (int)blockIdx.x, (int)blockIdx.y, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
