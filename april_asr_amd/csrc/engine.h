@@ -14,6 +14,7 @@
 // between feed calls; per joiner round 16 bytes per session come back (StepRecord), once per flight.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include <deque>
 #include <array>
@@ -86,7 +87,7 @@ public:
 
     int alloc_slot();                 // -1 when full; state zeroed (reference calloc, april_session.c:40-58)
     void free_slot(int slot);
-    int live_slots() const { return live_; }
+    int live_slots() const { return live_.load(std::memory_order_relaxed); }      // (read by aas_create_session's least-loaded placement on any thread)
 
     // ---- batched hot path (one stepping thread).  A FLIGHT is everything enqueued between two host waits: frames are cut,
     // chunk steps (encoder + the three joiner/decision/decoder rounds, all on the device) and decoder refreshes are queued
@@ -260,7 +261,7 @@ private:
     // slots
     std::vector<int> free_, zero_pending_;     // free slots (reset), freed slots waiting for their reset launch
     void zero_pending_slots();
-    int live_ = 0;
+    std::atomic<int> live_{0};                  // written under slot_mu_, read without it (live_slots)
     std::mutex slot_mu_;
     std::mutex capture_mu_;                    // held while stream_ is being captured into a graph, and by other threads' enqueues
     // gemm split factors (fixed per shape => batch-invariant numerics)

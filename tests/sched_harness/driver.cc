@@ -186,7 +186,11 @@ int main(int argc, char **argv)
         aas_free(s->h); delete s;
     }
 
-    AprilxStats st; aprilx_model_stats(m, 0, &st);
+    AprilxStats st; memset(&st, 0, sizeof st);
+    for (int dev = 0; dev < 8; ++dev) {                       // every engine of the model (APRIL_GPU_DEVICES=0,0,0: three on the one fake device)
+        AprilxStats one; aprilx_model_stats(m, dev, &one);
+        st.replay_mismatch += one.replay_mismatch; st.chunks += one.chunks; st.flights += one.flights; st.steps += one.steps; st.lm_steps += one.lm_steps; st.wave_steps += one.wave_steps;
+    }
     CHECK(st.replay_mismatch == 0, "replay_mismatch = %llu: the scheduler read records of a flight that had not completed, or replayed them out of order", (unsigned long long)st.replay_mismatch);
     CHECK(st.chunks > 0 && st.flights > 0, "nothing ran");
     double lat[64]; const int nl = aprilx_model_feed_latency(m, 0, lat, 64, 0);

@@ -48,6 +48,8 @@ def test_scheduler_under_thread_sanitizer(harness_dir, tiny_model):
     _run(exe, tiny_model["path"], APRIL_PIPELINE=1)                     # one flight at a time
     _run(exe, tiny_model["path"], FAKE_DELAY_US=0, FAKE_DELAY_US_MAX=5, FAKE_STEP_CAP=2)      # flights complete at once
     _run(exe, tiny_model["path"], APRIL_SPIN_STEP_US=0, APRIL_SPIN_WAIT_US=0)                 # no spinning: every hand-over through the condition variables
+    _run(exe, tiny_model["path"], APRIL_GPU_DEVICES="0,0,0")          # three engines = three stepping threads behind one model; least-loaded placement from client threads
+                                                                         # (found in round 5: Engine::live_slots() read the slot count without the lock -> now atomic)
 
 
 def test_scheduler_under_address_and_ub_sanitizers(harness_dir, tiny_model):
