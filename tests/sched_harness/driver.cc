@@ -73,12 +73,30 @@ static std::vector<uint64_t> stream(AprilASRModel m, int nsess, int steps, size_
     if (mode == THREADS) {
         const int nthreads = 8;
         std::vector<std::thread> th;
+        // a monitoring thread beside the clients: statistics, latencies, the speed-up estimate, idle-session readers
+        std::atomic<bool> mon_stop{false};
+        Sess *idle = make(m, 99u, 3200, 0);
+        aas_feed_pcm16(idle->h, idle->pcm.data(), 3200);
+        std::thread mon([&] {
+            double lat[32]; float rows[80 * 4];
+            while (!mon_stop.load()) {
+                AprilxStats st; aprilx_model_stats(m, 0, &st);
+                (void)aprilx_model_feed_latency(m, 0, lat, 32, 0);
+                for (int i = 0; i < nsess; i += 7) (void)aas_realtime_get_speedup(ss[(size_t)i]->h);
+                int32_t hc[2], dc[4];
+                aprilx_session_context(idle->h, hc, dc);                     // (an idle session's state, while others are stepped)
+                (void)aprilx_session_read_frames(idle->h, 0, 4, rows);
+                (void)aprilx_session_chunks(idle->h);
+            }
+        });
         for (int t = 0; t < nthreads; ++t) th.emplace_back([&, t] {
             for (int k = 0; k < steps; ++k)
                 for (int i = t; i < nsess; i += nthreads) aas_feed_pcm16(ss[(size_t)i]->h, ss[(size_t)i]->pcm.data() + (size_t)k * feed, feed);
             for (int i = t; i < nsess; i += nthreads) aas_flush(ss[(size_t)i]->h);
         });
         for (auto &t : th) t.join();
+        mon_stop.store(true); mon.join();
+        aas_free(idle->h); delete idle;
     } else {
         for (int k = 0; k < steps; ++k) {
             for (int i = 0; i < nsess; ++i) ptr[(size_t)i] = ss[(size_t)i]->pcm.data() + (size_t)k * feed;
