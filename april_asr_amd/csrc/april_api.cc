@@ -48,6 +48,7 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 // ncclCommInitAll) -- the one collective of this system, at model load (reference load site src/april_model.c:57-61).
 bool broadcast_local(Model &m)
 {
+    HipLegacyLock legacy;                   // (device copies / RCCL set-up beside another model's running engines: engine.h)
     std::vector<Engine *> peers;            // one engine per distinct device, root first
     std::vector<int> devs;
     // APRIL_FAULT_RCCL (fault injection, tests): 1 = every engine counts as a broadcast peer even when it shares a device with
@@ -423,6 +424,7 @@ size_t aprilx_model_blob_size(AprilASRModel model)
 
 int aprilx_model_export_blob(AprilASRModel model, void *dst, size_t dst_size)
 {
+    HipLegacyLock legacy;
     const std::string meta = make_meta(model->m);
     BlobHeader hd;
     memcpy(hd.magic, "APXBLOB1", 8);
@@ -520,6 +522,7 @@ AprilASRModel aprilx_model_load_blob(const char *path)
 
 AprilASRModel aprilx_model_from_blob(const void *blob, size_t size, int blob_is_device_ptr)
 {
+    HipLegacyLock legacy;
     // Without an initialised GPU runtime (aam_api_init not called / no device) a HOST blob still
     // yields a host-only model: metadata + packed weights, no engine, no sessions (loader tests,
     // and the gloo leg of the broadcast path on CPU-only machines).
@@ -562,6 +565,7 @@ int aprilx_broadcast_get_id(void *id_out, size_t cap)
 
 AprilASRModel aprilx_model_broadcast(AprilASRModel root_model, int rank, int world, const void *id_bytes)
 {
+    HipLegacyLock legacy;
     if (!g_inited || world < 1 || rank < 0 || rank >= world || !id_bytes) { LOGE("aprilx_model_broadcast: bad arguments or library not initialised"); return nullptr; }
     if (rank == 0 && (!root_model || root_model->m.engines.empty())) { LOGE("aprilx_model_broadcast: rank 0 must pass a model that lives on a GPU"); return nullptr; }
     auto fail = [&](const char *what, ncclResult_t r) { LOGE("RCCL: %s failed: %s", what, ncclGetErrorString(r)); return (AprilASRModel) nullptr; };

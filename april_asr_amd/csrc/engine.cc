@@ -130,6 +130,8 @@ void pack_weights(const HostModel &m, PackedLayout &L, std::vector<float> &blob)
 template <typename T> static T *dmalloc(size_t n) { T *p = nullptr; HIP_CHECK(hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T))); return p; }
 template <typename T> static T *hmalloc(size_t n) { T *p = nullptr; HIP_CHECK(hipHostMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault)); return p; }
 
+std::recursive_mutex &hip_legacy_mutex() { static std::recursive_mutex m; return m; }
+
 static int pick_kz(int K, int N, int kblk = 16)
 {
     int kz = 256 / std::max(1, N / 16);
@@ -142,6 +144,7 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
                const ModelParams &params, const FbankHostTables &ft, const std::vector<uint8_t> &tok_class)
     : cfg_(cfg), L_(layout), P_(params)
 {
+    HipLegacyLock legacy;                      // (allocations, memsets and copies on the legacy stream: not while another engine captures a graph)
     HIP_CHECK(hipSetDevice(cfg_.device));
     {
         // APRIL_STREAM_PRIO (measurement): 1 = the layer stream at the device's highest priority, front end and search at the lowest;
@@ -293,6 +296,7 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
 
 void Engine::finish_weights()
 {
+    HipLegacyLock legacy;
     HIP_CHECK(hipSetDevice(cfg_.device));
     if (cfg_.precision == 1 && !wh_) {
         // fp16 operand mode (BASELINE configs[4]): every Linear / LSTM weight matrix gets an fp16 copy in the same
@@ -352,6 +356,7 @@ void Engine::build_dec_table()
 
 Engine::~Engine()
 {
+    HipLegacyLock legacy;
     (void)hipSetDevice(cfg_.device);
     (void)hipStreamSynchronize(f_stream_); (void)hipStreamSynchronize(stream_); (void)hipStreamSynchronize(s_stream_);
     dump_stream_trace();
@@ -474,6 +479,14 @@ void Engine::sync()
     if (profiling_) collect_timing();
 }
 
+// Graph captures use hipStreamCaptureModeRelaxed AND hold hip_legacy_mutex() (engine.h): a capture begun in the thread-local (or
+// global) mode makes every "potentially unsafe" HIP call -- hipMalloc, hipMemcpy, hipFree ... -- of every OTHER thread that is in the
+// default global mode fail with hipErrorStreamCaptureUnsupported for as long as the capture lasts; in relaxed mode a legacy-stream copy
+// of another thread still fails ("would make the legacy stream depend on a capturing blocking stream", although the streams here are
+// non-blocking) and invalidates the capture.  Client threads make exactly such calls: another model being loaded,
+// aprilx_session_read_frames / aprilx_session_context on an idle session while other sessions stream (found in round 5 by running
+// tests/sched_harness/driver.cc against the real engine: the reader's hipMemcpy aborted the process).  The stepping thread itself
+// issues nothing but kernel launches, async copies and event records inside a capture.
 // ---------------------------------------------------------------- streams
 // Three in-order streams.  stream_ (M) carries the layer chain and every launch of the general paths; f_stream_ (F) the PCM
 // upload and the fbank kernel of every flight and, for a feed that runs as a split wavefront (lm_step mode 1), its index fetch
@@ -1228,7 +1241,8 @@ void Engine::run_lm_wavefront(int m, int T, bool dump_logits)
                 if (lm_search_graphs_.size() >= 64) { HIP_CHECK(hipStreamSynchronize(stream_)); /* execs launched earlier in this flight may still run */ for (auto &g : lm_search_graphs_) (void)hipGraphExecDestroy(g.second); lm_search_graphs_.clear(); }
                 hipGraph_t graph = nullptr;
                 hipGraphExec_t exec = nullptr;
-                HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+                HipLegacyLock capture_guard_1;      // (no legacy-stream call of any thread during the capture: see engine.h)
+                HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeRelaxed));
                 search();
                 HIP_CHECK(hipStreamEndCapture(stream_, &graph));
                 HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
@@ -1428,7 +1442,8 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
                     hipStream_t on[3] = {fe, stream_, s_stream_};
                     for (int part = 0; part < 3; ++part) {
                         hipGraph_t graph = nullptr;
-                        HIP_CHECK(hipStreamBeginCapture(on[part], hipStreamCaptureModeThreadLocal));
+                        HipLegacyLock capture_guard_2;      // (no legacy-stream call of any thread during the capture: see engine.h)
+                        HIP_CHECK(hipStreamBeginCapture(on[part], hipStreamCaptureModeRelaxed));
                         run_sw_chain(m, T, false, pl, part, on[part]);
                         HIP_CHECK(hipStreamEndCapture(on[part], &graph));
                         HIP_CHECK(hipGraphInstantiate(&pl.g3[part], graph, nullptr, nullptr, 0));
@@ -1437,7 +1452,8 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
                 } else {
                     if (pl.graph) continue;
                     hipGraph_t graph = nullptr;
-                    HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+                    HipLegacyLock capture_guard_3;      // (no legacy-stream call of any thread during the capture: see engine.h)
+                    HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeRelaxed));
                     run_sw_chain(m, T, false, pl, -1, stream_);
                     HIP_CHECK(hipStreamEndCapture(stream_, &graph));
                     HIP_CHECK(hipGraphInstantiate(&pl.graph, graph, nullptr, nullptr, 0));
@@ -1495,7 +1511,8 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
                 if (lm_graphs_.size() >= 32) { sync(); for (auto &g : lm_graphs_) (void)hipGraphExecDestroy(g.second); lm_graphs_.clear(); }
                 hipGraph_t graph = nullptr;
                 hipGraphExec_t exec = nullptr;
-                HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+                HipLegacyLock capture_guard_4;      // (no legacy-stream call of any thread during the capture: see engine.h)
+                HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeRelaxed));
                 run_lm_chain(m, T, false);
                 HIP_CHECK(hipStreamEndCapture(stream_, &graph));
                 HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
@@ -1577,7 +1594,8 @@ int Engine::step(int m, const int *slots, const int *ring_tails, const int *now_
                 select_parity(q);
                 hipGraph_t graph = nullptr;
                 hipGraphExec_t exec = nullptr;
-                HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+                HipLegacyLock capture_guard_5;      // (no legacy-stream call of any thread during the capture: see engine.h)
+                HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeRelaxed));
                 run_chain(m, false);
                 HIP_CHECK(hipStreamEndCapture(stream_, &graph));
                 HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
@@ -1677,6 +1695,7 @@ void Engine::zero_slots(int n)
 
 void Engine::debug_encoder(int n, const float *x, const float *h, const float *c, float *eout, float *h2, float *c2)
 {
+    HipLegacyLock legacy;
     HIP_CHECK(hipSetDevice(cfg_.device));
     const NetDims &d = L_.dims;
     const size_t S = (size_t)cfg_.max_slots;
@@ -1709,6 +1728,7 @@ void Engine::debug_encoder(int n, const float *x, const float *h, const float *c
 
 void Engine::debug_decoder(int n, const int64_t *ctx, float *dout)
 {
+    HipLegacyLock legacy;
     HIP_CHECK(hipSetDevice(cfg_.device));
     const NetDims &d = L_.dims;
     if (n > cfg_.max_batch) { LOGE("debug_decoder: n too large"); abort(); }
@@ -1738,6 +1758,7 @@ void Engine::debug_decoder(int n, const int64_t *ctx, float *dout)
 
 void Engine::debug_joiner(int n, const float *eout, const float *dout, float *logits)
 {
+    HipLegacyLock legacy;
     const NetDims &d = L_.dims;
     HIP_CHECK(hipSetDevice(cfg_.device));
     if (n > cfg_.max_batch) { LOGE("debug_joiner: n too large"); abort(); }
@@ -1764,6 +1785,7 @@ void Engine::debug_joiner(int n, const float *eout, const float *dout, float *lo
 
 void Engine::debug_decide(int n, int op, const float *logits, float early_emit, const int *now_ms, int round, int32_t *state_io, StepRecord *rec_out)
 {
+    HipLegacyLock legacy;
     const NetDims &d = L_.dims;
     HIP_CHECK(hipSetDevice(cfg_.device));
     if (n > cfg_.max_batch || n > cfg_.max_slots) { LOGE("debug_decide: n too large"); abort(); }
@@ -1805,6 +1827,7 @@ void Engine::debug_decide(int n, int op, const float *logits, float early_emit, 
 
 void Engine::debug_fbank(int n_frames, const int16_t *pcm_frames, float *out)
 {
+    HipLegacyLock legacy;
     // every frame goes to slot 0, consecutive ring rows (n_frames <= ring_frames)
     const int padded = ft_.padded;
     std::vector<FbankFrameDesc> desc((size_t)n_frames);
@@ -1817,6 +1840,7 @@ void Engine::debug_fbank(int n_frames, const int16_t *pcm_frames, float *out)
 
 void Engine::read_greedy_state(int slot, GreedyState *out)
 {
+    HipLegacyLock legacy;
     HIP_CHECK(hipSetDevice(cfg_.device));
     sync_streams();
     HIP_CHECK(hipMemcpy(out, gstate_ + slot, sizeof(GreedyState), hipMemcpyDeviceToHost));
@@ -1824,6 +1848,7 @@ void Engine::read_greedy_state(int slot, GreedyState *out)
 
 void Engine::read_ring(int slot, int row, int n_rows, float *out)
 {
+    HipLegacyLock legacy;
     HIP_CHECK(hipSetDevice(cfg_.device));
     sync_streams();
     const int nb = ft_.nbins;

@@ -54,6 +54,15 @@ std::vector<std::pair<size_t, size_t>> gemm_sections(const PackedLayout &L);
 // fills `blob` (L.total floats) from the neutral host weights
 void pack_weights(const HostModel &m, PackedLayout &L, std::vector<float> &blob);
 
+// Process-wide lock between graph captures and everything that uses the LEGACY stream or allocates (hipMemcpy, hipMemset, hipMalloc,
+// hipFree ...).  While any stream of the process is being captured, such a call from another thread fails
+// ("operation would make the legacy stream depend on a capturing blocking stream" / hipErrorStreamCaptureUnsupported) and poisons the
+// capture -- measured on ROCm 7.2 also for non-blocking streams and relaxed-mode captures -- and client threads make such calls: a
+// second model being loaded, aprilx_session_read_frames / aprilx_session_context on an idle session, blob export.  Captures hold the
+// lock for their few milliseconds, the legacy-stream users for theirs.  Recursive: the debug entry points hold it and may capture.
+std::recursive_mutex &hip_legacy_mutex();
+struct HipLegacyLock { std::lock_guard<std::recursive_mutex> g; HipLegacyLock() : g(hip_legacy_mutex()) {} };
+
 struct EngineConfig {
     int device = 0;
     int max_slots = 4096;
@@ -143,7 +152,7 @@ public:
     KernelTiming timing(int cls) const { return timing_[cls]; }
     void reset_timing();
     enum { T_GATES = 0, T_GEMM_OTHER = 1, T_ROW = 2, T_CONV = 3, T_FBANK = 4, T_DEC = 5, T_COUNT = 6 };
-    long kernels_per_step() const { return kernels_per_step_; }    // launches of the last eagerly issued chunk chain
+    long kernels_per_step() const { return kernels_per_step_.load(std::memory_order_relaxed); }    // launches of the last eagerly issued chunk chain
 
 private:
     void upload_tables(const FbankHostTables &ft);
@@ -281,7 +290,8 @@ private:
     GemmArgs *zargs_h_ = nullptr, *zargs_d_ = nullptr; size_t zargs_region_ = 0, zargs_pos_ = 0;     // three regions, round robin
     hipEvent_t zargs_done_[3] = {nullptr, nullptr, nullptr}; bool zargs_busy_[3] = {false, false, false}; int zargs_next_ = 0;
     int *lm_now_d_ = nullptr, *lm_rows_d_ = nullptr, *lm_rec_off_d_ = nullptr;
-    long kernels_per_step_ = 0, launch_count_ = 0;
+    std::atomic<long> kernels_per_step_{0};    // written by the stepping thread, read by aprilx_model_stats on any thread
+    long launch_count_ = 0;
     // profiling
     bool profiling_ = false;
     struct Ev { hipEvent_t a, b; int cls; };

@@ -137,7 +137,7 @@ int main(int argc, char **argv)
     // 1. the same sessions through every ingest mode: identical callbacks
     int calls = 0;
     const std::vector<uint64_t> ref = stream(m, NS, STEPS, 1600, LOCKSTEP, &calls);
-    CHECK(calls > NS, "the fake search produced only %d callbacks", calls);
+    CHECK(calls >= NS, "only %d callbacks in the reference pass", calls);
     const std::vector<uint64_t> a = stream(m, NS, STEPS, 1600, PIPE2), b = stream(m, NS, STEPS, 1600, ASYNC_PIPE2), c = stream(m, NS, STEPS, 1600, THREADS);
     CHECK(a == ref, "pipelined group feed: callbacks differ from the lock-step feed");
     CHECK(b == ref, "asynchronous sessions: callbacks differ from the lock-step feed");
