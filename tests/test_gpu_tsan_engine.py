@@ -29,3 +29,16 @@ def test_real_engine_scenarios_under_tsan(built, tiny_model):
         assert "HARNESS ok" in out, (extra, out[-4000:])
         assert "WARNING: ThreadSanitizer" not in out, (extra, out[:6000])
         assert r.returncode == 0, (extra, out[-2000:])
+
+
+def test_real_engine_scenarios_under_asan_ubsan(built, tiny_model):
+    """the same driver and engine under -fsanitize=address,undefined (host heap / stack / UB in engine.cc's staging, index rings, plans)"""
+    exe = os.path.join(ROOT, "tools", "asan_gpu_driver")
+    if not os.path.exists(exe):
+        subprocess.check_call(["bash", os.path.join(ROOT, "tools", "build_tsan_gpu_driver.sh")], timeout=1500)
+    env = dict(os.environ, APRIL_LOG_LEVEL="NONE", ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0", UBSAN_OPTIONS="halt_on_error=1")
+    for extra in ({}, {"APRIL_GPU_DEVICES": "0,0"}):
+        r = subprocess.run([exe, tiny_model["path"]], env=dict(env, **extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        out = r.stdout.decode() + r.stderr.decode()
+        assert "HARNESS ok" in out and r.returncode == 0, (extra, out[-4000:])
+        assert "AddressSanitizer" not in out and "runtime error" not in out, (extra, out[:6000])
