@@ -176,6 +176,33 @@ int main(int argc, char **argv)
         for (int i = 0; i < 20; ++i) CHECK(got[(size_t)i] == ref[(size_t)i], "churn: session %d differs from the reference run", i);
     }
 
+    // 2b. a second model is loaded, used and freed while client threads stream on the first (engine construction / destruction -- device
+    // allocations, copies on the legacy stream, table builds -- beside the first model's graph captures and launches)
+    {
+        std::vector<std::thread> th;
+        std::vector<uint64_t> got(12, 0);
+        for (int t = 0; t < 3; ++t) th.emplace_back([&, t] {
+            std::vector<Sess *> mine;
+            for (int i = 0; i < 4; ++i) mine.push_back(make(m, 4242u + (unsigned)(t * 4 + i), 1600 * (size_t)STEPS, 0));
+            for (int k = 0; k < STEPS; ++k) for (Sess *s : mine) aas_feed_pcm16(s->h, s->pcm.data() + (size_t)k * 1600, 1600);
+            for (Sess *s : mine) aas_flush(s->h);
+            for (int i = 0; i < 4; ++i) { got[(size_t)(t * 4 + i)] = mine[(size_t)i]->digest; aas_free(mine[(size_t)i]->h); delete mine[(size_t)i]; }
+        });
+        std::vector<uint64_t> second;
+        th.emplace_back([&] {
+            for (int rep = 0; rep < 2; ++rep) {
+                AprilASRModel m2 = aam_create_model(argv[1]);
+                if (!m2) { fprintf(stderr, "second model failed to load\n"); ++g_fail; return; }
+                second = stream(m2, 6, 8, 1600, rep ? PIPE2 : LOCKSTEP);
+                aam_free(m2);
+            }
+        });
+        for (auto &t : th) t.join();
+        for (int i = 0; i < 12; ++i) CHECK(got[(size_t)i] == ref[(size_t)i], "second model beside the first: session %d of the first model differs", i);
+        const std::vector<uint64_t> alone = stream(m, 6, 8, 1600, LOCKSTEP);
+        CHECK(second == alone, "the second model's sessions differ from the same sessions on the first model");
+    }
+
     // 3. frees from inside a handler
     {
         FreeCtx ctx;

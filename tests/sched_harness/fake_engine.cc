@@ -60,6 +60,8 @@ uint32_t mix(uint32_t a, uint32_t b, uint32_t c)
 
 }  // namespace
 
+std::recursive_mutex &hip_legacy_mutex() { static std::recursive_mutex m; return m; }
+
 void plan_layout(const NetDims &d, bool has_dec_conv_b, PackedLayout &L)
 {
     L = PackedLayout();
