@@ -952,7 +952,17 @@ static void plan_kw(const GemmArgs &g, TilePlan &t, int zc)
 {
     static const int enabled = env_int("APRIL_GM_KW", 1), min_rows = env_int("APRIL_KW_MIN_ROWS", 33), max_rows = env_int("APRIL_KW_MAX_ROWS", 1 << 30);
     static const int ff1 = env_int("APRIL_KW_FF1", 0), env_mt = env_int("APRIL_KW_MT", 0);
-    if (!(g_kw_enable < 0 ? enabled : g_kw_enable) || t.mode == GM_TILE || t.zs != g.kz) return;
+    if (!(g_kw_enable < 0 ? enabled : g_kw_enable) || t.zs != g.kz) return;
+    if (t.mode == GM_TILE) {
+        // a FUSED GM_TILE plan (all of K in the workgroup: the same caller-visible shape) keeps the launch unless its tiles fill the 512
+        // resident slots badly: half a round or less, or a small remainder behind whole rounds (tools/kw_bench, FFN down: 512 x 2 rows
+        // 31.3 (GM_TILE) vs 29.6 us (GM_KW); 768 x 3: 64.8 vs 59.0; 2300 x 2: 117 vs 112; but 1024 x 2: 47 vs 54, 2048 x 3: 123 vs 147)
+        static const int over_tile = env_int("APRIL_KW_OVER_TILE", 1);
+        if (!over_tile || (g.epi != EPI_HR && g.epi != EPI_RESID_SSQ) || t.nt != 4) return;
+        const long tiles = (long)(g.N / 64) * ((g.M + 16 * t.mt - 1) / (16 * t.mt)) * zc;
+        const long rem = tiles % 512;
+        if (!(tiles <= 256 || (tiles > 512 && rem > 0 && rem <= 128))) return;
+    }
     if (g.M < min_rows || g.M > max_rows) return;
     if (g.epi == EPI_BIAS_DSWISH ? !(g_kw_ff1 < 0 ? ff1 : g_kw_ff1) : (g.epi != EPI_HR && g.epi != EPI_RESID_SSQ)) return;
     const int nw = gemm_kw_waves(g);
