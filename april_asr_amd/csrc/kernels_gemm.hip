@@ -950,7 +950,7 @@ static int g_kw_enable = -1, g_kw_pin_mt = 0, g_kw_ff1 = -1;
 void gemm_kw_pin(int enable, int mt, int ff1) { g_kw_enable = enable; g_kw_pin_mt = mt; g_kw_ff1 = ff1; }
 static void plan_kw(const GemmArgs &g, TilePlan &t, int zc)
 {
-    static const int enabled = env_int("APRIL_GM_KW", 1), min_rows = env_int("APRIL_KW_MIN_ROWS", 33), max_rows = env_int("APRIL_KW_MAX_ROWS", 1 << 30);
+    static const int enabled = env_int("APRIL_GM_KW", 1), min_rows = env_int("APRIL_KW_MIN_ROWS", 3), max_rows = env_int("APRIL_KW_MAX_ROWS", 1 << 30);
     static const int ff1 = env_int("APRIL_KW_FF1", 0), env_mt = env_int("APRIL_KW_MT", 0);
     if (!(g_kw_enable < 0 ? enabled : g_kw_enable) || t.zs != g.kz) return;
     if (t.mode == GM_TILE) {
@@ -1014,10 +1014,20 @@ static TilePlan finalize_gemm(GemmArgs &g)
     return t;
 }
 
+// GM_KW instead of the weight-stream row kernel of kernels_recur.hip for the FFN-down GEMM from APRIL_KW_MIN_ROWS (3) rows:
+// 16 x 32 tiles on eight waves against two 16-column tiles on sixteen waves -- 4 / 8 / 16 sessions 0.499 / 0.537 / 0.602 -> 0.475 / 0.496 / 0.527 ms
+// per 100 ms feed, one or two rows the same within the noise (they stay on the stream kernels, as does the recurrent pair of a long feed)
+static bool kw_before_recur(const GemmArgs &g)
+{
+    static const int enabled = env_int("APRIL_GM_KW", 1), min_rows = env_int("APRIL_KW_MIN_ROWS", 3);
+    // (FFN down only: 9.5 .. 12.8 -> 8.2 us per launch at 8 .. 16 rows; the projection's stream kernel is the faster one there, 4.7 .. 5.4 vs 5.8 us)
+    return (g_kw_enable < 0 ? enabled : g_kw_enable) && min_rows <= 16 && g.M >= min_rows && g.M <= 16 && g.epi == EPI_RESID_SSQ && gemm_kw_waves(g) != 0;
+}
+
 void launch_gemm(const GemmArgs &g_in, hipStream_t s)
 {
     GemmArgs g = g_in;
-    if (const int rf = recur_form(g)) { launch_recur(g, rf, nullptr, 1, s); return; }
+    if (!kw_before_recur(g)) if (const int rf = recur_form(g)) { launch_recur(g, rf, nullptr, 1, s); return; }
     const TilePlan t = finalize_gemm(g);
     if (t.mode == GM_TILE) { launch_gemm_tile(g, t.mt, t.nt, nullptr, 0, s); return; }
     if (t.mode == GM_KW) { launch_gemm_kw(g, t.mt, t.nt, nullptr, 0, s); return; }
@@ -1091,7 +1101,7 @@ void launch_gemm_z(const GemmArgs *staged, int n, const GemmArgs *dev_args, hipS
 {
     if (n <= 0) return;
     const GemmArgs &g = staged[0];
-    if (const int rf = recur_form(g)) { launch_recur(g, rf, dev_args, n, s); return; }      // (stage_gemm_z checked that the n problems have one shape)
+    if (!kw_before_recur(g)) if (const int rf = recur_form(g)) { launch_recur(g, rf, dev_args, n, s); return; }      // (stage_gemm_z checked that the n problems have one shape)
     GemmArgs probe = g;
     const TilePlan t = finalize_gemm(probe);
     if (t.mode == GM_TILE) { launch_gemm_tile(g, t.mt, t.nt, dev_args, n, s); return; }

@@ -105,6 +105,11 @@ int main(int argc, char **argv)
     hipStream_t s; CK(hipStreamCreate(&s));
     struct Shape { const char *name; int M, N, K, kz, epi, n; bool idx = false; };
     const Shape shapes[] = {
+        {"proj    4x3", 4, 512, 1024, 8, EPI_HR, 3},                     // <= 16 rows: the reference is the weight-stream kernel of kernels_recur.hip
+        {"ffdn    8x2", 8, 512, 2048, 8, EPI_RESID_SSQ, 2},
+        {"proj   16x3", 16, 512, 1024, 8, EPI_HR, 3},
+        {"ffdn   16x3", 16, 512, 2048, 8, EPI_RESID_SSQ, 3},
+        {"ffdn   13x1", 13, 512, 2048, 8, EPI_RESID_SSQ, 1},
         {"proj  256x1", 256, 512, 1024, 8, EPI_HR, 1},
         {"proj  256x2", 256, 512, 1024, 8, EPI_HR, 2},
         {"proj  256x3", 256, 512, 1024, 8, EPI_HR, 3},
