@@ -964,6 +964,18 @@ static void plan_kw(const GemmArgs &g, TilePlan &t, int zc)
         if (!(tiles <= 256 || (tiles > 512 && rem > 0 && rem <= 128))) return;
     }
     if (g.M < min_rows || g.M > max_rows) return;
+    if (g.epi == EPI_LSTM) {
+        // MEASUREMENT FORM, off by default (APRIL_KW_GATES=1): the gates GEMM with its activation rows through the wave-private LDS rings, four
+        // waves = the four chunks, 32 / 64 x 32 tiles.  The idea: at one 64-row problem per launch the K-split 64 x 16 tiles spend 19.8 k cycles
+        // in a K loop of 8.2 k cycles of MFMA on their 16-row x 64-byte fragment loads (profiles/r05_gates_ffup_phase_trace.txt).  Bit-identical
+        // (tools/kw_bench), but the z-batched launches of the engine already run 64 x 32 / 64 x 64 hand-scheduled tiles that are within 25 % of
+        // their MFMA time: 64 rows x 1 / 2 / 3 problems 12.8 / 14.9 / 24.0 us (K-split) vs 9.5 / 15.0 / 23.8 (best GM_KW tile), 128 x 2:
+        // 22.8 vs 30.3, 256 x 2: 40.1 vs 55.3 -- a gain only for one-problem launches, a loss from 96 rows up.
+        static const int gates = env_int("APRIL_KW_GATES", 0), gates_max = env_int("APRIL_KW_GATES_MAX_ROWS", 96);
+        if (!gates || g.M < 17 || g.M > gates_max || gemm_kw_waves(g) != 4) return;
+        t.mt = g_kw_pin_mt ? g_kw_pin_mt : (g.M > 32 ? 4 : 2); t.nt = 2; t.zs = 1; t.mode = GM_KW;
+        return;
+    }
     if (g.epi == EPI_BIAS_DSWISH ? !(g_kw_ff1 < 0 ? ff1 : g_kw_ff1) : (g.epi != EPI_HR && g.epi != EPI_RESID_SSQ)) return;
     const int nw = gemm_kw_waves(g);
     if (!nw) return;

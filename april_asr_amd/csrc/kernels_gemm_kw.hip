@@ -61,7 +61,9 @@ __device__ __forceinline__ void gemm_kw_body(const GemmArgs &g, const int bx, co
     using G = KwGeom<MT, NT, NW, D>;
     constexpr int BM = G::BM, BN = G::BN, LDR = G::LDR, NTH = G::NTH, PLANE = G::PLANE;
     constexpr bool ROW_EPI = EPI == EPI_HR || EPI == EPI_RESID_SSQ;
-    static_assert(ROW_EPI || EPI == EPI_BIAS_DSWISH, "no GM_KW form of this epilogue");
+    constexpr bool LSTM = EPI == EPI_LSTM;                // gates: A = [y | h(slot)] in two K segments, four waves = the four chunks, cell epilogue
+    static_assert(ROW_EPI || EPI == EPI_BIAS_DSWISH || LSTM, "no GM_KW form of this epilogue");
+    static_assert(!LSTM || (NW == 4 && CPW == 1), "the gates GEMM has one slab: a chunk per wave");
     static_assert(NW == 4 || NW == 8, "four or eight waves");
     static_assert(CPW == 1 || CPW == 4, "a wave owns one chunk or one slab");
     constexpr bool DB1 = MT * NT >= 16;                    // 64 x 64 wave tiles: the register-lean form of the K loop (below)
@@ -92,8 +94,9 @@ __device__ __forceinline__ void gemm_kw_body(const GemmArgs &g, const int bx, co
     const int cs = c >> 1;                                // stages per chunk
 
     // ---- BasicNorm scale of the residual rows (EPI_HR): partials fetched first thing, reduced through LDS after the K loop
-    const RowScale &rsc = g.r_scale;
-    const bool NEED_SCL = EPI == EPI_HR && rsc.ssq != nullptr;
+    // (EPI_LSTM: the scale of x = y * scale(y), folded into the sum of the y half: ((p0 + p1) * scale + p2) + p3)
+    const RowScale &rsc = LSTM ? g.x_scale : g.r_scale;
+    const bool NEED_SCL = (EPI == EPI_HR || LSTM) && rsc.ssq != nullptr;
     float *scl = red + G::LDS_MAIN / 4;
     float stg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int TPR = NTH / BM;
@@ -113,23 +116,27 @@ __device__ __forceinline__ void gemm_kw_body(const GemmArgs &g, const int bx, co
     // (uniform 64-bit base that advances with the stage + one 32-bit byte offset per lane and piece: the saddr form of the load;
     // all operands are far below 4 GiB per array)
     uint32_t aoff[G::NPIECE];
-    const char *abase = reinterpret_cast<const char *>(g.a0) + (size_t)first_kb * 64;
+    // (EPI_LSTM: waves 0, 1 walk the two chunks of K segment 0 = the y rows, waves 2, 3 those of segment 1 = the h rows of the rows' slots)
+    const bool seg1 = LSTM && wave >= 2;                    // uniform
+    const char *abase = seg1 ? reinterpret_cast<const char *>(g.a1) + (size_t)(first_kb * 16 - g.K0) * 4 : reinterpret_cast<const char *>(g.a0) + (size_t)first_kb * 64;
     {
+        const int *aidx = seg1 ? g.aidx1 : g.aidx0;
+        const int lda = seg1 ? g.lda1 : g.lda0;
         int arows[G::NPIECE];
 #pragma unroll
         for (int i = 0; i < G::NPIECE; ++i) {
             const int row = m0 + i * 8 + (lane >> 3);
             arows[i] = row >= g.M ? g.M - 1 : row;         // padding rows recompute the last row; never stored
         }
-        if (g.aidx0) {
+        if (aidx) {
 #pragma unroll
-            for (int i = 0; i < G::NPIECE; ++i) arows[i] = gload<int>(g.aidx0 + arows[i]);
+            for (int i = 0; i < G::NPIECE; ++i) arows[i] = gload<int>(aidx + arows[i]);
         }
 #pragma unroll
         for (int i = 0; i < G::NPIECE; ++i) {
             const int R = i * 8 + (lane >> 3);
             const int gseg = (lane & 7) ^ ((R >> 1) & 7);
-            aoff[i] = (uint32_t)((size_t)arows[i] * g.lda0 * 4 + gseg * 16);
+            aoff[i] = (uint32_t)((size_t)arows[i] * lda * 4 + gseg * 16);
         }
     }
     char *my = lds + wave * G::WAVE_BYTES;
@@ -183,7 +190,30 @@ __device__ __forceinline__ void gemm_kw_body(const GemmArgs &g, const int bx, co
     f32x4 e_bias[QPT], e_res[ROW_EPI ? QPT : 1];
     int e_slot[ROW_EPI ? QPT : 1];
     bool e_ok[QPT];
+    float *l_cptr[LSTM ? QPT : 1];                        // EPI_LSTM: this thread's (row, hidden unit) cells: slot -> previous cell value, fetched up front
+    float l_cprev[LSTM ? QPT : 1];
     auto fetch_epilogue_operands = [&]() {
+    if constexpr (LSTM) {
+        int qslot[QPT];
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * NTH;
+            int r = m0 + q / QROW;
+            e_ok[i] = q < NQ && r < g.M;
+            if (r >= g.M) r = g.M - 1;
+            qslot[i] = gload<int>(g.slot_idx + r);
+        }
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * NTH;
+            const int n = q < NQ ? n0 + (q % QROW) * 4 : n0;
+            l_cptr[i] = g.c_state + (size_t)qslot[i] * g.hidden + (n >> 2);      // (padding rows point at the last row's cell: read, never stored)
+            e_bias[i] = gload<f32x4>(g.bias + n);
+        }
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) l_cprev[i] = gload<float>(l_cptr[i]);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < QPT; ++i) {
         const int q = threadIdx.x + i * NTH;
@@ -438,6 +468,28 @@ __device__ __forceinline__ void gemm_kw_body(const GemmArgs &g, const int bx, co
             return ((p0 + p1) + p2) + p3;                                                   // one slab of four chunks
         }
     };
+    if constexpr (LSTM) {
+        // every load this epilogue depends on was issued before the K loop: settle them once, so that nothing in the loop below waits on
+        // the memory counter while the previous quad's stores are in flight (gemm_body)
+        wait_vm<0>();
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = threadIdx.x + i * NTH;
+            const int row = q / QROW, col = (q % QROW) * 4;
+            const int o = row * LDR + col;
+            f32x4 gt = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (q < NQ) {
+                const f32x4 p0 = *reinterpret_cast<const f32x4 *>(red + o), p1 = *reinterpret_cast<const f32x4 *>(red + PLANE + o);
+                const f32x4 p2 = *reinterpret_cast<const f32x4 *>(red + 2 * PLANE + o), p3 = *reinterpret_cast<const f32x4 *>(red + 3 * PLANE + o);
+                // x = y * scale(y) entered the GEMM as y: the y half of the sum takes the row's scale; without a scale the plain slab
+                if (NEED_SCL) gt = (((p0 + p1) * scl[row] + p2) + p3) + e_bias[i];
+                else gt = (((p0 + p1) + p2) + p3) + e_bias[i];
+            }
+            const float c_new = fast_sigmoid(gt.y) * l_cprev[i] + fast_sigmoid(gt.x) * fast_tanh(gt.z);
+            const float u = fast_sigmoid(gt.w) * fast_tanh(c_new);
+            if (e_ok[i]) { gstore<float>(l_cptr[i], c_new); gstore<float>(g.out + (size_t)(m0 + row) * g.ldo + ((n0 + col) >> 2), u); }
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < QPT; ++i) {
         const int q = threadIdx.x + i * NTH;
@@ -477,14 +529,14 @@ __device__ __forceinline__ void gemm_kw_body(const GemmArgs &g, const int bx, co
 // waves per SIMD the register budget must allow: one eight-wave workgroup per CU (the 128 registers of two spill inside the K loop) -- three for the
 // 16-row projection tiles --, three four-wave ones
 template <int MT, int NT, int NW, int EPI, int D, int CPW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? ((MT == 1 && EPI == EPI_HR) ? 6 : 2) : 3) void gemm_kw_kernel(GemmArgs g)
+__global__ __launch_bounds__(64 * NW, NW == 8 ? ((MT == 1 && EPI == EPI_HR) ? 6 : 2) : (MT == 4 ? 2 : 3)) void gemm_kw_kernel(GemmArgs g)
 {
     gemm_kw_body<MT, NT, NW, EPI, D, CPW>(g, (int)blockIdx.x, (int)blockIdx.y, blockIdx.x + gridDim.x * blockIdx.y);
 }
 
 // n independent same-shape problems in one launch (see gemm_f32_zkernel): blockIdx.z picks the argument block
 template <int MT, int NT, int NW, int EPI, int D, int CPW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? ((MT == 1 && EPI == EPI_HR) ? 6 : 2) : 3) void gemm_kw_zkernel(const GemmArgs *__restrict__ zargs)
+__global__ __launch_bounds__(64 * NW, NW == 8 ? ((MT == 1 && EPI == EPI_HR) ? 6 : 2) : (MT == 4 ? 2 : 3)) void gemm_kw_zkernel(const GemmArgs *__restrict__ zargs)
 {
     const GemmArgs g = zargs[blockIdx.z];
     gemm_kw_body<MT, NT, NW, EPI, D, CPW>(g, (int)blockIdx.x, (int)blockIdx.y, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
@@ -495,7 +547,7 @@ void launch_kw_one(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream
 {
     using G = KwGeom<MT, NT, NW, D>;
     dim3 grid((unsigned)(g.N / G::BN), (unsigned)((g.M + G::BM - 1) / G::BM), (unsigned)std::max(1, n));
-    const int sg = (EPI == EPI_HR && g.r_scale.ssq) ? g.r_scale.groups : 0;
+    const int sg = (EPI == EPI_HR && g.r_scale.ssq) ? g.r_scale.groups : ((EPI == EPI_LSTM && g.x_scale.ssq) ? g.x_scale.groups : 0);
     const size_t lds = (size_t)G::LDS_MAIN + (size_t)(G::BM + (sg ? G::BM * (sg + 1) : 0)) * sizeof(float);
     // dynamic LDS beyond 64 KB has to be announced, per instantiation AND per device (see kernels_gemm_tile.hip)
     static std::atomic<uint64_t> attr_devs{0};
@@ -522,6 +574,7 @@ bool dispatch_kw(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t
         if (g.epi == EPI_RESID_SSQ && cpw == 1) { launch_kw_one<MT, NT, NW, EPI_RESID_SSQ, D, 1>(g, dev_args, n, s); return true; }
     } else {
         if (g.epi == EPI_BIAS_DSWISH && cpw == 1) { launch_kw_one<MT, NT, NW, EPI_BIAS_DSWISH, D, 1>(g, dev_args, n, s); return true; }
+        if constexpr (NT == 2) { if (g.epi == EPI_LSTM && cpw == 1) { launch_kw_one<MT, NT, NW, EPI_LSTM, D, 1>(g, dev_args, n, s); return true; } }
     }
     return false;
 }
@@ -532,7 +585,15 @@ bool dispatch_kw(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t
 // number of waves (8 or 4), or 0.
 int gemm_kw_waves(const GemmArgs &g)
 {
-    if (g.wt != 0 || g.a_op != AOP_NONE || g.K1 != 0 || g.wave_mask != 0xF || g.p_add || g.N % 32 != 0 || g.K % 64 != 0) return 0;
+    if (g.wt != 0 || g.a_op != AOP_NONE || g.wave_mask != 0xF || g.p_add || g.N % 32 != 0 || g.K % 64 != 0) return 0;
+    if (g.epi == EPI_LSTM) {
+        // the one-launch gates GEMM of a chunk step: [y | h(slot)] in two equal K segments, one slab, the cell epilogue
+        if (g.kz != 1 || g.K1 != g.K0 || g.K0 * 2 != g.K || !g.a1 || !g.slot_idx || !g.c_state || !g.out || g.out16) return 0;
+        const int c = g.K / 16 / 4;
+        if (c % 2 != 0 || (c / 2) % 2 != 0) return 0;       // chunks of whole stages, whole rounds of the two-stage ring
+        return 4;
+    }
+    if (g.K1 != 0) return 0;
     if (g.epi != EPI_HR && g.epi != EPI_RESID_SSQ && g.epi != EPI_BIAS_DSWISH) return 0;
     if (g.epi == EPI_BIAS_DSWISH && g.x_scale.ssq) return 0;
     const int KB = g.K / 16;
@@ -561,7 +622,11 @@ void launch_gemm_kw(const GemmArgs &g, int mt, int nt, const GemmArgs *dev_args,
         else if (mt == 2 && nt == 2) ok = dispatch_kw<2, 2, 8, 2>(g, dev_args, n, s);
         else if (mt == 1 && nt == 2) ok = dispatch_kw<1, 2, 8, 2>(g, dev_args, n, s);
     } else if (nw == 4) {
-        if (mt == 2 && nt == 4) ok = dispatch_kw<2, 4, 4, 2>(g, dev_args, n, s);
+        if (g.epi == EPI_LSTM) {
+            if (mt == 4 && nt == 2) ok = dispatch_kw<4, 2, 4, 2>(g, dev_args, n, s);
+            else if (mt == 2 && nt == 2) ok = dispatch_kw<2, 2, 4, 2>(g, dev_args, n, s);
+        }
+        else if (mt == 2 && nt == 4) ok = dispatch_kw<2, 4, 4, 2>(g, dev_args, n, s);
     }
     if (!ok) { fprintf(stderr, "libapril(mi355x): launch_gemm_kw: no kernel for epi %d tile %d x %d, %d waves\n", g.epi, 16 * mt, 16 * nt, nw); abort(); }
 }

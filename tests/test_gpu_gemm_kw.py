@@ -41,7 +41,8 @@ def test_kw_bench_every_output_bitwise(built):
     exe = os.path.join(ROOT, "tools", "kw_bench")
     if not os.path.exists(exe):
         subprocess.check_call(["bash", os.path.join(ROOT, "tools", "build_kw_bench.sh")], timeout=900)
-    r = subprocess.run([exe, "20"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    # (APRIL_KW_GATES: the gates form of GM_KW is a measurement form, off by default -- its outputs are still checked bit for bit here)
+    r = subprocess.run([exe, "20"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, APRIL_KW_GATES="1", APRIL_KW_GATES_MAX_ROWS="100000"))
     out = r.stdout.decode()
     assert r.returncode == 0 and "all configurations bit-identical" in out, out[-3000:] + r.stderr.decode()[-1000:]
     assert out.count("bit-identical") > 60 and "MISMATCH" not in out

@@ -20,7 +20,7 @@ template <class T> static T *dalloc(size_t n) { T *p; CK(hipMalloc((void **)&p, 
 
 struct Problem {
     int M, N, K, kz, epi; bool a_indexed = false;      // a_indexed: the activation rows are reached through the row -> slot indirection (aidx0)
-    float *a, *w, *bias, *resid, *ssq_in, *out, *state, *ssq_out;
+    float *a, *w, *bias, *resid, *ssq_in, *out, *state, *ssq_out, *cst = nullptr, *cst0 = nullptr;      // cst: cell state (gates), cst0: its initial values
     int *slots;
 };
 static void fill(std::vector<float> &h, unsigned seed, float scale)
@@ -42,6 +42,11 @@ static Problem make_problem(int M, int N, int K, int kz, int epi, unsigned seed)
     std::vector<int> perm((size_t)M); for (int i = 0; i < M; ++i) perm[(size_t)i] = i;
     unsigned s = seed; for (int i = M - 1; i > 0; --i) { s = s * 1664525u + 1013904223u; std::swap(perm[(size_t)i], perm[(size_t)((s >> 8) % (unsigned)(i + 1))]); }
     p.slots = dalloc<int>((size_t)M); CK(hipMemcpy(p.slots, perm.data(), (size_t)M * 4, hipMemcpyHostToDevice));
+    if (epi == EPI_LSTM) {      // gates: A = [y (M x K/2, rows) | h (M x K/2, by slot)], c state [M][N/4]
+        h.resize((size_t)M * (N / 4)); fill(h, seed + 5, 1.0f); p.cst0 = upload(h); p.cst = dalloc<float>(h.size());
+        h.resize((size_t)M * (K / 64)); fill(h, seed + 6, 1.0f); for (auto &v : h) v = v * v + 0.1f;
+        CK(hipFree(p.ssq_in)); p.ssq_in = upload(h);
+    }
     return p;
 }
 static GemmArgs gemm_of(const Problem &p, int zcount, int tile_ok = 0)
@@ -49,7 +54,12 @@ static GemmArgs gemm_of(const Problem &p, int zcount, int tile_ok = 0)
     GemmArgs g; g.tile_ok = tile_ok;
     g.a0 = p.a; g.lda0 = p.K; g.K0 = p.K; g.aidx0 = p.a_indexed ? p.slots : nullptr; g.wp = p.w; g.M = p.M; g.N = p.N; g.K = p.K; g.kz = p.kz; g.zcount = zcount;
     g.epi = p.epi; g.out = p.out; g.ldo = p.N; g.bias = p.bias;
-    if (p.epi == EPI_HR) { g.state = p.state; g.ld_state = p.N; g.slot_idx = p.slots; g.resid = p.resid; g.ldr = p.N;
+    if (p.epi == EPI_LSTM) {
+        g.K0 = p.K / 2; g.lda0 = p.K / 2; g.a1 = p.a + (size_t)p.M * (p.K / 2); g.lda1 = p.K / 2; g.aidx1 = p.slots; g.K1 = p.K / 2; g.aidx0 = nullptr;
+        g.c_state = p.cst; g.slot_idx = p.slots; g.hidden = p.N / 4; g.ldo = p.N / 4;
+        g.x_scale.ssq = p.ssq_in; g.x_scale.groups = (p.K / 2) / 32; g.x_scale.inv_n = 1.0f / (p.K / 2); g.x_scale.eps = 0.25f;
+    }
+    else if (p.epi == EPI_HR) { g.state = p.state; g.ld_state = p.N; g.slot_idx = p.slots; g.resid = p.resid; g.ldr = p.N;
                            g.r_scale.ssq = p.ssq_in; g.r_scale.groups = p.N / 32; g.r_scale.inv_n = 1.0f / p.N; g.r_scale.eps = 0.25f; g.bias = nullptr; g.force_fullk = 1; }
     else if (p.epi == EPI_RESID_SSQ) { g.resid = p.resid; g.ldr = p.N; g.ssq_out = p.ssq_out; g.force_fullk = 1; }
     return g;
@@ -74,8 +84,9 @@ static std::vector<float> snapshot(const std::vector<Problem> &ps)
 {
     std::vector<float> all;
     for (const Problem &p : ps) {
-        std::vector<float> h((size_t)p.M * p.N);
+        std::vector<float> h((size_t)p.M * (p.epi == EPI_LSTM ? p.N / 4 : p.N));
         CK(hipMemcpy(h.data(), p.out, h.size() * 4, hipMemcpyDeviceToHost)); all.insert(all.end(), h.begin(), h.end());
+        if (p.epi == EPI_LSTM) { CK(hipMemcpy(h.data(), p.cst, h.size() * 4, hipMemcpyDeviceToHost)); all.insert(all.end(), h.begin(), h.end()); }
         if (p.epi == EPI_HR) { CK(hipMemcpy(h.data(), p.state, h.size() * 4, hipMemcpyDeviceToHost)); all.insert(all.end(), h.begin(), h.end()); }
         if (p.epi == EPI_RESID_SSQ) { h.resize((size_t)p.M * (p.N / 32)); CK(hipMemcpy(h.data(), p.ssq_out, h.size() * 4, hipMemcpyDeviceToHost)); all.insert(all.end(), h.begin(), h.end()); }
     }
@@ -83,7 +94,8 @@ static std::vector<float> snapshot(const std::vector<Problem> &ps)
 }
 static void clear_outputs(const std::vector<Problem> &ps)
 {
-    for (const Problem &p : ps) { CK(hipMemset(p.out, 0xff, (size_t)p.M * p.N * 4)); CK(hipMemset(p.state, 0xff, (size_t)p.M * p.N * 4)); CK(hipMemset(p.ssq_out, 0xff, (size_t)p.M * (p.N / 32) * 4)); }
+    for (const Problem &p : ps) { if (p.cst) CK(hipMemcpy(p.cst, p.cst0, (size_t)p.M * (p.N / 4) * 4, hipMemcpyDeviceToDevice));      // (the cell state is updated in place: same start for every run)
+                                  CK(hipMemset(p.out, 0xff, (size_t)p.M * p.N * 4)); CK(hipMemset(p.state, 0xff, (size_t)p.M * p.N * 4)); CK(hipMemset(p.ssq_out, 0xff, (size_t)p.M * (p.N / 32) * 4)); }
 }
 static double time_chain(const Chain &c, hipStream_t s, int iters)
 {
@@ -110,6 +122,16 @@ int main(int argc, char **argv)
         {"proj   16x3", 16, 512, 1024, 8, EPI_HR, 3},
         {"ffdn   16x3", 16, 512, 2048, 8, EPI_RESID_SSQ, 3},
         {"ffdn   13x1", 13, 512, 2048, 8, EPI_RESID_SSQ, 1},
+        {"gates  64x1", 64, 4096, 1024, 1, EPI_LSTM, 1},
+        {"gates  64x2", 64, 4096, 1024, 1, EPI_LSTM, 2},
+        {"gates  64x3", 64, 4096, 1024, 1, EPI_LSTM, 3},
+        {"gates  24x3", 24, 4096, 1024, 1, EPI_LSTM, 3},
+        {"gates  40x2", 40, 4096, 1024, 1, EPI_LSTM, 2},
+        {"gates  96x2", 96, 4096, 1024, 1, EPI_LSTM, 2},
+        {"gates 128x2", 128, 4096, 1024, 1, EPI_LSTM, 2},
+        {"gates 128x3", 128, 4096, 1024, 1, EPI_LSTM, 3},
+        {"gates 256x2", 256, 4096, 1024, 1, EPI_LSTM, 2},
+        {"gates  50x2 L", 50, 6144, 1536, 1, EPI_LSTM, 2},              // larger encoder dims
         {"proj  256x1", 256, 512, 1024, 8, EPI_HR, 1},
         {"proj  256x2", 256, 512, 1024, 8, EPI_HR, 2},
         {"proj  256x3", 256, 512, 1024, 8, EPI_HR, 3},
@@ -170,6 +192,7 @@ int main(int argc, char **argv)
         }
         for (int mt : {0, 2, 1, 4}) {
             if ((mt == 1 || mt == 4) && sh.epi == EPI_BIAS_DSWISH) continue;
+            if (mt == 1 && sh.epi == EPI_LSTM) continue;
             gemm_kw_pin(1, mt, 1);
             Chain c = make_chain(ps, mt == 0 ? 1 : 0);      // (the planner's own choice as the engine makes it: GM_TILE allowed, GM_KW may take a fused GM_TILE plan over)
             if (c.gh[0].mode != GM_KW) { printf("    (GM_KW not planned for this shape, mt pin %d%s)\n", mt, c.gh[0].mode == GM_TILE ? ": the planner keeps GM_TILE" : ""); continue; }
@@ -178,7 +201,7 @@ int main(int argc, char **argv)
             size_t diff = 0; double maxd = 0;
             for (size_t i = 0; i < want.size(); ++i) if (memcmp(&want[i], &got[i], 4) != 0) { ++diff; maxd = std::max(maxd, (double)fabsf(want[i] - got[i])); }
             const double t = time_chain(c, s, iters);
-            clear_outputs(ps); for (int i = 0; i < 5; ++i) c.run(s); CK(hipStreamSynchronize(s));
+            clear_outputs(ps); for (int i = 0; i < (sh.epi == EPI_LSTM ? 1 : 5); ++i) c.run(s); CK(hipStreamSynchronize(s));      // (the gates update the cell state in place: one run)
             const std::vector<float> got2 = snapshot(ps);
             size_t diff2 = 0; for (size_t i = 0; i < want.size(); ++i) if (memcmp(&want[i], &got2[i], 4) != 0) ++diff2;
             if (getenv("KB_TRACE")) {      // (binary built with -DAPRIL_GEMM_TRACE) s_memtime stamps of wave 0: start, loop start, loop end, meet done, end
