@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 FP16_MFMA_PEAK_TFLOPS = 2500.0     # dense fp16 MFMA peak (--precision f16 only)
 HBM_PEAK_GBS = 8000.0              # spec; ~6300 measured achievable
-TRAFFIC_JSON = "r04_gates_traffic.json"      # the committed PMC pass the roofline's `traffic` is taken from
+TRAFFIC_JSON = "r05_gates_traffic.json"      # the committed PMC pass the roofline's `traffic` is taken from
 
 
 def config5_leg(args, A, SM, torch, np):
