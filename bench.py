@@ -396,6 +396,11 @@ def main():
                 if int(tr["sessions_per_gpu"]) == nsess and dd.precision == 0:
                     rl["traffic"] = int(tr["traffic_bytes_per_launch"] * rows_per_launch / float(tr["rows_per_launch"]))
                     rl["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950 x2 read correction; measured at %.1f rows per launch, scaled by rows)" % (traffic_json, float(tr["rows_per_launch"]))
+                    rk = tr.get("rocprof_kernel_time")
+                    if rk:      # the same kernels' execution time under rocprofv3 (committed summary of the default invocation): no event brackets, graph replay
+                        rl["kernel_time_rocprof"] = {"weighted_avg_us_per_launch": rk["weighted_avg_us_per_launch"], "tflops": rk["weighted_tflops"],
+                                                     "frac": rk["frac_of_157.3"], "source": rk["source"].split(" (")[0],
+                                                     "what": "committed rocprofv3 kernel durations of the two gates kernels (17 : 10 launch mix); `achieved` / `frac` above use the live HIP-event brackets of eager launches, which add launch overhead to every sample"}
             except Exception:
                 pass
         rl["algorithmic_bytes_per_launch"] = int(wbytes + sbytes)
