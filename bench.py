@@ -421,7 +421,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_sweep:          # single-GPU runs only (the driver computes scaling from per-N values)
         sweep = {}
         sweep_runs = {}
-        for nb in (1, 16, 64, 1024, 2048, 2304, 2560, 2816, 3072):
+        for nb in (1, 16, 64, 1024, 2048, 2304, 2432, 2560, 2816, 3072):
             ss, gg = make_group(nb, 0)
             wu, ts = 6, 20                                     # (both feed shapes -- 2 and 3 chunks -- are captured during warm-up)
             pp = pcm_for(nb, wu + ts, 20_000_000)
