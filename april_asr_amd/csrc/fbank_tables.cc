@@ -1,6 +1,6 @@
 // See fbank_tables.h.
 //
-// Third-party notice.  The radix-4 / radix-2 real-FFT pass structure and the twiddle-factor polynomial
+// Third-party notice.  The radix-4 / 2 / 3 / 5 real-FFT pass structure and the twiddle-factor polynomial
 // coefficients restated here follow pocketfft (the FFT the reference links, src/fft/pocketfft.c):
 //   Copyright (C) 2010-2019 Max-Planck-Society.  All rights reserved.  BSD 3-Clause License
 //   (https://gitlab.mpcdf.mpg.de/mtr/pocketfft/-/blob/81d171a6/LICENSE.md); the full text, including the
@@ -90,7 +90,9 @@ bool build_fbank_tables(int sample_rate, int frame_shift_ms, int frame_length_ms
     t.window_size = frame_length_ms * sample_rate / 1000;
     int padded = t.window_size;
     if (round_pow2) { padded = 1; while (padded < t.window_size) padded <<= 1; }
-    if (padded < 8 || (padded & (padded - 1)) != 0 || padded > 8192) return false;   // radix-4/2 passes only
+    // FFT lengths: multiples of 4 (the twiddle table below is pocketfft's n % 4 == 0 branch) whose prime factors are 2, 3 and 5 (the
+    // radix 4 / 2 / 3 / 5 passes of kernels_fbank.hip); round_pow2 = 0 models have the frame length itself, e.g. 400 at 16 kHz / 25 ms
+    if (padded < 8 || (padded & 3) != 0 || padded > 8192) return false;
     t.padded = padded; t.nfft_bins = padded / 2; t.nbins = nbins;
 
     // window: fbank.c:49-55 (N = padded length, denominator N)
@@ -120,12 +122,14 @@ bool build_fbank_tables(int sample_rate, int frame_shift_ms, int frame_length_ms
         t.mel_lo[(size_t)m] = lo; t.mel_hi[(size_t)m] = hi;
     }
 
-    // factors: all 4s, then at most one 2 moved to the front (pocketfft.c:1798-1812)
+    // factors: all 4s, then at most one 2 moved to the front, then the odd divisors in rising order (pocketfft.c:1798-1827)
     t.factors.clear();
     size_t len = (size_t)padded;
     while (len % 4 == 0) { t.factors.push_back(4); len >>= 2; }
     if (len % 2 == 0) { len >>= 1; t.factors.push_back(2); std::swap(t.factors.front(), t.factors.back()); }
-    if (len != 1) return false;
+    for (size_t divisor = 3; len > 1 && divisor <= 5; divisor += 2)
+        while (len % divisor == 0) { t.factors.push_back((int)divisor); len /= divisor; }
+    if (len != 1 || t.factors.size() > 16) return false;      // a prime factor above 5 (pocketfft's generic pass / Bluestein): not built
 
     // twiddles per factor (pocketfft.c:1843-1863): tw[(j-1)*(ido-1) + 2i-2 / 2i-1] = cos/sin(2 pi j l1 i / n)
     Circle circle((size_t)padded);

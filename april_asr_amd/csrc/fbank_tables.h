@@ -13,12 +13,12 @@ struct FbankHostTables {
     std::vector<float> window;            // [padded]
     std::vector<float> mel;               // [nbins][nfft_bins]
     std::vector<int> mel_lo, mel_hi;      // non-zero support per bin
-    std::vector<int> factors;             // pocketfft order, e.g. 2,4,4,4,4 for 512
+    std::vector<int> factors;             // pocketfft order, e.g. 2,4,4,4,4 for 512; 4,4,5,5 for 400
     std::vector<std::vector<double>> tw;  // per factor (last one empty)
     float pad_value = 0;                  // (float)log((double)kEps)
 };
 
-// returns false when the frame length is not supported (non power-of-two FFT)
+// returns false when the frame length is not supported (FFT length not a multiple of 4, or with a prime factor above 5)
 bool build_fbank_tables(int sample_rate, int frame_shift_ms, int frame_length_ms, int nbins, bool round_pow2,
                         int mel_low, int mel_high, FbankHostTables &out);
 

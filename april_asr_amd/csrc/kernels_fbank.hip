@@ -1,7 +1,7 @@
 // Online log-mel filterbank on gfx950: one wavefront per 10 ms frame, batched over
 // sessions x new frames.  Bit-compatible restatement of the reference's per-frame
 // arithmetic (src/fbank.c:228-296) including its FFT (src/fft/pocketfft.c radf4 /
-// radf2 passes, :1111-1134,1170-1209,1730-1764): fp64 butterflies in the same
+// radf2 / radf3 / radf5 passes, :1111-1260,1730-1764): fp64 butterflies in the same
 // operation order, fp32 power and mel accumulation in the same order, compiled
 // with -ffp-contract=off (the reference is built without FMA contraction).
 //
@@ -18,7 +18,7 @@
 // sum of the PCM samples / 32768, which is what the wave reduction computes.  For
 // larger frames lane 0 replays the sequential float chain.
 //
-// Third-party notice.  The radix-4 / radix-2 real-FFT pass structure and the twiddle-factor polynomial
+// Third-party notice.  The radix-4 / 2 / 3 / 5 real-FFT pass structure and the twiddle-factor polynomial
 // coefficients restated here follow pocketfft (the FFT the reference links, src/fft/pocketfft.c):
 //   Copyright (C) 2010-2019 Max-Planck-Society.  All rights reserved.  BSD 3-Clause License
 //   (https://gitlab.mpcdf.mpg.de/mtr/pocketfft/-/blob/81d171a6/LICENSE.md); the full text, including the
@@ -109,6 +109,94 @@ __device__ void fft_pass2(int ido, int l1, const double *in, double *out, const 
 #undef CH
 }
 
+// radix-3 pass (pocketfft.c:1136-1168): FFT lengths of models with round_pow2 = 0 (e.g. 480 = 2 4 4 3 5)
+__device__ void fft_pass3(int ido, int l1, const double *in, double *out, const double *w, int lane)
+{
+    const double taur = -0.5, taui = 0.86602540378443864676;
+#define CC(a, b, c) in[(a) + ido * ((b) + l1 * (c))]
+#define CH(a, b, c) out[(a) + ido * ((b) + 3 * (c))]
+#define WA(x, i) w[(i) + (x) * (ido - 1)]
+    for (int k = lane; k < l1; k += 64) {
+        const double cr2 = CC(0, k, 1) + CC(0, k, 2);
+        CH(0, 0, k) = CC(0, k, 0) + cr2;
+        CH(0, 2, k) = taui * (CC(0, k, 2) - CC(0, k, 1));
+        CH(ido - 1, 1, k) = CC(0, k, 0) + taur * cr2;
+    }
+    if (ido > 2) {
+        const int nq = (ido - 1) / 2;                 // i = 2, 4, ... < ido
+        for (int t = lane; t < l1 * nq; t += 64) {
+            const int k = t / nq, i = 2 + 2 * (t % nq), ic = ido - i;
+            const double dr2 = WA(0, i - 2) * CC(i - 1, k, 1) + WA(0, i - 1) * CC(i, k, 1);
+            const double di2 = WA(0, i - 2) * CC(i, k, 1) - WA(0, i - 1) * CC(i - 1, k, 1);
+            const double dr3 = WA(1, i - 2) * CC(i - 1, k, 2) + WA(1, i - 1) * CC(i, k, 2);
+            const double di3 = WA(1, i - 2) * CC(i, k, 2) - WA(1, i - 1) * CC(i - 1, k, 2);
+            const double cr2 = dr2 + dr3, ci2 = di2 + di3;
+            CH(i - 1, 0, k) = CC(i - 1, k, 0) + cr2;
+            CH(i, 0, k) = CC(i, k, 0) + ci2;
+            const double tr2 = CC(i - 1, k, 0) + taur * cr2;
+            const double ti2 = CC(i, k, 0) + taur * ci2;
+            const double tr3 = taui * (di2 - di3);
+            const double ti3 = taui * (dr3 - dr2);
+            CH(i - 1, 2, k) = tr2 + tr3;  CH(ic - 1, 1, k) = tr2 - tr3;
+            CH(i, 2, k) = ti3 + ti2;      CH(ic, 1, k) = ti3 - ti2;
+        }
+    }
+#undef CC
+#undef CH
+#undef WA
+}
+
+// radix-5 pass (pocketfft.c:1211-1260): 400 = 4 4 5 5 (16 kHz, 25 ms, round_pow2 = 0)
+__device__ void fft_pass5(int ido, int l1, const double *in, double *out, const double *w, int lane)
+{
+    const double tr11 = 0.3090169943749474241, ti11 = 0.95105651629515357212, tr12 = -0.8090169943749474241, ti12 = 0.58778525229247312917;
+#define CC(a, b, c) in[(a) + ido * ((b) + l1 * (c))]
+#define CH(a, b, c) out[(a) + ido * ((b) + 5 * (c))]
+#define WA(x, i) w[(i) + (x) * (ido - 1)]
+    for (int k = lane; k < l1; k += 64) {
+        const double cr2 = CC(0, k, 4) + CC(0, k, 1), ci5 = CC(0, k, 4) - CC(0, k, 1);
+        const double cr3 = CC(0, k, 3) + CC(0, k, 2), ci4 = CC(0, k, 3) - CC(0, k, 2);
+        CH(0, 0, k) = CC(0, k, 0) + cr2 + cr3;
+        CH(ido - 1, 1, k) = CC(0, k, 0) + tr11 * cr2 + tr12 * cr3;
+        CH(0, 2, k) = ti11 * ci5 + ti12 * ci4;
+        CH(ido - 1, 3, k) = CC(0, k, 0) + tr12 * cr2 + tr11 * cr3;
+        CH(0, 4, k) = ti12 * ci5 - ti11 * ci4;
+    }
+    if (ido > 2) {
+        const int nq = (ido - 1) / 2;
+        for (int t = lane; t < l1 * nq; t += 64) {
+            const int k = t / nq, i = 2 + 2 * (t % nq), ic = ido - i;
+            const double dr2 = WA(0, i - 2) * CC(i - 1, k, 1) + WA(0, i - 1) * CC(i, k, 1);
+            const double di2 = WA(0, i - 2) * CC(i, k, 1) - WA(0, i - 1) * CC(i - 1, k, 1);
+            const double dr3 = WA(1, i - 2) * CC(i - 1, k, 2) + WA(1, i - 1) * CC(i, k, 2);
+            const double di3 = WA(1, i - 2) * CC(i, k, 2) - WA(1, i - 1) * CC(i - 1, k, 2);
+            const double dr4 = WA(2, i - 2) * CC(i - 1, k, 3) + WA(2, i - 1) * CC(i, k, 3);
+            const double di4 = WA(2, i - 2) * CC(i, k, 3) - WA(2, i - 1) * CC(i - 1, k, 3);
+            const double dr5 = WA(3, i - 2) * CC(i - 1, k, 4) + WA(3, i - 1) * CC(i, k, 4);
+            const double di5 = WA(3, i - 2) * CC(i, k, 4) - WA(3, i - 1) * CC(i - 1, k, 4);
+            const double cr2 = dr5 + dr2, ci5 = dr5 - dr2;
+            const double ci2 = di2 + di5, cr5 = di2 - di5;
+            const double cr3 = dr4 + dr3, ci4 = dr4 - dr3;
+            const double ci3 = di3 + di4, cr4 = di3 - di4;
+            CH(i - 1, 0, k) = CC(i - 1, k, 0) + cr2 + cr3;
+            CH(i, 0, k) = CC(i, k, 0) + ci2 + ci3;
+            const double tr2 = CC(i - 1, k, 0) + tr11 * cr2 + tr12 * cr3;
+            const double ti2 = CC(i, k, 0) + tr11 * ci2 + tr12 * ci3;
+            const double tr3 = CC(i - 1, k, 0) + tr12 * cr2 + tr11 * cr3;
+            const double ti3 = CC(i, k, 0) + tr12 * ci2 + tr11 * ci3;
+            const double tr5 = cr5 * ti11 + cr4 * ti12, tr4 = cr5 * ti12 - cr4 * ti11;
+            const double ti5 = ci5 * ti11 + ci4 * ti12, ti4 = ci5 * ti12 - ci4 * ti11;
+            CH(i - 1, 2, k) = tr2 + tr5;  CH(ic - 1, 1, k) = tr2 - tr5;
+            CH(i, 2, k) = ti5 + ti2;      CH(ic, 1, k) = ti5 - ti2;
+            CH(i - 1, 4, k) = tr3 + tr4;  CH(ic - 1, 3, k) = tr3 - tr4;
+            CH(i, 4, k) = ti4 + ti3;      CH(ic, 3, k) = ti4 - ti3;
+        }
+    }
+#undef CC
+#undef CH
+#undef WA
+}
+
 __global__ __launch_bounds__(64) void fbank_kernel(FbankArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sh[];
@@ -158,7 +246,9 @@ __global__ __launch_bounds__(64) void fbank_kernel(FbankArgs a)
         const int ido = n / l1;
         l1 /= ip;
         if (ip == 4) fft_pass4(ido, l1, src, dst, a.t.tw[k], lane);
-        else fft_pass2(ido, l1, src, dst, a.t.tw[k], lane);
+        else if (ip == 2) fft_pass2(ido, l1, src, dst, a.t.tw[k], lane);
+        else if (ip == 3) fft_pass3(ido, l1, src, dst, a.t.tw[k], lane);
+        else fft_pass5(ido, l1, src, dst, a.t.tw[k], lane);
         __syncthreads();
         double *t = src; src = dst; dst = t;
     }

@@ -476,14 +476,15 @@ def container_bytes(networks, params, name="synthetic", description="seeded synt
 
 
 def write_model(path, dims=None, seed=2023, variant=None, punctuation=True, joiner_gain=6.0, blank_bias=4.7,
-                name=None):
-    """Write a synthetic .april file; returns (dims, weights, tokens)."""
+                name=None, params=None):
+    """Write a synthetic .april file; returns (dims, weights, tokens).  `params`: keyword overrides of the PARAMS block
+    (rate, shift_ms, length_ms, round_pow2, mel_low, mel_high -- e.g. round_pow2=0 for a 400-point FFT at 16 kHz / 25 ms)."""
     dims = dict(dims or APRILV0_DIMS)
     variant = dict(variant or {})
     w = make_weights(dims, seed=seed, joiner_gain=joiner_gain, blank_bias=blank_bias)
     toks = make_tokens(dims["vocab"], punctuation=punctuation)
     nets = [build_encoder(dims, w, variant), build_decoder(dims, w, variant), build_joiner(dims, w, variant)]
-    blob = container_bytes(nets, params_block(dims, toks), name=name or ("synthetic-L%d-d%d" % (dims["n_layers"], dims["d_model"])))
+    blob = container_bytes(nets, params_block(dims, toks, **dict(params or {})), name=name or ("synthetic-L%d-d%d" % (dims["n_layers"], dims["d_model"])))
     with open(path, "wb") as f:
         f.write(blob)
     return dims, w, toks

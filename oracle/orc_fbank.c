@@ -13,8 +13,8 @@
  *   src/fbank.c:308-325   flush padding          -> orc_fbank_flush
  *   src/fbank.c:327-349   pull_segments          -> orc_fbank_pull
  *   src/fft/pocketfft.c:65-228   twiddle generation (sincos_2pibyn_half, n%4==0 branch)
- *   src/fft/pocketfft.c:1111-1134 radf2, :1170-1209 radf4, :1730-1764 rfftp_forward,
- *   :1798-1827 factorisation, :1843-1881 twiddle layout.
+ *   src/fft/pocketfft.c:1111-1134 radf2, :1136-1168 radf3, :1170-1209 radf4, :1211-1260 radf5,
+ *   :1730-1764 rfftp_forward, :1798-1827 factorisation, :1843-1881 twiddle layout.
  *
  * Pinned: bit-exact against the reference's own fbank.c/pocketfft.c compiled
  * into oracle/_ref/libaprilref.so (tests/test_oracle_fbank.py) and against the
@@ -22,9 +22,12 @@
  *
  * Design differences from the reference (behaviour-preserving): the reference
  * carries a "previous leftover" array and three copy cases; here the stream is
- * a plain FIFO of samples and frame k is cut at stream offset k*shift.  Power
- * of two FFT lengths only (factor list of 4s and at most one 2), which is what
- * every exported model uses (round_pow2 = 1).
+ * a plain FIFO of samples and frame k is cut at stream offset k*shift.  FFT
+ * lengths: multiples of 4 whose prime factors are 2, 3 and 5 (the radix 4 / 2 /
+ * 3 / 5 passes; every exported model uses round_pow2 = 1 = a power of two, a
+ * model with round_pow2 = 0 has the frame length itself, e.g. 400).  Lengths
+ * with other prime factors (pocketfft's generic radix pass, or Bluestein) are
+ * refused.
  *
  * Build with -ffp-contract=off: the reference is built for baseline x86-64
  * (no FMA contraction) and bit-exactness depends on it.
@@ -110,15 +113,15 @@ static void half_circle_table(size_t n, double *res /* 2n doubles of room */)
 }
 
 /* ------------------------------------------------------------------ */
-/* real forward FFT plan (factors 4 and 2 only)                       */
+/* real forward FFT plan (factors 4, 2, 3, 5)                         */
 /* ------------------------------------------------------------------ */
 
 int orc_rfft_plan_init(OrcRfftPlan *p, size_t n)
 {
     memset(p, 0, sizeof(*p));
-    if (n < 4 || (n & (n - 1)) != 0 || n > ORC_FFT_MAX) return -1;
+    if (n < 4 || (n & 3) != 0 || n > ORC_FFT_MAX) return -1;      /* (the twiddle table below is the n % 4 == 0 branch) */
     p->n = n;
-    /* pocketfft.c:1798-1812: strip 4s, then one 2 which is swapped to the front */
+    /* pocketfft.c:1798-1827: strip 4s, then one 2 which is swapped to the front, then the odd divisors in rising order */
     size_t len = n, nf = 0;
     while ((len % 4) == 0) { p->fct[nf++] = 4; len >>= 2; }
     if ((len % 2) == 0) {
@@ -126,7 +129,9 @@ int orc_rfft_plan_init(OrcRfftPlan *p, size_t n)
         p->fct[nf++] = 2;
         size_t t = p->fct[0]; p->fct[0] = p->fct[nf - 1]; p->fct[nf - 1] = t;
     }
-    if (len != 1) return -1;
+    for (size_t divisor = 3; len > 1 && divisor <= 5; divisor += 2)
+        while ((len % divisor) == 0) { if (nf >= 16) return -1; p->fct[nf++] = divisor; len /= divisor; }
+    if (len != 1) return -1;                                       /* a prime factor above 5: not restated */
     p->nfct = nf;
     /* twiddle layout, pocketfft.c:1843-1863 */
     double *circle = (double *)malloc(2 * n * sizeof(double));
@@ -240,6 +245,94 @@ static void pass4(size_t ido, size_t l1, const double *in, double *out, const do
 #undef W4
 }
 
+/* radix-3 real butterfly pass, pocketfft.c:1136-1168 */
+static void pass3(size_t ido, size_t l1, const double *in, double *out, const double *w)
+{
+    static const double taur = -0.5, taui = 0.86602540378443864676;
+#define IN3(a, b, c) in[(a) + ido * ((b) + l1 * (c))]
+#define OUT3(a, b, c) out[(a) + ido * ((b) + 3 * (c))]
+#define W3(x, i) w[(i) + (x) * (ido - 1)]
+    for (size_t k = 0; k < l1; ++k) {
+        const double cr2 = IN3(0, k, 1) + IN3(0, k, 2);
+        OUT3(0, 0, k) = IN3(0, k, 0) + cr2;
+        OUT3(0, 2, k) = taui * (IN3(0, k, 2) - IN3(0, k, 1));
+        OUT3(ido - 1, 1, k) = IN3(0, k, 0) + taur * cr2;
+    }
+    if (ido == 1) return;
+    for (size_t k = 0; k < l1; ++k)
+        for (size_t i = 2; i < ido; i += 2) {
+            const size_t ic = ido - i;
+            /* d_j = conj(w_j) * x_j */
+            const double dr2 = W3(0, i - 2) * IN3(i - 1, k, 1) + W3(0, i - 1) * IN3(i, k, 1);
+            const double di2 = W3(0, i - 2) * IN3(i, k, 1) - W3(0, i - 1) * IN3(i - 1, k, 1);
+            const double dr3 = W3(1, i - 2) * IN3(i - 1, k, 2) + W3(1, i - 1) * IN3(i, k, 2);
+            const double di3 = W3(1, i - 2) * IN3(i, k, 2) - W3(1, i - 1) * IN3(i - 1, k, 2);
+            const double cr2 = dr2 + dr3, ci2 = di2 + di3;
+            OUT3(i - 1, 0, k) = IN3(i - 1, k, 0) + cr2;
+            OUT3(i, 0, k) = IN3(i, k, 0) + ci2;
+            const double tr2 = IN3(i - 1, k, 0) + taur * cr2;
+            const double ti2 = IN3(i, k, 0) + taur * ci2;
+            const double tr3 = taui * (di2 - di3);
+            const double ti3 = taui * (dr3 - dr2);
+            OUT3(i - 1, 2, k) = tr2 + tr3;  OUT3(ic - 1, 1, k) = tr2 - tr3;
+            OUT3(i, 2, k) = ti3 + ti2;      OUT3(ic, 1, k) = ti3 - ti2;
+        }
+#undef IN3
+#undef OUT3
+#undef W3
+}
+
+/* radix-5 real butterfly pass, pocketfft.c:1211-1260 */
+static void pass5(size_t ido, size_t l1, const double *in, double *out, const double *w)
+{
+    static const double tr11 = 0.3090169943749474241, ti11 = 0.95105651629515357212,
+                        tr12 = -0.8090169943749474241, ti12 = 0.58778525229247312917;
+#define IN5(a, b, c) in[(a) + ido * ((b) + l1 * (c))]
+#define OUT5(a, b, c) out[(a) + ido * ((b) + 5 * (c))]
+#define W5(x, i) w[(i) + (x) * (ido - 1)]
+    for (size_t k = 0; k < l1; ++k) {
+        const double cr2 = IN5(0, k, 4) + IN5(0, k, 1), ci5 = IN5(0, k, 4) - IN5(0, k, 1);
+        const double cr3 = IN5(0, k, 3) + IN5(0, k, 2), ci4 = IN5(0, k, 3) - IN5(0, k, 2);
+        OUT5(0, 0, k) = IN5(0, k, 0) + cr2 + cr3;
+        OUT5(ido - 1, 1, k) = IN5(0, k, 0) + tr11 * cr2 + tr12 * cr3;
+        OUT5(0, 2, k) = ti11 * ci5 + ti12 * ci4;
+        OUT5(ido - 1, 3, k) = IN5(0, k, 0) + tr12 * cr2 + tr11 * cr3;
+        OUT5(0, 4, k) = ti12 * ci5 - ti11 * ci4;
+    }
+    if (ido == 1) return;
+    for (size_t k = 0; k < l1; ++k)
+        for (size_t i = 2; i < ido; i += 2) {
+            const size_t ic = ido - i;
+            const double dr2 = W5(0, i - 2) * IN5(i - 1, k, 1) + W5(0, i - 1) * IN5(i, k, 1);
+            const double di2 = W5(0, i - 2) * IN5(i, k, 1) - W5(0, i - 1) * IN5(i - 1, k, 1);
+            const double dr3 = W5(1, i - 2) * IN5(i - 1, k, 2) + W5(1, i - 1) * IN5(i, k, 2);
+            const double di3 = W5(1, i - 2) * IN5(i, k, 2) - W5(1, i - 1) * IN5(i - 1, k, 2);
+            const double dr4 = W5(2, i - 2) * IN5(i - 1, k, 3) + W5(2, i - 1) * IN5(i, k, 3);
+            const double di4 = W5(2, i - 2) * IN5(i, k, 3) - W5(2, i - 1) * IN5(i - 1, k, 3);
+            const double dr5 = W5(3, i - 2) * IN5(i - 1, k, 4) + W5(3, i - 1) * IN5(i, k, 4);
+            const double di5 = W5(3, i - 2) * IN5(i, k, 4) - W5(3, i - 1) * IN5(i - 1, k, 4);
+            const double cr2 = dr5 + dr2, ci5 = dr5 - dr2;
+            const double ci2 = di2 + di5, cr5 = di2 - di5;
+            const double cr3 = dr4 + dr3, ci4 = dr4 - dr3;
+            const double ci3 = di3 + di4, cr4 = di3 - di4;
+            OUT5(i - 1, 0, k) = IN5(i - 1, k, 0) + cr2 + cr3;
+            OUT5(i, 0, k) = IN5(i, k, 0) + ci2 + ci3;
+            const double tr2 = IN5(i - 1, k, 0) + tr11 * cr2 + tr12 * cr3;
+            const double ti2 = IN5(i, k, 0) + tr11 * ci2 + tr12 * ci3;
+            const double tr3 = IN5(i - 1, k, 0) + tr12 * cr2 + tr11 * cr3;
+            const double ti3 = IN5(i, k, 0) + tr12 * ci2 + tr11 * ci3;
+            const double tr5 = cr5 * ti11 + cr4 * ti12, tr4 = cr5 * ti12 - cr4 * ti11;
+            const double ti5 = ci5 * ti11 + ci4 * ti12, ti4 = ci5 * ti12 - ci4 * ti11;
+            OUT5(i - 1, 2, k) = tr2 + tr5;  OUT5(ic - 1, 1, k) = tr2 - tr5;
+            OUT5(i, 2, k) = ti5 + ti2;      OUT5(ic, 1, k) = ti5 - ti2;
+            OUT5(i - 1, 4, k) = tr3 + tr4;  OUT5(ic - 1, 3, k) = tr3 - tr4;
+            OUT5(i, 4, k) = ti4 + ti3;      OUT5(ic, 3, k) = ti4 - ti3;
+        }
+#undef IN5
+#undef OUT5
+#undef W5
+}
+
 /* in-place forward real FFT, FFTPACK half-complex output (pocketfft.c:1730-1764) */
 void orc_rfft_forward(const OrcRfftPlan *p, double *c, double *scratch)
 {
@@ -252,7 +345,9 @@ void orc_rfft_forward(const OrcRfftPlan *p, double *c, double *scratch)
         const size_t ido = n / l1;
         l1 /= ip;
         if (ip == 4) pass4(ido, l1, a, b, p->tw[k]);
-        else         pass2(ido, l1, a, b, p->tw[k]);
+        else if (ip == 2) pass2(ido, l1, a, b, p->tw[k]);
+        else if (ip == 3) pass3(ido, l1, a, b, p->tw[k]);
+        else pass5(ido, l1, a, b, p->tw[k]);
         double *t = a; a = b; b = t;
     }
     if (a != c) memcpy(c, a, n * sizeof(double));

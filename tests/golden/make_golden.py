@@ -9,6 +9,9 @@ with the repo, the reference sources do not.
                       flush-phase chunks, chunk counts for 10 s (248 + 9/28), the sum of all
                       feed-phase values, window and mel tables.
   fbank_frames.npz  : 40 single frames (random / extreme / silent PCM) -> 80 log-mel values each.
+  fbank_nonpow2.npz : models with round_pow2 = 0 (the FFT length is the frame length): per geometry 24 single frames -> log-mel
+                      (400 = 4 4 5 5, 320 = 4 4 4 5, 480 = 2 4 4 3 5, 200 = 2 4 5 5 at 8 kHz, where the lowest of the 80 mel filters fall between FFT bins), and for the 400-point
+                      one the whole online fbank on 1 s of the LCG recipe (feed chunks + both flush phases).
 """
 import os
 import sys
@@ -26,8 +29,13 @@ def to_wave(pcm):
     return pcm.astype(np.float32) / np.float32(32768.0)
 
 
-def run_ref(pcm, seg=3200):
-    fb = O.RefFbank()
+# (name, RefFbank keywords, FFT length) of the round_pow2 = 0 geometries
+NONPOW2 = [("n400", dict(round_pow2=0), 400), ("n320", dict(round_pow2=0, len_ms=20), 320), ("n480", dict(round_pow2=0, len_ms=30), 480),
+           ("n200", dict(round_pow2=0, rate=8000), 200)]
+
+
+def run_ref(pcm, seg=3200, **kw):
+    fb = O.RefFbank(**kw)
     feed = []
     w = to_wave(pcm)
     for i in range(0, w.size, seg):
@@ -66,7 +74,24 @@ def main():
         fb.accept(np.concatenate([to_wave(f), np.zeros(8 * 160, np.float32)]))
         out.append(fb.pull_all()[0][0])
     np.savez_compressed(os.path.join(HERE, "fbank_frames.npz"), pcm=frames, logmel=np.array(out))
-    print("wrote goldens:", feed1.shape, len(feed10), len(p1), len(p1) + len(p2), feed10.astype(np.float64).sum())
+    out = {}
+    rng = np.random.RandomState(23)
+    for name, kw, n in NONPOW2:
+        shift = (kw.get("rate", 16000) // 100)
+        frames = np.concatenate([rng.randint(-32768, 32768, size=(14, n)), rng.randint(-200, 200, size=(4, n)), np.zeros((1, n)),
+                                 np.full((1, n), -32768), np.full((1, n), 32767), np.tile(np.array([32767, -32768]), (1, n // 2)),
+                                 O.lcg_pcm16_fast(2 * n, seed=77).reshape(2, n)]).astype(np.int16)
+        rows = []
+        for f in frames:
+            fb = O.RefFbank(**kw)
+            fb.accept(np.concatenate([to_wave(f), np.zeros(8 * shift, np.float32)]))
+            rows.append(fb.pull_all()[0][0])
+        out[name + "_pcm"] = frames
+        out[name + "_logmel"] = np.array(rows)
+    f400, a400, b400 = run_ref(pcm1, 3200, round_pow2=0)
+    out.update(seed=12345, n400_feed_1s=f400, n400_flush1_1s=a400, n400_flush2_1s=b400)
+    np.savez_compressed(os.path.join(HERE, "fbank_nonpow2.npz"), **out)
+    print("wrote goldens:", feed1.shape, len(feed10), len(p1), len(p1) + len(p2), feed10.astype(np.float64).sum(), "| nonpow2", f400.shape, a400.shape, b400.shape)
 
 
 if __name__ == "__main__":

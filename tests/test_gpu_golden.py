@@ -71,3 +71,58 @@ def test_online_fbank_on_golden_lcg_10s(gm):
     assert np.array_equal(bits(chunks[0]), bits(g["first_chunk_10s"]))
     assert np.array_equal(bits(chunks[-1]), bits(g["last_flush_chunk_10s"]))
     assert chunks[-1][-1][-1] == np.float32(-15.9423847)
+
+
+# ------------------------------------------------------------------ round_pow2 = 0: the FFT length is the frame length
+# (src/fbank.c:135-138).  400 = 4 4 5 5, 320 = 4 4 4 5, 480 = 2 4 4 3 5, 200 = 2 4 5 5 (8 kHz): pocketfft's radix 3 / 5 passes and
+# radix 4 / 2 with an odd inner stride, on the device, against vectors generated from the reference's own fbank.c + pocketfft.c.
+NONPOW2 = [("n400", dict(round_pow2=0), 400), ("n320", dict(round_pow2=0, length_ms=20), 320), ("n480", dict(round_pow2=0, length_ms=30), 480),
+           ("n200", dict(round_pow2=0, rate=8000), 200)]
+
+
+@pytest.fixture(scope="module")
+def nonpow2_models(model_dir, built):
+    import april_asr_amd as A
+    from april_asr_amd import synth_model as SM
+    ms = {}
+    for name, params, n in NONPOW2:
+        p = str(model_dir / ("tiny_%s.april" % name))
+        SM.write_model(p, SM.TINY_DIMS, params=params)
+        ms[name] = A.Model(p)
+        assert ms[name].dims.fft_size == n
+    yield ms
+    for m in ms.values():
+        m.close()
+
+
+@pytest.mark.parametrize("name", [g[0] for g in NONPOW2])
+def test_fbank_kernel_on_golden_nonpow2_frames(nonpow2_models, name):
+    g = np.load(os.path.join(G, "fbank_nonpow2.npz"))
+    got = nonpow2_models[name].run_fbank(g[name + "_pcm"])
+    want = g[name + "_logmel"]
+    assert np.array_equal(bits(got), bits(want)), "max |diff| = %g" % np.abs(got - want).max()
+
+
+def test_online_fbank_on_golden_nonpow2_400(nonpow2_models):
+    from oracle import orc_py as O
+    g = np.load(os.path.join(G, "fbank_nonpow2.npz"))
+    pcm = O.lcg_pcm16_fast(16000, seed=int(g["seed"]))
+    want = np.concatenate([g["n400_feed_1s"], g["n400_flush1_1s"], g["n400_flush2_1s"]])
+    for seg in (3200, 333, 16000):
+        n_feed, chunks = session_chunks(nonpow2_models["n400"], pcm, seg)
+        assert n_feed == len(g["n400_feed_1s"]) and chunks.shape == want.shape, (seg, n_feed, chunks.shape, want.shape)
+        assert np.array_equal(bits(chunks), bits(want)), "segments of %d samples" % seg
+
+
+def test_session_transcript_nonpow2_400(nonpow2_models, model_dir):
+    """the whole path on a round_pow2 = 0 model against the oracle session: logits within 1e-3, the same callbacks"""
+    from oracle import orc_py as O
+    from test_gpu_parity import run_oracle, run_gpu, assert_same_transcript, speech_like_pcm
+    om = O.Model(str(model_dir / "tiny_n400.april"))
+    pcm = np.concatenate([speech_like_pcm(2.0, seed=6), np.zeros(16000, np.int16)])
+    want, lg0, n0 = run_oracle(om, pcm, 1600)
+    got, lg1, n1 = run_gpu(nonpow2_models["n400"], pcm, 1600)
+    om.close()
+    assert n0 == n1
+    assert lg0.shape == lg1.shape and np.abs(lg0 - lg1).max() < 1e-3
+    assert_same_transcript(want, got)

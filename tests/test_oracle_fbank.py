@@ -96,3 +96,50 @@ def test_other_geometry_against_reference(built):
     b = run(O.RefFbank(**kw), pcm, 800)
     for x, y in zip(a, b):
         assert x.shape == y.shape and np.array_equal(bits(x), bits(y))
+
+
+# ------------------------------------------------------------------ round_pow2 = 0: the FFT length is the frame length
+# (src/fbank.c:135-138; pocketfft's radix 3 and 5 passes, radix 4 / 2 with an odd inner stride)
+NONPOW2 = [("n400", dict(round_pow2=0), 400), ("n320", dict(round_pow2=0, len_ms=20), 320), ("n480", dict(round_pow2=0, len_ms=30), 480),
+           ("n200", dict(round_pow2=0, rate=8000), 200)]
+
+
+@pytest.mark.parametrize("name,kw,n", NONPOW2)
+def test_golden_nonpow2_single_frames(built, name, kw, n):
+    g = np.load(os.path.join(G, "fbank_nonpow2.npz"))
+    pcm = g[name + "_pcm"]
+    assert pcm.shape[1] == n
+    fb = O.OrcFbank(**kw)
+    got = np.stack([fb.frame(wave(p)) for p in pcm])
+    assert np.array_equal(bits(got), bits(g[name + "_logmel"]))
+
+
+def test_golden_nonpow2_online_400(built):
+    g = np.load(os.path.join(G, "fbank_nonpow2.npz"))
+    pcm = O.lcg_pcm16_fast(16000, seed=int(g["seed"]))
+    for seg in (3200, 333):
+        feed, p1, p2 = run(O.OrcFbank(round_pow2=0), pcm, seg)
+        assert np.array_equal(bits(feed), bits(g["n400_feed_1s"]))
+        assert np.array_equal(bits(p1), bits(g["n400_flush1_1s"])) and np.array_equal(bits(p2), bits(g["n400_flush2_1s"]))
+
+
+@pytest.mark.skipif(not O.ref_available(), reason="compiled reference (oracle/_ref) not present")
+@pytest.mark.parametrize("kw", [dict(round_pow2=0), dict(round_pow2=0, len_ms=20), dict(round_pow2=0, len_ms=30), dict(round_pow2=0, len_ms=10),
+                                dict(round_pow2=0, len_ms=15), dict(round_pow2=0, rate=8000, nbins=40), dict(round_pow2=0, rate=48000, nbins=80),
+                                dict(round_pow2=0, rate=8000, len_ms=30, nbins=23)])
+def test_nonpow2_against_compiled_reference(built, kw):
+    """FFT lengths 400, 320, 480, 160, 240, 200, 1200, 240 (8 kHz): every factor list of 4 / 2 / 3 / 5 that frame lengths produce."""
+    pcm = np.concatenate([O.lcg_pcm16_fast(20000, seed=5), np.zeros(1500, np.int16)])
+    a = run(O.OrcFbank(**kw), pcm, 1600)
+    b = run(O.RefFbank(**kw), pcm, 1600)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and np.array_equal(bits(x), bits(y))
+
+
+def test_unsupported_fft_lengths_are_refused(built):
+    """a prime factor above 5 (pocketfft's generic pass) or a length that is not a multiple of 4: refused, not approximated"""
+    L = O.lib()
+    for kw in (dict(rate=22400, len_ms=25), dict(rate=16000, len_ms=13), dict(rate=44000, len_ms=21)):      # 560 = 2^4 5 7, 208 = 2^4 13, 924 = 2^2 3 7 11
+        o = dict(O.APRILV0_FBANK); o.update(kw); o["round_pow2"] = 0
+        h = L.orc_fbank_new(o["rate"], o["shift_ms"], o["len_ms"], o["nbins"], 0, o["mel_lo"], o["mel_hi"], o["seg_count"], o["seg_step"])
+        assert not h
