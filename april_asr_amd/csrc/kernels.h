@@ -116,6 +116,7 @@ struct GemmArgs {
                                            // the planner's occupancy rule (fp32 A in one K segment, N % 64 == 0, row epilogue or partial planes);
                                            // 2 = GM_TILE always (the fp16 tile path of an fp16 engine: every batch size runs the same chains)
     int skew = 0;                          // start delay (x 4096 cycles) for every second generation of workgroups
+    int xcd_rc = 0;                        // GM_KW: 2 = tiles dealt to the XCDs as 2 row halves x 4 column quarters (APRIL_KW_XCD; 0 = column tiles round robin)
     int asm_loop = 0;                      // != 0: hand-scheduled K loop (gemm_mainloop_asm.inc) in the fused-epilogue 64x64 fp32 tiles
     unsigned long long *trace = nullptr;   // measurement only: per-workgroup s_memtime stamps [wg][8] (wave 0, lane 0)
     int debug = 0;                         // measurement only: 1 = skip the MFMA main loop, 2 = skip the epilogue math, 3 = all k blocks read block 0

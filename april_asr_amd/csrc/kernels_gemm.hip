@@ -1023,6 +1023,8 @@ static TilePlan finalize_gemm(GemmArgs &g)
     g.skew = (long)(g.N / (16 * t.nt)) * ((g.M + 16 * t.mt - 1) / (16 * t.mt)) * (t.mode == GM_FULLK ? 1 : g.kz / g.zs) >= 512 ? skew : 0;   // two workgroups per CU
     static const int kw_skew = env_int("APRIL_KW_SKEW", 0);      // GM_KW: start delay of the second half of a workgroup's waves, x 64 cycles (measured: no effect; kernels_gemm_kw.hip)
     if (t.mode == GM_KW) g.skew = kw_skew;
+    static const int kw_xcd = env_int("APRIL_KW_XCD", 0);        // GM_KW: 2 = the 2 x 4 XCD order of the tiles (kernels_gemm_kw.hip kw_tile_of)
+    g.xcd_rc = t.mode == GM_KW ? kw_xcd : 0;
     return t;
 }
 

@@ -528,10 +528,29 @@ __device__ __forceinline__ void gemm_kw_body(const GemmArgs &g, const int bx, co
 
 // waves per SIMD the register budget must allow: one eight-wave workgroup per CU (the 128 registers of two spill inside the K loop) -- three for the
 // 16-row projection tiles --, three four-wave ones
+// Which tile a workgroup takes.  Workgroups go to the eight XCDs round robin in dispatch order, so with the plain mapping (column tile =
+// blockIdx.x) an XCD owns two of the sixteen column tiles of an N = 512 problem and ALL of its rows: the weights cross the fabric once,
+// the activation rows eight times.  xcd_rc = 2 deals the tiles as 2 row halves x 4 column quarters instead: XCD x = 4 r + c
+// takes rows of half r and columns of quarter c, the j-th workgroup it receives walks its sub-block column-fastest -- weights twice, rows
+// four times across the fabric.  Needs grid.x % 4 == 0 and grid.y % 2 == 0 (then every problem of a z-batched launch starts at XCD 0).
+__device__ __forceinline__ void kw_tile_of(const int xcd_rc, int &bx, int &by)
+{
+    const int gx = (int)gridDim.x, gy = (int)gridDim.y;
+    bx = (int)blockIdx.x; by = (int)blockIdx.y;
+    if (xcd_rc == 2 && (gx & 3) == 0 && (gy & 1) == 0) {
+        const int L = bx + gx * by;
+        const int x = L & 7, j = L >> 3, qx = gx >> 2, hy = gy >> 1;
+        by = (x >> 2) * hy + j / qx;
+        bx = (x & 3) * qx + j % qx;
+    }
+}
+
 template <int MT, int NT, int NW, int EPI, int D, int CPW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? ((MT == 1 && EPI == EPI_HR) ? 6 : 2) : (MT == 4 ? 2 : 3)) void gemm_kw_kernel(GemmArgs g)
 {
-    gemm_kw_body<MT, NT, NW, EPI, D, CPW>(g, (int)blockIdx.x, (int)blockIdx.y, blockIdx.x + gridDim.x * blockIdx.y);
+    int bx, by;
+    kw_tile_of(g.xcd_rc, bx, by);
+    gemm_kw_body<MT, NT, NW, EPI, D, CPW>(g, bx, by, blockIdx.x + gridDim.x * blockIdx.y);
 }
 
 // n independent same-shape problems in one launch (see gemm_f32_zkernel): blockIdx.z picks the argument block
@@ -539,7 +558,9 @@ template <int MT, int NT, int NW, int EPI, int D, int CPW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? ((MT == 1 && EPI == EPI_HR) ? 6 : 2) : (MT == 4 ? 2 : 3)) void gemm_kw_zkernel(const GemmArgs *__restrict__ zargs)
 {
     const GemmArgs g = zargs[blockIdx.z];
-    gemm_kw_body<MT, NT, NW, EPI, D, CPW>(g, (int)blockIdx.x, (int)blockIdx.y, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+    int bx, by;
+    kw_tile_of(g.xcd_rc, bx, by);
+    gemm_kw_body<MT, NT, NW, EPI, D, CPW>(g, bx, by, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
 }
 
 template <int MT, int NT, int NW, int EPI, int D, int CPW>

@@ -37,12 +37,14 @@ def test_kw_schedule_is_bit_identical_on_whole_sessions(built, medium_model, v0_
         assert on[0] == off[0], "GM_KW %r: logits or callbacks differ from the round-4 schedules" % env
 
 
-def test_kw_bench_every_output_bitwise(built):
+@pytest.mark.parametrize("xcd", ["0", "2"])
+def test_kw_bench_every_output_bitwise(built, xcd):
     exe = os.path.join(ROOT, "tools", "kw_bench")
     if not os.path.exists(exe):
         subprocess.check_call(["bash", os.path.join(ROOT, "tools", "build_kw_bench.sh")], timeout=900)
-    # (APRIL_KW_GATES: the gates form of GM_KW is a measurement form, off by default -- its outputs are still checked bit for bit here)
-    r = subprocess.run([exe, "20"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, APRIL_KW_GATES="1", APRIL_KW_GATES_MAX_ROWS="100000"))
+    # (APRIL_KW_GATES: the gates form of GM_KW is a measurement form, off by default -- its outputs are still checked bit for bit here;
+    # APRIL_KW_XCD=2: the 2 x 4 XCD order of the tiles, measured neutral and off by default, likewise)
+    r = subprocess.run([exe, "20"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=dict(os.environ, APRIL_KW_GATES="1", APRIL_KW_GATES_MAX_ROWS="100000", APRIL_KW_XCD=xcd))
     out = r.stdout.decode()
     assert r.returncode == 0 and "all configurations bit-identical" in out, out[-3000:] + r.stderr.decode()[-1000:]
     assert out.count("bit-identical") > 60 and "MISMATCH" not in out
