@@ -272,12 +272,13 @@ def main():
 
     step_wall = []                           # per-step wall time of the timed steps (p50/p99 latency of one 100 ms feed of all sessions)
 
-    def run_steps(group, pcms, s0, s1, record=None, ingest=None):
+    def run_steps(group, pcms, s0, s1, record=None, ingest=None, depth=None):
         """feeds s0 .. s1-1 of the plan; returns with every feed processed and every callback delivered"""
         ingest = ingest or args.ingest
+        depth = depth or args.pipeline_depth
         if s0 == 0:
             group.plan(pcms, step_samples)       # pointer arrays built outside the timed region
-        feed = group.feed_planned if ingest == "lockstep" else (lambda k: group.feed_planned_pipelined(k, args.pipeline_depth))
+        feed = group.feed_planned if ingest == "lockstep" else (lambda k: group.feed_planned_pipelined(k, depth))
         for s in range(s0, s1):
             if record is None:
                 feed(s)
@@ -352,6 +353,27 @@ def main():
                         args.steps, "aprilx_feed_many (one blocking call per 100 ms feed: nothing of the next feed can start before the previous one has been delivered)"
                         if other == "lockstep" else "aprilx_feed_many_pipelined depth 2")}
     del more_o
+    # a deeper hand-over queue on the same sessions (never `value`): with depth 4 the stepping thread finds two feeds queued and steps
+    # them as ONE wavefront of five chunks -- fewer, larger launches, one more feed of latency.  Reported so that the trade is visible.
+    deeper = None
+    if args.ingest == "pipelined" and args.pipeline_depth < 4:
+        more_d = pcm_for(B, args.steps + 8, 50_000_000 + rank * B)
+        run_steps(grp, more_d, 0, 8, depth=4)                   # (the five-chunk wavefront's launch chains are captured here)
+        barrier()
+        a = time.perf_counter()
+        model.feed_latencies(reset=True)
+        run_steps(grp, more_d, 8, args.steps + 8, depth=4)
+        barrier()
+        el_d = time.perf_counter() - a
+        lat_d = model.feed_latencies(reset=True)
+        if world > 1:
+            tt = torch.tensor([el_d], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el_d = float(tt.item())
+        deeper = {"depth": 4, "steps": args.steps, "ms_per_step": round(el_d / args.steps * 1e3, 3), "rtf": round(el_d / (args.steps * 0.1), 5),
+                  "feed_latency_ms": None if lat_d.size == 0 else {"p50": round(float(np.percentile(lat_d, 50)), 3), "p99": round(float(np.percentile(lat_d, 99)), 3), "n": int(lat_d.size)},
+                  "what": "the same sessions, %d further feeds through aprilx_feed_many_pipelined with depth 4 (up to three earlier feeds open): throughput against latency" % args.steps}
+        del more_d
     st = model.stats()
     audio_per_session = args.steps * step_samples / 16000.0
     value = world * B * audio_per_session / elapsed
@@ -567,7 +589,7 @@ def main():
             "ingest": {"mode": args.ingest, "depth": args.pipeline_depth if args.ingest == "pipelined" else 1, "what": "aprilx_feed_many_pipelined, depth 2 by default: feed k + 1 is queued (samples copied) while feed k is on the GPU, every callback "
                                                      "of the K timed feeds is delivered inside the timed region (drain before the closing barrier)"
                        if args.ingest == "pipelined" else "aprilx_feed_many: one blocking call per feed"},
-            "other_ingest": other_ingest, "steady": steady, "config5_f16": config5,
+            "other_ingest": other_ingest, "deeper_pipeline": deeper, "steady": steady, "config5_f16": config5,
             "rccl_fallback": rccl_fallback, "rccl_libs_mapped": sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln}),
             # the duration of the feed CALL: in lockstep mode that is the latency of a feed (the call returns with every callback
             # delivered); in pipelined mode it is only the hand-over (the call returns when at most one earlier feed is still open)
