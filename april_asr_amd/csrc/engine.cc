@@ -1695,6 +1695,7 @@ void Engine::zero_slots(int n)
 
 void Engine::debug_encoder(int n, const float *x, const float *h, const float *c, float *eout, float *h2, float *c2)
 {
+    std::lock_guard<std::mutex> cg(capture_mu_);      // (lock order everywhere: capture_mu_, then the process-wide legacy-stream lock -- step() takes them in that order)
     HipLegacyLock legacy;
     HIP_CHECK(hipSetDevice(cfg_.device));
     const NetDims &d = L_.dims;
@@ -1728,6 +1729,7 @@ void Engine::debug_encoder(int n, const float *x, const float *h, const float *c
 
 void Engine::debug_decoder(int n, const int64_t *ctx, float *dout)
 {
+    std::lock_guard<std::mutex> cg(capture_mu_);      // (lock order everywhere: capture_mu_, then the process-wide legacy-stream lock -- step() takes them in that order)
     HipLegacyLock legacy;
     HIP_CHECK(hipSetDevice(cfg_.device));
     const NetDims &d = L_.dims;
@@ -1758,6 +1760,7 @@ void Engine::debug_decoder(int n, const int64_t *ctx, float *dout)
 
 void Engine::debug_joiner(int n, const float *eout, const float *dout, float *logits)
 {
+    std::lock_guard<std::mutex> cg(capture_mu_);      // (lock order everywhere: capture_mu_, then the process-wide legacy-stream lock -- step() takes them in that order)
     HipLegacyLock legacy;
     const NetDims &d = L_.dims;
     HIP_CHECK(hipSetDevice(cfg_.device));
@@ -1785,6 +1788,7 @@ void Engine::debug_joiner(int n, const float *eout, const float *dout, float *lo
 
 void Engine::debug_decide(int n, int op, const float *logits, float early_emit, const int *now_ms, int round, int32_t *state_io, StepRecord *rec_out)
 {
+    std::lock_guard<std::mutex> cg(capture_mu_);      // (lock order everywhere: capture_mu_, then the process-wide legacy-stream lock -- step() takes them in that order)
     HipLegacyLock legacy;
     const NetDims &d = L_.dims;
     HIP_CHECK(hipSetDevice(cfg_.device));
@@ -1827,13 +1831,14 @@ void Engine::debug_decide(int n, int op, const float *logits, float early_emit, 
 
 void Engine::debug_fbank(int n_frames, const int16_t *pcm_frames, float *out)
 {
-    HipLegacyLock legacy;
     // every frame goes to slot 0, consecutive ring rows (n_frames <= ring_frames)
     const int padded = ft_.padded;
     std::vector<FbankFrameDesc> desc((size_t)n_frames);
     for (int i = 0; i < n_frames; ++i) { desc[(size_t)i].slot = 0; desc[(size_t)i].ring_row = i; desc[(size_t)i].pcm_off = i * padded; }
     std::pair<const int16_t *, size_t> part(pcm_frames, (size_t)n_frames * padded);
-    fbank(n_frames, desc.data(), &part, 1, (size_t)n_frames * padded);
+    fbank(n_frames, desc.data(), &part, 1, (size_t)n_frames * padded);      // (takes capture_mu_ itself: the legacy lock only afterwards, in the same order as step())
+    std::lock_guard<std::mutex> cg(capture_mu_);
+    HipLegacyLock legacy;
     sync();
     HIP_CHECK(hipMemcpy(out, ring_, (size_t)n_frames * ft_.nbins * 4, hipMemcpyDeviceToHost));
 }
