@@ -305,8 +305,10 @@ class Session:
         out = np.zeros((total, self.model.dims.mel), np.float32)
         if total:
             got = int(self._L.aprilx_session_read_frames(self._handle, 0, total, out.ctypes.data))
-            if got != total:      # UINT64_MAX: the first rows have left the ring (more than ring_frames rows written)
+            if got == 2 ** 64 - 1:      # UINT64_MAX: the first rows have left the ring (more than ring_frames rows written)
                 raise RuntimeError("frames(): %d rows written, the feature ring no longer holds the first ones" % total)
+            if got != total:            # (a count: rows of the range were not written yet -- cannot happen for [0, total) on an idle session)
+                raise RuntimeError("frames(): asked for %d rows, the session reports %d" % (total, got))
         return out
 
     def contexts(self):

@@ -48,7 +48,11 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 // ncclCommInitAll) -- the one collective of this system, at model load (reference load site src/april_model.c:57-61).
 bool broadcast_local(Model &m)
 {
-    HipLegacyLock legacy;                   // (device copies / RCCL set-up beside another model's running engines: engine.h)
+    // The process-wide legacy-stream lock (engine.h) is taken around this function's own device copies only, NEVER across RCCL
+    // bootstrap or collective waits: those block on other ranks for an unbounded time, and a stepping thread of another live model
+    // that needs a new graph shape would wait behind them holding its capture lock.  RCCL's own set-up work is safe beside
+    // a relaxed-mode capture of another thread -- measured: tools/rccl_capture_probe (profiles/r06_rccl_capture_probe.txt), 27 720
+    // captures beside communicator init + broadcast + destroy, none failed; the same probe's legacy-stream hipMemcpy leg aborts.
     std::vector<Engine *> peers;            // one engine per distinct device, root first
     std::vector<int> devs;
     // APRIL_FAULT_RCCL (fault injection, tests): 1 = every engine counts as a broadcast peer even when it shares a device with
@@ -105,6 +109,7 @@ bool broadcast_local(Model &m)
             if (env_int("APRIL_STRICT_RCCL", 0)) { LOGE("aam: RCCL weight broadcast failed and APRIL_STRICT_RCCL=1: giving up"); return false; }
             LOGE("aam: RCCL weight broadcast failed: falling back to peer copies from device %d (used_rccl = 0)", devs[0]);
             const double t2 = now_ms();
+            HipLegacyLock legacy;           // (legacy-stream copies: not while another engine captures a graph)
             for (size_t i = 1; i < peers.size(); ++i) {
                 HIP_CHECK(hipSetDevice(devs[i]));
                 if (devs[i] == devs[0]) HIP_CHECK(hipMemcpy(peers[i]->weights_mut(), peers[0]->weights_device(), count * 4, hipMemcpyDeviceToDevice));
@@ -115,6 +120,7 @@ bool broadcast_local(Model &m)
         }
     }
     // further engines on a device that already holds the weights ("lanes"): a device-to-device copy
+    HipLegacyLock legacy;
     for (Engine *e : m.engines) {
         if (std::find(peers.begin(), peers.end(), e) != peers.end()) continue;
         Engine *src = peers[(size_t)(std::find(devs.begin(), devs.end(), e->device()) - devs.begin())];
@@ -522,7 +528,8 @@ AprilASRModel aprilx_model_load_blob(const char *path)
 
 AprilASRModel aprilx_model_from_blob(const void *blob, size_t size, int blob_is_device_ptr)
 {
-    HipLegacyLock legacy;
+    // (the legacy-stream lock is taken around this function's own copies and, recursively, by the engines' constructors -- not
+    // around build_runtime as a whole: its weight broadcast may wait on RCCL, see broadcast_local)
     // Without an initialised GPU runtime (aam_api_init not called / no device) a HOST blob still
     // yields a host-only model: metadata + packed weights, no engine, no sessions (loader tests,
     // and the gloo leg of the broadcast path on CPU-only machines).
@@ -531,12 +538,12 @@ AprilASRModel aprilx_model_from_blob(const void *blob, size_t size, int blob_is_
     BlobHeader hd;
     if (size < sizeof hd) return nullptr;
     if (!host_only && g_devices.empty()) { LOGE("aprilx: no device selected"); return nullptr; }
-    if (blob_is_device_ptr) { HIP_CHECK(hipSetDevice(g_devices[0])); HIP_CHECK(hipMemcpy(&hd, blob, sizeof hd, hipMemcpyDeviceToHost)); }
+    if (blob_is_device_ptr) { HipLegacyLock legacy; HIP_CHECK(hipSetDevice(g_devices[0])); HIP_CHECK(hipMemcpy(&hd, blob, sizeof hd, hipMemcpyDeviceToHost)); }
     else memcpy(&hd, blob, sizeof hd);
     if (memcmp(hd.magic, "APXBLOB1", 8) != 0 || hd.weights_offset > size || hd.weight_floats > (size - hd.weights_offset) / 4 ||
         hd.meta_bytes > size || sizeof hd + hd.meta_bytes > hd.weights_offset) { LOGE("aprilx: bad blob"); return nullptr; }
     std::string meta((size_t)hd.meta_bytes, '\0');
-    if (blob_is_device_ptr) HIP_CHECK(hipMemcpy(&meta[0], (const char *)blob + sizeof hd, meta.size(), hipMemcpyDeviceToHost));
+    if (blob_is_device_ptr) { HipLegacyLock legacy; HIP_CHECK(hipMemcpy(&meta[0], (const char *)blob + sizeof hd, meta.size(), hipMemcpyDeviceToHost)); }
     else memcpy(&meta[0], (const char *)blob + sizeof hd, meta.size());
     AprilASRModel_i *h = new AprilASRModel_i();
     if (!parse_meta(meta.data(), meta.size(), h->m) || h->m.layout.total != hd.weight_floats) { LOGE("aprilx: blob metadata invalid"); delete h; return nullptr; }
@@ -565,7 +572,10 @@ int aprilx_broadcast_get_id(void *id_out, size_t cap)
 
 AprilASRModel aprilx_model_broadcast(AprilASRModel root_model, int rank, int world, const void *id_bytes)
 {
-    HipLegacyLock legacy;
+    // The legacy-stream lock (engine.h) is held around this function's allocations and host <-> device copies only; the RCCL
+    // bootstrap and the three collectives run WITHOUT it (they wait on the other ranks; two ranks driven from threads of one process
+    // would otherwise deadlock on it, and another model's stepping thread would stall behind it: ADVICE r5; broadcast_local has the
+    // measurement that makes this safe).
     if (!g_inited || world < 1 || rank < 0 || rank >= world || !id_bytes) { LOGE("aprilx_model_broadcast: bad arguments or library not initialised"); return nullptr; }
     if (rank == 0 && (!root_model || root_model->m.engines.empty())) { LOGE("aprilx_model_broadcast: rank 0 must pass a model that lives on a GPU"); return nullptr; }
     auto fail = [&](const char *what, ncclResult_t r) { LOGE("RCCL: %s failed: %s", what, ncclGetErrorString(r)); return (AprilASRModel) nullptr; };
@@ -580,9 +590,12 @@ AprilASRModel aprilx_model_broadcast(AprilASRModel root_model, int rank, int wor
     struct Cleanup {
         ncclComm_t &comm; hipStream_t &st; uint64_t *&hdr_d; char *&meta_d; float *&scratch;
         ~Cleanup() {
-            if (hdr_d) (void)hipFree(hdr_d);
-            if (meta_d) (void)hipFree(meta_d);
-            if (scratch) (void)hipFree(scratch);
+            {
+                HipLegacyLock legacy;
+                if (hdr_d) (void)hipFree(hdr_d);
+                if (meta_d) (void)hipFree(meta_d);
+                if (scratch) (void)hipFree(scratch);
+            }
             if (comm) (void)ncclCommDestroy(comm);
             if (st) (void)hipStreamDestroy(st);
         }
@@ -592,23 +605,29 @@ AprilASRModel aprilx_model_broadcast(AprilASRModel root_model, int rank, int wor
     const double t1 = now_ms();
     HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     // 1. sizes, 2. metadata (names, PARAMS, token table, dimensions), 3. the packed weights straight into the engine
-    HIP_CHECK(hipMalloc((void **)&hdr_d, 16));
     std::string meta;
     uint64_t hdr[2] = {0, 0};
-    if (rank == 0) { meta = make_meta(root_model->m); hdr[0] = meta.size(); hdr[1] = root_model->m.layout.total; HIP_CHECK(hipMemcpy(hdr_d, hdr, 16, hipMemcpyHostToDevice)); }
+    {
+        HipLegacyLock legacy;
+        HIP_CHECK(hipMalloc((void **)&hdr_d, 16));
+        if (rank == 0) { meta = make_meta(root_model->m); hdr[0] = meta.size(); hdr[1] = root_model->m.layout.total; HIP_CHECK(hipMemcpy(hdr_d, hdr, 16, hipMemcpyHostToDevice)); }
+    }
     if ((r = ncclBroadcast(hdr_d, hdr_d, 16, ncclUint8, 0, comm, st)) != ncclSuccess) return fail("ncclBroadcast(sizes)", r);
     HIP_CHECK(hipStreamSynchronize(st));
-    HIP_CHECK(hipMemcpy(hdr, hdr_d, 16, hipMemcpyDeviceToHost));
-    if (hdr[0] == 0 || hdr[0] > ((uint64_t)1 << 30) || hdr[1] == 0) { LOGE("aprilx_model_broadcast: implausible sizes"); return nullptr; }
-    HIP_CHECK(hipMalloc((void **)&meta_d, (size_t)hdr[0]));
-    if (rank == 0) HIP_CHECK(hipMemcpy(meta_d, meta.data(), meta.size(), hipMemcpyHostToDevice));
+    {
+        HipLegacyLock legacy;
+        HIP_CHECK(hipMemcpy(hdr, hdr_d, 16, hipMemcpyDeviceToHost));
+        if (hdr[0] == 0 || hdr[0] > ((uint64_t)1 << 30) || hdr[1] == 0) { LOGE("aprilx_model_broadcast: implausible sizes"); return nullptr; }
+        HIP_CHECK(hipMalloc((void **)&meta_d, (size_t)hdr[0]));
+        if (rank == 0) HIP_CHECK(hipMemcpy(meta_d, meta.data(), meta.size(), hipMemcpyHostToDevice));
+    }
     if ((r = ncclBroadcast(meta_d, meta_d, (size_t)hdr[0], ncclUint8, 0, comm, st)) != ncclSuccess) return fail("ncclBroadcast(metadata)", r);
     HIP_CHECK(hipStreamSynchronize(st));
     AprilASRModel_i *h = nullptr;
     if (rank == 0) h = root_model;
     else {
         meta.resize((size_t)hdr[0]);
-        HIP_CHECK(hipMemcpy(&meta[0], meta_d, meta.size(), hipMemcpyDeviceToHost));
+        { HipLegacyLock legacy; HIP_CHECK(hipMemcpy(&meta[0], meta_d, meta.size(), hipMemcpyDeviceToHost)); }
         h = new AprilASRModel_i();
         if (!parse_meta(meta.data(), meta.size(), h->m) || h->m.layout.total != hdr[1] || !create_engines(h->m, nullptr, nullptr)) {
             LOGE("aprilx_model_broadcast: received metadata is invalid"); delete h; h = nullptr;
@@ -616,7 +635,7 @@ AprilASRModel aprilx_model_broadcast(AprilASRModel root_model, int rank, int wor
     }
     // every rank takes part in the weight broadcast even if its model could not be built (a missing rank would hang the others)
     float *buf = h ? h->m.engines[0]->weights_mut() : nullptr;
-    if (!buf) { HIP_CHECK(hipMalloc((void **)&scratch, (size_t)hdr[1] * 4)); buf = scratch; }
+    if (!buf) { HipLegacyLock legacy; HIP_CHECK(hipMalloc((void **)&scratch, (size_t)hdr[1] * 4)); buf = scratch; }
     const double t2 = now_ms();
     r = ncclBroadcast(buf, buf, (size_t)hdr[1], ncclFloat, 0, comm, st);
     if (r == ncclSuccess) HIP_CHECK(hipStreamSynchronize(st));
@@ -776,7 +795,8 @@ uint64_t aprilx_session_read_frames(AprilASRSession session, uint64_t first, int
     const uint64_t total = s->fb.rows_written;
     if (out && n > 0) {
         const int R = s->eng->ring_frames();
-        if (first + (uint64_t)n > total || total - first > (uint64_t)R) return UINT64_MAX;      // not written yet / already overwritten: nothing copied
+        if (first + (uint64_t)n > total) return total;                      // (part of) the range has not been written yet: nothing copied, the count as before
+        if (total - first > (uint64_t)R) return UINT64_MAX;                 // the first rows of the range have been overwritten: nothing copied
         int done = 0;
         while (done < n) {          // (the ring may wrap inside the range)
             const int row = (int)((first + (uint64_t)done) % (uint64_t)R), cnt = std::min(n - done, R - row);

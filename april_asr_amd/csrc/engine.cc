@@ -127,8 +127,10 @@ void pack_weights(const HostModel &m, PackedLayout &L, std::vector<float> &blob)
 }
 
 // ---------------------------------------------------------------- engine
-template <typename T> static T *dmalloc(size_t n) { T *p = nullptr; HIP_CHECK(hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T))); return p; }
-template <typename T> static T *hmalloc(size_t n) { T *p = nullptr; HIP_CHECK(hipHostMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault)); return p; }
+// (every allocation holds the process-wide legacy lock, engine.h: an allocation of one engine's stepping thread -- staging regrowth, a
+// new launch plan -- must not coincide with another engine's graph capture; recursive, so the constructor's own guard nests)
+template <typename T> static T *dmalloc(size_t n) { HipLegacyLock legacy; T *p = nullptr; HIP_CHECK(hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T))); return p; }
+template <typename T> static T *hmalloc(size_t n) { HipLegacyLock legacy; T *p = nullptr; HIP_CHECK(hipHostMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault)); return p; }
 
 std::recursive_mutex &hip_legacy_mutex() { static std::recursive_mutex m; return m; }
 
@@ -584,6 +586,7 @@ void Engine::fbank(int n_frames, const FbankFrameDesc *desc, const std::pair<con
     HIP_CHECK(hipSetDevice(cfg_.device));
     if (n_frames > desc_cap_ || n_pcm > pcm_cap_) {
         sync();
+        HipLegacyLock regrow_guard;                   // (frees imply a device synchronisation: not beside another engine's capture; order: capture_mu_, then this)
         for (int b = 0; b < 2; ++b) {
             if (hs_desc_[b]) { (void)hipHostFree(hs_desc_[b]); (void)hipFree(ds_desc_[b]); }
             if (hs_pcm_[b]) { (void)hipHostFree(hs_pcm_[b]); (void)hipFree(ds_pcm_[b]); }
@@ -1151,6 +1154,7 @@ void Engine::run_lm_wavefront(int m, int T, bool dump_logits)
     const size_t need = (size_t)(NB + L + 1) * (size_t)(2 * blk + 6) * (size_t)L;
     if (need > zargs_region_) {
         HIP_CHECK(hipStreamSynchronize(cs));
+        HipLegacyLock regrow_guard;                   // (see fbank())
         if (zargs_h_) { (void)hipHostFree(zargs_h_); (void)hipFree(zargs_d_); }
         zargs_region_ = need + need / 4;
         zargs_h_ = hmalloc<GemmArgs>(3 * zargs_region_); zargs_d_ = dmalloc<GemmArgs>(3 * zargs_region_);
@@ -1275,6 +1279,7 @@ Engine::SwPlan &Engine::sw_plan(int m, int T)
     if (it != sw_plans_.end()) return it->second;
     if (sw_plans_.size() >= 64) {
         sync();
+        HipLegacyLock evict_guard;                    // (see fbank())
         for (auto &p : sw_plans_) { if (p.second.graph) (void)hipGraphExecDestroy(p.second.graph); for (hipGraphExec_t x : p.second.g3) if (x) (void)hipGraphExecDestroy(x); if (p.second.dev) (void)hipFree(p.second.dev); if (p.second.rdev) (void)hipFree(p.second.rdev); }
         sw_plans_.clear();
     }

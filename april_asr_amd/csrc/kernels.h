@@ -29,6 +29,12 @@ namespace aprilx {
 //               meet ONCE as (R0+R1)+(R2+R3).  No partial planes; the row work (state write, residual, bias,
 //               sum of squares, slot store) runs in the GEMM epilogue.  Used as soon as output tiles alone give
 //               enough workgroups.
+//   fp16 one-chain rule (round 6; binary16 operands, wt == 1, on the GM_TILE / GM_PP schedules, kz = 1: gates, FFN up, the layer-major
+//   halves of the gate GEMM): the sum is ONE MFMA chain over all 32-k blocks in k order -- each v_mfma_f32_16x16x32_f16 adds its 32
+//   products to the running fp32 sum -- and where the y half of K ends (K0) the running sum is multiplied by the row's BasicNorm scale:
+//   s * sum_y + sum_h.  EPI_XPART leaves s * sum_y, EPI_LSTM + p_add continues the chain from it.  No chunk sums: the accumulator is the
+//   only register set, which is what lets GM_PP hold 256 x 128 tiles with double-buffered fragments.  Still a property of the layer:
+//   every batch size, streamed or layer-major, runs the same chain.  fp32 operands keep the chunk / slab / tree form above.
 enum GemmEpilogue {
     EPI_PARTIAL = 0,      // ws[z][m][n] = tree sum of this workgroup's slabs      (consumer: row kernels; FULLK: one plane)
     EPI_LSTM = 1,         // columns are unit-major (unit*4 + gate i,f,g,o): cell update, c in place, u out
@@ -45,13 +51,17 @@ enum GemmAOp { AOP_NONE = 0, AOP_TANH_ADD = 1 };
 //   - a GEMM over x (LSTM gates' input half, encoder_proj) runs over y and multiplies the finished partial sum by the row's
 //     scale in its epilogue (`x_scale`): scale * sum_k(y_k w_k), one rounding away from sum_k((scale y_k) w_k);
 //   - the residual x + h' reads y and multiplies (`r_scale`).
-enum GemmMode { GM_SLAB = 0, GM_FULLK = 1, GM_TILE = 2, GM_KW = 3 };
+enum GemmMode { GM_SLAB = 0, GM_FULLK = 1, GM_TILE = 2, GM_KW = 3, GM_PP = 4 };
 //     GM_TILE   (kernels_gemm_tile.hip) the four waves split the OUTPUT tile and share both operands through LDS; every wave
 //               folds chunk -> slab -> tree in registers over the workgroup's zs slabs.  zs == kz: row epilogue fused;
 //               zs < kz: kz / zs partial planes, finished by the row kernels exactly as for GM_SLAB.
 //     GM_KW     (kernels_gemm_kw.hip, round 5) the waves split K as in GM_FULLK (eight waves: one slab each at kz = 8), but every wave's
 //               activation rows arrive in full 128-byte lines through a wave-private LDS ring (no barrier in the K loop); 32 x 32 tiles.
 //               The N = d_model GEMMs (and FFN up) at a few hundred rows per launch.
+
+//     GM_PP     (kernels_gemm_pp.hip, round 6) the fp16 gates / FFN-up GEMMs (kz = 1) from a few hundred rows per launch: 256 / 128 x 128
+//               tiles on eight waves = two groups of four that run one phase apart (one group's MFMAs beside the other's DMA issue and
+//               fragment reads); same chains and folds as GM_TILE.
 
 constexpr int SSQ_COLS = 32;       // columns per sum-of-squares partial (one granule = 8 consecutive 4-column quads)
 
@@ -127,6 +137,13 @@ void launch_gemm_tile(const GemmArgs &g, int mt, int nt, const GemmArgs *dev_arg
 // (internal) GM_KW launch (kernels_gemm_kw.hip): tile 16 * mt rows x 16 * nt columns, all of K in the workgroup; dev_args != null: n z-batched
 // problems.  gemm_kw_waves: 8 / 4 = the waves a GM_KW workgroup would use for this GEMM (operands, epilogue, chunk structure), 0 = not eligible
 int gemm_kw_waves(const GemmArgs &g);
+// (internal) GM_PP launch (kernels_gemm_pp.hip): tile 16 * mt (256 / 128) rows x 128 columns; dev_args != null: n z-batched problems.
+// gemm_pp_ok: the operands of g fit the schedule (binary16 operands, kz = 1, LSTM / DoubleSwish / XPART epilogue, whole stages)
+bool gemm_pp_ok(const GemmArgs &g, int mt);
+void launch_gemm_pp(const GemmArgs &g, int mt, const GemmArgs *dev_args, int n, hipStream_t s);
+// measurement only (tools/pp_bench): enable -1 = environment default (APRIL_GM_PP), 0 / 1 = off / on; mt = 0 (planner) or pinned 16 / 8
+void gemm_pp_pin(int enable, int mt);
+bool gemm_kw_has_kernel(const GemmArgs &g, int mt, int nt);      // a GM_KW kernel exists for this GEMM on 16 mt x 16 nt tiles
 void launch_gemm_kw(const GemmArgs &g, int mt, int nt, const GemmArgs *dev_args, int n, hipStream_t s);
 // measurement only (tools/kw_bench): enable / ff1 (FFN up on GM_KW): -1 = environment default, 0 / 1 = off / on; mt = 0 (planner) or pinned tile rows / 16
 void gemm_kw_pin(int enable, int mt, int ff1);

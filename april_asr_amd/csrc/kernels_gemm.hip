@@ -770,7 +770,30 @@ static bool plan_fullk(int M, int N, int kz, TilePlan &t, bool force = false, in
 static int g_tile_pin_mt = env_int("APRIL_TILE_MT", 0), g_tile_pin_zs = env_int("APRIL_TILE_ZS", 0), g_tile_enable = -1;
 void gemm_tile_pin(int enable, int mt, int zs) { g_tile_enable = enable; g_tile_pin_mt = mt; g_tile_pin_zs = zs; }
 
-static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePlan &t, bool always = false, bool big_ok = false, bool wide_ok = false)
+// GM_PP (kernels_gemm_pp.hip): the fp16 gates / FFN-up GEMMs on 256 (128) x 128 ping-pong tiles.  One workgroup per CU (144 KB of stage
+// buffers), so a launch is ceil(tiles / 256) rounds of one tile time; 256-row tiles are the efficient ones (85 flop per operand byte,
+// 16 MFMAs per 8 fragment reads), 128-row tiles fill the chip at fewer rows.  APRIL_GM_PP=0 keeps the round-3 GM_TILE forms;
+// APRIL_PP_MT pins the tile rows / 16 (gemm_pp_pin for tools/pp_bench).
+static int g_pp_enable = -1, g_pp_pin_mt = 0;
+void gemm_pp_pin(int enable, int mt) { g_pp_enable = enable; g_pp_pin_mt = mt; }
+static bool plan_pp(int M, int N, int zcount, TilePlan &t)
+{
+    static const int enabled = env_int("APRIL_GM_PP", 1), env_mt = env_int("APRIL_PP_MT", 0), min_tiles = env_int("APRIL_PP_MIN_TILES", 128);
+    if (!(g_pp_enable < 0 ? enabled : g_pp_enable) || N % 128 != 0) return false;
+    const long zc = std::max(1, zcount);
+    const long t16 = (long)(N / 128) * ((M + 255) / 256) * zc, t8 = (long)(N / 128) * ((M + 127) / 128) * zc;
+    int mt = g_pp_pin_mt ? g_pp_pin_mt : env_mt;
+    if (mt != 16 && mt != 8) {
+        if (t8 < min_tiles) return false;                 // a handful of tiles: the small-batch forms stream the weights with more workgroups
+        // rounds of one workgroup per CU; a 128-row tile costs ~0.6 of a 256-row one (half the MFMAs, the same weight pieces)
+        const long c16 = ((t16 + 255) / 256) * 100, c8 = ((t8 + 255) / 256) * 60;
+        mt = c16 <= c8 ? 16 : 8;
+    }
+    t.mt = mt; t.nt = 8; t.zs = 1; t.mode = GM_PP;
+    return true;
+}
+
+static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePlan &t, bool always = false, bool big_ok = false, bool wide_ok = false, bool pp_ok = false)
 {
     static const int enabled = env_int("APRIL_GM_TILE", 1);
     static const int min_rows = env_int("APRIL_TILE_MIN_ROWS", 32);
@@ -785,6 +808,7 @@ static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePla
     static const int f16_mt = env_int("APRIL_TILE_F16_MT", 0);
     const int mt = pin_mt ? (pin_mt == 4 ? 4 : 2) : ((always && f16_mt) ? f16_mt : (tiles4 >= fused_tiles ? 4 : 2));
     const long tiles = mt == 4 ? tiles4 : tiles2;
+    if (pp_ok && kz == 1 && pin_mt == 0 && plan_pp(M, N, zcount, t)) return true;
     if (big_ok && kz == 1 && N % 128 == 0 && pin_mt == 0) {
         // fp16 gates / FFN up: 128 x 128 tiles (eight waves) once they give most CUs a workgroup -- twice the flops per operand byte
         static const int big = env_int("APRIL_TILE_BIG", 1), big_tiles = env_int("APRIL_TILE_BIG_TILES", 192), big_min_n = env_int("APRIL_TILE_BIG_MIN_N", 0);
@@ -850,7 +874,7 @@ bool gemm_fullk(int M, int N, int kz, bool force, int zcount, int tile_ok)
 }
 
 // Tile shape and slabs per workgroup.  Depends on M only through occupancy; numerics are tile-independent.
-static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = false, int zcount = 1, int tile_ok = 0, int zcount_true = 1, bool f16 = false)
+static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = false, int zcount = 1, int tile_ok = 0, int zcount_true = 1, bool f16 = false, bool pp_ok = false)
 {
     // measurement knobs (default 0): 1/2 = smaller tiles for the fused-epilogue GEMMs (measured slower on MI355X:
     // B=256 gates 27 -> 32..36 us, the kernel is limited by operand loads per MFMA, not by occupancy);
@@ -860,7 +884,7 @@ static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = fal
     if (tile_ok && (epi == EPI_PARTIAL || epi == EPI_HR || epi == EPI_RESID_SSQ || epi == EPI_SLOT_STORE || epi == EPI_LSTM || epi == EPI_BIAS_DSWISH || (epi == EPI_XPART && tile_ok == 2))) {
         // the caller asked gemm_fullk first: a row epilogue arrives only when that plan keeps all of K in the workgroup
         if (plan_tile(M, N, kz, zcount_true, force_fullk || epi != EPI_PARTIAL, t, tile_ok == 2, (f16 || env_int("APRIL_TILE_BIG_F32", 0)) && tile_ok == 2 && (epi == EPI_LSTM || epi == EPI_BIAS_DSWISH || epi == EPI_XPART),
-                      tile_ok == 2 && (epi == EPI_PARTIAL || epi == EPI_HR || epi == EPI_RESID_SSQ))) return t;
+                      tile_ok == 2 && (epi == EPI_PARTIAL || epi == EPI_HR || epi == EPI_RESID_SSQ), pp_ok && f16 && tile_ok == 2)) return t;
         if (tile_ok == 2) { fprintf(stderr, "libapril(mi355x): launch_gemm: no GM_TILE plan for an always-tile GEMM (M=%d N=%d kz=%d)\n", M, N, kz); abort(); }
     }
     if (epi != EPI_LSTM && epi != EPI_BIAS_DSWISH && epi != EPI_XPART && plan_fullk(M, N, kz, t, force_fullk, zcount)) return t;
@@ -973,7 +997,9 @@ static void plan_kw(const GemmArgs &g, TilePlan &t, int zc)
         // 22.8 vs 30.3, 256 x 2: 40.1 vs 55.3 -- a gain only for one-problem launches, a loss from 96 rows up.
         static const int gates = env_int("APRIL_KW_GATES", 0), gates_max = env_int("APRIL_KW_GATES_MAX_ROWS", 96);
         if (!gates || g.M < 17 || g.M > gates_max || gemm_kw_waves(g) != 4) return;
-        t.mt = g_kw_pin_mt ? g_kw_pin_mt : (g.M > 32 ? 4 : 2); t.nt = 2; t.zs = 1; t.mode = GM_KW;
+        const int gmt = g_kw_pin_mt ? g_kw_pin_mt : (g.M > 32 ? 4 : 2);
+        if (!gemm_kw_has_kernel(g, gmt, 2)) return;         // (a pinned tile shape without a kernel: the previous plan stays)
+        t.mt = gmt; t.nt = 2; t.zs = 1; t.mode = GM_KW;
         return;
     }
     if (g.epi == EPI_BIAS_DSWISH ? !(g_kw_ff1 < 0 ? ff1 : g_kw_ff1) : (g.epi != EPI_HR && g.epi != EPI_RESID_SSQ)) return;
@@ -988,7 +1014,11 @@ static void plan_kw(const GemmArgs &g, TilePlan &t, int zc)
         mt = (nw == 8 && ((t16 + 255) / 256) * 55 < ((t32 + 255) / 256) * 100) ? 1 : 2;
     }
     if (nw == 4 && mt == 1) mt = 2;
-    t.mt = mt; t.nt = (mt == 4 && nw == 8 && g.N % 64 == 0) ? 4 : nt; t.zs = g.kz; t.mode = GM_KW;      // (pinned 64-row tiles: 64 x 64, a wave tile of one memory instruction per eight MFMAs)
+    const int knt = (mt == 4 && nw == 8 && g.N % 64 == 0) ? 4 : nt;      // (pinned 64-row tiles: 64 x 64, a wave tile of one memory instruction per eight MFMAs)
+    // environment knobs and pins can ask for shapes that were never instantiated (APRIL_KW_FF1 with N % 64 != 0, 64-row tiles on four
+    // waves or at N % 64 != 0 ...): the previous plan stays instead of an abort in launch_gemm_kw
+    if (!gemm_kw_has_kernel(g, mt, knt)) return;
+    t.mt = mt; t.nt = knt; t.zs = g.kz; t.mode = GM_KW;
 }
 
 // plan + checks + measurement knobs: everything launch_gemm decides on the host
@@ -1008,7 +1038,8 @@ static TilePlan finalize_gemm(GemmArgs &g)
     const bool plain = g.a_op == AOP_NONE && g.N % 64 == 0 && ((g.wave_mask == 0xF && !g.p_add) || lm_half);
     const int tile_ok = !plain ? 0 : (g.tile_ok == 2 ? 2 : ((g.tile_ok == 1 && g.K1 == 0 && g.wt == 0 && g.epi != EPI_LSTM && g.epi != EPI_BIAS_DSWISH) ? 1 : 0));
     if (g.tile_ok == 2 && !tile_ok) { fprintf(stderr, "libapril(mi355x): launch_gemm: always-tile GEMM with a prologue / wave mask / odd N\n"); abort(); }
-    TilePlan t = plan_tiles(g.M, g.N, g.kz, g.epi, g.force_fullk != 0, (z_tiles == 1 || (z_tiles == 2 && is_slab_epi) || (z_tiles == 3 && !is_slab_epi)) ? zc : 1, tile_ok, zc, g.wt == 1);
+    TilePlan t = plan_tiles(g.M, g.N, g.kz, g.epi, g.force_fullk != 0, (z_tiles == 1 || (z_tiles == 2 && is_slab_epi) || (z_tiles == 3 && !is_slab_epi)) ? zc : 1, tile_ok, zc, g.wt == 1,
+                            g.wt == 1 && is_slab_epi && gemm_pp_ok(g, 16));
     plan_kw(g, t, zc);
     const bool row_epi = g.epi == EPI_HR || g.epi == EPI_RESID_SSQ || g.epi == EPI_SLOT_STORE;
     if (row_epi && t.zs != g.kz) { fprintf(stderr, "libapril(mi355x): launch_gemm: row epilogue %d needs the full-K plan (M=%d N=%d kz=%d)\n", g.epi, g.M, g.N, g.kz); abort(); }
@@ -1023,6 +1054,8 @@ static TilePlan finalize_gemm(GemmArgs &g)
     g.skew = (long)(g.N / (16 * t.nt)) * ((g.M + 16 * t.mt - 1) / (16 * t.mt)) * (t.mode == GM_FULLK ? 1 : g.kz / g.zs) >= 512 ? skew : 0;   // two workgroups per CU
     static const int kw_skew = env_int("APRIL_KW_SKEW", 0);      // GM_KW: start delay of the second half of a workgroup's waves, x 64 cycles (measured: no effect; kernels_gemm_kw.hip)
     if (t.mode == GM_KW) g.skew = kw_skew;
+    static const int pp_prio = env_int("APRIL_PP_PRIO", 0);      // GM_PP: wave priority policy (kernels_gemm_pp.hip: 0 none, 1 compute phase, 2 load phase)
+    if (t.mode == GM_PP) g.skew = pp_prio;
     static const int kw_xcd = env_int("APRIL_KW_XCD", 0);        // GM_KW: 2 = the 2 x 4 XCD order of the tiles (kernels_gemm_kw.hip kw_tile_of)
     g.xcd_rc = t.mode == GM_KW ? kw_xcd : 0;
     return t;
@@ -1043,6 +1076,7 @@ void launch_gemm(const GemmArgs &g_in, hipStream_t s)
     GemmArgs g = g_in;
     if (!kw_before_recur(g)) if (const int rf = recur_form(g)) { launch_recur(g, rf, nullptr, 1, s); return; }
     const TilePlan t = finalize_gemm(g);
+    if (t.mode == GM_PP) { launch_gemm_pp(g, t.mt, nullptr, 0, s); return; }
     if (t.mode == GM_TILE) { launch_gemm_tile(g, t.mt, t.nt, nullptr, 0, s); return; }
     if (t.mode == GM_KW) { launch_gemm_kw(g, t.mt, t.nt, nullptr, 0, s); return; }
     const int mt = t.mt, nt = t.nt;
@@ -1118,6 +1152,7 @@ void launch_gemm_z(const GemmArgs *staged, int n, const GemmArgs *dev_args, hipS
     if (!kw_before_recur(g)) if (const int rf = recur_form(g)) { launch_recur(g, rf, dev_args, n, s); return; }      // (stage_gemm_z checked that the n problems have one shape)
     GemmArgs probe = g;
     const TilePlan t = finalize_gemm(probe);
+    if (t.mode == GM_PP) { launch_gemm_pp(g, t.mt, dev_args, n, s); return; }
     if (t.mode == GM_TILE) { launch_gemm_tile(g, t.mt, t.nt, dev_args, n, s); return; }
     if (t.mode == GM_KW) { launch_gemm_kw(g, t.mt, t.nt, dev_args, n, s); return; }
     const int mt = t.mt, nt = t.nt;

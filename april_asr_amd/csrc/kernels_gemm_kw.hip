@@ -585,17 +585,17 @@ void launch_kw_one(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream
 }
 
 template <int MT, int NT, int NW, int D>
-bool dispatch_kw(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s)
+bool dispatch_kw(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s, bool dry)
 {
     const int cpw = 4 * g.kz / NW;
     if constexpr (NW == 8) {
-        if (g.epi == EPI_HR && cpw == 4) { launch_kw_one<MT, NT, NW, EPI_HR, D, 4>(g, dev_args, n, s); return true; }
-        if (g.epi == EPI_HR && cpw == 1) { launch_kw_one<MT, NT, NW, EPI_HR, D, 1>(g, dev_args, n, s); return true; }
-        if (g.epi == EPI_RESID_SSQ && cpw == 4) { launch_kw_one<MT, NT, NW, EPI_RESID_SSQ, D, 4>(g, dev_args, n, s); return true; }
-        if (g.epi == EPI_RESID_SSQ && cpw == 1) { launch_kw_one<MT, NT, NW, EPI_RESID_SSQ, D, 1>(g, dev_args, n, s); return true; }
+        if (g.epi == EPI_HR && cpw == 4) { if (!dry) launch_kw_one<MT, NT, NW, EPI_HR, D, 4>(g, dev_args, n, s); return true; }
+        if (g.epi == EPI_HR && cpw == 1) { if (!dry) launch_kw_one<MT, NT, NW, EPI_HR, D, 1>(g, dev_args, n, s); return true; }
+        if (g.epi == EPI_RESID_SSQ && cpw == 4) { if (!dry) launch_kw_one<MT, NT, NW, EPI_RESID_SSQ, D, 4>(g, dev_args, n, s); return true; }
+        if (g.epi == EPI_RESID_SSQ && cpw == 1) { if (!dry) launch_kw_one<MT, NT, NW, EPI_RESID_SSQ, D, 1>(g, dev_args, n, s); return true; }
     } else {
-        if (g.epi == EPI_BIAS_DSWISH && cpw == 1) { launch_kw_one<MT, NT, NW, EPI_BIAS_DSWISH, D, 1>(g, dev_args, n, s); return true; }
-        if constexpr (NT == 2) { if (g.epi == EPI_LSTM && cpw == 1) { launch_kw_one<MT, NT, NW, EPI_LSTM, D, 1>(g, dev_args, n, s); return true; } }
+        if (g.epi == EPI_BIAS_DSWISH && cpw == 1) { if (!dry) launch_kw_one<MT, NT, NW, EPI_BIAS_DSWISH, D, 1>(g, dev_args, n, s); return true; }
+        if constexpr (NT == 2) { if (g.epi == EPI_LSTM && cpw == 1) { if (!dry) launch_kw_one<MT, NT, NW, EPI_LSTM, D, 1>(g, dev_args, n, s); return true; } }
     }
     return false;
 }
@@ -631,25 +631,38 @@ int gemm_kw_waves(const GemmArgs &g)
 }
 
 // launch of a GEMM whose plan chose GM_KW: tile 16 mt x 16 nt, g.zs == g.kz
-void launch_gemm_kw(const GemmArgs &g, int mt, int nt, const GemmArgs *dev_args, int n, hipStream_t s)
+// the kernel of (g, tile): launched, or (dry) only looked up -- ONE table for plan_kw's question and for the launch
+static bool kw_find(const GemmArgs &g, int mt, int nt, const GemmArgs *dev_args, int n, hipStream_t s, bool dry)
 {
     const int nw = gemm_kw_waves(g);
     bool ok = false;
     static const int ring = [] { const char *v = getenv("APRIL_KW_RING"); return v && *v ? atoi(v) : 2; }();      // ring stages per wave: 2; 4 measured the same (tools/kw_bench: the loads are never waited for) at twice the LDS
     const int nstage = nw ? (4 * g.kz / nw) * (g.K / 16 / (4 * g.kz)) / 2 : 0;
-    if (nw == 8 && ring == 4 && nstage % 4 == 0 && mt == 2 && nt == 2) ok = dispatch_kw<2, 2, 8, 4>(g, dev_args, n, s);
+    if (nw == 8 && ring == 4 && nstage % 4 == 0 && mt == 2 && nt == 2) ok = dispatch_kw<2, 2, 8, 4>(g, dev_args, n, s, dry);
     else if (nw == 8) {
-        if (mt == 4 && nt == 4) ok = dispatch_kw<4, 4, 8, 2>(g, dev_args, n, s);
-        else if (mt == 2 && nt == 2) ok = dispatch_kw<2, 2, 8, 2>(g, dev_args, n, s);
-        else if (mt == 1 && nt == 2) ok = dispatch_kw<1, 2, 8, 2>(g, dev_args, n, s);
+        if (mt == 4 && nt == 4) ok = dispatch_kw<4, 4, 8, 2>(g, dev_args, n, s, dry);
+        else if (mt == 2 && nt == 2) ok = dispatch_kw<2, 2, 8, 2>(g, dev_args, n, s, dry);
+        else if (mt == 1 && nt == 2) ok = dispatch_kw<1, 2, 8, 2>(g, dev_args, n, s, dry);
     } else if (nw == 4) {
         if (g.epi == EPI_LSTM) {
-            if (mt == 4 && nt == 2) ok = dispatch_kw<4, 2, 4, 2>(g, dev_args, n, s);
-            else if (mt == 2 && nt == 2) ok = dispatch_kw<2, 2, 4, 2>(g, dev_args, n, s);
+            if (mt == 4 && nt == 2) ok = dispatch_kw<4, 2, 4, 2>(g, dev_args, n, s, dry);
+            else if (mt == 2 && nt == 2) ok = dispatch_kw<2, 2, 4, 2>(g, dev_args, n, s, dry);
         }
-        else if (mt == 2 && nt == 4) ok = dispatch_kw<2, 4, 4, 2>(g, dev_args, n, s);
+        else if (mt == 2 && nt == 4) ok = dispatch_kw<2, 4, 4, 2>(g, dev_args, n, s, dry);
     }
-    if (!ok) { fprintf(stderr, "libapril(mi355x): launch_gemm_kw: no kernel for epi %d tile %d x %d, %d waves\n", g.epi, 16 * mt, 16 * nt, nw); abort(); }
+    return ok;
+}
+
+// is there a GM_KW kernel for this GEMM on 16 mt x 16 nt tiles?  (plan_kw asks before it commits to the schedule: pinned tile shapes and
+// environment knobs must never pick a form that was not instantiated)
+bool gemm_kw_has_kernel(const GemmArgs &g, int mt, int nt) { return kw_find(g, mt, nt, nullptr, 0, nullptr, true); }
+
+void launch_gemm_kw(const GemmArgs &g, int mt, int nt, const GemmArgs *dev_args, int n, hipStream_t s)
+{
+    if (!kw_find(g, mt, nt, dev_args, n, s, false)) {
+        fprintf(stderr, "libapril(mi355x): launch_gemm_kw: no kernel for epi %d tile %d x %d, %d waves\n", g.epi, 16 * mt, 16 * nt, gemm_kw_waves(g));
+        abort();
+    }
 }
 
 }  // namespace aprilx

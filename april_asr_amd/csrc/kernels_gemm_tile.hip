@@ -272,9 +272,14 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
     int top = 0;
     while ((1 << top) < g.zs) ++top;
     int chunk_i = 0, slab_done = 0, in_chunk = 0;
+    // binary16 operands, kz = 1 (gates, FFN up and the layer-major halves of the gate GEMM; round 6, kernels.h "fp16 one-chain rule"):
+    // ONE MFMA chain over all k blocks in k order, the BasicNorm scale multiplied into the running sum where the y half of K ends
+    // -- no chunk sums, no slab register set.  GM_PP (kernels_gemm_pp.hip) computes exactly this; the two are compared bitwise by
+    // tools/pp_bench.  (fp32 operands keep the chunk / slab form of the K-split kernels.)
+    constexpr bool ONE_CHAIN = WT == 1 && (EPI == EPI_LSTM || EPI == EPI_BIAS_DSWISH || EPI == EPI_XPART);
     if (EPI == EPI_LSTM && half_h && g.p_add) {
         // the slab starts as P (this lane's accumulator elements of the tile, fetched now, used at the first chunk end): S = P,
-        // then S + c2, then S + c3 -- the canonical ((P + c2) + c3)
+        // then S + c2, then S + c3 -- the canonical ((P + c2) + c3); one-chain form: the chain continues from P
         chunk_i = 2;
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
@@ -284,7 +289,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
                 for (int r = 0; r < 4; ++r) {
                     int row = m0 + (wm * MTW + mt) * 16 + (lane >> 4) * 4 + r;
                     if (row >= g.M) row = g.M - 1;
-                    S[mt][nt][r] = g.p_add[(size_t)row * g.ldp + n0 + (wn * NTW + nt) * 16 + (lane & 15)];
+                    (ONE_CHAIN ? acc : S)[mt][nt][r] = g.p_add[(size_t)row * g.ldp + n0 + (wn * NTW + nt) * 16 + (lane & 15)];
                 }
     }
     // EPI_LSTM with x_scale: x = y * scale(y) entered the GEMM as y, the first two chunks are exactly the y half of K (kz = 1,
@@ -296,6 +301,18 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
         for (int r = 0; r < 4; ++r) xrs[mt][r] = 1.0f;
     const bool fold_scale = (EPI == EPI_LSTM || EPI == EPI_XPART) && NEED_SCL;
     auto chunk_end = [&]() {
+        if constexpr (ONE_CHAIN) {
+            if (fold_scale && chunk_i == 1) {              // the y half of K ends here: the running sum takes the row's BasicNorm scale
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[mt][nt][r] = acc[mt][nt][r] * xrs[mt][r];
+            }
+            ++chunk_i;
+            return;
+        }
         if (chunk_i == 0) { APRIL_TILE_EACH(S[mt][nt] = acc[mt][nt]) }
         else { APRIL_TILE_EACH(S[mt][nt] = S[mt][nt] + acc[mt][nt]) }
         if ((EPI == EPI_LSTM || EPI == EPI_XPART) && fold_scale && chunk_i == 1) {
@@ -509,7 +526,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
     tr_t = __builtin_amdgcn_s_memtime();
 #endif
 
-    if (EPI == EPI_XPART) { APRIL_TILE_EACH(res[mt][nt] = S[mt][nt]) }      // (c0 + c1) * scale: half a slab, by design
+    if constexpr (ONE_CHAIN) { APRIL_TILE_EACH(res[mt][nt] = acc[mt][nt]) }      // the one chain (EPI_XPART: its y half, scaled)
+    else if (EPI == EPI_XPART) { APRIL_TILE_EACH(res[mt][nt] = S[mt][nt]) }      // (c0 + c1) * scale: half a slab, by design
     // ---- the workgroup's sums -> LDS plane (each wave owns its columns; no cross-wave addition) -> 4-column quads per thread
     __syncthreads();                                       // the last stage has been read by every wave
 #pragma unroll

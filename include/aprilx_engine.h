@@ -128,9 +128,10 @@ APRIL_EXPORT void aprilx_session_trace_logits(AprilASRSession session, float *bu
 APRIL_EXPORT uint64_t aprilx_session_chunks(AprilASRSession session);
 /* parity tests of the online fbank (reference src/fbank.c:174-349): copies log-mel rows [first, first + n) of everything the
  * session's feature ring has received so far -- real frames and flush padding, in the order the reference's ring sees them --
- * into out[n][mel] and returns the number of rows written so far; when the range is not (or no longer) in the ring nothing is
- * copied and UINT64_MAX is returned.  n = 0 / out = NULL: only the count.  Waits for the session to be idle.  Chunk j of the
- * session is rows [j * segment_step, j * segment_step + segment_size).                                                         */
+ * into out[n][mel] and returns the number of rows written so far.  Nothing is copied when the range is not available: rows that have
+ * not been written yet (first + n > rows written) return the count as usual -- the caller sees count < first + n -- and rows that
+ * have already left the ring (more than ring_frames rows written since `first`) return UINT64_MAX.  n = 0 / out = NULL: only the
+ * count.  Waits for the session to be idle.  Chunk j of the session is rows [j * segment_step, j * segment_step + segment_size).  */
 APRIL_EXPORT uint64_t aprilx_session_read_frames(AprilASRSession session, uint64_t first, int n, float *out);
 /* The token context as the host's result state machine holds it (host_ctx[2]) and the search state the device keeps for the
    session's slot (device_state[4]: context[0], context[1], last active token or -1, time of the last emission in ms).  The two

@@ -12,12 +12,16 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ORC_SO = os.path.join(HERE, "liborc.so")
+# APRIL_ORC_SO: another build of the oracle to load instead (tests/mutate_state_machine.py runs the hand-derived state-machine
+# fixtures against deliberately broken copies of orc_session.c); never set outside that test
+ORC_SO = os.environ.get("APRIL_ORC_SO") or os.path.join(HERE, "liborc.so")
 REF_SO = os.path.join(HERE, "_ref", "libaprilref.so")
 
 
 def build(force=False):
     """Compile liborc.so (and _ref when /root/reference exists)."""
+    if os.environ.get("APRIL_ORC_SO"):
+        return                                      # (a mutant build: loaded as it is)
     if force or not os.path.exists(ORC_SO) or any(
         os.path.getmtime(os.path.join(HERE, f)) > os.path.getmtime(ORC_SO)
         for f in os.listdir(HERE) if f.endswith((".c", ".h"))

@@ -15,7 +15,9 @@ Flags: 1 = APRIL_TOKEN_FLAG_WORD_BOUNDARY_BIT, 2 = APRIL_TOKEN_FLAG_SENTENCE_END
 A case is a list of PHASES.  ("chunks", [...]) = joiner rounds grouped the way the reference's chunk loop consumes them
 (:449-454: up to 3 rounds per chunk, early_emit 1, 0, 0, the loop stops at the first blank round); chunk j (1-based, flush
 chunks included) runs at current_time_ms = 40 j (:442-443).  A round is (token, max logit, blank logit): the scripted
-joiner puts `max` on that token, `blank` on the blank id and -1000 everywhere else.  ("flush", filler) = aas_flush (:547-564):
+joiner puts `max` on that token, `blank` on the blank id and -1000 everywhere else.  A round with a fourth element
+(token, max, blank, other) puts `max` on `other` as well: an arg-max tie, which the reference's strict `>` scan (:311-320) gives to
+the LOWER token id -- the expectations name the winner (the tests resolve W1 < W2 and C1 < C2 by construction).  ("flush", filler) = aas_flush (:547-564):
 the padded chunks the flush itself runs (their number depends on the fbank state) all see the `filler` round.
 ("after", filler) = everything beyond the script sees `filler`.
 
@@ -278,4 +280,201 @@ CASES = [
                 (False, (BLK, "C1"), "C1"), (True, (BLK, "C1"), "C1")],
         flush_state=((BLK, BLK), None),
     ),
+
+    # ---- round 6: cases added for the mutants of tests/mutate_state_machine.py that the cases above let live --------------------
+    # (each was derived by hand from the reference lines quoted, like the ones above; the comment names the mutants it kills)
+    _overflow_case("overflow_word_boundary_beats_word_search", {0: "W1", 68: "W2"}, "W1", 71,
+                   "the new token starts a word: everything is finalised (:216-218) even though the search would find a word start at 68"),
+    # word starts at 30 and 70: the search runs DOWN from head - 1 = 70 (:226) and stops at the first hit (`break`, :229): FINAL(70
+    # tokens 0..69), token 70 moves to the front, head = 1, the new token is appended -> PARTIAL [tok 70, new]
+    _overflow_case("overflow_search_starts_at_last_token_and_stops_at_first_hit", {0: "W1", 30: "W1", 70: "W2"}, "C1", 70,
+                   "word starts at 30 and at 70 (the last active token): the search starts at head - 1 and takes the highest one"),
+
+    dict(
+        name="argmax_tie_goes_to_lower_id",
+        doc="two tokens share the maximum: the strict `>` scan (:311-320) keeps the first = lower id",
+        phases=[("chunks", [
+            # chunk 1: W1 and W2 both at 5.0 -> W1 (lower id); r1: C2 and C1 both at 5.0 -> C1; r2 blank, nothing to report
+            [("W2", 5.0, 0.0, "W1"), ("C2", 5.0, 0.0, "C1"), ("C2", -20.0, 10.0)],
+        ])],
+        events=[
+            (P, [_t("W1", 5.0, 1, 1)]),
+            (P, [_t("W1", 5.0, 1, 1), _t("C1", 5.0, 0, 1)]),
+        ],
+        rounds=[(False, (BLK, "W1"), "W1"), (False, ("W1", "C1"), "C1"), (True, ("W1", "C1"), "C1")],
+    ),
+
+    dict(
+        name="override_and_provisional_thresholds",
+        doc="the exact margins: override needs max > blank - 3.5 (:357), a provisional token max' > blank - 4.0 (:409), both strict",
+        phases=[("chunks", [
+            # chunk 1 (t = 40): W1 emitted (last_emission 40).  r1 "." 6.0 vs 10.0, early 0: blank by logits; punctuation after a word,
+            # context not cleared, not equal: override iff 6.0 > 10 - 3.5 = 6.5 -> no.  Blank branch: time_since 0, max' = 6.0 > 10 - 4 = 6.0
+            # is false (strict) -> not confident; aas_emit_token(NULL): last_call_head 1 == head 1 -> nothing
+            [("W1", 5.0, 0.0), ("DOT", 6.0, 10.0)],
+            # chunk 2 (t = 80): "." 6.5 vs 10.0, early 1: 9 > 6.5 blank by logits; override iff 6.5 > 6.5 -> no (strict).  Blank branch:
+            # time_since 40, max' = 6.5 - 40/3000 = 6.48667 > 6.0 -> provisional, logprob 6.5 - 8 = -1.5, SENTENCE_END (:353): PARTIAL
+            # [W1, .'], head back to 1
+            [("DOT", 6.5, 10.0)],
+            # chunk 3 (t = 120): "." 6.75 vs 10.0: 9 > 6.75 blank by logits; override: 6.75 > 6.5 -> non-blank (:356-358): PARTIAL [W1, .(6.75, 2)]
+            # (forced: the provisional de-duplication does not apply); r1 blank -20: nothing (last_call_head 2 == head 2)
+            [("DOT", 6.75, 10.0), ("C1", -20.0, 10.0)],
+        ])],
+        events=[
+            (P, [_t("W1", 5.0, 1, 1)]),
+            (P, [_t("W1", 5.0, 1, 1), _t("DOT", -1.5, 2, 2)]),
+            (P, [_t("W1", 5.0, 1, 1), _t("DOT", 6.75, 2, 3)]),
+        ],
+        rounds=[(False, (BLK, "W1"), "W1"), (True, (BLK, "W1"), "W1"), (True, (BLK, "W1"), "W1"),
+                (False, ("W1", "DOT"), "DOT"), (True, ("W1", "DOT"), "DOT")],
+    ),
+
+    dict(
+        name="override_needs_uncleared_context",
+        doc="punctuation on a cleared context ([blk, blk], :322) is not forced through (:356): it stays blank and only shows as a provisional token",
+        phases=[("chunks", [
+            # chunk 1 (t = 40): "." 7.0 vs 10.0, early 1: 9 > 7 blank by logits; punctuation (head = 0: no digit rule), 7 > 6.5, not equal --
+            # but context[1] == blank -> was_context_cleared -> no override.  Blank branch: time_since = 40 - 0, max' = 7 - 40/3000 > 6 ->
+            # provisional: PARTIAL [.'(-1.0, SENTENCE_END)], head back to 0
+            [("DOT", 7.0, 10.0)],
+            # chunk 2: the same again: last_call_head 1 == head + 1 and active[0] is that "." -> suppressed (:272-276)
+            [("DOT", 7.0, 10.0)],
+        ])],
+        events=[(P, [_t("DOT", -1.0, 2, 1)])],
+        rounds=[(True, (BLK, BLK), None), (True, (BLK, BLK), None)],
+    ),
+
+    dict(
+        name="silence_clock_restarts_at_every_emission",
+        doc="time_since_last_emission counts from the LAST emitted token (:362) and 2160 ms of it are not yet silence (:411)",
+        phases=[("chunks",
+                 # chunk 1 (t = 40): W1 (last_emission 40); chunks 2..55 (t = 80..2200): blank, time_since <= 2160 < 2200: nothing
+                 [[("W1", 5.0, 0.0), ("C2", -20.0, 10.0)]] + [[("C2", -20.0, 10.0)]] * 54
+                 # chunk 56 (t = 2240): C1 non-blank (early 1: -1 > 5 false): the non-blank branch never looks at the clock -> PARTIAL
+                 # [W1, C1]; last_emission = 2240.  r1 blank: time_since 0, nothing to report
+                 + [[("C1", 5.0, 0.0), ("C2", -20.0, 10.0)]]
+                 # chunks 57..110 (t = 2280..4400): blank, time_since = t - 2240 <= 2160: still no silence
+                 + [[("C2", -20.0, 10.0)]] * 54
+                 # chunk 111 (t = 4440): time_since 2200 -> FINAL [W1, C1], context cleared, SILENCE
+                 + [[("C2", -20.0, 10.0)]])],
+        events=[
+            (P, [_t("W1", 5.0, 1, 1)]),
+            (P, [_t("W1", 5.0, 1, 1), _t("C1", 5.0, 0, 56)]),
+            (F, [_t("W1", 5.0, 1, 1), _t("C1", 5.0, 0, 56)]),
+            (S, []),
+        ],
+        rounds=[(False, (BLK, "W1"), "W1"), (True, (BLK, "W1"), "W1")] + [(True, (BLK, "W1"), "W1")] * 54
+        + [(False, ("W1", "C1"), "C1"), (True, ("W1", "C1"), "C1")] + [(True, ("W1", "C1"), "C1")] * 54 + [(True, (BLK, BLK), None)],
+    ),
+
+    dict(
+        name="provisional_confidence_decays_with_time",
+        doc="max' = max - time_since / 3000 (:408): the same runner-up is shown 1200 ms after the last token and no longer 1520 ms after it; a blank round after a withdrawn provisional token refreshes the PARTIAL (:287-293)",
+        phases=[("chunks",
+                 # chunk 1 (t = 40): W1; chunks 2..30: blank, nothing
+                 [[("W1", 5.0, 0.0), ("C2", -20.0, 10.0)]] + [[("C2", -20.0, 10.0)]] * 29
+                 # chunk 31 (t = 1240): C1 6.5 vs 10.0 -> blank; time_since 1200: max' = 6.5 - 0.4 = 6.1 > 6.0 -> provisional PARTIAL
+                 # [W1, C1'(-1.5)], last_call_head = 2, head back to 1
+                 + [[("C1", 6.5, 10.0)]]
+                 # chunk 32: blank, not confident: aas_emit_token(NULL): last_call_head 2 != head 1 -> PARTIAL [W1] (the provisional
+                 # token is withdrawn), last_call_head = 1; chunks 33..38: nothing
+                 + [[("C2", -20.0, 10.0)]] * 7
+                 # chunk 39 (t = 1560): C1 6.5 vs 10.0 again; time_since 1520: max' = 6.5 - 0.50667 = 5.99333 > 6.0 is false -> not
+                 # confident; last_call_head 1 == head 1 -> nothing
+                 + [[("C1", 6.5, 10.0)]])],
+        events=[
+            (P, [_t("W1", 5.0, 1, 1)]),
+            (P, [_t("W1", 5.0, 1, 1), _t("C1", -1.5, 0, 31)]),
+            (P, [_t("W1", 5.0, 1, 1)]),
+        ],
+        rounds=[(False, (BLK, "W1"), "W1"), (True, (BLK, "W1"), "W1")] + [(True, (BLK, "W1"), "W1")] * 38,
+    ),
+
+    dict(
+        name="early_emit_bonus_only_in_the_first_round",
+        doc="early_emit is 1.0 in round 0 and 0.0 in rounds 1, 2 (:449-454): the same margin is a token in round 0 and blank in round 1",
+        phases=[("chunks", [
+            # chunk 1: W1; r1 C1 7.0 vs 7.5, early 0: 7.5 > 7.0 -> blank; time_since 0, 7.0 > 3.5, not equal -> provisional PARTIAL [W1, C1'(-1.0)]
+            [("W1", 5.0, 0.0), ("C1", 7.0, 7.5)],
+            # chunk 2 (t = 80): r0 C1 7.0 vs 7.5, early 1: 6.5 > 7.0 false -> non-blank: PARTIAL [W1, C1(7.0, t 80)] (forced);
+            # r1 C2 7.0 vs 7.5, early 0 -> blank; provisional PARTIAL [W1, C1, C2'(-1.0)]
+            [("C1", 7.0, 7.5), ("C2", 7.0, 7.5)],
+        ])],
+        events=[
+            (P, [_t("W1", 5.0, 1, 1)]),
+            (P, [_t("W1", 5.0, 1, 1), _t("C1", -1.0, 0, 1)]),
+            (P, [_t("W1", 5.0, 1, 1), _t("C1", 7.0, 0, 2)]),
+            (P, [_t("W1", 5.0, 1, 1), _t("C1", 7.0, 0, 2), _t("C2", -1.0, 0, 2)]),
+        ],
+        rounds=[(False, (BLK, "W1"), "W1"), (True, (BLK, "W1"), "W1"), (False, ("W1", "C1"), "C1"), (True, ("W1", "C1"), "C1")],
+    ),
+
+    dict(
+        name="flush_then_provisional_equal_to_stale_slot",
+        doc="the provisional de-duplication (:272-276) needs BOTH conditions: a stale active_tokens[0] equal to the new provisional token does not suppress it when last_handler_call_head != head + 1",
+        phases=[
+            ("chunks", [[("W1", 5.0, 0.0), ("C1", 5.0, 0.0), ("C2", -20.0, 10.0)]]),      # PARTIAL [W1], PARTIAL [W1, C1]; context [W1, C1]
+            # padded chunks: blank, not confident, last_call_head 2 == head 2 -> nothing.  End of flush: FINAL [W1, C1] (last_call_head = 2,
+            # head = 0; active_tokens[0] still holds W1), context -> [blk, blk], SILENCE
+            ("flush", ("C2", -20.0, 10.0)),
+            ("chunks", [
+                # W1 7.0 vs 10.0: early 1: 9 > 7 -> blank; not equal (context[1] = blk); time_since < 2200 and 7 - dt/3000 > 6 (dt <= 1280 ms:
+                # at most 28 + 2 chunks since the last token) -> provisional: last_call_head 2 != head + 1 = 1 -> NOT a repeat although
+                # active_tokens[0].token == W1: PARTIAL [W1'(-1.0, WORD_BOUNDARY)], last_call_head = 1, head back to 0
+                [("W1", 7.0, 10.0)],
+                # the same again: last_call_head 1 == head + 1 and active_tokens[0].token == W1 -> suppressed
+                [("W1", 7.0, 10.0)],
+            ]),
+            ("after", ("W1", 7.0, 10.0)),
+        ],
+        events=[
+            (P, [_t("W1", 5.0, 1, 1)]),
+            (P, [_t("W1", 5.0, 1, 1), _t("C1", 5.0, 0, 1)]),
+            (F, [_t("W1", 5.0, 1, 1), _t("C1", 5.0, 0, 1)]),
+            (S, []),
+            (P, [_t("W1", -1.0, 1, ("post", 1))]),
+        ],
+        rounds=[(False, (BLK, "W1"), "W1"), (False, ("W1", "C1"), "C1"), (True, ("W1", "C1"), "C1"), "FLUSH",
+                (True, (BLK, BLK), None), (True, (BLK, BLK), None)],
+        flush_state=((BLK, BLK), None),
+    ),
+
+    dict(
+        name="exact_ties_and_sentence_check_needs_a_word_boundary",
+        doc="blank - early_emit == max is NOT blank (strict `>`, :329-330), in round 0 and later; a continuation token after '.' does not finalise the sentence (:368)",
+        phases=[("chunks", [
+            # chunk 1 (t = 40)
+            [("W1", 5.0, 0.0),       # PARTIAL [W1]
+             ("DOT", 7.0, 10.0),     # override (:356-358): PARTIAL [W1, .(7.0, SENTENCE_END)]; context [W1, .]
+             ("C1", 7.0, 7.0)],      # r2 early 0: 7.0 > 7.0 is false -> non-blank.  C1 is no word boundary: the sentence check (:368-388) is
+                                     #    skipped although the last token is "." -> no FINAL: PARTIAL [W1, ., C1]
+            # chunk 2 (t = 80)
+            [("C2", 6.0, 7.0),       # r0 early 1: (7 - 1) > 6.0 is false -> non-blank: PARTIAL [W1, ., C1, C2]
+             ("C1", -20.0, 10.0)],   # blank, not confident, last_call_head 4 == head 4 -> nothing
+        ])],
+        events=[
+            (P, [_t("W1", 5.0, 1, 1)]),
+            (P, [_t("W1", 5.0, 1, 1), _t("DOT", 7.0, 2, 1)]),
+            (P, [_t("W1", 5.0, 1, 1), _t("DOT", 7.0, 2, 1), _t("C1", 7.0, 0, 1)]),
+            (P, [_t("W1", 5.0, 1, 1), _t("DOT", 7.0, 2, 1), _t("C1", 7.0, 0, 1), _t("C2", 6.0, 0, 2)]),
+        ],
+        rounds=[(False, (BLK, "W1"), "W1"), (False, ("W1", "DOT"), "DOT"), (False, ("DOT", "C1"), "C1"),
+                (False, ("C1", "C2"), "C2"), (True, ("C1", "C2"), "C2")],
+    ),
+
+    dict(
+        name="dot_after_a_single_digit_token",
+        doc="the digit rule (:345-351) applies from ONE active token on (active_token_head > 0)",
+        phases=[("chunks", [
+            # chunk 1: "2" emitted (head = 1).  r1 "." 7.0 vs 10.0: blank by logits; head 1 > 0 and the last token starts with a digit -> no
+            # punctuation -> no override -> blank; time_since 0, 7 > 6, not equal -> provisional PARTIAL ["2", .'(-1.0, no SENTENCE_END)]
+            [("D2", 5.0, 0.0), ("DOT", 7.0, 10.0)],
+        ])],
+        events=[
+            (P, [_t("D2", 5.0, 0, 1)]),
+            (P, [_t("D2", 5.0, 0, 1), _t("DOT", -1.0, 0, 1)]),
+        ],
+        rounds=[(False, (BLK, "D2"), "D2"), (True, (BLK, "D2"), "D2")],
+    ),
+
 ]

@@ -39,9 +39,12 @@ class DeviceSearch:
         self.blank = model.dims.blank_id
         self.state = np.array([self.blank, self.blank, -1, 0], np.int32)
 
-    def round(self, idx, mx, bl, early, now, rnd):
+    def round(self, idx, mx, bl, early, now, rnd, tie=None):
         lg = np.full(self.V, -1000.0, np.float32)
         lg[idx] = mx
+        if tie is not None:           # an arg-max tie with a higher token id: the device must still report idx (:311-320)
+            assert tie > idx
+            lg[tie] = mx
         lg[self.blank] = bl
         nowa = np.array([now], np.int32)
         rec = np.zeros(4, np.uint32)
@@ -81,9 +84,9 @@ def test_device_decision_matches_hand_derived(gpu_tiny, tiny_model, case):
             want_ctx, want_last = case["flush_state"]
             assert dev.ctx == (sym[want_ctx[0]], sym[want_ctx[1]]) and dev.last_tok == (-1 if want_last is None else sym[want_last])
             continue
-        _, idx, mx, bl, early, now, scripted = it
+        _, idx, mx, bl, early, now, scripted, tie = it
         rnd = 0 if early == 1.0 else rnd + 1
-        blank = dev.round(idx, mx, bl, early, now, rnd)
+        blank = dev.round(idx, mx, bl, early, now, rnd, tie)
         if not scripted:
             assert blank
             continue

@@ -55,20 +55,30 @@ class PhasedOracle(ScriptedOracle):
         parent = self
 
         def joi(ud, e, d, logits):
+            parent.ctx_before.append((parent.cur_ctx, parent.pos < len(parent.triples)))      # (context in front of this round, scripted?)
             if parent.pos < len(parent.triples):
-                idx, mx, bl = parent.triples[parent.pos]
+                idx, mx, bl = parent.triples[parent.pos][:3]
+                tie = parent.triples[parent.pos][3] if len(parent.triples[parent.pos]) > 3 else None
                 parent.pos += 1
             else:
                 assert parent.filler is not None, "the oracle ran a joiner round the script does not have"
                 idx, mx, bl = parent.filler
+                tie = None
                 parent.fill_used += 1
             for i in range(parent.V):
                 logits[i] = -1000.0
             logits[idx] = mx
+            if tie is not None:
+                logits[tie] = mx
             logits[parent.P.blank_id] = bl
 
+        def dec(ud, ctx, dout):
+            parent.cur_ctx = (int(ctx[0]), int(ctx[1]))
+
+        self.ctx_before = []
+        self.cur_ctx = None
         self.fill_used = 0
-        self._fns = (self._fns[0], self._fns[1], O.JOI_FN(joi))
+        self._fns = (self._fns[0], O.DEC_FN(dec), O.JOI_FN(joi))
         self.nets = O.OrcNets(None, *self._fns)
         self.L.orc_session_free(self.s)
         self.s = self.L.orc_session_new_scripted(C.byref(self.P), C.byref(self.nets), 1, 8, 8, 8, self.V, self._h, None)
@@ -96,7 +106,7 @@ def run_oracle_case(case, model_path, sym):
     post_base = None
     for ph in case["phases"]:
         if ph[0] == "chunks":
-            rounds = [(sym[s], mx, bl) for ch in ph[1] for (s, mx, bl) in ch]
+            rounds = [(sym[r[0]], r[1], r[2]) + ((sym[r[3]],) if len(r) > 3 else ()) for ch in ph[1] for r in ch]
             o.triples = o.triples + rounds
             o.filler = None
             o.run_more_chunks(len(ph[1]))
@@ -109,8 +119,25 @@ def run_oracle_case(case, model_path, sym):
             o.filler = (sym[ph[1][0]], ph[1][1], ph[1][2])
             o.run_more_chunks(3)
     ev = list(o.events)
+    # the context after every scripted round = the context in front of the next joiner round (or the last one the decoder saw)
+    before = o.ctx_before + [(o.cur_ctx, False)]
+    ctx_after = [before[k + 1][0] for k in range(len(o.ctx_before)) if o.ctx_before[k][1]]
     o.close()
-    return ev, post_base
+    return ev, post_base, ctx_after
+
+
+def check_oracle_case(case, model_path, sym):
+    """the oracle's callbacks AND its token context after every scripted round against the hand-derived expectations
+    (also what tests/mutant_worker.py runs against every mutant of oracle/orc_session.c)"""
+    ev, post_base, ctx_after = run_oracle_case(case, model_path, sym)
+    want = resolve_events(case, sym, post_base or 0)
+    assert [e[0] for e in ev] == [e[0] for e in want], (case["name"], [e[0] for e in ev], [e[0] for e in want])
+    for i, (a, b) in enumerate(zip(ev, want)):
+        assert a == b, (case["name"], i, a[0], a[1][-3:], b[1][-3:])
+    exp = [e for e in case["rounds"] if e != "FLUSH"]
+    assert len(ctx_after) == len(exp), (case["name"], len(ctx_after), len(exp))
+    for i, (got, e) in enumerate(zip(ctx_after, exp)):
+        assert got == (sym[e[1][0]], sym[e[1][1]]), (case["name"], "context after scripted round", i, got, e)
 
 
 def product_rounds(case, sym):
@@ -121,17 +148,20 @@ def product_rounds(case, sym):
         if ph[0] == "chunks":
             for ch in ph[1]:
                 chunk += 1
-                for r, (s, mx, bl) in enumerate(ch):
-                    out.append(("r", sym[s], mx, bl, 1.0 if r == 0 else 0.0, 40 * chunk, True))
+                for r, rd in enumerate(ch):
+                    s, mx, bl = rd[:3]
+                    tie = sym[rd[3]] if len(rd) > 3 else None
+                    # (an arg-max tie goes to the lower id, :311-320: the host state machine is handed the winner, the device finds it)
+                    out.append(("r", sym[s] if tie is None else min(sym[s], tie), mx, bl, 1.0 if r == 0 else 0.0, 40 * chunk, True, tie if tie is None else max(sym[s], tie)))
         elif ph[0] == "flush":
             for _ in range(FLUSH_CHUNKS_PRODUCT):
                 chunk += 1
-                out.append(("r", sym[ph[1][0]], ph[1][1], ph[1][2], 1.0, 40 * chunk, False))
+                out.append(("r", sym[ph[1][0]], ph[1][1], ph[1][2], 1.0, 40 * chunk, False, None))
             out.append(("flush", chunk))
         elif ph[0] == "after":
             for _ in range(3):
                 chunk += 1
-                out.append(("r", sym[ph[1][0]], ph[1][1], ph[1][2], 1.0, 40 * chunk, False))
+                out.append(("r", sym[ph[1][0]], ph[1][1], ph[1][2], 1.0, 40 * chunk, False, None))
     return out
 
 
@@ -152,7 +182,7 @@ def run_product_case(case, model, sym):
             post_base = it[1]
             decisions.append("FLUSH")
             continue
-        _, idx, mx, bl, early, now, scripted = it
+        _, idx, mx, bl, early, now, scripted, _tie = it
         blank = bool(L.aprilx_greedy_step(g, idx, mx, bl, early, now, ctx))
         if scripted:
             decisions.append((blank, (int(ctx[0]), int(ctx[1]))))
@@ -172,11 +202,7 @@ def host_model(tiny_model):
 @pytest.mark.parametrize("case", G.CASES, ids=[c["name"] for c in G.CASES])
 def test_oracle_matches_hand_derived(built, tiny_model, case):
     sym = symbols(tiny_model["tokens"])
-    ev, post_base = run_oracle_case(case, tiny_model["path"], sym)
-    want = resolve_events(case, sym, post_base or 0)
-    assert [e[0] for e in ev] == [e[0] for e in want]
-    for i, (a, b) in enumerate(zip(ev, want)):
-        assert a == b, (case["name"], i, a[0], a[1][-3:], b[1][-3:])
+    check_oracle_case(case, tiny_model["path"], sym)
 
 
 @pytest.mark.parametrize("case", G.CASES, ids=[c["name"] for c in G.CASES])
