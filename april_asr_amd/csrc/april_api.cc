@@ -16,6 +16,7 @@
 #include "../../include/aprilx_engine.h"
 #include "common.h"
 #include "session.h"
+#include "rccl_group.h"
 
 using namespace aprilx;
 
@@ -42,6 +43,7 @@ int env_int(const char *name, int def)
     } while (0)
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+double aprilx_now_ms() { return now_ms(); }
 
 // One process, several GPUs (APRIL_GPU_DEVICES=0,1,...): the packed weights are uploaded ONCE, to the first device, and
 // broadcast from there to the other devices' engines with RCCL over xGMI (grouped ncclBroadcast on a communicator made by
@@ -69,37 +71,27 @@ bool broadcast_local(Model &m)
         const double t0 = now_ms();
         std::vector<ncclComm_t> comms(devs.size(), nullptr);
         double t1 = t0;
-        auto rccl_path = [&]() -> bool {
-            RCCL_TRY(ncclCommInitAll(comms.data(), (int)devs.size(), devs.data()));
-            t1 = now_ms();
-            RCCL_TRY(ncclGroupStart());
-            bool ok = true;
-            for (size_t i = 0; i < peers.size() && ok; ++i) {
-                HIP_CHECK(hipSetDevice(devs[i]));
+        // RCCL + HIP behind the policy of rccl_group.h (the same function runs against a failing stub in tests/cpp/rccl_group_test.cc)
+        struct RealRccl {
+            typedef ncclComm_t Comm;
+            std::vector<Engine *> &peers; const std::vector<int> &devs; size_t count; int fault;
+            bool comm_init_all(Comm *c, int n, const int *d) { RCCL_TRY(ncclCommInitAll(c, n, d)); return true; }
+            bool group_start() { RCCL_TRY(ncclGroupStart()); return true; }
+            bool group_end() { const ncclResult_t r = ncclGroupEnd(); if (r != ncclSuccess) { LOGE("RCCL: ncclGroupEnd failed: %s", ncclGetErrorString(r)); return false; } return true; }
+            bool broadcast(int i, Comm comm) {
                 // (fault 2: the call itself is made with null buffers, so that RCCL's own argument check fails INSIDE the group and
                 // records the group error, as a real failure would)
                 const bool inject = fault == 2 && i == 1;
-                const ncclResult_t r = ncclBroadcast(inject ? nullptr : peers[0]->weights_device(), inject ? nullptr : peers[i]->weights_mut(), count, ncclFloat, 0, comms[i], peers[i]->stream());
-                if (r != ncclSuccess) { LOGE("RCCL: ncclBroadcast (device %d) failed: %s", devs[i], ncclGetErrorString(r)); ok = false; }
+                const ncclResult_t r = ncclBroadcast(inject ? nullptr : peers[0]->weights_device(), inject ? nullptr : peers[(size_t)i]->weights_mut(), count, ncclFloat, 0, comm, peers[(size_t)i]->stream());
+                if (r != ncclSuccess) { LOGE("RCCL: ncclBroadcast (device %d) failed: %s", devs[(size_t)i], ncclGetErrorString(r)); return false; }
+                return true;
             }
-            if (!ok) {
-                // some ranks have queued their part of the collective, the failing one has not.  A call that fails inside an open
-                // group records the error in the group: ncclGroupEnd then discards what was queued and returns that error instead
-                // of launching a broadcast that would wait for the missing rank.  So: close the group FIRST (the queued tasks
-                // still point at live communicators), THEN abort the communicators; the streams are left alone.
-                (void)ncclGroupEnd();
-                for (ncclComm_t &c : comms) if (c) { (void)ncclCommAbort(c); c = nullptr; }
-                return false;
-            }
-            const ncclResult_t ge = ncclGroupEnd();
-            if (ge != ncclSuccess) {
-                LOGE("RCCL: ncclGroupEnd failed: %s", ncclGetErrorString(ge));
-                for (ncclComm_t &c : comms) if (c) { (void)ncclCommAbort(c); c = nullptr; }
-                return false;
-            }
-            for (size_t i = 0; i < peers.size(); ++i) { HIP_CHECK(hipSetDevice(devs[i])); HIP_CHECK(hipStreamSynchronize(peers[i]->stream())); }
-            return true;
-        };
+            void comm_abort(Comm c) { (void)ncclCommAbort(c); }
+            bool set_device(int d) { return hipSetDevice(d) == hipSuccess; }
+            bool stream_sync(int i) { return hipStreamSynchronize(peers[(size_t)i]->stream()) == hipSuccess; }
+            double now_ms() { return aprilx_now_ms(); }
+        } api{peers, devs, count, fault};
+        auto rccl_path = [&]() -> bool { return rccl_group_broadcast(api, devs, comms, &t1); };
         const bool used = rccl_path();
         for (ncclComm_t c : comms) if (c) (void)ncclCommDestroy(c);
         if (used) {

@@ -1054,8 +1054,7 @@ static TilePlan finalize_gemm(GemmArgs &g)
     g.skew = (long)(g.N / (16 * t.nt)) * ((g.M + 16 * t.mt - 1) / (16 * t.mt)) * (t.mode == GM_FULLK ? 1 : g.kz / g.zs) >= 512 ? skew : 0;   // two workgroups per CU
     static const int kw_skew = env_int("APRIL_KW_SKEW", 0);      // GM_KW: start delay of the second half of a workgroup's waves, x 64 cycles (measured: no effect; kernels_gemm_kw.hip)
     if (t.mode == GM_KW) g.skew = kw_skew;
-    static const int pp_prio = env_int("APRIL_PP_PRIO", 0);      // GM_PP: wave priority policy (kernels_gemm_pp.hip: 0 none, 1 compute phase, 2 load phase)
-    if (t.mode == GM_PP) g.skew = pp_prio;
+    if (t.mode == GM_PP) g.skew = 0;
     static const int kw_xcd = env_int("APRIL_KW_XCD", 0);        // GM_KW: 2 = the 2 x 4 XCD order of the tiles (kernels_gemm_kw.hip kw_tile_of)
     g.xcd_rc = t.mode == GM_KW ? kw_xcd : 0;
     return t;
@@ -1152,7 +1151,25 @@ void launch_gemm_z(const GemmArgs *staged, int n, const GemmArgs *dev_args, hipS
     if (!kw_before_recur(g)) if (const int rf = recur_form(g)) { launch_recur(g, rf, dev_args, n, s); return; }      // (stage_gemm_z checked that the n problems have one shape)
     GemmArgs probe = g;
     const TilePlan t = finalize_gemm(probe);
-    if (t.mode == GM_PP) { launch_gemm_pp(g, t.mt, dev_args, n, s); return; }
+    if (t.mode == GM_PP) {
+        // MEASUREMENT FORM, off by default (APRIL_PP_SPLIT=1).  One workgroup per CU, so a launch costs whole rounds of one tile time; when
+        // the n problems give more than one round of 256-row tiles but n - 1 of them exactly one (the larger encoder's gates at 512
+        // sessions: 96 tiles per problem, three problems = 288), the launch can be cut in two: n - 1 problems on 256-row tiles, the last
+        // one on the planner's choice for it alone (192 128-row tiles).  tools/pp_bench: 45.0 us against 50.6 (128-row tiles for all
+        // three) -- but inside the engine the three-problem launch already runs in 47.9 us and the pair costs 31.8 + 19: nothing gained
+        // (configs[4] step 1.881 vs 1.888 ms), so one launch stays the rule.
+        static const int split = env_int("APRIL_PP_SPLIT", 0);
+        const long per16 = (long)(g.N / 128) * ((g.M + 255) / 256);
+        if (split && g_pp_pin_mt == 0 && n >= 2 && per16 * n > 256 && per16 * (n - 1) <= 256 && per16 * (n - 1) >= 160) {
+            launch_gemm_pp(g, 16, dev_args, n - 1, s);
+            TilePlan t1;
+            if (!plan_pp(g.M, g.N, 1, t1)) { t1.mt = 8; }
+            launch_gemm_pp(staged[n - 1], t1.mt, dev_args + (n - 1), 1, s);
+            return;
+        }
+        launch_gemm_pp(g, t.mt, dev_args, n, s);
+        return;
+    }
     if (t.mode == GM_TILE) { launch_gemm_tile(g, t.mt, t.nt, dev_args, n, s); return; }
     if (t.mode == GM_KW) { launch_gemm_kw(g, t.mt, t.nt, dev_args, n, s); return; }
     const int mt = t.mt, nt = t.nt;

@@ -1,36 +1,49 @@
 // GM_PP schedule of the binary16-operand MFMA GEMM (kernels.h) for gfx950 -- round 6, BASELINE configs[4] (fp16 MFMA path).
 //
 // What it replaces: the eight-wave 128 x 128 form of GM_TILE (kernels_gemm_tile.hip) ran the fp16 gates GEMM at 0.17 of the
-// dense fp16 MFMA peak: every wave issued its DMA pieces, its fragment reads and its MFMAs in one in-order stream, so whatever
-// sat between two MFMA blocks ran while the matrix pipe drained (a 64 x 32 wave tile: 6 KB of fragment reads and 2 DMA
-// instructions per 8 MFMAs = 128 cycles of matrix work).
+// dense fp16 MFMA peak: every wave issued its DMA pieces, its fragment reads and its MFMAs in one in-order stream, in lock step
+// with the seven others (one barrier per stage), so whatever sat between two MFMA blocks ran while the matrix pipe drained (a
+// 64 x 32 wave tile: 6 KB of fragment reads and 2 DMA instructions per 8 MFMAs = 128 cycles of matrix work).
 //
 // Schedule: one workgroup = eight waves = TWO GROUPS of four (waves 0-3 / 4-7: one wave of each group per SIMD).  The tile is
 // 16 MT rows x 128 columns; group g owns rows [g BM/2, (g+1) BM/2), its four waves split that half 2 x 2 -- at MT = 16 a wave
 // tile is 64 x 64 = 16 v_mfma_f32_16x16x32_f16 per k block against 8 fragment reads (the densest ratio the 16 x 16 shape
-// allows).  The groups run ONE PHASE APART (ping-pong): while group 0 issues the 16 MFMAs of k block j (s_setprio 1), group 1
-// is in its load phase (DMA pieces of a later stage, fragment reads of its next k block, chunk folds), then they swap:
+// allows).  The groups run ONE PHASE APART (ping-pong): while group 0 is in the compute phase of k block j -- its 16 MFMAs with
+// the fragment reads of k block j + 1 spread between them, into a second register set -- group 1 is in its load phase (the DMA
+// pieces of a later stage: scalar instructions and buffer_load ... lds only), then they swap:
 //
 //     barrier index   0      1      2      3      4      5     ...   2n+1
 //     group 0         | L0   | C0   | L1   | C1   | L2   | ...  C(n-1) |  -   |
 //     group 1         | -    | L0   | C0   | L1   | C1   | ...  L(n-1) | C(n-1)
 //
-// so the SIMD's matrix pipe always has one wave in a compute phase and its other wave's memory instructions issue beside it
-// instead of in front of it.  Both groups share the weight pieces of a stage (one B image per 256 rows: 85 flop per operand
-// byte at MT = 16, 64 at MT = 8).
+// so a SIMD's two waves are never in the same kind of phase: one wave's memory instructions issue beside the other's MFMAs
+// instead of in front of its own.  Both groups share the weight pieces of a stage (one B image per 256 rows: 85 flop per operand
+// byte at MT = 16, 64 at MT = 8).  What made room for the second fragment set is the fp16 one-chain rule (kernels.h): the
+// accumulator is the only persistent register set.
+//
+// Measured (tools/pp_bench, s_memtime phase trace of the 256-row tile, cycles per k block and wave): load phase 280 + 210..260 at its
+// barrier, compute phase 490..530 + 25..40 -- i.e. the phases are now set by the compute phase, whose 16 MFMAs take ~24 cycles each
+// (~19 is the instruction's floor) plus ~12 per interleaved ds_read_b128.  Variants measured and not kept: all eight reads in the load
+// phase (load 416 > compute 382: 29.2 vs 28.3 us per 256-row tile round), s_setprio around either phase (no effect), k-block-major
+// weight addressing (an L2 channel experiment: no effect), the fragment reads + MFMAs of a k block as one phase per group without
+// the second register set (first form: 1376 cycles per k block).  The prologue (~4 us: the first two stages come from HBM) and the
+// LSTM epilogue (~5 us at MT = 16: 16 cells per thread) are a third of a tile's time and run on an otherwise empty CU (144 KB of
+// stage buffers: one workgroup per CU).
 //
 // LDS image of one stage (two k blocks = 64 k = 128 bytes per activation row), as GM_TILE's:
 //   A: [BM rows][128 B], 16-byte segment g of row R stored at segment g ^ ((R >> 1) & 7) (conflict-free ds_read_b128 of the A
 //      fragment; the DMA writes LDS linearly, so the swizzle is applied to the per-lane SOURCE address)
 //   B: [2 k blocks][8 n tiles][1 KB] in the packed weight order (launch_repack_x32) = the B fragment of every lane.
 // Three stage buffers.  The pieces of stage s + 2 are issued during the two load phases of stage s (a wave's share: PPW / 2 per
-// load phase), into the buffer stage s - 1 was read from -- its last reads (group 1's load phase of k block 2 s - 1) were
-// retired by lgkmcnt(0) before barrier 4 s, and the first of those DMA instructions issues behind that barrier.  Stage s + 1 is
-// waited for (counted vmcnt: the pieces of stage s + 2 stay in flight) in the load phase of k block 2 s + 1 of either group,
-// i.e. before barrier 4 s + 4, behind which group 0 reads it.
+// load phase), into the buffer stage s - 1 was read from -- its last reads (the compute phase of k block 2 s - 2, group 1 last)
+// were retired by lgkmcnt(0) before barrier 4 s - 1, and the first of those DMA instructions issues behind barrier 4 s.  Stage
+// s + 1 is waited for (counted vmcnt: younger pieces stay in flight) by group 0 at the end of the load phase of k block 2 s + 1 and
+// by group 1 at the end of the compute phase of k block 2 s -- both in front of barrier 4 s + 3, behind which group 0 reads it.
+// DMA pieces cost no vector ALU instruction: buffer descriptors in SGPRs, 32-bit lane offsets fixed per tile, scalar stage offsets.
 //
-// Canonical summation (kernels.h) is GM_TILE's, bit for bit: a chunk is one in-order MFMA chain over its k blocks (k block order),
-// the slab is ((c0 + c1) + c2) + c3 with the BasicNorm scale of the y half folded in after chunk 1 (EPI_LSTM / EPI_XPART), kz = 1.
+// Summation: the fp16 one-chain rule (kernels.h) -- one MFMA chain over all k blocks in k order, multiplied by the row's BasicNorm
+// scale where the y half of K ends (EPI_LSTM / EPI_XPART); the layer-major h half continues the chain from P.  GM_TILE's fp16 forms
+// of the same GEMMs compute exactly this; tools/pp_bench compares every output of the two bitwise (tests/test_gpu_gemm_pp.py).
 // Epilogues: EPI_LSTM (two A segments [y16 | h16(slot)], cell update), EPI_BIAS_DSWISH, and the layer-major halves of the gate
 // GEMM (EPI_XPART + wave_mask 0x3, EPI_LSTM + wave_mask 0xC + p_add).  Every other GEMM keeps GM_TILE.
 // Replaces the ORT MatMul nodes of the encoder's LSTM / FFN blocks (reference call site src/april_session.c:131-148).
@@ -57,7 +70,7 @@ template <int MT> struct PPGeom {
     static constexpr int MTW = MT / 4, NTW = NT / 2;              // MFMA tiles per wave: (BM / 2 / 2 / 16) x (BN / 2 / 16)
     static constexpr int PLANE_BYTES = BM * LDR * 4;
     static constexpr int LDS_MAIN = NS * STAGE_BYTES > PLANE_BYTES ? NS * STAGE_BYTES : PLANE_BYTES;
-    static constexpr int LDS_BYTES = LDS_MAIN + 2 * BM * 4;       // + the rows' BasicNorm scales + the rows' slots (EPI_LSTM)
+    static constexpr int LDS_BYTES = LDS_MAIN + BM * 4;           // + the rows' BasicNorm scales
     static_assert(MT == 16 || MT == 8, "tile rows 256 or 128");
     static_assert(PPW % 2 == 0, "a wave issues half of its pieces in either load phase of a stage");
 };
@@ -69,7 +82,12 @@ template <int N> __device__ __forceinline__ void wait_vm()
 }
 __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }      // s_waitcnt lgkmcnt(0) only
 
-template <int MT, int EPI, int PRIO>
+// Every pointer of a GemmArgs block is global memory.  The z-batched entry point reads the block from memory, so the compiler only
+// knows generic pointers and emits FLAT loads / stores -- and a pending flat operation forces s_waitcnt vmcnt(0) lgkmcnt(0) at the next
+// wait (it may be served by either path), which would drain the DMA stages the prologue has just put in flight.  gp() says "global".
+template <class T> __device__ __forceinline__ __attribute__((address_space(1))) T *gp(T *p) { return (__attribute__((address_space(1))) T *)p; }
+
+template <int MT, int EPI>
 __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
 {
     using G = PPGeom<MT>;
@@ -78,7 +96,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
     extern __shared__ __attribute__((aligned(1024))) float red[];
     char *lds = reinterpret_cast<char *>(red);
 
-    if (g.run_flag && *g.run_flag != g.run_gen) return;
+    if (g.run_flag && *gp(g.run_flag) != g.run_gen) return;
 #ifdef APRIL_GEMM_TRACE
     const unsigned long long tr_start = __builtin_amdgcn_s_memtime();
     unsigned long long tr_loop0 = tr_start, tr_loop1 = tr_start;
@@ -107,7 +125,23 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
         int r = m0 + srow;
         if (r >= g.M) r = g.M - 1;
 #pragma unroll
-        for (int k = 0; k < STG; ++k) stg[k] = (k < ppt && sj0 + k < rsc.groups) ? rsc.ssq[(size_t)r * rsc.groups + sj0 + k] : 0.0f;
+        for (int k = 0; k < STG; ++k) stg[k] = (k < ppt && sj0 + k < rsc.groups) ? gp(rsc.ssq)[(size_t)r * rsc.groups + sj0 + k] : 0.0f;
+    }
+
+    // ---- the epilogue's thread -> cell map (thread t owns the 4-column quad t % 32 of rows t / 32 + 16 i) and, for EPI_LSTM, the rows'
+    // slots: loaded FIRST, in front of every DMA piece
+    constexpr int QROW = BN / 4, NQ = BM * QROW, QPT = NQ / NTH, QRS = NTH / QROW;
+    static_assert(QROW == 32 && NQ % NTH == 0, "quad layout of the epilogue");
+    const int qcol = threadIdx.x % QROW, qrow0 = threadIdx.x / QROW;
+    const int ncol = n0 + qcol * 4, l_unit = ncol >> 2;
+    int l_slot[EPI == EPI_LSTM ? QPT : 1];
+    if (EPI == EPI_LSTM) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            int r = m0 + qrow0 + QRS * i;
+            if (r >= g.M) r = g.M - 1;                    // (padding rows read the last row's cell: never stored)
+            l_slot[i] = gp(g.slot_idx)[r];
+        }
     }
 
     // ---- DMA pieces of this wave.  i < APW: activation rows 8 P .. 8 P + 7 of the tile, P = wave + 8 i (lane -> row P 8 + (lane >> 3),
@@ -118,9 +152,13 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
     const bool two_seg = g.K1 > 0;
     const bool start_in_1 = two_seg && k_begin >= g.K0;
     const int seg1_stage = (two_seg && !start_in_1) ? (g.K0 - k_begin) / 64 : 0x7fffffff;
-    unsigned aoff0[APW], aoff1[APW];
+    // (segment 1's rows are slots: the indirection is LOADED here and turned into offsets where it is first needed -- the switch of
+    // the pieces to segment 1, deep inside the K loop -- so that the first DMA stages do not wait for it)
+    unsigned aoff0[APW];
+    int arows1[APW];
+    unsigned gsegv[APW];
     {
-        int arows[APW], arows1[APW];
+        int arows[APW];
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
             int row = m0 + (wave + 8 * i) * 8 + (lane >> 3);
@@ -129,18 +167,17 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
         }
         if (g.aidx0) {
 #pragma unroll
-            for (int i = 0; i < APW; ++i) arows[i] = g.aidx0[arows[i]];
+            for (int i = 0; i < APW; ++i) arows[i] = gp(g.aidx0)[arows[i]];
         }
         if (two_seg && g.aidx1) {
 #pragma unroll
-            for (int i = 0; i < APW; ++i) arows1[i] = g.aidx1[arows1[i]];
+            for (int i = 0; i < APW; ++i) arows1[i] = gp(g.aidx1)[arows1[i]];
         }
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
             const int R = (wave + 8 * i) * 8 + (lane >> 3);
-            const unsigned gseg = (unsigned)(((lane & 7) ^ ((R >> 1) & 7)) * 16);
-            aoff0[i] = (unsigned)arows[i] * (unsigned)g.lda0 * 2u + gseg;
-            aoff1[i] = two_seg ? (unsigned)arows1[i] * (unsigned)g.lda1 * 2u + gseg : 0u;
+            gsegv[i] = (unsigned)(((lane & 7) ^ ((R >> 1) & 7)) * 16);
+            aoff0[i] = (unsigned)arows[i] * (unsigned)g.lda0 * 2u + gsegv[i];
         }
     }
     // buffer descriptors (wave-uniform, SGPRs) + 32-bit lane offsets + scalar stage offsets: a DMA piece costs no vector ALU
@@ -157,8 +194,13 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
     int seg_base = 0;                                      // first stage of the segment being issued
     __amdgpu_buffer_rsrc_t rs_a = start_in_1 ? rs_a1 : rs_a0;
     unsigned aoff[APW];
+    if (start_in_1) {                                      // (a branch, not a select: segment 0's offsets do not wait for the slot indirection of segment 1)
 #pragma unroll
-    for (int i = 0; i < APW; ++i) aoff[i] = start_in_1 ? aoff1[i] : aoff0[i];
+        for (int i = 0; i < APW; ++i) aoff[i] = (unsigned)arows1[i] * (unsigned)g.lda1 * 2u + gsegv[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < APW; ++i) aoff[i] = aoff0[i];
+    }
 #ifdef APRIL_GEMM_TRACE
     const int dbg = g.debug;                               // measurement builds (tools/pp_bench_trace, APRIL_GEMM_DEBUG): 8 = no DMA (stale LDS), 10 = no MFMAs
 #else
@@ -169,7 +211,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
         if (p == 0 && issued == seg1_stage) {              // (once per tile: the activation pieces move on to segment 1)
             rs_a = rs_a1; seg_base = seg1_stage;
 #pragma unroll
-            for (int i = 0; i < APW; ++i) aoff[i] = aoff1[i];
+            for (int i = 0; i < APW; ++i) aoff[i] = (unsigned)arows1[i] * (unsigned)g.lda1 * 2u + gsegv[i];
         }
         char *db = lds + buf * G::STAGE_BYTES;
 #pragma unroll
@@ -185,26 +227,9 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
         }
         if (p == 1) ++issued;
     };
-
-    // ---- what the epilogue reads besides the sums, fetched before the K loop.  Thread t owns the 4-column quad t % 32 of rows
-    // t / 32 + 16 i: EPI_LSTM: the quad = gates i, f, g, o of one hidden unit (columns are unit-major)
-    constexpr int QROW = BN / 4, NQ = BM * QROW, QPT = NQ / NTH;
-    static_assert(QROW == 32 && NQ % NTH == 0, "quad layout of the epilogue");
-    const int qcol = threadIdx.x % QROW, qrow0 = threadIdx.x / QROW;      // rows qrow0 + (NTH / QROW) i
-    constexpr int QRS = NTH / QROW;
-    const int ncol = n0 + qcol * 4;
+    // ---- what the epilogue reads besides the sums, fetched before the K loop
     f32x4 l_bias = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (EPI == EPI_LSTM || EPI == EPI_BIAS_DSWISH) l_bias = *reinterpret_cast<const f32x4 *>(g.bias + ncol);
-    // EPI_LSTM: the rows' slots wait in LDS (fetched now); the previous cell values are fetched behind the K loop, when the
-    // fragment registers are free, and arrive while the sums cross the LDS plane
-    int *slot_lds = reinterpret_cast<int *>(red + G::LDS_MAIN / 4 + BM);
-    const int l_unit = ncol >> 2;
-    if (EPI == EPI_LSTM && threadIdx.x < BM) {
-        int r = m0 + (int)threadIdx.x;
-        if (r >= g.M) r = g.M - 1;                        // (padding rows read the last row's cell: never stored)
-        slot_lds[threadIdx.x] = g.slot_idx[r];
-    }
-
+    if (EPI == EPI_LSTM || EPI == EPI_BIAS_DSWISH) l_bias = *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(gp(g.bias) + ncol);
     // ---- fragment addresses inside a stage buffer
     const int mrow = lane & 15, kq = lane >> 4;
     int a_rd[2];                                          // k block p of the stage: row mrow, segment (4 p + kq) ^ ((mrow >> 1) & 7)
@@ -226,7 +251,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
                 for (int r = 0; r < 4; ++r) {
                     int row = m0 + wrow + mt * 16 + kq * 4 + r;
                     if (row >= g.M) row = g.M - 1;
-                    acc[mt][nt][r] = g.p_add[(size_t)row * g.ldp + n0 + (wn * NTW + nt) * 16 + mrow];
+                    acc[mt][nt][r] = gp(g.p_add)[(size_t)row * g.ldp + n0 + (wn * NTW + nt) * 16 + mrow];
                 }
     }
     float xrs[MTW][4];
@@ -244,10 +269,22 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
                 for (int r = 0; r < 4; ++r) acc[mt][nt][r] = acc[mt][nt][r] * xrs[mt][r];
     };
 
-    if (g.debug != 1) {
-        // ---- prologue: stages 0 and 1 on their way, then (behind them) the rows' scales through the third buffer
-        issue_half(0, 0); issue_half(1, 0);
-        if (nstage > 1) { issue_half(0, 1); issue_half(1, 1); }
+    // ---- stages 0 and 1 are on their way before anything else of the prologue waits for memory (every independent load of the prologue -- scale partials, slots, bias, P -- was issued in front of them)
+    // (unconditional, always two stages -- gemm_pp_ok guarantees them: the compiler can then COUNT the DMA pieces behind the slot loads and
+    // waits for the slots with vmcnt(2 PPW) instead of draining the DMA before the cell prefetch goes out)
+    issue_half(0, 0); issue_half(1, 0);
+    issue_half(0, 1); issue_half(1, 1);
+
+    // EPI_LSTM: the previous cell values of this thread's cells, behind the first DMA stages (their slots were fetched in front of them,
+    // so waiting for the slots does not wait for the DMA: memory operations retire in order); nothing in the epilogue waits for memory
+    float l_cprev[EPI == EPI_LSTM ? QPT : 1];
+    if (EPI == EPI_LSTM) {
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) l_cprev[i] = gp(g.c_state)[(size_t)l_slot[i] * g.hidden + l_unit];
+    }
+
+    {
+        // ---- prologue (stages 0 and 1 are in flight): the rows' scales through the third buffer
         if (fold_scale) {
             // partials (in registers since the first instruction of the kernel) -> LDS, BM threads add them in column order (the
             // order of row_scale()); rows are padded to Gn + 1 floats (conflict-free column walks).  Staged in stage buffer 2,
@@ -261,22 +298,25 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
                 for (int i = threadIdx.x; i < BM * Gn; i += NTH) {
                     int r = m0 + i / Gn;
                     if (r >= g.M) r = g.M - 1;
-                    part[(i / Gn) * (Gn + 1) + i % Gn] = rsc.ssq[(size_t)r * Gn + i % Gn];
+                    part[(i / Gn) * (Gn + 1) + i % Gn] = gp(rsc.ssq)[(size_t)r * Gn + i % Gn];
                 }
             }
-            __syncthreads();
+            // (raw barriers: __syncthreads() would drain every DMA stage and the cell prefetch in flight)
+            wait_lgkm0(); __builtin_amdgcn_s_barrier();
             if (threadIdx.x < BM) {
                 float t = 0.0f;
                 for (int j = 0; j < Gn; ++j) t += part[threadIdx.x * (Gn + 1) + j];
                 scl[threadIdx.x] = __builtin_amdgcn_rsqf(t * rsc.inv_n + rsc.eps);
             }
-            __syncthreads();
+            wait_lgkm0(); __builtin_amdgcn_s_barrier();
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xrs[mt][r] = scl[wrow + mt * 16 + kq * 4 + r];
         }
-        if (nstage > 1) wait_vm<PPW>(); else wait_vm<0>();      // stage 0 has landed (this wave's pieces)
+        // stage 0 has landed (this wave's pieces); younger than it: stage 1 and the cell prefetch
+        constexpr int CPV = EPI == EPI_LSTM ? QPT : 0;
+        wait_vm<PPW + CPV>();
         wait_lgkm0();
         __builtin_amdgcn_s_barrier();                      // barrier 0
 
@@ -303,8 +343,6 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
 #else
         auto lapt = [](int) {};
 #endif
-        constexpr int prio = PRIO;
-        if (prio == 2) __builtin_amdgcn_s_setprio(1);
         // One k block of one group: load phase | barrier | compute phase | barrier.
         //   load phase     the DMA pieces of stage u + 2 (half p of this wave's share): no vector ALU, no LDS instruction;
         //   compute phase  the MFMAs of k block j with the fragment reads of k block j + 1 spread between them (one ds_read_b128 behind
@@ -325,8 +363,6 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
             lapt(1);
             __builtin_amdgcn_sched_barrier(0);
             if (jkb == scale_at) { apply_scale(); lapt(4); __builtin_amdgcn_sched_barrier(0); }
-            if (prio == 1) __builtin_amdgcn_s_setprio(1);
-            else if (prio == 2) __builtin_amdgcn_s_setprio(0);
             // (the reads are unconditional -- behind the last k block they fetch a stage nobody needs -- so that the phase is ONE scheduling
             // region and the interleave below applies)
             read_frags(nsb, 1 - p, fan, fbn);
@@ -354,8 +390,6 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
                 if constexpr (NM > NI) __builtin_amdgcn_sched_group_barrier(0x008, NM - NI, 0);
                 if constexpr (NR > NI) __builtin_amdgcn_sched_group_barrier(0x100, NR - NI, 0);
             }
-            if (prio == 1) __builtin_amdgcn_s_setprio(0);
-            else if (prio == 2) __builtin_amdgcn_s_setprio(1);
             __builtin_amdgcn_sched_barrier(0);             // (the MFMAs stay IN FRONT of the wait: they do not depend on the reads in flight)
             wait_lgkm0();                                  // the fragments of k block j + 1 are in (and this wave's reads of their stage are done)
             if (p == 0 && grp == 1) { if (do_issue) wait_vm<HP>(); else wait_vm<0>(); }
@@ -389,15 +423,6 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
     }
 
     // ---- the workgroup's sums -> LDS plane (each wave owns its part; no cross-wave addition) -> 4-column quads per thread
-    int l_slot[EPI == EPI_LSTM ? QPT : 1];
-    float l_cprev[EPI == EPI_LSTM ? QPT : 1];
-    if (EPI == EPI_LSTM) {
-        if (g.debug == 1) __syncthreads();                 // (measurement form without the K loop: nothing else orders the slot stores)
-#pragma unroll
-        for (int i = 0; i < QPT; ++i) l_slot[i] = slot_lds[qrow0 + QRS * i];
-#pragma unroll
-        for (int i = 0; i < QPT; ++i) l_cprev[i] = g.c_state[(size_t)l_slot[i] * g.hidden + l_unit];
-    }
     __syncthreads();                                       // the last stage has been read by every wave
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
@@ -415,7 +440,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
             const int m = m0 + qrow0 + QRS * i;
-            if (m < g.M) *reinterpret_cast<f32x4 *>(g.out + (size_t)m * g.ldo + ncol) = v[i];
+            if (m < g.M) *reinterpret_cast<__attribute__((address_space(1))) f32x4 *>(gp(g.out) + (size_t)m * g.ldo + ncol) = v[i];
         }
     } else if (EPI == EPI_BIAS_DSWISH) {
 #pragma unroll
@@ -426,8 +451,8 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
                 f32x4 o;
                 o.x = y.x * fast_sigmoid(y.x - 1.0f); o.y = y.y * fast_sigmoid(y.y - 1.0f);
                 o.z = y.z * fast_sigmoid(y.z - 1.0f); o.w = y.w * fast_sigmoid(y.w - 1.0f);
-                if (g.out) *reinterpret_cast<f32x4 *>(g.out + (size_t)m * g.ldo + ncol) = o;
-                if (g.out16) *reinterpret_cast<h4 *>(reinterpret_cast<_Float16 *>(g.out16) + (size_t)m * g.ldo + ncol) = to_h4(o);
+                if (g.out) *reinterpret_cast<__attribute__((address_space(1))) f32x4 *>(gp(g.out) + (size_t)m * g.ldo + ncol) = o;
+                if (g.out16) *reinterpret_cast<__attribute__((address_space(1))) h4 *>(gp(reinterpret_cast<_Float16 *>(g.out16)) + (size_t)m * g.ldo + ncol) = to_h4(o);
             }
         }
     } else {   // EPI_LSTM: the quad = gates i, f, g, o of one hidden unit; the BasicNorm scale of the y half was folded in after chunk 1
@@ -438,9 +463,9 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
             const float c_new = fast_sigmoid(gt.y) * l_cprev[i] + fast_sigmoid(gt.x) * fast_tanh(gt.z);
             const float u = fast_sigmoid(gt.w) * fast_tanh(c_new);
             if (m < g.M) {
-                g.c_state[(size_t)l_slot[i] * g.hidden + l_unit] = c_new;
-                if (g.out) g.out[(size_t)m * g.ldo + l_unit] = u;
-                if (g.out16) reinterpret_cast<_Float16 *>(g.out16)[(size_t)m * g.ldo + l_unit] = (_Float16)u;
+                gp(g.c_state)[(size_t)l_slot[i] * g.hidden + l_unit] = c_new;
+                if (g.out) gp(g.out)[(size_t)m * g.ldo + l_unit] = u;
+                if (g.out16) gp(reinterpret_cast<_Float16 *>(g.out16))[(size_t)m * g.ldo + l_unit] = (_Float16)u;
             }
         }
     }
@@ -453,22 +478,22 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
 #undef APRIL_PP_EACH
 }
 
-template <int MT, int EPI, int PRIO>
+template <int MT, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmArgs g)
 {
-    gemm_pp_body<MT, EPI, PRIO>(g);
+    gemm_pp_body<MT, EPI>(g);
 }
 
 // n independent same-shape problems in one launch (see gemm_f32_zkernel): blockIdx.z picks the argument block
-template <int MT, int EPI, int PRIO>
+template <int MT, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_pp_zkernel(const GemmArgs *__restrict__ zargs)
 {
     const GemmArgs g = zargs[blockIdx.z];
-    gemm_pp_body<MT, EPI, PRIO>(g);
+    gemm_pp_body<MT, EPI>(g);
 }
 
-template <int MT, int EPI, int PRIO>
-void launch_pp_prio(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s)
+template <int MT, int EPI>
+void launch_pp_one(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s)
 {
     using G = PPGeom<MT>;
     dim3 grid((unsigned)(g.N / G::BN), (unsigned)((g.M + G::BM - 1) / G::BM), (unsigned)(dev_args ? n : 1));
@@ -478,21 +503,12 @@ void launch_pp_prio(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStrea
     (void)hipGetDevice(&dev);
     const uint64_t bit = 1ull << (dev & 63);
     if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_pp_kernel<MT, EPI, PRIO>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_pp_zkernel<MT, EPI, PRIO>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_pp_kernel<MT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_pp_zkernel<MT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_devs.fetch_or(bit, std::memory_order_release);
     }
-    if (dev_args) hipLaunchKernelGGL((gemm_pp_zkernel<MT, EPI, PRIO>), grid, dim3(G::NTH), (size_t)G::LDS_BYTES, s, dev_args);
-    else hipLaunchKernelGGL((gemm_pp_kernel<MT, EPI, PRIO>), grid, dim3(G::NTH), (size_t)G::LDS_BYTES, s, g);
-}
-
-template <int MT, int EPI>
-void launch_pp_one(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s)
-{
-    // g.skew = wave priority policy (APRIL_PP_PRIO; measurement): 0 none, 1 raised in the compute phase, 2 raised in the load phase
-    if (g.skew == 1) launch_pp_prio<MT, EPI, 1>(g, dev_args, n, s);
-    else if (g.skew == 2) launch_pp_prio<MT, EPI, 2>(g, dev_args, n, s);
-    else launch_pp_prio<MT, EPI, 0>(g, dev_args, n, s);
+    if (dev_args) hipLaunchKernelGGL((gemm_pp_zkernel<MT, EPI>), grid, dim3(G::NTH), (size_t)G::LDS_BYTES, s, dev_args);
+    else hipLaunchKernelGGL((gemm_pp_kernel<MT, EPI>), grid, dim3(G::NTH), (size_t)G::LDS_BYTES, s, g);
 }
 
 }  // namespace
@@ -507,7 +523,7 @@ bool gemm_pp_ok(const GemmArgs &g, int mt)
     if (!half_x && !half_h && g.wave_mask != 0xF) return false;
     if (half_x && g.epi == EPI_BIAS_DSWISH) return false;
     const int c = g.K / 128;
-    if ((half_x || half_h) && (c & 1)) return false;                        // the half walks 2 c k blocks = whole stages
+    if ((half_x || half_h) && ((c & 1) || g.K < 256)) return false;         // the half walks 2 c k blocks = whole stages, at least two of them
     if (g.K1 > 0 && (g.K0 % 64 != 0 || g.K0 + g.K1 != g.K)) return false;
     if (g.K1 == 0 && g.K0 != g.K) return false;
     if ((g.epi == EPI_LSTM || g.epi == EPI_XPART) && g.x_scale.ssq) {

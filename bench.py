@@ -244,6 +244,21 @@ def main():
         del blob
     load_s = time.time() - t_load0
     d = model.dims
+    # every rank's view of the load (not only rank 0's): which RCCL it has mapped, how long its communicator set-up and its share of
+    # the weight broadcast took, what the library says it used -- so that the first real multi-GPU line is diagnosable from the line
+    try:
+        li_r = model.load_info()
+        rank_rec = {"rank": rank, "device": local_rank, "model_load_s": round(load_s, 2),
+                    "weight_broadcast_ms": None if bcast_ms is None else round(float(bcast_ms), 2),
+                    "comm_init_ms": round(float(li_r.comm_init_ms), 1), "library_broadcast_ms": round(float(li_r.broadcast_ms), 2),
+                    "used_rccl": int(li_r.used_rccl), "library_ranks": int(li_r.ranks), "rccl_fallback": bool(rccl_fallback),
+                    "rccl_libs_mapped": sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln}), "pid": os.getpid()}
+    except Exception as e:                          # noqa: BLE001 -- diagnostics must not take the run down
+        rank_rec = {"rank": rank, "error": repr(e)}
+    per_rank = [rank_rec]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, rank_rec)
 
     # ---------------- sessions + synthetic audio
     B = args.sessions
@@ -591,6 +606,7 @@ def main():
                        if args.ingest == "pipelined" else "aprilx_feed_many: one blocking call per feed"},
             "other_ingest": other_ingest, "deeper_pipeline": deeper, "steady": steady, "config5_f16": config5,
             "rccl_fallback": rccl_fallback, "rccl_libs_mapped": sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln}),
+            "per_rank": per_rank,
             # the duration of the feed CALL: in lockstep mode that is the latency of a feed (the call returns with every callback
             # delivered); in pipelined mode it is only the hand-over (the call returns when at most one earlier feed is still open)
             ("step_latency_ms" if args.ingest == "lockstep" else "handover_ms"): {

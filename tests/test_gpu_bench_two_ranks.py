@@ -43,3 +43,8 @@ def test_bench_two_ranks_on_one_gpu(built, v0_model):
     # value = the units ALL ranks processed / the slowest rank's time
     assert abs(j["value"] - 32 * 3 * 0.1 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-2
     assert len(j["rccl_libs_mapped"]) <= 1, j["rccl_libs_mapped"]       # one RCCL build per process (shared SONAME librccl.so.1)
+    # every rank reports its own view of the load: device, load time, what the library used, which RCCL it has mapped
+    pr = j["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and all("error" not in r for r in pr), pr
+    assert all(r["model_load_s"] >= 0 and len(r["rccl_libs_mapped"]) <= 1 and r["rccl_fallback"] is False for r in pr)
+    assert pr[0]["pid"] != pr[1]["pid"]
