@@ -229,8 +229,10 @@ class Model:
             self._L.aprilx_model_feed_latency(self._handle, device_index, None, 0, 1)
         return out[:n]
 
-    def profile(self, enable: bool):
-        self._L.aprilx_model_profile(self._handle, 1 if enable else 0)
+    def profile(self, enable):
+        """True / 1: launches one by one with hipEvents around them (per-class times in stats().kernel_ms); 2: the gates clock (feeds run as
+        always, the gates kernels time themselves; stats().gates_clock_* after the next profile(0)); False / 0: off"""
+        self._L.aprilx_model_profile(self._handle, int(enable))
 
 
 def _dispatch(userdata, result_type, count, tokens):

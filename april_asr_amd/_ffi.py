@@ -40,7 +40,9 @@ class AprilxStats(C.Structure):
                [("kernel_ms", C.c_double * 6), ("kernel_launches", C.c_uint64 * 6), ("host_ms", C.c_double * 8),
                 ("flights", C.c_uint64), ("replay_mismatch", C.c_uint64), ("kernels_per_step", C.c_uint64),
                 ("lm_steps", C.c_uint64), ("lm_chunks", C.c_uint64),
-                ("wave_steps", C.c_uint64), ("wave_chunks", C.c_uint64)]
+                ("wave_steps", C.c_uint64), ("wave_chunks", C.c_uint64),
+                ("gates_clock_ms", C.c_double), ("gates_clock_launches", C.c_uint64), ("gates_clock_rows", C.c_uint64),
+                ("gates_clock_ms_by_n", C.c_double * 4), ("gates_clock_launches_by_n", C.c_uint64 * 4)]
 
 
 class AprilxLoadInfo(C.Structure):

@@ -822,6 +822,12 @@ void aprilx_model_stats(AprilASRModel model, int device_index, AprilxStats *out)
     Engine *e = model->m.engines[(size_t)device_index];
     out->kernels_per_step = (uint64_t)e->kernels_per_step();
     for (int i = 0; i < 6; ++i) { out->kernel_ms[i] = e->timing(i).ms; out->kernel_launches[i] = (uint64_t)e->timing(i).launches; }
+    double gms = 0; long gl = 0, gr = 0;
+    e->gates_clock(&gms, &gl, &gr);
+    out->gates_clock_ms = gms; out->gates_clock_launches = (uint64_t)gl; out->gates_clock_rows = (uint64_t)gr;
+    double ms4[4]; long l4[4];
+    e->gates_clock_by_n(ms4, l4);
+    for (int i = 0; i < 4; ++i) { out->gates_clock_ms_by_n[i] = ms4[i]; out->gates_clock_launches_by_n[i] = (uint64_t)l4[i]; }
 }
 
 int aprilx_model_feed_latency(AprilASRModel model, int device_index, double *out_ms, int cap, int reset)
@@ -832,7 +838,10 @@ int aprilx_model_feed_latency(AprilASRModel model, int device_index, double *out
 
 void aprilx_model_profile(AprilASRModel model, int enable)
 {
-    for (Engine *e : model->m.engines) { e->set_profiling(enable != 0); if (enable) e->reset_timing(); }
+    for (Engine *e : model->m.engines) {
+        e->set_profiling(enable == 1); if (enable == 1) e->reset_timing();
+        e->set_gates_clock(enable == 2);
+    }
 }
 
 struct AprilxGreedy_i {

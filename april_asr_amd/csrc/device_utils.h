@@ -4,7 +4,20 @@
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 
+#include <hip/hip_ext.h>
+
 namespace aprilx {
+
+// host side: every GEMM kernel goes out through APRIL_LAUNCH so that a pending pair of profiling events (gemm_profile_next_launch,
+// kernels.h) rides in the kernel's own dispatch packet
+struct ProfileEvents { hipEvent_t a = nullptr, b = nullptr; };
+ProfileEvents &tl_profile_events();
+#define APRIL_LAUNCH(kernel, grid, block, lds, stream, ...)                                                                         \
+    do {                                                                                                                           \
+        aprilx::ProfileEvents &pe_ = aprilx::tl_profile_events();                                                                  \
+        if (pe_.a) { hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(lds), stream, pe_.a, pe_.b, 0, __VA_ARGS__); pe_.a = pe_.b = nullptr; } \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                                    \
+    } while (0)
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -75,6 +88,39 @@ __device__ __forceinline__ float granule_ssq(const f32x4 &y)
     q += __shfl_xor(q, 2);
     q += __shfl_xor(q, 4);
     return q;
+}
+
+// gates clock (GemmArgs::stamp): called by every thread of a workgroup at kernel entry / exit; total = workgroups of the launch.
+// Slot layout (128 words): [0] start, [1] arrivals, [2] sum of durations (10 ns ticks), [3] launches, [8 .. 71] 64 end stamps.
+// Contention is what a clock must not add: 512 co-resident workgroups hitting ONE L2 word with an atomic at the same moment are
+// served one after the other (~12 ns each = 6 us), and a wave's first loads retire behind its own atomic -- the first version of this
+// clock (every workgroup atomicMin on the start word, a returning atomicMax on one end word) read 43.7 us where rocprofv3 reports 36.3.
+// So: the start is workgroup 0's alone (the grid starts first to last within 0.3 .. 0.7 us), the end stamps are spread over 64 words.
+__device__ __forceinline__ void stamp_begin(unsigned long long *slot, bool first_wg)
+{
+    if (slot && first_wg && threadIdx.x == 0) __hip_atomic_store(slot, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stamp_end(unsigned long long *slot, unsigned total, unsigned wg_linear)
+{
+    if (!slot) return;
+    // (every wave has ISSUED its last store -- not "the stores have been acknowledged": the command processor's end-of-kernel stamp, which
+    // rocprofv3 reports, does not wait for them either; with the wait, 512 co-resident workgroups ending together read 39.0 us where
+    // rocprofv3 says 34.8, their 6 MB of cell state and u rows draining)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // (no fences: a release fence writes back the XCD's L2 -- microseconds per workgroup.  The returned old maximum makes the wave
+        // wait until its own end stamp has landed before it takes a ticket, so the workgroup that draws the last ticket finds every end
+        // stamp in place; the ticket word is contended, but only a workgroup's retirement waits for it, after its end stamp was taken.)
+        const unsigned long long old = atomicMax(slot + STAMP_ENDS + (wg_linear & (STAMP_NENDS - 1)), (unsigned long long)wall_clock64());
+        asm volatile("" :: "v"(old));
+        if (atomicAdd(slot + 1, 1ull) == (unsigned long long)total - 1) {      // the last workgroup of the launch closes the sample
+            unsigned long long t1 = 0;
+            for (int i = 0; i < STAMP_NENDS; ++i) { const unsigned long long e = atomicExch(slot + STAMP_ENDS + i, 0ull); t1 = e > t1 ? e : t1; }
+            const unsigned long long t0 = atomicExch(slot, 0ull);
+            atomicExch(slot + 1, 0ull);
+            if (t0 && t1 > t0) { atomicAdd(slot + 2, t1 - t0); atomicAdd(slot + 3, 1ull); }
+        }
+    }
 }
 
 // sigma and tanh on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each); absolute error ~1e-7, far inside

@@ -555,19 +555,54 @@ void Engine::general_prologue()
 // ---------------------------------------------------------------- profiling
 void Engine::set_profiling(bool on) { std::lock_guard<std::mutex> cg(capture_mu_); sync(); profiling_ = on; }
 void Engine::reset_timing() { for (auto &t : timing_) t = KernelTiming(); }
+void Engine::set_gates_clock(bool on)
+{
+    std::lock_guard<std::mutex> cg(capture_mu_);
+    HIP_CHECK(hipSetDevice(cfg_.device));
+    sync();
+    if (on) {
+        if (!gclk_slots_) gclk_slots_ = dmalloc<unsigned long long>((size_t)GCLK_SLOTS * STAMP_WORDS);
+        HIP_CHECK(hipMemsetAsync(gclk_slots_, 0, (size_t)GCLK_SLOTS * STAMP_WORDS * 8, stream_));
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        gclk_ms_ = 0; gclk_launches_ = 0; gclk_rows_ = 0;
+        for (int i = 0; i < 4; ++i) { gclk_ms_n_[i] = 0; gclk_launches_n_[i] = 0; }
+        gclk_ = true;
+        return;
+    }
+    if (gclk_ && gclk_slots_) {
+        // every plan built while the clock was on: its slots' sums (10 ns ticks of s_memrealtime) and launch counts
+        std::vector<unsigned long long> h((size_t)GCLK_SLOTS * STAMP_WORDS);
+        HIP_CHECK(hipMemcpyAsync(h.data(), gclk_slots_, h.size() * 8, hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        for (auto &kv : sw_plans_)
+            for (size_t i = 0; i < kv.second.stamp_slots.size(); ++i) {
+                const auto &sl = kv.second.stamp_slots[i];
+                const unsigned long long ticks = h[(size_t)sl.first * STAMP_WORDS + 2], n = h[(size_t)sl.first * STAMP_WORDS + 3];
+                gclk_ms_ += (double)ticks * 1e-5; gclk_launches_ += (long)n; gclk_rows_ += (long)n * sl.second;
+                const int bn = std::min(std::max(kv.second.stamp_n[i], 1), 4) - 1;
+                gclk_ms_n_[bn] += (double)ticks * 1e-5; gclk_launches_n_[bn] += (long)n;
+            }
+    }
+    gclk_ = false;
+}
 void Engine::timed_begin(int cls)
 {
     ++launch_count_;
     if (!profiling_) return;
     if (ev_used_ == ev_pool_.size()) { Ev e; HIP_CHECK(hipEventCreate(&e.a)); HIP_CHECK(hipEventCreate(&e.b)); e.cls = cls; ev_pool_.push_back(e); }
     ev_pool_[ev_used_].cls = cls;
-    HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].a, stream_));
+    // gates launches: the kernel's own dispatch time stamps (hipExtLaunchKernel through APRIL_LAUNCH) instead of event packets around
+    // it -- the clock of rocprofv3's per-kernel duration, which bench.py's roofline is priced on; other classes: brackets on the stream
+    if (cls == T_GATES) gemm_profile_next_launch(ev_pool_[ev_used_].a, ev_pool_[ev_used_].b);
+    else HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].a, stream_));
 }
 void Engine::timed_end(int cls)
 {
     if (!profiling_) return;
-    (void)cls;
-    HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].b, stream_));
+    if (cls == T_GATES) {
+        // (a launch path that does not go through APRIL_LAUNCH left the pair untouched: drop the sample instead of reading unrecorded events)
+        if (gemm_profile_pending()) { gemm_profile_next_launch(nullptr, nullptr); return; }
+    } else HIP_CHECK(hipEventRecord(ev_pool_[ev_used_].b, stream_));
     ++ev_used_;
 }
 void Engine::collect_timing()
@@ -1274,7 +1309,9 @@ void Engine::run_lm_wavefront(int m, int T, bool dump_logits)
 // The argument blocks depend on (m, T) only: built once per shape, kept in device memory, and the whole chain is one graph.
 Engine::SwPlan &Engine::sw_plan(int m, int T)
 {
-    const std::pair<int, int> key(m, T * 2 + flight_parity_);      // (the argument blocks point into the parity's buffers)
+    // (the argument blocks point into the parity's buffers; plans built under the gates clock carry stamp slots and are kept apart:
+    // negative m)
+    const std::pair<int, int> key(gclk_ ? -m : m, T * 2 + flight_parity_);
     auto it = sw_plans_.find(key);
     if (it != sw_plans_.end()) return it->second;
     if (sw_plans_.size() >= 64) {
@@ -1305,6 +1342,10 @@ Engine::SwPlan &Engine::sw_plan(int m, int T)
                 if (t < 0 || t >= T) continue;
                 GemmArgs g = kind == 0 ? sw_args_gates(l, m, t) : kind == 1 ? lm_args_whr(l, m, t) : kind == 2 ? lm_args_ff1(l, m, t, t + 1) : lm_args_ff2(l, m, t, t + 1);
                 if (kind == 0 && cfg_.precision == 0) g.tile_ok = gates_tile_rows((long)m * n_act) ? 2 : 0;
+                if (kind == 0 && gclk_ && gclk_slots_ && gclk_used_ < GCLK_SLOTS) {      // one slot per gates LAUNCH: all its problems point at it
+                    if (items.empty()) { p.stamp_slots.push_back(std::make_pair(gclk_used_, (long)m * n_act)); p.stamp_n.push_back(n_act); ++gclk_used_; }
+                    g.stamp = gclk_slots_ + (size_t)p.stamp_slots.back().first * STAMP_WORDS;
+                }
                 if (kind == 2 && cfg_.precision == 0) g.tile_ok = ff1_tile_rows((long)m * n_act) ? 2 : 0;
                 if (split) {
                     float *ws = ws_ + (size_t)t * m * d.d_model;
@@ -1429,13 +1470,15 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
         // or empty flight flips the pairing), and a capture in the middle of a stream is a 3 ms hiccup.
         const int par = flight_parity_;
         sw_plan(m, T);
-        SwPlan *pp = &sw_plans_.find(std::make_pair(m, T * 2 + par))->second;
+        SwPlan *pp = &sw_plans_.find(std::make_pair(gclk_ ? -m : m, T * 2 + par))->second;
         int &uses = sw_uses_[std::make_pair(m, T)];
         const bool graphs = use_graphs_ && !profiling_ && !logits_out && (pp->graph || pp->g3[0] || ++uses >= 2);
         // (split: only the FIRST step of a flight: the per-parity buffers keep neighbouring FLIGHTS apart, a second step of the same
         // flight -- a flush runs several -- would have its index fetch and front end overwrite what the first step's layers and
         // search still read; it takes the one-stream path, behind everything the first step put on F and S)
-        const bool split = graphs && split_streams_ > 0 && overlap_hint_ && flight_steps_ == 1;
+        // (gates clock on: one stream for everything, so that no other stream's kernel shares the CUs with a gates launch while it times itself;
+        // the feeds still arrive pipelined, the GPU stays busy and at speed)
+        const bool split = graphs && split_streams_ > 0 && overlap_hint_ && flight_steps_ == 1 && !gclk_;
         hipStream_t fe = split_streams_ >= 2 ? f_stream_ : stream_;
         if (graphs && (split ? !pp->g3[0] : !pp->graph)) {
             for (int k2 = 0; k2 < 2; ++k2) {
@@ -1465,7 +1508,7 @@ int Engine::lm_step(int m, int T, const int *slots, const int *ring_tails, const
                     HIP_CHECK(hipGraphDestroy(graph));
                 }
             }
-            pp = &sw_plans_.find(std::make_pair(m, T * 2 + par))->second;      // (a plan-cache eviction in between would have moved it)
+            pp = &sw_plans_.find(std::make_pair(gclk_ ? -m : m, T * 2 + par))->second;      // (a plan-cache eviction in between would have moved it)
         }
         SwPlan &p = *pp;
         if (split) {

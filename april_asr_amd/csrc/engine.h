@@ -149,6 +149,13 @@ public:
 
     // ---- profiling: when enabled every launch of the named classes is bracketed by hipEvents
     void set_profiling(bool on);
+    // Gates clock (bench.py's roofline): while it is on, the feed-wavefront launch plans are built with a stamp slot per gates launch
+    // (GemmArgs::stamp): the kernels time themselves under graph replay.  Switching it off reads the slots back.
+    void set_gates_clock(bool on);
+    void gates_clock(double *ms, long *launches, long *rows) const { *ms = gclk_ms_; *launches = gclk_launches_; *rows = gclk_rows_; }
+    // ... and split by the number of problems sharing the launch (index min(n, 4) - 1): the three gates kernels of the trace
+    // (one problem: gemm_f32_kernel, two: gemm_f32_zkernel, three at 256 sessions: gemm_f32_zkernel_walk) map onto it one to one
+    void gates_clock_by_n(double *ms4, long *launches4) const { for (int i = 0; i < 4; ++i) { ms4[i] = gclk_ms_n_[i]; launches4[i] = gclk_launches_n_[i]; } }
     KernelTiming timing(int cls) const { return timing_[cls]; }
     void reset_timing();
     enum { T_GATES = 0, T_GEMM_OTHER = 1, T_ROW = 2, T_CONV = 3, T_FBANK = 4, T_DEC = 5, T_COUNT = 6 };
@@ -186,6 +193,7 @@ private:
         std::vector<GemmArgs> host; GemmArgs *dev = nullptr; std::vector<Batch> batches; hipGraphExec_t graph = nullptr; int uses = 0;
         hipGraphExec_t g3[3] = {nullptr, nullptr, nullptr};                      // split feed: front end / layers / search, one graph per stream
         std::vector<RowArgs> rhost; RowArgs *rdev = nullptr;
+        std::vector<std::pair<int, long>> stamp_slots; std::vector<int> stamp_n;  // gates clock: (slot, rows) and problem count of every gates launch of a plan built while it was on
     };
     SwPlan &sw_plan(int m, int T);
     void run_sw_chain(int m, int T, bool dump_logits, const SwPlan &p, int part, hipStream_t st);
@@ -294,6 +302,9 @@ private:
     long launch_count_ = 0;
     // profiling
     bool profiling_ = false;
+    bool gclk_ = false; unsigned long long *gclk_slots_ = nullptr; int gclk_used_ = 0;      // gates clock (set_gates_clock): 8-word device slots
+    static constexpr int GCLK_SLOTS = 2048;       // launch sites x 1 KB (STAMP_WORDS, device_utils.h)
+    double gclk_ms_ = 0; long gclk_launches_ = 0, gclk_rows_ = 0; double gclk_ms_n_[4] = {0, 0, 0, 0}; long gclk_launches_n_[4] = {0, 0, 0, 0};
     struct Ev { hipEvent_t a, b; int cls; };
     std::vector<Ev> ev_pool_; size_t ev_used_ = 0;
     KernelTiming timing_[T_COUNT];

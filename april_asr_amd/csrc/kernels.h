@@ -76,6 +76,8 @@ struct RowScale {                  // BasicNorm scale of a row from its sum-of-s
 // last active token; src/april_session.h:32-73); see "greedy search on the device" below.
 struct GreedyState { int32_t ctx0, ctx1; int32_t last_tok; uint32_t last_emit_ms; };
 
+constexpr int STAMP_WORDS = 128, STAMP_ENDS = 8, STAMP_NENDS = 64;      // layout of a gates-clock slot (GemmArgs::stamp; device_utils.h)
+
 struct GemmArgs {
     // A operand as up to two K segments with optional row indirection (slot ids)
     const float *a0 = nullptr; int lda0 = 0; const int *aidx0 = nullptr; int K0 = 0;
@@ -129,9 +131,20 @@ struct GemmArgs {
     int xcd_rc = 0;                        // GM_KW: 2 = tiles dealt to the XCDs as 2 row halves x 4 column quarters (APRIL_KW_XCD; 0 = column tiles round robin)
     int asm_loop = 0;                      // != 0: hand-scheduled K loop (gemm_mainloop_asm.inc) in the fused-epilogue 64x64 fp32 tiles
     unsigned long long *trace = nullptr;   // measurement only: per-workgroup s_memtime stamps [wg][8] (wave 0, lane 0)
+    // Gates launches only (EPI_LSTM; the engine's "gates clock", aprilx_model_profile(model, 2)): one slot per LAUNCH (all problems
+    // of a z-batched launch point at the same one).  Every workgroup stamps real time (s_memrealtime, 10 ns) when it starts and when it has
+    // finished; the last one to finish adds (latest end - earliest start) to the slot's sum and re-arms it -- the launch's duration under
+    // whatever launch path is in use (graph replay), with no event packet near the kernel.  null (the product's case): two scalar branches.
+    unsigned long long *stamp = nullptr;   // slot of 128 words (device_utils.h stamp_begin / stamp_end): [0] start, [1] arrivals, [2] sum of durations (ticks), [3] launches, [8..71] end stamps
     int debug = 0;                         // measurement only: 1 = skip the MFMA main loop, 2 = skip the epilogue math, 3 = all k blocks read block 0
 };
 void launch_gemm(const GemmArgs &g, hipStream_t s);
+// Measurement (the engine's profiling mode, bench.py's roofline clock): the NEXT GEMM kernel this thread launches records its own start
+// and stop into these events -- hipExtLaunchKernel puts them into the dispatch packet, i.e. the time stamps rocprofv3 reports as the
+// kernel's duration, with no event packets around the kernel.  Consumed (cleared) by that launch; gemm_profile_pending() tells whether
+// a launch has taken them.
+void gemm_profile_next_launch(hipEvent_t start, hipEvent_t stop);
+bool gemm_profile_pending();
 // (internal) GM_TILE launch, called by launch_gemm / launch_gemm_z once the plan is made: tile 16 * mt rows x 16 * nt columns; dev_args != null: n z-batched problems
 void launch_gemm_tile(const GemmArgs &g, int mt, int nt, const GemmArgs *dev_args, int n, hipStream_t s);
 // (internal) GM_KW launch (kernels_gemm_kw.hip): tile 16 * mt rows x 16 * nt columns, all of K in the workgroup; dev_args != null: n z-batched

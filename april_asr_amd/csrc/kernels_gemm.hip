@@ -23,6 +23,12 @@
 // (reference call sites src/april_session.c:145,160,176).
 #include "kernels.h"
 #include "device_utils.h"
+// the head of the hand-scheduled K loop on an 8-byte boundary: every instruction of the loop is an 8-byte encoding, so the phase of the
+// head is the phase of all of them (MI355X_MICROARCH.md: a hand-written stream loses up to 13 % at shifts of 4 mod 8; the round-5 build
+// had the gates kernel's head at 4 mod 8)
+#ifndef APRIL_ASM_LOOP_ALIGN
+#define APRIL_ASM_LOOP_ALIGN ".p2align 3\n"
+#endif
 #include "gemm_mainloop_asm.inc"
 #ifndef APRIL_ASM_NB
 #define APRIL_ASM_NB 2      // operand buffers of the hand-scheduled K loop: 2 keeps two workgroups per CU, 3 needs > 256 registers
@@ -691,7 +697,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int zg, const
 template <int MT, int NT, int EPI, int AOP, int WT, int MODE, int ASM, int NW = 4>
 __global__ __launch_bounds__(NW * 64, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_kernel(GemmArgs g)
 {
+    if constexpr (EPI == EPI_LSTM) stamp_begin(g.stamp, (blockIdx.x | blockIdx.y | blockIdx.z) == 0);
     gemm_body<MT, NT, EPI, AOP, WT, MODE, ASM, NW>(g, (int)blockIdx.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), (int)blockIdx.x, (int)blockIdx.y, gridDim.y == 1);
+    if constexpr (EPI == EPI_LSTM) stamp_end(g.stamp, gridDim.x * gridDim.y * gridDim.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
 }
 
 // The same GEMM for `gridDim.z / zdiv` INDEPENDENT problems of one shape in one launch: blockIdx.z / zdiv selects the argument
@@ -706,7 +714,9 @@ __global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_zkern
     // are generic to the compiler -- flat_load / flat_store instead of global_load with an SGPR base -- and neither assumptions
     // nor address-space round trips change that; measured against the by-value kernel at one problem per launch: no difference.)
     const GemmArgs g = zargs[zl];
+    if constexpr (EPI == EPI_LSTM) stamp_begin(g.stamp, (blockIdx.x | blockIdx.y | blockIdx.z) == 0);
     gemm_body<MT, NT, EPI, AOP, WT, MODE, ASM, 4>(g, (int)blockIdx.z - zl * zdiv, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), (int)blockIdx.x, (int)blockIdx.y, gridDim.y == 1);
+    if constexpr (EPI == EPI_LSTM) stamp_end(g.stamp, gridDim.x * gridDim.y * gridDim.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
 }
 
 // Balanced form of the z-batched launch for tile counts that are not a whole number of rounds (three 256-row gate problems =
@@ -720,11 +730,13 @@ __global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_zkern
 {
     // (at most two tiles per workgroup, as two straight-line copies of the body: a loop around it costs 20 registers, which
     // takes the hand-scheduled 64 x 64 tile over 256 and the kernel down to one workgroup per CU)
+    unsigned long long *stamp = nullptr;                         // (gates clock: the slot of the launch = of any of its problems)
     {
         const int tile = (int)blockIdx.x;
         const int bx = tile % gx, r = tile / gx, by = r % gy, bz = r / gy;
         const int zl = bz / zdiv;
         const GemmArgs g = zargs[zl];
+        if constexpr (EPI == EPI_LSTM) { stamp = g.stamp; stamp_begin(stamp, blockIdx.x == 0); }
         gemm_body<MT, NT, EPI, AOP, WT, MODE, ASM, 4>(g, bz - zl * zdiv, (unsigned)tile, bx, by, gy == 1);
     }
     const int tile = (int)blockIdx.x + (int)gridDim.x;
@@ -735,10 +747,15 @@ __global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_zkern
         const GemmArgs g = zargs[zl];
         gemm_body<MT, NT, EPI, AOP, WT, MODE, ASM, 4>(g, bz - zl * zdiv, (unsigned)tile, bx, by, gy == 1);
     }
+    if constexpr (EPI == EPI_LSTM) stamp_end(stamp, gridDim.x, blockIdx.x);
 }
 
 // ---------------------------------------------------------------- host side
 struct TilePlan { int mt, nt, zs, mode; };
+
+ProfileEvents &tl_profile_events() { static thread_local ProfileEvents pe; return pe; }
+void gemm_profile_next_launch(hipEvent_t start, hipEvent_t stop) { ProfileEvents &pe = tl_profile_events(); pe.a = start; pe.b = stop; }
+bool gemm_profile_pending() { return tl_profile_events().a != nullptr; }
 
 static int env_int(const char *name, int def) { const char *v = getenv(name); return v && *v ? atoi(v) : def; }
 
@@ -931,8 +948,8 @@ static void launch_one(const GemmArgs &g, hipStream_t s)
             dim3 grid8((unsigned)(g.N / Cfg8::BN), (unsigned)((g.M + Cfg8::BM - 1) / Cfg8::BM), 1);
             const int sg8 = EPI == EPI_HR ? g.r_scale.groups : (EPI == EPI_SLOT_STORE && g.x_scale.ssq ? g.x_scale.groups : 0);
             const size_t lds8 = (size_t)(Cfg8::LDS_FLOATS + Cfg8::BM + (sg8 ? Cfg8::BM * (sg8 + 1) : 0)) * sizeof(float);
-            if (g.wt == 1) hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, EPI, AOP, 1, MODE, 0, 8>), grid8, dim3(512), lds8, s, g);
-            else hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, EPI, AOP, 0, MODE, 0, 8>), grid8, dim3(512), lds8, s, g);
+            if (g.wt == 1) APRIL_LAUNCH((gemm_f32_kernel<MT, NT, EPI, AOP, 1, MODE, 0, 8>), grid8, dim3(512), lds8, s, g);
+            else APRIL_LAUNCH((gemm_f32_kernel<MT, NT, EPI, AOP, 0, MODE, 0, 8>), grid8, dim3(512), lds8, s, g);
             return;
         }
     }
@@ -941,11 +958,11 @@ static void launch_one(const GemmArgs &g, hipStream_t s)
     static const int ldspad = env_int("APRIL_GEMM_LDSPAD", 0);   // measurement: KiB of LDS to request at least (> 80 forces one workgroup per CU)
     const int sg = EPI == EPI_HR ? g.r_scale.groups : ((EPI == EPI_LSTM || EPI == EPI_SLOT_STORE || EPI == EPI_XPART) && g.x_scale.ssq ? g.x_scale.groups : 0);
     const size_t lds = std::max((size_t)(Cfg::LDS_FLOATS + Cfg::BM + (sg ? Cfg::BM * (sg + 1) : 0)) * sizeof(float), (size_t)ldspad * 1024);
-    if (g.wt == 1) { hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, EPI, AOP, 1, MODE, 0>), grid, dim3(256), lds, s, g); return; }
+    if (g.wt == 1) { APRIL_LAUNCH((gemm_f32_kernel<MT, NT, EPI, AOP, 1, MODE, 0>), grid, dim3(256), lds, s, g); return; }
     if constexpr (HAS_ASM) {
-        if (g.asm_loop && g.debug != 1) { hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, EPI, AOP, 0, MODE, 1>), grid, dim3(256), lds, s, g); return; }
+        if (g.asm_loop && g.debug != 1) { APRIL_LAUNCH((gemm_f32_kernel<MT, NT, EPI, AOP, 0, MODE, 1>), grid, dim3(256), lds, s, g); return; }
     }
-    hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, EPI, AOP, 0, MODE, 0>), grid, dim3(256), lds, s, g);
+    APRIL_LAUNCH((gemm_f32_kernel<MT, NT, EPI, AOP, 0, MODE, 0>), grid, dim3(256), lds, s, g);
 }
 
 // (epilogue, prologue, schedule) combinations that exist; everything else is a programming error
@@ -1096,7 +1113,7 @@ static void launch_one_z(const GemmArgs &g, const GemmArgs *dev_args, int n, hip
     const int sg = EPI == EPI_HR ? g.r_scale.groups : ((EPI == EPI_LSTM || EPI == EPI_SLOT_STORE || EPI == EPI_XPART) && g.x_scale.ssq ? g.x_scale.groups : 0);
     const size_t lds = (size_t)(Cfg::LDS_FLOATS + Cfg::BM + (sg ? Cfg::BM * (sg + 1) : 0)) * sizeof(float);
     constexpr bool HAS_ASM = MODE == GM_SLAB && MT == 4 && (NT == 4 || NT == 2) && AOP == AOP_NONE && (EPI == EPI_LSTM || EPI == EPI_BIAS_DSWISH);
-    if (g.wt == 1) { hipLaunchKernelGGL((gemm_f32_zkernel<MT, NT, EPI, AOP, 1, MODE, 0>), grid, dim3(256), lds, s, dev_args, zdiv); return; }
+    if (g.wt == 1) { APRIL_LAUNCH((gemm_f32_zkernel<MT, NT, EPI, AOP, 1, MODE, 0>), grid, dim3(256), lds, s, dev_args, zdiv); return; }
     if constexpr (HAS_ASM) {
         if (g.asm_loop && g.debug != 1) {
             if constexpr (EPI == EPI_LSTM && MT == 4 && NT == 4) {
@@ -1105,14 +1122,14 @@ static void launch_one_z(const GemmArgs &g, const GemmArgs *dev_args, int n, hip
                 static const int walk = env_int("APRIL_GEMM_WALK", 1);
                 const long ntiles = (long)grid.x * grid.y * grid.z;
                 if (walk && ntiles > 512 && ntiles < 1024) {
-                    hipLaunchKernelGGL((gemm_f32_zkernel_walk<MT, NT, EPI, AOP, 0, MODE, 1>), dim3(512), dim3(256), lds, s, dev_args, zdiv, (int)grid.x, (int)grid.y, (int)ntiles);
+                    APRIL_LAUNCH((gemm_f32_zkernel_walk<MT, NT, EPI, AOP, 0, MODE, 1>), dim3(512), dim3(256), lds, s, dev_args, zdiv, (int)grid.x, (int)grid.y, (int)ntiles);
                     return;
                 }
             }
-            hipLaunchKernelGGL((gemm_f32_zkernel<MT, NT, EPI, AOP, 0, MODE, 1>), grid, dim3(256), lds, s, dev_args, zdiv); return;
+            APRIL_LAUNCH((gemm_f32_zkernel<MT, NT, EPI, AOP, 0, MODE, 1>), grid, dim3(256), lds, s, dev_args, zdiv); return;
         }
     }
-    hipLaunchKernelGGL((gemm_f32_zkernel<MT, NT, EPI, AOP, 0, MODE, 0>), grid, dim3(256), lds, s, dev_args, zdiv);
+    APRIL_LAUNCH((gemm_f32_zkernel<MT, NT, EPI, AOP, 0, MODE, 0>), grid, dim3(256), lds, s, dev_args, zdiv);
 }
 
 template <int MT, int NT>

@@ -481,7 +481,9 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs &g)
 template <int MT, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(GemmArgs g)
 {
+    if constexpr (EPI == EPI_LSTM) stamp_begin(g.stamp, (blockIdx.x | blockIdx.y | blockIdx.z) == 0);
     gemm_pp_body<MT, EPI>(g);
+    if constexpr (EPI == EPI_LSTM) stamp_end(g.stamp, gridDim.x * gridDim.y * gridDim.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
 }
 
 // n independent same-shape problems in one launch (see gemm_f32_zkernel): blockIdx.z picks the argument block
@@ -489,7 +491,9 @@ template <int MT, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_pp_zkernel(const GemmArgs *__restrict__ zargs)
 {
     const GemmArgs g = zargs[blockIdx.z];
+    if constexpr (EPI == EPI_LSTM) stamp_begin(g.stamp, (blockIdx.x | blockIdx.y | blockIdx.z) == 0);
     gemm_pp_body<MT, EPI>(g);
+    if constexpr (EPI == EPI_LSTM) stamp_end(g.stamp, gridDim.x * gridDim.y * gridDim.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
 }
 
 template <int MT, int EPI>
@@ -507,8 +511,8 @@ void launch_pp_one(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_pp_zkernel<MT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_devs.fetch_or(bit, std::memory_order_release);
     }
-    if (dev_args) hipLaunchKernelGGL((gemm_pp_zkernel<MT, EPI>), grid, dim3(G::NTH), (size_t)G::LDS_BYTES, s, dev_args);
-    else hipLaunchKernelGGL((gemm_pp_kernel<MT, EPI>), grid, dim3(G::NTH), (size_t)G::LDS_BYTES, s, g);
+    if (dev_args) APRIL_LAUNCH((gemm_pp_zkernel<MT, EPI>), grid, dim3(G::NTH), (size_t)G::LDS_BYTES, s, dev_args);
+    else APRIL_LAUNCH((gemm_pp_kernel<MT, EPI>), grid, dim3(G::NTH), (size_t)G::LDS_BYTES, s, g);
 }
 
 }  // namespace

@@ -641,7 +641,9 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
 template <int MT, int EPI, int WT, int NT = 4, int NWM = 2, int NWN = 2, int NSB = TILE_STAGES>
 __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void gemm_tile_kernel(GemmArgs g)
 {
+    if constexpr (EPI == EPI_LSTM) stamp_begin(g.stamp, (blockIdx.x | blockIdx.y | blockIdx.z) == 0);
     gemm_tile_body<MT, EPI, WT, NT, NWM, NWN, NSB>(g, (int)blockIdx.z);
+    if constexpr (EPI == EPI_LSTM) stamp_end(g.stamp, gridDim.x * gridDim.y * gridDim.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
 }
 
 // n independent same-shape problems in one launch (see gemm_f32_zkernel): blockIdx.z / zdiv picks the argument block
@@ -650,7 +652,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void gemm_t
 {
     const int zl = (int)blockIdx.z / zdiv;
     const GemmArgs g = zargs[zl];
+    if constexpr (EPI == EPI_LSTM) stamp_begin(g.stamp, (blockIdx.x | blockIdx.y | blockIdx.z) == 0);
     gemm_tile_body<MT, EPI, WT, NT, NWM, NWN, NSB>(g, (int)blockIdx.z - zl * zdiv);
+    if constexpr (EPI == EPI_LSTM) stamp_end(g.stamp, gridDim.x * gridDim.y * gridDim.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
 }
 
 template <class G> size_t tile_lds_bytes(const GemmArgs &g)
@@ -683,8 +687,8 @@ void launch_tile_one(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStre
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_tile_zkernel<MT, EPI, WT, NT, NWM, NWN, NSB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_devs.fetch_or(bit, std::memory_order_release);
     }
-    if (dev_args) hipLaunchKernelGGL((gemm_tile_zkernel<MT, EPI, WT, NT, NWM, NWN, NSB>), grid, dim3(G::NTH), lds, s, dev_args, zdiv);
-    else hipLaunchKernelGGL((gemm_tile_kernel<MT, EPI, WT, NT, NWM, NWN, NSB>), grid, dim3(G::NTH), lds, s, g);
+    if (dev_args) APRIL_LAUNCH((gemm_tile_zkernel<MT, EPI, WT, NT, NWM, NWN, NSB>), grid, dim3(G::NTH), lds, s, dev_args, zdiv);
+    else APRIL_LAUNCH((gemm_tile_kernel<MT, EPI, WT, NT, NWM, NWN, NSB>), grid, dim3(G::NTH), lds, s, g);
 }
 
 template <int MT, int WT>

@@ -411,6 +411,30 @@ def main():
         # rows per gates launch, averaged: every session-chunk passes the gates GEMM of each layer once; a launch covers one
         # layer of one chunk step, or the same launch of up to T layers when a feed's chunk steps run as a wavefront (z-batched)
         rows_per_launch = rows * dd.n_layers / launches
+        eager = {"avg_launch_us": round(avg_ms * 1e3, 2), "rows_per_launch": round(rows_per_launch, 1), "launches": int(launches),
+                 "what": "launches one by one (no graph replay), each gates kernel's own dispatch time stamps (hipExtLaunchKernel): the kernels run "
+                         "slower than under replay (idle queue between launches: clocks and caches)"}
+        # THE CLOCK OF `achieved` / `frac`: the gates clock -- further feeds under GRAPH REPLAY with the timed region's ingest, every flight on
+        # one stream while the clock is on (with the three streams of the split feeds the front end and the search of the neighbouring flights
+        # share the CUs with a gates launch and its span measures the contention: 73.7 us; one flight at a time leaves the GPU idle between
+        # feeds and the kernels run at a lower clock: 48.5 us), the gates kernels stamping their own first start and last end
+        # (s_memrealtime); rows per launch from the launch plans.
+        # This is the quantity rocprofv3 --kernel-trace reports per kernel for the same invocation (profiles/r06_b256_pipelined_kernel_stats.csv).
+        clocked = None
+        more2 = pcm_for(nsess, args.profile_steps, 20_000_000)
+        mdl.profile(2)
+        run_steps(group, more2, 0, args.profile_steps)      # (the timed region's ingest; the engine keeps every flight on ONE stream while the clock is on: no other stream's kernels beside the gates launches -- what rocprofv3's serialised trace sees too -- and no idle GPU between feeds)
+        mdl.profile(0)
+        sg = mdl.stats()
+        if sg.gates_clock_launches:
+            avg_ms = sg.gates_clock_ms / sg.gates_clock_launches
+            rows_per_launch = sg.gates_clock_rows / sg.gates_clock_launches
+            launches = sg.gates_clock_launches
+            clocked = {"avg_launch_us": round(avg_ms * 1e3, 2), "rows_per_launch": round(rows_per_launch, 1), "launches": int(launches),
+                       "by_problems_per_launch": {str(i + 1): {"launches": int(sg.gates_clock_launches_by_n[i]),
+                                                               "avg_launch_us": round(sg.gates_clock_ms_by_n[i] / sg.gates_clock_launches_by_n[i] * 1e3, 2)}
+                                                  for i in range(4) if sg.gates_clock_launches_by_n[i]},
+                       "what": "1 / 2 / 3 problems per launch = the kernels gemm_f32_kernel / gemm_f32_zkernel / gemm_f32_zkernel_walk <4, 4, 1, ...> of a rocprofv3 kernel trace at 256 sessions"}
         layers_per_launch = max(1.0, rows_per_launch / nsess)      # a z-batched launch holds that many layers' weight matrices
         flops = 2.0 * rows_per_launch * (2 * dd.d_model) * (4 * dd.hidden)
         wbytes = (2 * dd.d_model) * (4 * dd.hidden) * 4 * layers_per_launch
@@ -437,10 +461,15 @@ def main():
                     if rk:      # the same kernels' execution time under rocprofv3 (committed summary of the default invocation): no event brackets, graph replay
                         rl["kernel_time_rocprof"] = {"weighted_avg_us_per_launch": rk["weighted_avg_us_per_launch"], "tflops": rk["weighted_tflops"],
                                                      "frac": rk["frac_of_157.3"], "source": rk["source"].split(" (")[0],
-                                                     "what": "committed rocprofv3 kernel durations of the two gates kernels (17 : 10 launch mix); `achieved` / `frac` above use the live HIP-event brackets of eager launches, which add launch overhead to every sample"}
+                                                     "what": "committed rocprofv3 kernel durations of the two gates kernels of an earlier round, for comparison; `achieved` / `frac` above are live and on the same clock (dispatch time stamps)"}
             except Exception:
                 pass
         rl["algorithmic_bytes_per_launch"] = int(wbytes + sbytes)
+        rl["clock"] = ("gates clock: %d further feeds under graph replay, pipelined ingest, every flight on one stream; every gates kernel stamps its first workgroup's start and its last "
+                       "workgroup's end (s_memrealtime, 10 ns) -- the kernel duration rocprofv3 --kernel-trace (which serialises the queues) reports for the same "
+                       "invocation" % args.profile_steps) if clocked else "eager launches with their dispatch time stamps (the gates clock saw no feed wavefront)"
+        rl["gates_clock"] = clocked
+        rl["eager_clock"] = eager
         rl.update({"kernel": "LSTM gates GEMM [rows,%d]x[%d,%d] + BasicNorm row scale + LSTM cell epilogue (rows = sessions x layers sharing the z-batched launch)" % (2 * dd.d_model, 2 * dd.d_model, 4 * dd.hidden),
                    "avg_launch_us": round(avg_ms * 1e3, 2), "rows_per_launch": round(rows_per_launch, 1),
                    "launches": int(launches), "alt_frac_hbm": round(frac_hbm, 4), "alt_frac_mfma": round(frac_mfma, 4),

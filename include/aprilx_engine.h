@@ -154,6 +154,11 @@ typedef struct AprilxStats {
     uint64_t kernels_per_step;   /* launches of the last eagerly issued chunk chain (profiling / APRIL_NO_GRAPHS runs) */
     uint64_t lm_steps, lm_chunks;/* layer-major steps (long feeds) and the session-chunks they covered (included in steps / chunks) */
     uint64_t wave_steps, wave_chunks;/* feeds whose 2..7 chunk steps ran as one wavefront over the layers, and the session-chunks they covered (included in steps / chunks) */
+    /* the gates clock (aprilx_model_profile(model, 2) ... (model, 0)): every gates launch of the feed wavefronts timed ITSELF under graph
+       replay (first workgroup's start to last workgroup's end, s_memrealtime) -- accumulated ms, launches and rows (sessions x layers
+       sharing the launch) of the last clocked interval */
+    double gates_clock_ms; uint64_t gates_clock_launches, gates_clock_rows;
+    double gates_clock_ms_by_n[4]; uint64_t gates_clock_launches_by_n[4];   /* the same, split by the problems sharing the launch (1, 2, 3, >= 4) */
 } AprilxStats;
 APRIL_EXPORT void aprilx_model_stats(AprilASRModel model, int device_index, AprilxStats *out);
 /* Hand-over -> delivery latency of the last (up to 8192) completed ticks of one GPU's stepping thread, in ms, oldest first: from the
@@ -163,7 +168,10 @@ APRIL_EXPORT void aprilx_model_stats(AprilASRModel model, int device_index, Apri
  * (reference: the time aas_feed_pcm16 blocks, src/april_session.c:479-538).  out_ms = NULL: returns the number available; reset != 0
  * empties the ring afterwards.                                                                                                    */
 APRIL_EXPORT int aprilx_model_feed_latency(AprilASRModel model, int device_index, double *out_ms, int cap, int reset);
-/* bracket every launch with hipEvents on the engine's stream (measurement runs only) */
+/* enable 1: launches go out one by one with hipEvents around them on the engine's stream (gates launches: their own dispatch time
+   stamps), per-class times in AprilxStats.kernel_ms -- measurement runs only.  enable 2: the gates clock -- nothing changes in how feeds
+   run (graphs replay, flights overlap) except that the feed wavefronts' gates kernels stamp their own start and end; switching back to 0
+   publishes AprilxStats.gates_clock_*.  0: off. */
 APRIL_EXPORT void aprilx_model_profile(AprilASRModel model, int enable);
 
 /* state machine alone, for host-logic tests: feed (idx, max, blank) triples, receive events */

@@ -28,12 +28,20 @@ def main():
     grp = A.SessionGroup(sess)
     pcm = [SM.lcg_pcm16(feed * steps, seed=4242 + i) for i in range(nsess)]
     grp.plan(pcm, feed)
+    prof = int(os.environ.get("APRIL_TEST_PROFILE", "0"))      # 2: the gates clock from the 5th feed on (aprilx_model_profile(model, 2))
     for k in range(steps):
+        if prof and k == 4:
+            grp.drain()
+            m.profile(prof)
         if mode == "sync":
             grp.feed_planned(k)
         else:
             grp.feed_planned_pipelined(k, 2 if mode == "async" else int(mode[4:]))
     grp.drain()
+    if prof:
+        m.profile(0)
+        sg = m.stats()
+        print("GCLOCK", int(sg.gates_clock_launches), "%.4f" % float(sg.gates_clock_ms), int(sg.gates_clock_rows), flush=True)
     lat = m.feed_latencies(reset=True)          # hand-over -> delivery per tick (aprilx_model_feed_latency), before the flush
     if flush:
         grp.flush()

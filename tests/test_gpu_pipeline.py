@@ -103,3 +103,24 @@ def test_eight_engines_on_one_device(built, medium_model, v0_model):
         used = [c for c in eight["engines"] if c]
         assert len(used) == 8 and len(set(used)) == 1, "sessions were not dealt evenly: chunks per engine %r" % eight["engines"]
         assert [c for c in one["engines"] if c] == [one["chunks"]]
+
+
+def test_gates_clock_times_replayed_launches_and_changes_nothing(built, v0_model):
+    """aprilx_model_profile(model, 2) -- bench.py's roofline clock: feeds run as always (graphs replay, flights overlap) while the gates
+    kernels of the feed wavefronts stamp their own start and end.  Every callback stays the same, and the clock reports the launches,
+    their rows and a plausible time."""
+    path = v0_model["path"]
+    ref = run(path, 64, 12, "pipe2")
+    e = dict(os.environ, APRIL_MAX_SESSIONS="512", APRIL_MAX_BATCH="2048", APRIL_TEST_PROFILE="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "stream_worker.py"), path, "64", "12", "pipe2", "1600", "1"],
+                       env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out = r.stdout.decode().splitlines()
+    dig = [ln for ln in out if ln.startswith("DIGEST")][-1].split()
+    clk = [ln for ln in out if ln.startswith("GCLOCK")][-1].split()
+    assert dig[1] == ref["digest"] and int(dig[3]) == 0
+    launches, ms, rows = int(clk[1]), float(clk[2]), int(clk[3])
+    # 8 clocked feeds of 2..3 chunks x 12 layers: a wavefront of T chunks has L + T - 1 gates launches; rows = sessions x layer-chunks
+    assert launches >= 8 * 13, clk
+    assert rows % 64 == 0 and rows // 64 >= 8 * 2 * 12, clk
+    assert 1e-3 * launches < ms < 1.0 * launches, clk                                        # 1 us .. 1 ms per launch

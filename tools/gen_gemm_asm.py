@@ -48,6 +48,7 @@ def emit(nb, name, NT=4, scaled=False):
     for b in range(nb - 1):
         ld, adv = loads_and_advance(b)
         out.extend(ld); out.extend(adv)
+    A("@ALIGN@")                         # APRIL_ASM_LOOP_ALIGN: a macro of kernels_gemm.hip (".p2align 3\n": the loop head on an 8-byte boundary)
     A("L_top_%=:")
     for b in range(nb):
         r = (b + nb - 1) % nb
@@ -92,7 +93,7 @@ def emit(nb, name, NT=4, scaled=False):
     A("L_end_%=:")
     A("s_waitcnt vmcnt(0)")
     A("s_nop 7"); A("s_nop 7"); A("s_nop 7")
-    text = "".join('    "%s\\n"\n' % l for l in out)
+    text = "".join(('    APRIL_ASM_LOOP_ALIGN\n' if l == "@ALIGN@" else '    "%s\\n"\n' % l) for l in out)
     clob = ", ".join('"v%d"' % r for r in range(BASE, BASE + nb * BUF))
     clob += ', "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "scc", "memory"'
     return "#define %s_TEXT \\\n%s\n#define %s_CLOBBERS %s\n" % (
