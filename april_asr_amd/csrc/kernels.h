@@ -154,6 +154,9 @@ int gemm_kw_waves(const GemmArgs &g);
 // gemm_pp_ok: the operands of g fit the schedule (binary16 operands, kz = 1, LSTM / DoubleSwish / XPART epilogue, whole stages)
 bool gemm_pp_ok(const GemmArgs &g, int mt);
 void launch_gemm_pp(const GemmArgs &g, int mt, const GemmArgs *dev_args, int n, hipStream_t s);
+// (internal) the 256 x 192 form of GM_PP (kernels_gemm_pw.hip; TilePlan.nt = 12): N a multiple of 192, EPI_LSTM / EPI_BIAS_DSWISH, all of K
+bool gemm_pw_ok(const GemmArgs &g);
+void launch_gemm_pw(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s);
 // measurement only (tools/pp_bench): enable -1 = environment default (APRIL_GM_PP), 0 / 1 = off / on; mt = 0 (planner) or pinned 16 / 8
 void gemm_pp_pin(int enable, int mt);
 bool gemm_kw_has_kernel(const GemmArgs &g, int mt, int nt);      // a GM_KW kernel exists for this GEMM on 16 mt x 16 nt tiles

@@ -793,24 +793,33 @@ void gemm_tile_pin(int enable, int mt, int zs) { g_tile_enable = enable; g_tile_
 // APRIL_PP_MT pins the tile rows / 16 (gemm_pp_pin for tools/pp_bench).
 static int g_pp_enable = -1, g_pp_pin_mt = 0;
 void gemm_pp_pin(int enable, int mt) { g_pp_enable = enable; g_pp_pin_mt = mt; }
-static bool plan_pp(int M, int N, int zcount, TilePlan &t)
+static bool plan_pp(int M, int N, int zcount, TilePlan &t, bool wide_ok = false)
 {
     static const int enabled = env_int("APRIL_GM_PP", 1), env_mt = env_int("APRIL_PP_MT", 0), min_tiles = env_int("APRIL_PP_MIN_TILES", 128);
+    static const int wide = env_int("APRIL_PP_WIDE", 1);      // 256 x 192 tiles (kernels_gemm_pw.hip) where they save a round of workgroups
     if (!(g_pp_enable < 0 ? enabled : g_pp_enable) || N % 128 != 0) return false;
     const long zc = std::max(1, zcount);
     const long t16 = (long)(N / 128) * ((M + 255) / 256) * zc, t8 = (long)(N / 128) * ((M + 127) / 128) * zc;
     int mt = g_pp_pin_mt ? g_pp_pin_mt : env_mt;
-    if (mt != 16 && mt != 8) {
+    int nt = 8;
+    if (mt == 12) { if (!wide_ok) return false; mt = 16; nt = 12; }      // (pinned: the wide form or nothing)
+    else if (mt != 16 && mt != 8) {
         if (t8 < min_tiles) return false;                 // a handful of tiles: the small-batch forms stream the weights with more workgroups
-        // rounds of one workgroup per CU; a 128-row tile costs ~0.6 of a 256-row one (half the MFMAs, the same weight pieces)
+        // rounds of one workgroup per CU; a 128-row tile costs ~0.6 of a 256-row one (half the MFMAs, the same weight pieces), a
+        // 256 x 192 tile 1.5 of it: the larger encoder's gates at three 512-row problems are 288 tiles of 256 x 128 (two rounds) but 192
+        // of 256 x 192 (one)
         const long c16 = ((t16 + 255) / 256) * 100, c8 = ((t8 + 255) / 256) * 60;
         mt = c16 <= c8 ? 16 : 8;
+        if (wide && wide_ok && N % 192 == 0) {
+            const long tw = (long)(N / 192) * ((M + 255) / 256) * zc, cw = ((tw + 255) / 256) * 150;
+            if (cw < std::min(c16, c8)) { mt = 16; nt = 12; }
+        }
     }
-    t.mt = mt; t.nt = 8; t.zs = 1; t.mode = GM_PP;
+    t.mt = mt; t.nt = nt; t.zs = 1; t.mode = GM_PP;
     return true;
 }
 
-static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePlan &t, bool always = false, bool big_ok = false, bool wide_ok = false, bool pp_ok = false)
+static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePlan &t, bool always = false, bool big_ok = false, bool wide_ok = false, int pp_ok = 0)
 {
     static const int enabled = env_int("APRIL_GM_TILE", 1);
     static const int min_rows = env_int("APRIL_TILE_MIN_ROWS", 32);
@@ -825,7 +834,7 @@ static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePla
     static const int f16_mt = env_int("APRIL_TILE_F16_MT", 0);
     const int mt = pin_mt ? (pin_mt == 4 ? 4 : 2) : ((always && f16_mt) ? f16_mt : (tiles4 >= fused_tiles ? 4 : 2));
     const long tiles = mt == 4 ? tiles4 : tiles2;
-    if (pp_ok && kz == 1 && pin_mt == 0 && plan_pp(M, N, zcount, t)) return true;
+    if ((pp_ok & 1) && kz == 1 && pin_mt == 0 && plan_pp(M, N, zcount, t, (pp_ok & 2) != 0)) return true;
     if (big_ok && kz == 1 && N % 128 == 0 && pin_mt == 0) {
         // fp16 gates / FFN up: 128 x 128 tiles (eight waves) once they give most CUs a workgroup -- twice the flops per operand byte
         static const int big = env_int("APRIL_TILE_BIG", 1), big_tiles = env_int("APRIL_TILE_BIG_TILES", 192), big_min_n = env_int("APRIL_TILE_BIG_MIN_N", 0);
@@ -840,7 +849,12 @@ static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePla
         }
     }
     int zs = kz;
-    if (pin_zs > 0) { if (!force_full) zs = std::min(kz, pin_zs); }
+    // fp16 N = d_model GEMMs (projection, FFN down) keep all of K in the workgroup, i.e. their fused row epilogue: the cost model below
+    // prices a K cut at 5 % + 300, but the row kernel behind the planes and its launch boundary cost ~8 us at these sizes -- configs[4]
+    // at 512 sessions 1.887 -> 1.820 ms per step with the cut forbidden (round 6; APRIL_TILE_F16_FULLK=0 restores the model's choice)
+    static const int f16_fullk = env_int("APRIL_TILE_F16_FULLK", 1);
+    if (always && f16_fullk && wide_ok) { }
+    else if (pin_zs > 0) { if (!force_full) zs = std::min(kz, pin_zs); }
     else if (pin_mt > 0) { /* measurement: pinned tile rows, all of K */ }
     else {
         if (tiles2 < split_tiles && !always) return false;          // small launches keep the round-2 schedules
@@ -891,7 +905,7 @@ bool gemm_fullk(int M, int N, int kz, bool force, int zcount, int tile_ok)
 }
 
 // Tile shape and slabs per workgroup.  Depends on M only through occupancy; numerics are tile-independent.
-static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = false, int zcount = 1, int tile_ok = 0, int zcount_true = 1, bool f16 = false, bool pp_ok = false)
+static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = false, int zcount = 1, int tile_ok = 0, int zcount_true = 1, bool f16 = false, int pp_ok = 0)
 {
     // measurement knobs (default 0): 1/2 = smaller tiles for the fused-epilogue GEMMs (measured slower on MI355X:
     // B=256 gates 27 -> 32..36 us, the kernel is limited by operand loads per MFMA, not by occupancy);
@@ -901,7 +915,7 @@ static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = fal
     if (tile_ok && (epi == EPI_PARTIAL || epi == EPI_HR || epi == EPI_RESID_SSQ || epi == EPI_SLOT_STORE || epi == EPI_LSTM || epi == EPI_BIAS_DSWISH || (epi == EPI_XPART && tile_ok == 2))) {
         // the caller asked gemm_fullk first: a row epilogue arrives only when that plan keeps all of K in the workgroup
         if (plan_tile(M, N, kz, zcount_true, force_fullk || epi != EPI_PARTIAL, t, tile_ok == 2, (f16 || env_int("APRIL_TILE_BIG_F32", 0)) && tile_ok == 2 && (epi == EPI_LSTM || epi == EPI_BIAS_DSWISH || epi == EPI_XPART),
-                      tile_ok == 2 && (epi == EPI_PARTIAL || epi == EPI_HR || epi == EPI_RESID_SSQ), pp_ok && f16 && tile_ok == 2)) return t;
+                      tile_ok == 2 && (epi == EPI_PARTIAL || epi == EPI_HR || epi == EPI_RESID_SSQ), (f16 && tile_ok == 2) ? pp_ok : 0)) return t;
         if (tile_ok == 2) { fprintf(stderr, "libapril(mi355x): launch_gemm: no GM_TILE plan for an always-tile GEMM (M=%d N=%d kz=%d)\n", M, N, kz); abort(); }
     }
     if (epi != EPI_LSTM && epi != EPI_BIAS_DSWISH && epi != EPI_XPART && plan_fullk(M, N, kz, t, force_fullk, zcount)) return t;
@@ -1056,7 +1070,7 @@ static TilePlan finalize_gemm(GemmArgs &g)
     const int tile_ok = !plain ? 0 : (g.tile_ok == 2 ? 2 : ((g.tile_ok == 1 && g.K1 == 0 && g.wt == 0 && g.epi != EPI_LSTM && g.epi != EPI_BIAS_DSWISH) ? 1 : 0));
     if (g.tile_ok == 2 && !tile_ok) { fprintf(stderr, "libapril(mi355x): launch_gemm: always-tile GEMM with a prologue / wave mask / odd N\n"); abort(); }
     TilePlan t = plan_tiles(g.M, g.N, g.kz, g.epi, g.force_fullk != 0, (z_tiles == 1 || (z_tiles == 2 && is_slab_epi) || (z_tiles == 3 && !is_slab_epi)) ? zc : 1, tile_ok, zc, g.wt == 1,
-                            g.wt == 1 && is_slab_epi && gemm_pp_ok(g, 16));
+                            (g.wt == 1 && is_slab_epi && gemm_pp_ok(g, 16)) ? (1 | (gemm_pw_ok(g) ? 2 : 0)) : 0);
     plan_kw(g, t, zc);
     const bool row_epi = g.epi == EPI_HR || g.epi == EPI_RESID_SSQ || g.epi == EPI_SLOT_STORE;
     if (row_epi && t.zs != g.kz) { fprintf(stderr, "libapril(mi355x): launch_gemm: row epilogue %d needs the full-K plan (M=%d N=%d kz=%d)\n", g.epi, g.M, g.N, g.kz); abort(); }
@@ -1092,7 +1106,7 @@ void launch_gemm(const GemmArgs &g_in, hipStream_t s)
     GemmArgs g = g_in;
     if (!kw_before_recur(g)) if (const int rf = recur_form(g)) { launch_recur(g, rf, nullptr, 1, s); return; }
     const TilePlan t = finalize_gemm(g);
-    if (t.mode == GM_PP) { launch_gemm_pp(g, t.mt, nullptr, 0, s); return; }
+    if (t.mode == GM_PP) { if (t.nt == 12) launch_gemm_pw(g, nullptr, 0, s); else launch_gemm_pp(g, t.mt, nullptr, 0, s); return; }
     if (t.mode == GM_TILE) { launch_gemm_tile(g, t.mt, t.nt, nullptr, 0, s); return; }
     if (t.mode == GM_KW) { launch_gemm_kw(g, t.mt, t.nt, nullptr, 0, s); return; }
     const int mt = t.mt, nt = t.nt;
@@ -1177,14 +1191,15 @@ void launch_gemm_z(const GemmArgs *staged, int n, const GemmArgs *dev_args, hipS
         // (configs[4] step 1.881 vs 1.888 ms), so one launch stays the rule.
         static const int split = env_int("APRIL_PP_SPLIT", 0);
         const long per16 = (long)(g.N / 128) * ((g.M + 255) / 256);
-        if (split && g_pp_pin_mt == 0 && n >= 2 && per16 * n > 256 && per16 * (n - 1) <= 256 && per16 * (n - 1) >= 160) {
+        if (split && t.nt != 12 && g_pp_pin_mt == 0 && n >= 2 && per16 * n > 256 && per16 * (n - 1) <= 256 && per16 * (n - 1) >= 160) {
             launch_gemm_pp(g, 16, dev_args, n - 1, s);
             TilePlan t1;
             if (!plan_pp(g.M, g.N, 1, t1)) { t1.mt = 8; }
             launch_gemm_pp(staged[n - 1], t1.mt, dev_args + (n - 1), 1, s);
             return;
         }
-        launch_gemm_pp(g, t.mt, dev_args, n, s);
+        if (t.nt == 12) launch_gemm_pw(g, dev_args, n, s);
+        else launch_gemm_pp(g, t.mt, dev_args, n, s);
         return;
     }
     if (t.mode == GM_TILE) { launch_gemm_tile(g, t.mt, t.nt, dev_args, n, s); return; }

@@ -43,7 +43,8 @@ def config5_leg(args, A, SM, torch, np):
     nb5, wu5, ts5 = 512, 6, 20
     config5 = {"sessions": nb5, "dims": "large (16 layers, d_model 768, cell 1536, ffn 3072; synthetic seeded weights)", "feed_ms": 100, "steps": ts5, "ingest": getattr(args, "ingest", "pipelined")}
     prev = os.environ.get("APRIL_PRECISION")
-    for prec in ("f16", "f32"):
+    precs = tuple(os.environ.get("APRIL_BENCH_C5_PRECS", "f16,f32").split(","))      # (measurement aid: "f16" alone halves an A/B run)
+    for prec in precs:
         os.environ["APRIL_PRECISION"] = prec
         m5 = A.Model(lpath)
         s5 = [A.Session(m5, None, counters=counts) for _ in range(nb5)]
@@ -96,7 +97,8 @@ def config5_leg(args, A, SM, torch, np):
         del os.environ["APRIL_PRECISION"]
     else:
         os.environ["APRIL_PRECISION"] = prev
-    config5["f16_speedup_vs_f32"] = round(config5["f32"]["ms_per_step"] / config5["f16"]["ms_per_step"], 3)
+    if "f32" in config5 and "f16" in config5:
+        config5["f16_speedup_vs_f32"] = round(config5["f32"]["ms_per_step"] / config5["f16"]["ms_per_step"], 3)
     config5["bound"] = ("fp16: with 64 x 64 tiles a k block moves 8 KB through LDS for 64 SIMD cycles of MFMA, so the step is bound by the "
                         "CU's L2 -> LDS operand traffic (and the fixed costs of ~70 launches per feed), not by the matrix pipe or HBM; see DESIGN.md")
     return config5

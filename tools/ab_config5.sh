@@ -8,6 +8,6 @@ for envs in "$@"; do
 import json, sys
 d=json.load(open(sys.argv[2]))
 g=d['f16'].get('gates_gemm') or {}
-print("%-50s f16 %.3f f32 %.3f | f16 gates %.1f us (%.3f of peak) mism %d" % (sys.argv[1], d['f16']['ms_per_step'], d['f32']['ms_per_step'], g.get('avg_launch_us', 0), g.get('frac_of_mfma_peak', 0), d['f16']['replay_mismatch']))
+print("%-50s f16 %.3f f32 %.3f | f16 gates %.1f us (%.3f of peak) mism %d" % (sys.argv[1], d['f16']['ms_per_step'], d.get('f32', {}).get('ms_per_step', 0.0), g.get('avg_launch_us', 0), g.get('frac_of_mfma_peak', 0), d['f16']['replay_mismatch']))
 PY
 done

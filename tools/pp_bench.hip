@@ -150,11 +150,12 @@ static void run_case(const char *name, int M, int d, int hidden, int kind, int n
     const int N = kind == 1 ? hidden : 4 * hidden, K = kind == 1 ? d : 2 * d;
     const double flops = 2.0 * M * N * ((kind == 2 || kind == 3) ? K / 2 : K) * n;
     // forms: GM_TILE (GM_PP off), GM_PP planner, GM_PP 256-row, GM_PP 128-row
-    struct Form { const char *tag; int enable, mt; } forms[] = {{"tile", 0, 0}, {"pp", 1, 0}, {"pp16", 1, 16}, {"pp8", 1, 8}};
+    struct Form { const char *tag; int enable, mt; } forms[] = {{"tile", 0, 0}, {"pp", 1, 0}, {"pp16", 1, 16}, {"pp8", 1, 8}, {"ppw", 1, 12}};
+    constexpr int NF = 5;
     std::vector<unsigned char> ref;
-    double us[4] = {0, 0, 0, 0};
-    bool same[4] = {true, true, true, true};
-    for (int f = 0; f < 4; ++f) {
+    double us[NF] = {0, 0, 0, 0, 0};
+    bool same[NF] = {true, true, true, true, true};
+    for (int f = 0; f < NF; ++f) {
         gemm_pp_pin(forms[f].enable, forms[f].mt);
         Chain c = make_chain(ps);
         reset(ps);
@@ -184,16 +185,16 @@ static void run_case(const char *name, int M, int d, int hidden, int kind, int n
         if (c.gd) CK(hipFree(c.gd));
     }
     // second round of timings, interleaved the other way round (clock / cache state)
-    for (int f = 3; f >= 0; --f) {
+    for (int f = NF - 1; f >= 0; --f) {
         gemm_pp_pin(forms[f].enable, forms[f].mt);
         Chain c = make_chain(ps);
         us[f] = std::min(us[f], time_chain(c, s, iters));
         if (c.gd) CK(hipFree(c.gd));
     }
     gemm_pp_pin(-1, 0);
-    printf("%-28s M %5d x %d  N %5d K %5d | tile %7.2f us (%6.1f TF) | pp %7.2f (%6.1f TF) %s | pp16 %7.2f (%6.1f TF) %s | pp8 %7.2f (%6.1f TF) %s\n", name, M, n, N, K,
+    printf("%-28s M %5d x %d  N %5d K %5d | tile %7.2f us (%6.1f TF) | pp %7.2f (%6.1f TF) %s | pp16 %7.2f (%6.1f TF) %s | pp8 %7.2f (%6.1f TF) %s | ppw %7.2f (%6.1f TF) %s\n", name, M, n, N, K,
            us[0], flops / us[0] * 1e-6, us[1], flops / us[1] * 1e-6, same[1] ? "same" : "DIFF", us[2], flops / us[2] * 1e-6, same[2] ? "same" : "DIFF",
-           us[3], flops / us[3] * 1e-6, same[3] ? "same" : "DIFF");
+           us[3], flops / us[3] * 1e-6, same[3] ? "same" : "DIFF", us[4], flops / us[4] * 1e-6, same[4] ? "same" : "DIFF");
     fflush(stdout);
     for (const Problem &p : ps) {
         CK(hipFree(p.y16)); CK(hipFree(p.h16)); CK(hipFree(p.w16)); CK(hipFree(p.out16)); CK(hipFree(p.ssq)); CK(hipFree(p.bias));
@@ -218,6 +219,18 @@ int main(int argc, char **argv)
         run_case("large lstm h-half", 512, 768, 1536, 3, 1, s, iters);
         run_case("large ffn-up 1536 rows", 1536, 768, 3072, 1, 1, s, iters);
         run_case("large gates 100 rows", 100, 768, 1536, 0, 3, s, iters);
+    }
+    if (dims == "probe") {
+        // shapes of the N = d_model GEMMs (projection K = cell, FFN down K = ffn) under the FFN-up epilogue, and the gates at twice the K:
+        // what GM_PP would do there, and how a launch splits into per-tile fixed time and K-proportional time
+        for (int n = 1; n <= 3; ++n) run_case("probe N768 K1536 (proj)", 512, 1536, 768, 1, n, s, iters);
+        for (int n = 1; n <= 3; ++n) run_case("probe N768 K3072 (ffn-down)", 512, 3072, 768, 1, n, s, iters);
+        run_case("probe gates K 1536", 512, 768, 1536, 0, 1, s, iters);
+        run_case("probe gates K 3072", 512, 1536, 1536, 0, 1, s, iters);
+        run_case("probe gates K 1536 x2", 512, 768, 1536, 0, 2, s, iters);
+        run_case("probe gates K 3072 x2", 512, 1536, 1536, 0, 2, s, iters);
+        run_case("probe ffn-up K 768", 512, 768, 3072, 1, 1, s, iters);
+        run_case("probe ffn-up K 1536", 512, 1536, 3072, 1, 1, s, iters);
     }
     if (dims == "v0" || dims == "both") {
         // aprilv0 dims on binary16 operands: d_model 512, cell 1024, ffn 2048
