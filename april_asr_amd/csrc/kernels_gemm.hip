@@ -852,8 +852,9 @@ static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePla
     // fp16 N = d_model GEMMs (projection, FFN down) keep all of K in the workgroup, i.e. their fused row epilogue: the cost model below
     // prices a K cut at 5 % + 300, but the row kernel behind the planes and its launch boundary cost ~8 us at these sizes -- configs[4]
     // at 512 sessions 1.887 -> 1.820 ms per step with the cut forbidden (round 6; APRIL_TILE_F16_FULLK=0 restores the model's choice)
-    static const int f16_fullk = env_int("APRIL_TILE_F16_FULLK", 1);
-    if (always && f16_fullk && wide_ok) { }
+    // -- from 192 tiles per launch (one 512-row problem); below that the cut is what spreads the weights over the chip
+    static const int f16_fullk = env_int("APRIL_TILE_F16_FULLK", 1), f16_fullk_tiles = env_int("APRIL_TILE_F16_FULLK_TILES", 192);
+    if (always && f16_fullk && wide_ok && tiles >= f16_fullk_tiles) { }
     else if (pin_zs > 0) { if (!force_full) zs = std::min(kz, pin_zs); }
     else if (pin_mt > 0) { /* measurement: pinned tile rows, all of K */ }
     else {
