@@ -32,7 +32,7 @@ class AprilConfig(C.Structure):
 class AprilxDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_layers", "d_model", "hidden", "ffn", "joiner", "vocab", "mel", "seg",
                                          "seg_step", "context", "fft_size", "frame_shift", "sample_rate", "blank_id",
-                                         "n_devices", "precision", "reserved0")] + [("param_count", C.c_int64)]
+                                         "n_devices", "precision", "d_model_file")] + [("param_count", C.c_int64)]
 
 
 class AprilxStats(C.Structure):

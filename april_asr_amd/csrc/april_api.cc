@@ -132,7 +132,7 @@ bool create_engines(Model &m, const float *blob_host, const float *blob_device)
         return false;
     }
     if (m.layout.dims.embed_in % 64 || m.layout.dims.d_model % 64 || m.layout.dims.hidden % 64 || m.layout.dims.ffn % 64 || m.layout.dims.joiner % 64 || m.layout.dims.conv_ch[2] % 16) {
-        LOGE("aam: layer widths must be multiples of 64 for the MFMA kernels");
+        LOGE("aam: layer widths must be multiples of 64 for the MFMA kernels (pad_host_model rounds multiples of 16 up at load)");
         return false;
     }
     if (m.layout.dims.d_model > 2048) { LOGE("aam: d_model > 2048 unsupported (row scales are staged for at most 64 column groups)"); return false; }
@@ -222,7 +222,7 @@ bool parse_meta(const char *p, size_t n, Model &m)
         !in(d.conv_ch[0], 1, 4096) || !in(d.conv_ch[1], 1, 4096) || !in(d.conv_ch[2], 1, 4096) ||
         d.seg != P.segment_size || d.mel != P.mel_features ||                      // the network input is the PARAMS chunk (april_model.c:65-72)
         !in(d.conv_stride[0], 1, 8) || !in(d.conv_stride[1], 1, 8) || !in(d.conv_stride[2], 1, 8) ||
-        d.embed_in != d.conv_ch[2] * d.f_out)
+        d.embed_in != d.conv_ch[2] * d.f_out || !in(d.d_norm, 0, d.d_model))
         return false;
     plan_layout(d, hb, m.layout);
     m.layout.embed_eps = r.val<float>();
@@ -288,7 +288,7 @@ AprilASRModel aam_create_model(const char *model_path)
     if (!g_inited) { LOGE("aam: not initialised (call aam_api_init; a HIP device is required)"); return nullptr; }
     AprilASRModel_i *h = new AprilASRModel_i();
     std::string err;
-    if (!load_april_file(model_path, h->m.host, err)) { LOGE("aam: failed to load %s: %s", model_path ? model_path : "(null)", err.c_str()); delete h; return nullptr; }
+    if (!load_april_file(model_path, h->m.host, err) || !pad_host_model(h->m.host, err)) { LOGE("aam: failed to load %s: %s", model_path ? model_path : "(null)", err.c_str()); delete h; return nullptr; }
     plan_layout(h->m.host.dims, !h->m.host.dec_conv_b.empty(), h->m.layout);
     std::vector<float> blob;
     pack_weights(h->m.host, h->m.layout, blob);
@@ -304,7 +304,7 @@ AprilASRModel aprilx_model_load_host(const char *model_path)
 {
     AprilASRModel_i *h = new AprilASRModel_i();
     std::string err;
-    if (!load_april_file(model_path, h->m.host, err)) { LOGE("aam: failed to load %s: %s", model_path ? model_path : "(null)", err.c_str()); delete h; return nullptr; }
+    if (!load_april_file(model_path, h->m.host, err) || !pad_host_model(h->m.host, err)) { LOGE("aam: failed to load %s: %s", model_path ? model_path : "(null)", err.c_str()); delete h; return nullptr; }
     plan_layout(h->m.host.dims, !h->m.host.dec_conv_b.empty(), h->m.layout);
     pack_weights(h->m.host, h->m.layout, h->m.host_blob);
     const ModelParams &P = h->m.host.params;
@@ -396,7 +396,7 @@ int aprilx_model_dims(AprilASRModel model, AprilxDims *o)
     o->fft_size = model->m.ftab.padded; o->frame_shift = model->m.ftab.shift; o->sample_rate = P.sample_rate; o->blank_id = P.blank_id;
     o->n_devices = (int)model->m.engines.size();
     o->precision = model->m.engines.empty() ? 0 : model->m.engines[0]->precision();
-    o->reserved0 = 0;
+    o->d_model_file = d.d_norm;
     int64_t n = 0; int cin = 1;
     for (int i = 0; i < 3; ++i) { n += (int64_t)d.conv_ch[i] * cin * 9 + d.conv_ch[i]; cin = d.conv_ch[i]; }
     n += (int64_t)d.embed_in * d.d_model + d.d_model;
@@ -425,7 +425,7 @@ int aprilx_model_export_blob(AprilASRModel model, void *dst, size_t dst_size)
     HipLegacyLock legacy;
     const std::string meta = make_meta(model->m);
     BlobHeader hd;
-    memcpy(hd.magic, "APXBLOB1", 8);
+    memcpy(hd.magic, "APXBLOB2", 8);
     hd.meta_bytes = meta.size(); hd.weight_floats = model->m.layout.total;
     hd.weights_offset = (sizeof(BlobHeader) + meta.size() + 255) & ~(size_t)255;
     if (dst_size < hd.weights_offset + hd.weight_floats * 4) return -1;
@@ -450,7 +450,7 @@ int aprilx_model_save_blob(AprilASRModel model, const char *path)
     return (fclose(f) == 0 && ok) ? 0 : -1;
 }
 
-// The fp16 cache file (BASELINE configs[4]): same header and metadata, magic "APXBLB16"; the payload walks the blob's float
+// The fp16 cache file (BASELINE configs[4]): same header and metadata, magic "APXBL16B"; the payload walks the blob's float
 // index space in order -- MFMA-packed Linear / LSTM matrices as binary16 (round to nearest even, what the engine's fp16
 // copies hold), everything else (convolutions, biases, embeddings) as fp32.  Half the size of the fp32 file; loading expands
 // it to the fp32 blob whose fp16 copies are bit-identical to those of the original model, so it serves fp16-operand mode only.
@@ -462,7 +462,7 @@ int aprilx_model_save_blob_f16(AprilASRModel model, const char *path)
     BlobHeader hd; memcpy(&hd, full.data(), sizeof hd);
     const float *w = (const float *)(full.data() + hd.weights_offset);
     std::string out(full.data(), (size_t)hd.weights_offset);
-    memcpy(&out[0], "APXBLB16", 8);
+    memcpy(&out[0], "APXBL16B", 8);
     size_t pos = 0;
     auto raw = [&](size_t upto) { if (upto > pos) out.append((const char *)(w + pos), (upto - pos) * 4); pos = upto; };
     for (const auto &sec : gemm_sections(model->m.layout)) {
@@ -486,7 +486,7 @@ AprilASRModel aprilx_model_load_blob(const char *path)
     std::vector<char> buf;
     if (fseek(f, 0, SEEK_END) == 0) { const long n = ftell(f); if (n > 0) { buf.resize((size_t)n); rewind(f); if (fread(buf.data(), 1, buf.size(), f) != buf.size()) buf.clear(); } }
     fclose(f);
-    if (buf.size() >= sizeof(BlobHeader) && memcmp(buf.data(), "APXBLB16", 8) == 0) {
+    if (buf.size() >= sizeof(BlobHeader) && memcmp(buf.data(), "APXBL16B", 8) == 0) {
         // expand to the fp32 blob; only the fp16-operand engine may use the rounded matrices
         if (g_inited) {
             const char *pv = getenv("APRIL_PRECISION");
@@ -498,7 +498,7 @@ AprilASRModel aprilx_model_load_blob(const char *path)
         if (!parse_meta(buf.data() + sizeof hd, (size_t)hd.meta_bytes, probe.m) || probe.m.layout.total != hd.weight_floats) { LOGE("aprilx: blob metadata invalid"); return nullptr; }
         std::vector<char> full((size_t)hd.weights_offset + (size_t)hd.weight_floats * 4);
         memcpy(full.data(), buf.data(), (size_t)hd.weights_offset);
-        memcpy(full.data(), "APXBLOB1", 8);
+        memcpy(full.data(), "APXBLOB2", 8);
         float *w = (float *)(full.data() + hd.weights_offset);
         const char *src = buf.data() + hd.weights_offset, *end = buf.data() + buf.size();
         size_t pos = 0;
@@ -532,7 +532,7 @@ AprilASRModel aprilx_model_from_blob(const void *blob, size_t size, int blob_is_
     if (!host_only && g_devices.empty()) { LOGE("aprilx: no device selected"); return nullptr; }
     if (blob_is_device_ptr) { HipLegacyLock legacy; HIP_CHECK(hipSetDevice(g_devices[0])); HIP_CHECK(hipMemcpy(&hd, blob, sizeof hd, hipMemcpyDeviceToHost)); }
     else memcpy(&hd, blob, sizeof hd);
-    if (memcmp(hd.magic, "APXBLOB1", 8) != 0 || hd.weights_offset > size || hd.weight_floats > (size - hd.weights_offset) / 4 ||
+    if (memcmp(hd.magic, "APXBLOB2", 8) != 0 || hd.weights_offset > size || hd.weight_floats > (size - hd.weights_offset) / 4 ||
         hd.meta_bytes > size || sizeof hd + hd.meta_bytes > hd.weights_offset) { LOGE("aprilx: bad blob"); return nullptr; }
     std::string meta((size_t)hd.meta_bytes, '\0');
     if (blob_is_device_ptr) { HipLegacyLock legacy; HIP_CHECK(hipMemcpy(&meta[0], (const char *)blob + sizeof hd, meta.size(), hipMemcpyDeviceToHost)); }

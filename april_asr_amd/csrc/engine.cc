@@ -675,7 +675,7 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
     const NetDims &d = L_.dims;
     const size_t S = (size_t)cfg_.max_slots;
     const int G = d.d_model / SSQ_COLS;
-    auto scale_of = [&](float eps) { RowScale r; r.ssq = ssq_; r.groups = G; r.inv_n = 1.0f / (float)d.d_model; r.eps = eps; return r; };
+    auto scale_of = [&](float eps) { RowScale r; r.ssq = ssq_; r.groups = G; r.inv_n = 1.0f / (float)(d.d_norm ? d.d_norm : d.d_model); r.eps = eps; return r; };
     // conv front end
     ConvEmbedArgs ca;
     ca.ring = ring_; ca.ring_frames = ring_frames_; ca.mel = d.mel; ca.seg = d.seg;
@@ -916,7 +916,7 @@ GemmArgs Engine::lm_args_xpart(int l, int m, int t0, int t1) const
     const PackedLayout::Layer &o = L_.layers[(size_t)l];
     const size_t b0 = (size_t)t0 * m;
     GemmArgs g; g.a0 = y_ + b0 * d.d_model; g.lda0 = d.d_model; g.K0 = d.d_model;
-    g.x_scale.ssq = ssq_ + b0 * G; g.x_scale.groups = G; g.x_scale.inv_n = 1.0f / (float)d.d_model; g.x_scale.eps = l == 0 ? L_.embed_eps : L_.norm_eps[(size_t)l - 1];
+    g.x_scale.ssq = ssq_ + b0 * G; g.x_scale.groups = G; g.x_scale.inv_n = 1.0f / (float)(d.d_norm ? d.d_norm : d.d_model); g.x_scale.eps = l == 0 ? L_.embed_eps : L_.norm_eps[(size_t)l - 1];
     g.a1 = g.a0; g.lda1 = d.d_model; g.K1 = d.d_model;          // never read (wave_mask)
     lin(g, o.wg); g.M = (t1 - t0) * m; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_XPART; g.wave_mask = 0x3;
     g.out = p_lm_ + b0 * 4 * d.hidden; g.ldo = 4 * d.hidden;
@@ -971,7 +971,7 @@ GemmArgs Engine::sw_args_gates(int l, int m, int t) const
     const PackedLayout::Layer &o = L_.layers[(size_t)l];
     const size_t r0 = (size_t)t * m;
     GemmArgs g; g.a0 = y_ + r0 * d.d_model; g.lda0 = d.d_model; g.K0 = d.d_model;
-    g.x_scale.ssq = ssq_ + r0 * G; g.x_scale.groups = G; g.x_scale.inv_n = 1.0f / (float)d.d_model; g.x_scale.eps = l == 0 ? L_.embed_eps : L_.norm_eps[(size_t)l - 1];
+    g.x_scale.ssq = ssq_ + r0 * G; g.x_scale.groups = G; g.x_scale.inv_n = 1.0f / (float)(d.d_norm ? d.d_norm : d.d_model); g.x_scale.eps = l == 0 ? L_.embed_eps : L_.norm_eps[(size_t)l - 1];
     g.a1 = h_ + (size_t)l * S * d.d_model; g.lda1 = d.d_model; g.aidx1 = step_d_; g.K1 = d.d_model;
     lin(g, o.wg); g.M = m; g.N = 4 * d.hidden; g.K = 2 * d.d_model; g.kz = 1; g.epi = EPI_LSTM;
     g.out = u_ + r0 * d.hidden; g.ldo = d.hidden; g.bias = w_ + o.bg; g.c_state = c_ + (size_t)l * S * d.hidden; g.slot_idx = step_d_; g.hidden = d.hidden;
@@ -993,7 +993,7 @@ GemmArgs Engine::lm_args_whr(int l, int m, int t) const
     GemmArgs g; g.a0 = u_ + r0 * d.hidden; g.lda0 = d.hidden; g.K0 = d.hidden; lin(g, o.whr);
     g.M = m; g.N = d.d_model; g.K = d.hidden; g.kz = kz_hr_; g.tile_ok = tile_ok(); g.force_fullk = 1;
     g.epi = EPI_HR; g.state = h_ + (size_t)l * S * d.d_model; g.ld_state = d.d_model; g.slot_idx = step_d_; g.resid = y_ + r0 * d.d_model; g.ldr = d.d_model;
-    g.r_scale.ssq = ssq_ + r0 * G; g.r_scale.groups = G; g.r_scale.inv_n = 1.0f / (float)d.d_model; g.r_scale.eps = l == 0 ? L_.embed_eps : L_.norm_eps[(size_t)l - 1];
+    g.r_scale.ssq = ssq_ + r0 * G; g.r_scale.groups = G; g.r_scale.inv_n = 1.0f / (float)(d.d_norm ? d.d_norm : d.d_model); g.r_scale.eps = l == 0 ? L_.embed_eps : L_.norm_eps[(size_t)l - 1];
     g.out = xb_ + r0 * d.d_model; g.ldo = d.d_model;
     if (f16_tile_) {
         g.a0 = reinterpret_cast<const float *>(u16_ + r0 * d.hidden); lin16(g, o.whr); g.kz = kzx_hr_;
@@ -1099,7 +1099,7 @@ void Engine::lm_stage_proj(int m, int t0, int t1, hipStream_t st, float *ws)
     const int G = d.d_model / SSQ_COLS;
     const size_t b0 = (size_t)t0 * m;
     const int brows = (t1 - t0) * m;
-    RowScale ys; ys.ssq = ssq_ + b0 * G; ys.groups = G; ys.inv_n = 1.0f / (float)d.d_model; ys.eps = L_.norm_eps[(size_t)d.n_layers - 1];
+    RowScale ys; ys.ssq = ssq_ + b0 * G; ys.groups = G; ys.inv_n = 1.0f / (float)(d.d_norm ? d.d_norm : d.d_model); ys.eps = L_.norm_eps[(size_t)d.n_layers - 1];
     GemmArgs g; g.a0 = y_ + b0 * d.d_model; g.lda0 = d.d_model; g.K0 = d.d_model; lin(g, L_.w_encproj);
     g.M = brows; g.N = d.joiner; g.K = d.d_model; g.kz = kz_proj_; g.tile_ok = tile_ok();
     float *eo = eout_lm_ + b0 * d.joiner;

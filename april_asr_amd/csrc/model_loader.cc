@@ -691,6 +691,69 @@ bool extract_joiner(const OGraph &g, HostModel &M, std::string &err)
 
 }  // namespace
 
+namespace {
+// rows x cols (row-major) -> new_rows x new_cols, element (r, c) -> (rmap(r), cmap(c)), zeros elsewhere
+template <class RM, class CM>
+std::vector<float> pad2(const std::vector<float> &src, int rows, int cols, int new_rows, int new_cols, RM rmap, CM cmap)
+{
+    std::vector<float> dst((size_t)new_rows * new_cols, 0.0f);
+    for (int r = 0; r < rows; ++r) {
+        const float *s = src.data() + (size_t)r * cols;
+        float *d = dst.data() + (size_t)rmap(r) * new_cols;
+        for (int c = 0; c < cols; ++c) d[cmap(c)] = s[c];
+    }
+    return dst;
+}
+std::vector<float> pad1(const std::vector<float> &src, int new_n)
+{
+    std::vector<float> dst((size_t)new_n, 0.0f);
+    std::copy(src.begin(), src.end(), dst.begin());
+    return dst;
+}
+int up64(int v) { return (v + 63) & ~63; }
+}  // namespace
+
+bool pad_host_model(HostModel &m, std::string &err)
+{
+    NetDims &D = m.dims;
+    const int d = D.d_model, h = D.hidden, f = D.ffn, j = D.joiner, c2 = D.conv_ch[2], F = D.f_out;
+    const int d2 = up64(d), h2 = up64(h), f2 = up64(f), j2 = up64(j);
+    int c22 = (c2 + 15) & ~15;
+    while ((c22 * F) % 64) c22 += 16;
+    if (d2 == d && h2 == h && f2 == f && j2 == j && c22 == c2) return true;
+    const int gs = d / D.dec_groups;                     // channels per group of the decoder's convolution
+    if ((d2 - d) % gs) { err = "d_model cannot be padded to a multiple of 64 in whole groups of the decoder convolution"; return false; }
+    auto id = [](int i) { return i; };
+    // third conv: [c2][c1 * 9] output channels; embed linear rows are channel-major (c * F + f)
+    const int k9 = D.conv_ch[1] * 9;
+    m.conv_w[2] = pad2(m.conv_w[2], c2, k9, c22, k9, id, id);
+    m.conv_b[2] = pad1(m.conv_b[2], c22);
+    m.w_embed = pad2(m.w_embed, c2 * F, d, c22 * F, d2, id, id);      // (rows c * F + f keep their index: new channels follow)
+    m.b_embed = pad1(m.b_embed, d2);
+    auto xh_row = [&](int r) { return r < d ? r : d2 + (r - d); };          // gate GEMM rows: x part, then h part
+    auto gate_col = [&](int c) { return (c / h) * h2 + c % h; };             // gate-major columns i, f, g, o
+    for (LayerWeights &lw : m.layers) {
+        lw.w_gates = pad2(lw.w_gates, 2 * d, 4 * h, 2 * d2, 4 * h2, xh_row, gate_col);
+        {
+            std::vector<float> b((size_t)4 * h2, 0.0f);
+            for (int c = 0; c < 4 * h; ++c) b[(size_t)gate_col(c)] = lw.b_gates[(size_t)c];
+            lw.b_gates.swap(b);
+        }
+        lw.w_hr = pad2(lw.w_hr, h, d, h2, d2, id, id);
+        lw.w_ff1 = pad2(lw.w_ff1, d, f, d2, f2, id, id); lw.b_ff1 = pad1(lw.b_ff1, f2);
+        lw.w_ff2 = pad2(lw.w_ff2, f, d, f2, d2, id, id); lw.b_ff2 = pad1(lw.b_ff2, d2);
+    }
+    m.w_encproj = pad2(m.w_encproj, d, j, d2, j2, id, id); m.b_encproj = pad1(m.b_encproj, j2);
+    m.emb = pad2(m.emb, D.vocab, d, D.vocab, d2, id, id);
+    m.dec_conv = pad2(m.dec_conv, d, gs * D.context, d2, gs * D.context, id, id);
+    if (!m.dec_conv_b.empty()) m.dec_conv_b = pad1(m.dec_conv_b, d2);
+    m.w_decproj = pad2(m.w_decproj, d, j, d2, j2, id, id); m.b_decproj = pad1(m.b_decproj, j2);
+    m.w_out = pad2(m.w_out, j, D.vocab, j2, D.vocab, id, id);
+    D.d_norm = d;
+    D.d_model = d2; D.hidden = h2; D.ffn = f2; D.joiner = j2; D.conv_ch[2] = c22; D.embed_in = c22 * F; D.dec_groups = d2 / gs;
+    return true;
+}
+
 bool load_april_file(const char *path, HostModel &out, std::string &err)
 {
     if (!path) { err = "no model path given"; return false; }

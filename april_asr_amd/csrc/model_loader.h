@@ -24,6 +24,7 @@ struct NetDims {
     int conv_stride[3] = {1, 2, 2};
     int f_out = 0;                         // frequency bins after the conv stack
     int embed_in = 0;                      // conv_ch[2] * f_out
+    int d_norm = 0;                        // pad_host_model: the file's d_model (the BasicNorm mean runs over it); 0 = d_model, nothing was padded
 };
 
 // Weights in a neutral host layout: every linear map is stored K x N row-major
@@ -57,6 +58,14 @@ struct HostModel {
 // Returns false and fills err on any validation failure (the C API then returns NULL,
 // reference src/april_model.c:25-40,65-72,99-102).
 bool load_april_file(const char *path, HostModel &out, std::string &err);
+
+// Layer widths that are multiples of 16 but not of 64 (the MFMA kernels' tile: 4 waves x 16 columns, 64-k stages): every width --
+// d_model, cell, ffn, joiner, the third conv's channels -- is rounded up to the next multiple of 64 with zero weights and biases.
+// Padded units compute exact zeros (LSTM cell: sigma(0) c + sigma(0) tanh(0); DoubleSwish(0) = 0; tanh(0) = 0 in the joiner) and feed
+// zero rows of the next matrix, so the real outputs are the file's network; the one place the true width shows is the BasicNorm mean
+// (dims.d_norm).  The decoder's grouped convolution grows by whole groups.  False (with err) when the padding is not a whole number
+// of groups.  The reference runs any width through ONNXRuntime (src/april_session.c:131-180); nothing there corresponds to this.
+bool pad_host_model(HostModel &m, std::string &err);
 
 // Container-only parse (no network interpretation); used by tests of rejection cases.
 struct ContainerInfo {

@@ -158,6 +158,9 @@ TINY_DIMS = dict(n_layers=2, d_model=64, hidden=128, ffn=128, joiner=64, vocab=4
 # multiple of 16 (exercises the padded joiner columns), a different decoder grouping
 MEDIUM_DIMS = dict(n_layers=3, d_model=192, hidden=320, ffn=448, joiner=192, vocab=131, mel=80, seg=9,
                    context=2, dec_groups=48, conv_ch=(8, 24, 64))
+# widths that are multiples of 16 but not of 64 (the loader pads them: csrc/model_loader.cc pad_host_model)
+NARROW_DIMS = dict(n_layers=2, d_model=144, hidden=208, ffn=304, joiner=80, vocab=60, mel=80, seg=9,
+                   context=2, dec_groups=36, conv_ch=(8, 16, 48))
 LARGE_DIMS = dict(n_layers=16, d_model=768, hidden=1536, ffn=3072, joiner=768, vocab=500, mel=80, seg=9,
                   context=2, dec_groups=192, conv_ch=(8, 32, 128))
 

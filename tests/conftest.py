@@ -61,6 +61,15 @@ def medium_model(model_dir, built):
 
 
 @pytest.fixture(scope="session")
+def narrow_model(model_dir, built):
+    """widths that are multiples of 16 but not of 64 (d 144, cell 208, ffn 304, joiner 80, 48 conv channels): padded at load"""
+    from april_asr_amd import synth_model as SM
+    p = str(model_dir / "narrow.april")
+    dims, w, toks = SM.write_model(p, SM.NARROW_DIMS, seed=3)
+    return dict(path=p, dims=dims, weights=w, tokens=toks)
+
+
+@pytest.fixture(scope="session")
 def v0_model(model_dir, built):
     """aprilv0 dimensions (12 layers, 84 M parameters) -- ~10 s to write."""
     from april_asr_amd import synth_model as SM

@@ -685,6 +685,35 @@ def test_odd_dimensions_model(medium_model):
     gm.close(); om.close()
 
 
+def test_widths_padded_at_load_match_the_oracle(narrow_model):
+    """d 144, cell 208, ffn 304, joiner 80, 48 conv-3 channels: multiples of 16, not of 64.  The loader rounds every width up to 64 with
+    zero weights (csrc/model_loader.cc pad_host_model; the BasicNorm mean keeps the file's 144) -- the encoder call on the real
+    columns and a full session (logits, transcript) against the oracle, which runs the file's widths; the padded state columns stay 0."""
+    import april_asr_amd as A
+    from oracle import orc_py as O
+    gm = A.Model(narrow_model["path"]); om = O.Model(narrow_model["path"])
+    d = gm.dims
+    assert (d.n_layers, d.d_model, d.hidden, d.ffn, d.joiner, d.vocab, d.d_model_file) == (2, 192, 256, 320, 128, 60, 144)
+    D0, H0 = 144, 208
+    rng = np.random.RandomState(19)
+    x = rng.uniform(-16, 8, size=(2, d.seg, d.mel)).astype(np.float32)
+    h = np.zeros((2, d.n_layers, d.d_model), np.float32); c = np.zeros((2, d.n_layers, d.hidden), np.float32)
+    h[:, :, :D0] = rng.uniform(-0.5, 0.5, size=(2, d.n_layers, D0)); c[:, :, :H0] = rng.uniform(-1, 1, size=(2, d.n_layers, H0))
+    eout, h2, c2 = gm.run_encoder(x, h, c)
+    assert not h2[:, :, D0:].any() and np.abs(c2[:, :, H0:]).max() < 1e-6 and not eout[:, 80:].any()
+    for i in range(2):
+        e0, h0, c0 = om.encoder(x[i:i + 1], np.ascontiguousarray(h[i][:, None, :D0]), np.ascontiguousarray(c[i][:, None, :H0]))
+        assert np.abs(eout[i][:80] - e0.ravel()).max() < 1e-4
+        assert np.abs(h2[i][:, :D0] - h0[:, 0, :]).max() < 1e-4 and np.abs(c2[i][:, :H0] - c0[:, 0, :]).max() < 1e-4
+    pcm = speech_like_pcm(3.0, seed=18, silence=(1.0, 1.4))
+    want, lg0, n0 = run_oracle(om, pcm, 1600)
+    got, lg1, n1 = run_gpu(gm, pcm, 1600)
+    assert n0 == n1 and lg0.shape == lg1.shape and lg1.shape[1] == 60
+    assert np.abs(lg0 - lg1).max() < 1e-3
+    assert_same_transcript(want, got)
+    gm.close(); om.close()
+
+
 def test_config5_larger_encoder_512_sessions(large_model):
     """BASELINE configs[4] shape (fp32 here): the larger encoder (16 x {768, 1536, 3072}), 512 concurrent sessions in
     100 ms feeds on one GPU.  Session 0 against the CPU oracle (token-exact, logits within 1e-3); sessions 1 and 511

@@ -12,7 +12,7 @@ from april_asr_amd import synth_model as SM
 
 def split_blob(blob):
     magic, meta_bytes, wfloats, woff = struct.unpack("<8sQQQ", blob[:32].tobytes())
-    assert magic == b"APXBLOB1"
+    assert magic == b"APXBLOB2"
     return np.frombuffer(blob[woff:woff + wfloats * 4].tobytes(), np.float32)
 
 
@@ -103,6 +103,56 @@ def test_extraction_and_packing(built, tiny_model):
            (d["n_layers"], d["d_model"], d["hidden"], d["ffn"], d["joiner"], d["vocab"])
     assert (m.dims.seg, m.dims.seg_step, m.dims.mel, m.dims.context, m.dims.fft_size, m.dims.frame_shift) == (9, 4, 80, 2, 512, 160)
     check_blob(split_blob(m.export_blob()), d, tiny_model["weights"])
+    m.close()
+
+
+def test_widths_that_are_multiples_of_16_are_padded_to_64(built, narrow_model):
+    """csrc/model_loader.cc pad_host_model: d 144, cell 208, ffn 304, joiner 80, 48 conv-3 channels -> 192 / 256 / 320 / 128 / 64.
+    Every real weight sits where the padded network expects it, every padded row / column / bias is zero, the decoder convolution
+    grows by whole groups, and the BasicNorm mean keeps the file's width (dims.d_model_file)."""
+    m = A.Model.load_host_only(narrow_model["path"])
+    d0, wts = narrow_model["dims"], narrow_model["weights"]
+    assert (m.dims.d_model, m.dims.hidden, m.dims.ffn, m.dims.joiner, m.dims.vocab, m.dims.d_model_file) == (192, 256, 320, 128, 60, 144)
+    D0, H0, F0, J0, V = d0["d_model"], d0["hidden"], d0["ffn"], d0["joiner"], d0["vocab"]
+    c0, c1, c20 = d0["conv_ch"]
+    d = dict(d0, d_model=192, hidden=256, ffn=320, joiner=128, conv_ch=(c0, c1, 64), dec_groups=192 // (D0 // d0["dec_groups"]))
+    D, H, F, J = 192, 256, 320, 128
+    w = split_blob(m.export_blob())
+    L, ein, vp = layout_offsets(d)
+
+    def padded(src, rows, cols):
+        out = np.zeros((rows, cols), np.float32)
+        out[:src.shape[0], :src.shape[1]] = src
+        return out
+    w3 = unpack_mfma(w[L["conv_w2"]:], L["k3"], 64, 64)
+    assert np.array_equal(w3[:c1 * 9], padded(wts["conv2.w"].reshape(c20, c1 * 9).T, c1 * 9, 64)) and not w3[c1 * 9:].any()
+    assert np.array_equal(w[L["conv_b2"]:][:64], np.concatenate([wts["conv2.b"], np.zeros(16, np.float32)]))
+    f_out = ein // 64
+    we = unpack_mfma(w[L["w_embed"]:], ein, D, D).reshape(f_out, 64, D)                 # position-major rows (f * c2 + c)
+    src = wts["embed.w"].T.reshape(c20, f_out, D0).transpose(1, 0, 2)
+    assert np.array_equal(we[:, :c20, :D0], src) and not we[:, c20:, :].any() and not we[:, :, D0:].any()
+    assert np.array_equal(w[L["b_embed"]:][:D], np.concatenate([wts["embed.b"], np.zeros(D - D0, np.float32)]))
+    for l in range(d["n_layers"]):
+        p = "l%d." % l
+        Wg = unpack_mfma(w[L["wg%d" % l]:], 2 * D, 4 * H, 4 * H).reshape(2, D, H, 4)      # [x | h][row][unit][gate]
+        for half, key in enumerate(("w_ih", "w_hh")):
+            want = wts[p + key].T.reshape(D0, 4, H0).transpose(0, 2, 1)                   # [row][unit][gate]
+            assert np.array_equal(Wg[half, :D0, :H0], want) and not Wg[half, D0:].any() and not Wg[half, :, H0:].any()
+        bg = w[L["bg%d" % l]:][:4 * H].reshape(H, 4)
+        assert np.array_equal(bg[:H0], (wts[p + "b_ih"] + wts[p + "b_hh"]).reshape(4, H0).T) and not bg[H0:].any()
+        assert np.array_equal(unpack_mfma(w[L["whr%d" % l]:], H, D, D), padded(wts[p + "w_hr"].T, H, D))
+        assert np.array_equal(unpack_mfma(w[L["wff1%d" % l]:], D, F, F), padded(wts[p + "ff1.w"].T, D, F))
+        assert np.array_equal(unpack_mfma(w[L["wff2%d" % l]:], F, D, D), padded(wts[p + "ff2.w"].T, F, D))
+        assert np.array_equal(w[L["bff1%d" % l]:][:F], np.concatenate([wts[p + "ff1.b"], np.zeros(F - F0, np.float32)]))
+        assert np.array_equal(w[L["bff2%d" % l]:][:D], np.concatenate([wts[p + "ff2.b"], np.zeros(D - D0, np.float32)]))
+    assert np.array_equal(unpack_mfma(w[L["w_encproj"]:], D, J, J), padded(wts["enc_proj.w"].T, D, J))
+    assert np.array_equal(w[L["emb"]:][:V * D].reshape(V, D), padded(wts["emb"], V, D))
+    gs = D0 // d0["dec_groups"]
+    dc = w[L["dec_conv"]:][:D * gs * d["context"]].reshape(D, gs * d["context"])
+    assert np.array_equal(dc[:D0], wts["dec_conv.w"].reshape(D0, -1)) and not dc[D0:].any()
+    assert np.array_equal(unpack_mfma(w[L["w_decproj"]:], D, J, J), padded(wts["dec_proj.w"].T, D, J))
+    out = unpack_mfma(w[L["w_out"]:], J, vp, vp)
+    assert np.array_equal(out[:J0, :V], wts["out.w"].T) and not out[J0:].any() and not out[:, V:].any()
     m.close()
 
 
@@ -381,7 +431,7 @@ def test_convert_cli(built, tiny_model, tmp_path):
     a = A.Model.load_host_only(tiny_model["path"]); b = A.Model.load_blob(out32, init_gpu=False)
     assert np.array_equal(a.export_blob(), b.export_blob())
     a.close(); b.close()
-    assert open(out16, "rb").read(8) == b"APXBLB16" and os.path.getsize(out16) < 0.62 * os.path.getsize(out32)
+    assert open(out16, "rb").read(8) == b"APXBL16B" and os.path.getsize(out16) < 0.62 * os.path.getsize(out32)
     bad = tmp_path / "bad.april"; bad.write_bytes(open(tiny_model["path"], "rb").read()[:5000])
     r = subprocess.run([sys.executable, "-m", "april_asr_amd.convert", str(bad), str(tmp_path / "x")], env=env, cwd=str(tmp_path), capture_output=True)
     assert r.returncode == 1

@@ -202,6 +202,36 @@ static void run_case(const char *name, int M, int d, int hidden, int kind, int n
     }
 }
 
+// the same launch over R different problem sets in turn (R x weights > the 256 MB memory-side cache): every launch streams its
+// weights from HBM, as inside the engine (16 layers = 0.5 GB of weights per step), instead of finding them where the launch before left them
+static void run_cold_case(const char *name, int M, int d, int hidden, int kind, int n, int R, hipStream_t s, int iters)
+{
+    std::vector<std::vector<Problem>> sets((size_t)R);
+    std::vector<Chain> chains;
+    for (int r = 0; r < R; ++r) for (int i = 0; i < n; ++i) sets[(size_t)r].push_back(make_problem(M, d, hidden, kind));
+    gemm_pp_pin(-1, 0);
+    for (int r = 0; r < R; ++r) chains.push_back(make_chain(sets[(size_t)r]));
+    auto time_rot = [&](int rot) {
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int i = 0; i < 2 * R; ++i) chains[(size_t)(i % rot)].run(s);
+        CK(hipStreamSynchronize(s));
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) chains[(size_t)(i % rot)].run(s);
+        CK(hipEventRecord(e1, s));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        return ms * 1e3 / iters;
+    };
+    const double warm = time_rot(1), cold = time_rot(R);
+    printf("%-28s M %5d x %d | planner's form, one problem set over and over %7.2f us | %d sets in turn (weights from HBM) %7.2f us\n", name, M, n, warm, R, cold);
+    fflush(stdout);
+    for (auto &c : chains) if (c.gd) CK(hipFree(c.gd));
+    for (auto &ps : sets) for (const Problem &p : ps) {
+        CK(hipFree(p.y16)); CK(hipFree(p.h16)); CK(hipFree(p.w16)); CK(hipFree(p.out16)); CK(hipFree(p.ssq)); CK(hipFree(p.bias));
+        CK(hipFree(p.c_state)); CK(hipFree(p.c_init)); CK(hipFree(p.p_out)); CK(hipFree(p.p_in)); CK(hipFree(p.slots));
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int iters = argc > 1 ? atoi(argv[1]) : 200;
@@ -219,6 +249,10 @@ int main(int argc, char **argv)
         run_case("large lstm h-half", 512, 768, 1536, 3, 1, s, iters);
         run_case("large ffn-up 1536 rows", 1536, 768, 3072, 1, 1, s, iters);
         run_case("large gates 100 rows", 100, 768, 1536, 0, 3, s, iters);
+    }
+    if (dims == "cold") {
+        for (int n = 1; n <= 3; ++n) run_cold_case("large gates", 512, 768, 1536, 0, n, 24 / n, s, iters);
+        for (int n = 2; n <= 3; ++n) run_cold_case("large ffn-up", 512, 768, 3072, 1, n, 24, s, iters);
     }
     if (dims == "probe") {
         // shapes of the N = d_model GEMMs (projection K = cell, FFN down K = ffn) under the FFN-up epilogue, and the gates at twice the K:
