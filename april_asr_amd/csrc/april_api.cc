@@ -128,7 +128,7 @@ bool create_engines(Model &m, const float *blob_host, const float *blob_device)
 {
     const ModelParams &P = m.host.params;
     if (!build_fbank_tables(P.sample_rate, P.frame_shift_ms, P.frame_length_ms, P.mel_features, P.round_pow2 != 0, P.mel_low, P.mel_high, m.ftab)) {
-        LOGE("aam: unsupported frame length (the FFT size must be a multiple of 4 with no prime factor above 5)");
+        LOGE("aam: unsupported frame length (an FFT size of 8 .. 8192 that pocketfft runs through its radix passes; a large prime factor means Bluestein, which is not built)");
         return false;
     }
     if (m.layout.dims.embed_in % 64 || m.layout.dims.d_model % 64 || m.layout.dims.hidden % 64 || m.layout.dims.ffn % 64 || m.layout.dims.joiner % 64 || m.layout.dims.conv_ch[2] % 16) {

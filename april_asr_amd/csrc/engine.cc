@@ -415,6 +415,7 @@ void Engine::upload_tables(const FbankHostTables &ft)
     for (int k = 0; k < ft_.nfct; ++k) {
         ft_.fct[k] = ft.factors[(size_t)k];
         ft_.tw[k] = (const double *)up(ft.tw[(size_t)k].data(), ft.tw[(size_t)k].size() * 8);
+        ft_.tws[k] = ft.tws[(size_t)k].empty() ? nullptr : (const double *)up(ft.tws[(size_t)k].data(), ft.tws[(size_t)k].size() * 8);
     }
     ft_.padded = ft.padded; ft_.nbins = ft.nbins;
     pad_value_ = ft.pad_value;

@@ -78,6 +78,82 @@ struct Circle {
     }
 };
 
+// (cos, sin)(2 pi m / n) for m in [0, n / 2], any n: pocketfft takes the first octant of n, 2 n or 4 n (n mod 4 = 0, 2, odd) and reaches
+// the rest by exact symmetries (pocketfft.c:121-226); which octant sample a point comes from is part of the bit pattern
+std::vector<double> half_circle(size_t n)
+{
+    std::vector<double> t(2 * (n / 2 + 1), 0.0);
+    if ((n & 3) == 0) {
+        Circle c(n);
+        for (size_t m = 0; m < n / 2; ++m) c.point(m, t[2 * m], t[2 * m + 1]);
+        return t;
+    }
+    std::vector<double> oct;
+    if ((n & 1) == 0) {                                  // n = 4 q + 2: octant of 2 n
+        first_octant(2 * n, oct);
+        const size_t cnt = (n + 2) >> 2, half = n >> 1;
+        for (size_t e = 0; e < cnt; ++e) {
+            if (e < (cnt + 1) / 2) { t[2 * e] = oct[4 * e]; t[2 * e + 1] = oct[4 * e + 1]; }
+            else { const size_t m = 2 * (cnt - 1 - e) + 1; t[2 * e] = oct[2 * m + 1]; t[2 * e + 1] = oct[2 * m]; }      // mirrored at pi / 4
+        }
+        for (size_t e = 1; 2 * e < half; ++e) { t[2 * (half - e)] = -t[2 * e]; t[2 * (half - e) + 1] = t[2 * e + 1]; }   // mirrored at pi / 2
+    } else {                                             // n odd: point 4 i of the circle of 4 n, folded into its first octant
+        first_octant(4 * n, oct);
+        const size_t cnt = (n + 1) >> 1;
+        for (size_t i = 0; i < cnt; ++i) {
+            const size_t i4 = 4 * i;
+            if (2 * i4 <= n) { t[2 * i] = oct[2 * i4]; t[2 * i + 1] = oct[2 * i4 + 1]; }
+            else if (i4 <= n) { const size_t m = n - i4; t[2 * i] = oct[2 * m + 1]; t[2 * i + 1] = oct[2 * m]; }
+            else if (2 * i4 <= 3 * n) { const size_t m = i4 - n; t[2 * i] = -oct[2 * m + 1]; t[2 * i + 1] = oct[2 * m]; }
+            else { const size_t m = 2 * n - i4; t[2 * i] = -oct[2 * m]; t[2 * i + 1] = oct[2 * m + 1]; }
+        }
+    }
+    return t;
+}
+
+// pocketfft.c:234-289, 2155-2182: does make_rfft_plan() run length n through its radix passes, or through Bluestein's algorithm?
+size_t largest_prime_factor(size_t n)
+{
+    size_t res = 1;
+    while ((n & 1) == 0) { res = 2; n >>= 1; }
+    size_t limit = (size_t)std::sqrt((double)n + 0.01);
+    for (size_t x = 3; x <= limit; x += 2)
+        while (n % x == 0) { res = x; n /= x; limit = (size_t)std::sqrt((double)n + 0.01); }
+    return n > 1 ? n : res;
+}
+double cost_guess(size_t n)
+{
+    const size_t n0 = n;
+    double cost = 0.0;
+    auto price = [](size_t f) { return f <= 5 ? (double)f : 1.1 * (double)f; };      // factors without a hard-coded pass cost more
+    while ((n & 1) == 0) { cost += 2; n >>= 1; }
+    size_t limit = (size_t)std::sqrt((double)n + 0.01);
+    for (size_t x = 3; x <= limit; x += 2)
+        while (n % x == 0) { cost += price(x); n /= x; limit = (size_t)std::sqrt((double)n + 0.01); }
+    if (n > 1) cost += price(n);
+    return cost * (double)n0;
+}
+size_t good_size(size_t n)                               // the smallest 2-3-5-7-11-smooth number >= n
+{
+    if (n <= 6) return n;
+    size_t best = 2 * n;
+    for (size_t a = 1; a < best; a *= 2)
+        for (size_t b = a; b < best; b *= 3)
+            for (size_t c = b; c < best; c *= 5)
+                for (size_t d = c; d < best; d *= 7)
+                    for (size_t e = d; e < best; e *= 11)
+                        if (e >= n) best = e;
+    return best;
+}
+bool radix_plan_chosen(size_t n)
+{
+    if (n < 50 || (double)largest_prime_factor(n) <= std::sqrt((double)n)) return true;
+    const double radix = 0.5 * cost_guess(n);
+    double blue = 2 * cost_guess(good_size(2 * n - 1));
+    blue *= 1.5;
+    return !(blue < radix);
+}
+
 double mel_of(double hz) { return 1127.0 * std::log(1.0 + hz / 700.0); }
 
 }  // namespace
@@ -90,9 +166,10 @@ bool build_fbank_tables(int sample_rate, int frame_shift_ms, int frame_length_ms
     t.window_size = frame_length_ms * sample_rate / 1000;
     int padded = t.window_size;
     if (round_pow2) { padded = 1; while (padded < t.window_size) padded <<= 1; }
-    // FFT lengths: multiples of 4 (the twiddle table below is pocketfft's n % 4 == 0 branch) whose prime factors are 2, 3 and 5 (the
-    // radix 4 / 2 / 3 / 5 passes of kernels_fbank.hip); round_pow2 = 0 models have the frame length itself, e.g. 400 at 16 kHz / 25 ms
-    if (padded < 8 || (padded & 3) != 0 || padded > 8192) return false;
+    // FFT lengths: whatever pocketfft runs through its radix passes -- 4 / 2 / 3 / 5 and the generic pass for any other factor
+    // (kernels_fbank.hip); round_pow2 = 0 models have the frame length itself, e.g. 400 at 16 kHz / 25 ms, 882 = 2 3 3 7 7 at 44.1 kHz /
+    // 20 ms.  Lengths pocketfft would hand to Bluestein's algorithm (a large prime factor) are refused.
+    if (padded < 8 || padded > 8192 || !radix_plan_chosen((size_t)padded)) return false;
     t.padded = padded; t.nfft_bins = padded / 2; t.nbins = nbins;
 
     // window: fbank.c:49-55 (N = padded length, denominator N)
@@ -122,18 +199,25 @@ bool build_fbank_tables(int sample_rate, int frame_shift_ms, int frame_length_ms
         t.mel_lo[(size_t)m] = lo; t.mel_hi[(size_t)m] = hi;
     }
 
-    // factors: all 4s, then at most one 2 moved to the front, then the odd divisors in rising order (pocketfft.c:1798-1827)
+    // factors: all 4s, then at most one 2 moved to the front, then the odd divisors in rising order, then what is left (pocketfft.c:1798-1827)
     t.factors.clear();
     size_t len = (size_t)padded;
     while (len % 4 == 0) { t.factors.push_back(4); len >>= 2; }
     if (len % 2 == 0) { len >>= 1; t.factors.push_back(2); std::swap(t.factors.front(), t.factors.back()); }
-    for (size_t divisor = 3; len > 1 && divisor <= 5; divisor += 2)
-        while (len % divisor == 0) { t.factors.push_back((int)divisor); len /= divisor; }
-    if (len != 1 || t.factors.size() > 16) return false;      // a prime factor above 5 (pocketfft's generic pass / Bluestein): not built
+    size_t maxl = (size_t)std::sqrt((double)len) + 1;
+    for (size_t divisor = 3; len > 1 && divisor < maxl; divisor += 2)
+        if (len % divisor == 0) {
+            while (len % divisor == 0) { t.factors.push_back((int)divisor); len /= divisor; }
+            maxl = (size_t)std::sqrt((double)len) + 1;
+        }
+    if (len > 1) t.factors.push_back((int)len);
+    if (t.factors.size() > 16) return false;
 
-    // twiddles per factor (pocketfft.c:1843-1863): tw[(j-1)*(ido-1) + 2i-2 / 2i-1] = cos/sin(2 pi j l1 i / n)
-    Circle circle((size_t)padded);
+    // twiddles per factor (pocketfft.c:1843-1881): tw[(j-1)*(ido-1) + 2i-2 / 2i-1] = cos/sin(2 pi j l1 i / n); a factor above 5 also gets
+    // its own roots of unity (cos, sin)(2 pi i / ip), the upper half by conjugation
+    const std::vector<double> circle = half_circle((size_t)padded);
     t.tw.assign(t.factors.size(), {});
+    t.tws.assign(t.factors.size(), {});
     size_t l1 = 1;
     for (size_t k = 0; k < t.factors.size(); ++k) {
         const size_t ip = (size_t)t.factors[k], ido = (size_t)padded / (l1 * ip);
@@ -141,11 +225,20 @@ bool build_fbank_tables(int sample_rate, int frame_shift_ms, int frame_length_ms
             t.tw[k].assign((ip - 1) * (ido - 1), 0.0);
             for (size_t j = 1; j < ip; ++j)
                 for (size_t i = 1; i <= (ido - 1) / 2; ++i) {
-                    double c, s;
-                    circle.point(j * l1 * i, c, s);
-                    t.tw[k][(j - 1) * (ido - 1) + 2 * i - 2] = c;
-                    t.tw[k][(j - 1) * (ido - 1) + 2 * i - 1] = s;
+                    t.tw[k][(j - 1) * (ido - 1) + 2 * i - 2] = circle[2 * (j * l1 * i)];
+                    t.tw[k][(j - 1) * (ido - 1) + 2 * i - 1] = circle[2 * (j * l1 * i) + 1];
                 }
+        }
+        if (ip > 5) {
+            std::vector<double> &r = t.tws[k];
+            r.assign(2 * ip, 0.0);
+            r[0] = 1.0;
+            const size_t step = (size_t)padded / ip;
+            for (size_t i = 1; i <= ip / 2; ++i) {
+                r[2 * i] = r[2 * (ip - i)] = circle[2 * (i * step)];
+                r[2 * i + 1] = circle[2 * (i * step) + 1];
+                r[2 * (ip - i) + 1] = -circle[2 * (i * step) + 1];
+            }
         }
         l1 *= ip;
     }

@@ -15,10 +15,11 @@ struct FbankHostTables {
     std::vector<int> mel_lo, mel_hi;      // non-zero support per bin
     std::vector<int> factors;             // pocketfft order, e.g. 2,4,4,4,4 for 512; 4,4,5,5 for 400
     std::vector<std::vector<double>> tw;  // per factor (last one empty)
+    std::vector<std::vector<double>> tws; // per factor above 5 (generic pass): (cos, sin)(2 pi i / ip), i in [0, ip); else empty
     float pad_value = 0;                  // (float)log((double)kEps)
 };
 
-// returns false when the frame length is not supported (FFT length not a multiple of 4, or with a prime factor above 5)
+// returns false when the frame length is not supported (an FFT length pocketfft would run through Bluestein's algorithm: a large prime factor)
 bool build_fbank_tables(int sample_rate, int frame_shift_ms, int frame_length_ms, int nbins, bool round_pow2,
                         int mel_low, int mel_high, FbankHostTables &out);
 

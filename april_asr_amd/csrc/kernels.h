@@ -342,6 +342,7 @@ void launch_repack_x32(const float *src_packed, void *dst, int K, int N, hipStre
 struct FbankTables {                       // device pointers
     const float *window = nullptr;         // [padded]
     const double *tw[16] = {nullptr};      // per factor twiddles (pocketfft layout)
+    const double *tws[16] = {nullptr};     // factors above 5: the generic pass's roots of unity (cos, sin)(2 pi i / ip)
     int fct[16] = {0}; int nfct = 0;
     const float *mel = nullptr;            // [nbins][padded/2]
     const int *mel_lo = nullptr;           // [nbins] first non-zero fft bin

@@ -1,7 +1,8 @@
 // Online log-mel filterbank on gfx950: one wavefront per 10 ms frame, batched over
 // sessions x new frames.  Bit-compatible restatement of the reference's per-frame
 // arithmetic (src/fbank.c:228-296) including its FFT (src/fft/pocketfft.c radf4 /
-// radf2 / radf3 / radf5 passes, :1111-1260,1730-1764): fp64 butterflies in the same
+// radf2 / radf3 / radf5 passes and the generic radfg pass for any other factor,
+// :1111-1409,1730-1764): fp64 butterflies in the same
 // operation order, fp32 power and mel accumulation in the same order, compiled
 // with -ffp-contract=off (the reference is built without FMA contraction).
 //
@@ -18,7 +19,7 @@
 // sum of the PCM samples / 32768, which is what the wave reduction computes.  For
 // larger frames lane 0 replays the sequential float chain.
 //
-// Third-party notice.  The radix-4 / 2 / 3 / 5 real-FFT pass structure and the twiddle-factor polynomial
+// Third-party notice.  The radix-4 / 2 / 3 / 5 / generic real-FFT pass structure and the twiddle-factor polynomial
 // coefficients restated here follow pocketfft (the FFT the reference links, src/fft/pocketfft.c):
 //   Copyright (C) 2010-2019 Max-Planck-Society.  All rights reserved.  BSD 3-Clause License
 //   (https://gitlab.mpcdf.mpg.de/mtr/pocketfft/-/blob/81d171a6/LICENSE.md); the full text, including the
@@ -197,6 +198,97 @@ __device__ void fft_pass5(int ido, int l1, const double *in, double *out, const 
 #undef WA
 }
 
+// generic pass for any odd factor ip > 5 (pocketfft.c:1266-1409, radfg): three sweeps with a barrier between them, every element of a
+// sweep one lane task with the reference's operation order (oracle/orc_fbank.c passg states the same tasks sequentially):
+//   1. in place on x: twiddle products of the columns j / ip - j and their sum / difference pairs (the i = 0 column without twiddles);
+//   2. x -> y: row l of the ip x ip real DFT over the columns -- cosine sums into y[.][l], sine sums into y[.][ip - l]; the terms are
+//      added three at first, then in groups of four, two, one (the grouping is part of the bit pattern) -- and the plain sum into y[.][0];
+//   3. y -> x: the half-complex interleave.  The result is in x (the pass's INPUT buffer).
+__device__ void fft_pass_generic(int ido, int ip, int l1, double *x, double *y, const double *w, const double *cs, int lane)
+{
+    const int half = (ip + 1) / 2, idl1 = ido * l1, nq = (ido - 1) / 2;
+#define X1(a, b, c) x[(a) + ido * ((b) + l1 * (c))]
+#define X2(a, b) x[(a) + idl1 * (b)]
+#define Y2(a, b) y[(a) + idl1 * (b)]
+#define Y1(a, b, c) y[(a) + ido * ((b) + l1 * (c))]
+#define XO(a, b, c) x[(a) + ido * ((b) + ip * (c))]
+    // sweep 1: tasks (j, k, q) with q = nq standing for the i = 0 column
+    for (int t = lane; t < (half - 1) * l1 * (nq + 1); t += 64) {
+        const int q = t % (nq + 1), k = (t / (nq + 1)) % l1, j = 1 + t / ((nq + 1) * l1), jc = ip - j;
+        if (q == nq) {
+            const double a = X1(0, k, j), b = X1(0, k, jc);
+            X1(0, k, j) = a + b;
+            X1(0, k, jc) = b - a;
+        } else {
+            const int i = 1 + 2 * q;
+            const double *wj = w + (j - 1) * (ido - 1) + 2 * q, *wc = w + (jc - 1) * (ido - 1) + 2 * q;
+            const double t1 = X1(i, k, j), t2 = X1(i + 1, k, j), t3 = X1(i, k, jc), t4 = X1(i + 1, k, jc);
+            const double x1 = wj[0] * t1 + wj[1] * t2, x2 = wj[0] * t2 - wj[1] * t1;
+            const double x3 = wc[0] * t3 + wc[1] * t4, x4 = wc[0] * t4 - wc[1] * t3;
+            X1(i, k, j) = x1 + x3;  X1(i, k, jc) = x2 - x4;
+            X1(i + 1, k, j) = x2 + x4;  X1(i + 1, k, jc) = x3 - x1;
+        }
+    }
+    __syncthreads();
+    // sweep 2: tasks (l, ik), l = 0 standing for the plain column sum
+    for (int t = lane; t < half * idl1; t += 64) {
+        const int ik = t % idl1, l = t / idl1;
+        if (l == 0) {
+            double s = X2(ik, 0);
+            for (int j = 1; j < half; ++j) s += X2(ik, j);
+            Y2(ik, 0) = s;
+            continue;
+        }
+        double re = X2(ik, 0) + cs[2 * l] * X2(ik, 1) + cs[4 * l] * X2(ik, 2);
+        double im = cs[2 * l + 1] * X2(ik, ip - 1) + cs[4 * l + 1] * X2(ik, ip - 2);
+        int ang = 2 * l, j = 3, jc = ip - 3;
+        for (; j + 3 < half; j += 4, jc -= 4) {
+            int a1 = ang + l; if (a1 >= ip) a1 -= ip;
+            int a2 = a1 + l; if (a2 >= ip) a2 -= ip;
+            int a3 = a2 + l; if (a3 >= ip) a3 -= ip;
+            int a4 = a3 + l; if (a4 >= ip) a4 -= ip;
+            ang = a4;
+            re += cs[2 * a1] * X2(ik, j) + cs[2 * a2] * X2(ik, j + 1) + cs[2 * a3] * X2(ik, j + 2) + cs[2 * a4] * X2(ik, j + 3);
+            im += cs[2 * a1 + 1] * X2(ik, jc) + cs[2 * a2 + 1] * X2(ik, jc - 1) + cs[2 * a3 + 1] * X2(ik, jc - 2) + cs[2 * a4 + 1] * X2(ik, jc - 3);
+        }
+        for (; j + 1 < half; j += 2, jc -= 2) {
+            int a1 = ang + l; if (a1 >= ip) a1 -= ip;
+            int a2 = a1 + l; if (a2 >= ip) a2 -= ip;
+            ang = a2;
+            re += cs[2 * a1] * X2(ik, j) + cs[2 * a2] * X2(ik, j + 1);
+            im += cs[2 * a1 + 1] * X2(ik, jc) + cs[2 * a2 + 1] * X2(ik, jc - 1);
+        }
+        for (; j < half; ++j, --jc) {
+            ang += l; if (ang >= ip) ang -= ip;
+            re += cs[2 * ang] * X2(ik, j);
+            im += cs[2 * ang + 1] * X2(ik, jc);
+        }
+        Y2(ik, l) = re;
+        Y2(ik, ip - l) = im;
+    }
+    __syncthreads();
+    // sweep 3: tasks (j, k, q); j = 0: the copy of column 0 (q runs over all ido elements there)
+    for (int t = lane; t < l1 * ido; t += 64) { const int i = t % ido, k = t / ido; XO(i, 0, k) = Y1(i, k, 0); }
+    for (int t = lane; t < (half - 1) * l1 * (nq + 1); t += 64) {
+        const int q = t % (nq + 1), k = (t / (nq + 1)) % l1, j = 1 + t / ((nq + 1) * l1), jc = ip - j, j2 = 2 * j - 1;
+        if (q == nq) {
+            XO(ido - 1, j2, k) = Y1(0, k, j);
+            XO(0, j2 + 1, k) = Y1(0, k, jc);
+        } else {
+            const int i = 1 + 2 * q, ic = ido - i - 2;
+            XO(i, j2 + 1, k) = Y1(i, k, j) + Y1(i, k, jc);
+            XO(ic, j2, k) = Y1(i, k, j) - Y1(i, k, jc);
+            XO(i + 1, j2 + 1, k) = Y1(i + 1, k, j) + Y1(i + 1, k, jc);
+            XO(ic + 1, j2, k) = Y1(i + 1, k, jc) - Y1(i + 1, k, j);
+        }
+    }
+#undef X1
+#undef X2
+#undef Y2
+#undef Y1
+#undef XO
+}
+
 __global__ __launch_bounds__(64) void fbank_kernel(FbankArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sh[];
@@ -248,7 +340,8 @@ __global__ __launch_bounds__(64) void fbank_kernel(FbankArgs a)
         if (ip == 4) fft_pass4(ido, l1, src, dst, a.t.tw[k], lane);
         else if (ip == 2) fft_pass2(ido, l1, src, dst, a.t.tw[k], lane);
         else if (ip == 3) fft_pass3(ido, l1, src, dst, a.t.tw[k], lane);
-        else fft_pass5(ido, l1, src, dst, a.t.tw[k], lane);
+        else if (ip == 5) fft_pass5(ido, l1, src, dst, a.t.tw[k], lane);
+        else { fft_pass_generic(ido, ip, l1, src, dst, a.t.tw[k], a.t.tws[k], lane); __syncthreads(); continue; }      // (its result is in src)
         __syncthreads();
         double *t = src; src = dst; dst = t;
     }

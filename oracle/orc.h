@@ -33,6 +33,7 @@ typedef struct OrcRfftPlan {
     size_t n, nfct;
     size_t fct[16];
     double *tw[16];
+    double *tws[16];      /* factors above 5 (generic pass): (cos, sin)(2 pi i / ip), i in [0, ip) */
     double *tw_store;
 } OrcRfftPlan;
 

@@ -12,9 +12,9 @@
  *   src/fbank.c:174-306   accept_waveform        -> orc_fbank_accept (+ frame math in orc_fbank_frame)
  *   src/fbank.c:308-325   flush padding          -> orc_fbank_flush
  *   src/fbank.c:327-349   pull_segments          -> orc_fbank_pull
- *   src/fft/pocketfft.c:65-228   twiddle generation (sincos_2pibyn_half, n%4==0 branch)
- *   src/fft/pocketfft.c:1111-1134 radf2, :1136-1168 radf3, :1170-1209 radf4, :1211-1260 radf5,
- *   :1730-1764 rfftp_forward, :1798-1827 factorisation, :1843-1881 twiddle layout.
+ *   src/fft/pocketfft.c:65-228   twiddle generation (sincos_2pibyn_half: all three branches, n % 4 == 0, n even, n odd)
+ *   src/fft/pocketfft.c:1111-1134 radf2, :1136-1168 radf3, :1170-1209 radf4, :1211-1260 radf5, :1266-1409 radfg (any other factor),
+ *   :1730-1764 rfftp_forward, :1798-1827 factorisation, :1843-1881 twiddle layout, :2155-2182 the choice between this plan and Bluestein.
  *
  * Pinned: bit-exact against the reference's own fbank.c/pocketfft.c compiled
  * into oracle/_ref/libaprilref.so (tests/test_oracle_fbank.py) and against the
@@ -23,11 +23,11 @@
  * Design differences from the reference (behaviour-preserving): the reference
  * carries a "previous leftover" array and three copy cases; here the stream is
  * a plain FIFO of samples and frame k is cut at stream offset k*shift.  FFT
- * lengths: multiples of 4 whose prime factors are 2, 3 and 5 (the radix 4 / 2 /
- * 3 / 5 passes; every exported model uses round_pow2 = 1 = a power of two, a
- * model with round_pow2 = 0 has the frame length itself, e.g. 400).  Lengths
- * with other prime factors (pocketfft's generic radix pass, or Bluestein) are
- * refused.
+ * lengths: whatever pocketfft runs through its radix passes (4 / 2 / 3 / 5 and
+ * the generic pass for any other factor; every exported model uses round_pow2 = 1
+ * = a power of two, a model with round_pow2 = 0 has the frame length itself, e.g.
+ * 400, or 882 = 2 3 3 7 7 at 44.1 kHz / 20 ms).  Lengths for which pocketfft
+ * picks Bluestein's algorithm instead (a large prime factor) are refused.
  *
  * Build with -ffp-contract=off: the reference is built for baseline x86-64
  * (no FMA contraction) and bit-exactness depends on it.
@@ -112,35 +112,119 @@ static void half_circle_table(size_t n, double *res /* 2n doubles of room */)
     }
 }
 
+/* table of (cos,sin)(2 pi i / n), i in [0, n/2], for any n: pocketfft builds it from the first octant of n, 2n or 4n by exact
+ * symmetries, depending on n mod 4 (pocketfft.c:121-226).  res: 2n doubles of room. */
+static int half_circle_table_any(size_t n, double *res)
+{
+    if ((n & 3) == 0) { half_circle_table(n, res); return 0; }
+    const size_t den = (n & 1) ? 4 * n : 2 * n;
+    double *oct = (double *)malloc((2 * ((den + 4) >> 3) + 2) * sizeof(double));
+    if (!oct) return -1;
+    first_octant(den, oct);
+    if ((n & 1) == 0) {
+        /* n = 4q + 2: the quarter circle [0, q] from the octant of 2n (even multiples directly, the upper part mirrored at pi/4 from the
+         * odd ones), then the second quarter mirrored at pi/2 */
+        const size_t cnt = (n + 2) >> 2;
+        for (size_t e = 0; e < cnt; ++e) {
+            if (e < (cnt + 1) / 2) { res[2 * e] = oct[4 * e]; res[2 * e + 1] = oct[4 * e + 1]; }
+            else { const size_t m = 2 * (cnt - 1 - e) + 1; res[2 * e] = oct[2 * m + 1]; res[2 * e + 1] = oct[2 * m]; }
+        }
+        const size_t half = n >> 1;
+        for (size_t e = 1; 2 * e < half; ++e) { res[2 * (half - e)] = -res[2 * e]; res[2 * (half - e) + 1] = res[2 * e + 1]; }
+    } else {
+        /* n odd: entry i is the point 4 i of the circle of 4n, folded into its first octant */
+        const size_t cnt = (n + 1) >> 1;
+        for (size_t i = 0; i < cnt; ++i) {
+            const size_t i4 = 4 * i;
+            if (2 * i4 <= n) { res[2 * i] = oct[2 * i4]; res[2 * i + 1] = oct[2 * i4 + 1]; }
+            else if (i4 <= n) { const size_t m = n - i4; res[2 * i] = oct[2 * m + 1]; res[2 * i + 1] = oct[2 * m]; }
+            else if (2 * i4 <= 3 * n) { const size_t m = i4 - n; res[2 * i] = -oct[2 * m + 1]; res[2 * i + 1] = oct[2 * m]; }
+            else { const size_t m = 2 * n - i4; res[2 * i] = -oct[2 * m]; res[2 * i + 1] = oct[2 * m + 1]; }
+        }
+    }
+    free(oct);
+    return 0;
+}
+
+/* pocketfft.c:234-274, 2155-2182: would make_rfft_plan() run this length through the radix passes (1) or through Bluestein (0)? */
+static size_t largest_prime_factor(size_t n)
+{
+    size_t res = 1;
+    while ((n & 1) == 0) { res = 2; n >>= 1; }
+    size_t limit = (size_t)sqrt((double)n + 0.01);
+    for (size_t x = 3; x <= limit; x += 2)
+        while (n % x == 0) { res = x; n /= x; limit = (size_t)sqrt((double)n + 0.01); }
+    if (n > 1) res = n;
+    return res;
+}
+static double cost_guess(size_t n)
+{
+    const double lfp = 1.1;
+    const size_t ni = n;
+    double result = 0.0;
+    while ((n & 1) == 0) { result += 2; n >>= 1; }
+    size_t limit = (size_t)sqrt((double)n + 0.01);
+    for (size_t x = 3; x <= limit; x += 2)
+        while (n % x == 0) { result += (x <= 5) ? (double)x : lfp * (double)x; n /= x; limit = (size_t)sqrt((double)n + 0.01); }
+    if (n > 1) result += (n <= 5) ? (double)n : lfp * (double)n;
+    return result * (double)ni;
+}
+static size_t good_size(size_t n)
+{
+    if (n <= 6) return n;
+    size_t best = 2 * n;
+    for (size_t f2 = 1; f2 < best; f2 *= 2)
+        for (size_t f23 = f2; f23 < best; f23 *= 3)
+            for (size_t f235 = f23; f235 < best; f235 *= 5)
+                for (size_t f2357 = f235; f2357 < best; f2357 *= 7)
+                    for (size_t f = f2357; f < best; f *= 11)
+                        if (f >= n) best = f;
+    return best;
+}
+static int radix_plan_chosen(size_t n)
+{
+    if (n < 50 || (double)largest_prime_factor(n) <= sqrt((double)n)) return 1;
+    const double comp1 = 0.5 * cost_guess(n);
+    double comp2 = 2 * cost_guess(good_size(2 * n - 1));
+    comp2 *= 1.5;
+    return !(comp2 < comp1);
+}
+
 /* ------------------------------------------------------------------ */
-/* real forward FFT plan (factors 4, 2, 3, 5)                         */
+/* real forward FFT plan (factors 4, 2, 3, 5, anything else)          */
 /* ------------------------------------------------------------------ */
 
 int orc_rfft_plan_init(OrcRfftPlan *p, size_t n)
 {
     memset(p, 0, sizeof(*p));
-    if (n < 4 || (n & 3) != 0 || n > ORC_FFT_MAX) return -1;      /* (the twiddle table below is the n % 4 == 0 branch) */
+    if (n < 2 || n > ORC_FFT_MAX || !radix_plan_chosen(n)) return -1;      /* (Bluestein lengths: not restated) */
     p->n = n;
-    /* pocketfft.c:1798-1827: strip 4s, then one 2 which is swapped to the front, then the odd divisors in rising order */
+    /* pocketfft.c:1798-1827: strip 4s, then one 2 which is swapped to the front, then the odd divisors in rising order, then what is left */
     size_t len = n, nf = 0;
-    while ((len % 4) == 0) { p->fct[nf++] = 4; len >>= 2; }
+    while ((len % 4) == 0) { if (nf >= 16) return -1; p->fct[nf++] = 4; len >>= 2; }
     if ((len % 2) == 0) {
         len >>= 1;
+        if (nf >= 16) return -1;
         p->fct[nf++] = 2;
         size_t t = p->fct[0]; p->fct[0] = p->fct[nf - 1]; p->fct[nf - 1] = t;
     }
-    for (size_t divisor = 3; len > 1 && divisor <= 5; divisor += 2)
-        while ((len % divisor) == 0) { if (nf >= 16) return -1; p->fct[nf++] = divisor; len /= divisor; }
-    if (len != 1) return -1;                                       /* a prime factor above 5: not restated */
+    size_t maxl = (size_t)sqrt((double)len) + 1;
+    for (size_t divisor = 3; len > 1 && divisor < maxl; divisor += 2)
+        if ((len % divisor) == 0) {
+            while ((len % divisor) == 0) { if (nf >= 16) return -1; p->fct[nf++] = divisor; len /= divisor; }
+            maxl = (size_t)sqrt((double)len) + 1;
+        }
+    if (len > 1) { if (nf >= 16) return -1; p->fct[nf++] = len; }
     p->nfct = nf;
-    /* twiddle layout, pocketfft.c:1843-1863 */
-    double *circle = (double *)malloc(2 * n * sizeof(double));
+    /* twiddle layout, pocketfft.c:1843-1881 */
+    double *circle = (double *)malloc(2 * n * sizeof(double) + 64);
     if (!circle) return -1;
-    half_circle_table(n, circle);
+    if (half_circle_table_any(n, circle)) { free(circle); return -1; }
     size_t total = 0, l1 = 1;
     for (size_t k = 0; k < nf; ++k) {
         size_t ip = p->fct[k], ido = n / (l1 * ip);
         total += (ip - 1) * (ido - 1);
+        if (ip > 5) total += 2 * ip;
         l1 *= ip;
     }
     p->tw_store = (double *)calloc(total ? total : 1, sizeof(double));
@@ -156,6 +240,16 @@ int orc_rfft_plan_init(OrcRfftPlan *p, size_t n)
                     p->tw[k][(j - 1) * (ido - 1) + 2 * i - 2] = circle[2 * j * l1 * i];
                     p->tw[k][(j - 1) * (ido - 1) + 2 * i - 1] = circle[2 * j * l1 * i + 1];
                 }
+        }
+        if (ip > 5) {       /* the generic pass's own roots of unity: (cos, sin)(2 pi i / ip), the upper half by conjugation */
+            double *r = p->tws[k] = ptr;
+            ptr += 2 * ip;
+            r[0] = 1.0; r[1] = 0.0;
+            for (size_t i = 1; i <= (ip >> 1); ++i) {
+                const double c = circle[2 * i * (n / ip)], sn = circle[2 * i * (n / ip) + 1];
+                r[2 * i] = c; r[2 * i + 1] = sn;
+                r[2 * (ip - i)] = c; r[2 * (ip - i) + 1] = -sn;
+            }
         }
         l1 *= ip;
     }
@@ -333,6 +427,100 @@ static void pass5(size_t ido, size_t l1, const double *in, double *out, const do
 #undef W5
 }
 
+/* generic real butterfly pass for any odd factor ip > 5, pocketfft.c:1266-1409 (radfg).  Three sweeps; every element of a sweep is
+ * an independent task with a fixed operation order (the device kernel runs the same tasks one per lane, a barrier between sweeps):
+ *   1. in place on x: the twiddle products of the columns j / ip - j and their sum / difference pairs (the i = 0 column without twiddles);
+ *   2. x -> y: row l of the ip x ip real DFT over the columns (cosine sums into y[.][l], sine sums into y[.][ip - l]; the terms are
+ *      added three at first, then in groups of four, two, one -- the grouping is part of the result), and the plain sum into y[.][0];
+ *   3. y -> x: the half-complex interleave.
+ * The result is in x (the caller's INPUT buffer); y is scratch. */
+static void passg(size_t ido, size_t ip, size_t l1, double *x, double *y, const double *w, const double *cs)
+{
+    const size_t half = (ip + 1) / 2, idl1 = ido * l1, nq = (ido - 1) / 2;
+#define X1(a, b, c) x[(a) + ido * ((b) + l1 * (c))]
+#define X2(a, b) x[(a) + idl1 * (b)]
+#define Y2(a, b) y[(a) + idl1 * (b)]
+#define Y1(a, b, c) y[(a) + ido * ((b) + l1 * (c))]
+#define XO(a, b, c) x[(a) + ido * ((b) + ip * (c))]
+    /* sweep 1 */
+    for (size_t j = 1; j < half; ++j) {
+        const size_t jc = ip - j;
+        for (size_t k = 0; k < l1; ++k) {
+            for (size_t q = 0; q < nq; ++q) {
+                const size_t i = 1 + 2 * q;
+                const double *wj = w + (j - 1) * (ido - 1) + 2 * q, *wc = w + (jc - 1) * (ido - 1) + 2 * q;
+                const double t1 = X1(i, k, j), t2 = X1(i + 1, k, j), t3 = X1(i, k, jc), t4 = X1(i + 1, k, jc);
+                const double x1 = wj[0] * t1 + wj[1] * t2, x2 = wj[0] * t2 - wj[1] * t1;
+                const double x3 = wc[0] * t3 + wc[1] * t4, x4 = wc[0] * t4 - wc[1] * t3;
+                X1(i, k, j) = x1 + x3;  X1(i, k, jc) = x2 - x4;
+                X1(i + 1, k, j) = x2 + x4;  X1(i + 1, k, jc) = x3 - x1;
+            }
+            const double a = X1(0, k, j), b = X1(0, k, jc);
+            X1(0, k, j) = a + b;
+            X1(0, k, jc) = b - a;
+        }
+    }
+    /* sweep 2 */
+    for (size_t l = 1; l < half; ++l) {
+        const size_t lc = ip - l;
+        for (size_t ik = 0; ik < idl1; ++ik) {
+            double re = X2(ik, 0) + cs[2 * l] * X2(ik, 1) + cs[4 * l] * X2(ik, 2);
+            double im = cs[2 * l + 1] * X2(ik, ip - 1) + cs[4 * l + 1] * X2(ik, ip - 2);
+            size_t ang = 2 * l, j = 3, jc = ip - 3;
+            for (; j + 3 < half; j += 4, jc -= 4) {
+                size_t a1 = ang + l; if (a1 >= ip) a1 -= ip;
+                size_t a2 = a1 + l; if (a2 >= ip) a2 -= ip;
+                size_t a3 = a2 + l; if (a3 >= ip) a3 -= ip;
+                size_t a4 = a3 + l; if (a4 >= ip) a4 -= ip;
+                ang = a4;
+                re += cs[2 * a1] * X2(ik, j) + cs[2 * a2] * X2(ik, j + 1) + cs[2 * a3] * X2(ik, j + 2) + cs[2 * a4] * X2(ik, j + 3);
+                im += cs[2 * a1 + 1] * X2(ik, jc) + cs[2 * a2 + 1] * X2(ik, jc - 1) + cs[2 * a3 + 1] * X2(ik, jc - 2) + cs[2 * a4 + 1] * X2(ik, jc - 3);
+            }
+            for (; j + 1 < half; j += 2, jc -= 2) {
+                size_t a1 = ang + l; if (a1 >= ip) a1 -= ip;
+                size_t a2 = a1 + l; if (a2 >= ip) a2 -= ip;
+                ang = a2;
+                re += cs[2 * a1] * X2(ik, j) + cs[2 * a2] * X2(ik, j + 1);
+                im += cs[2 * a1 + 1] * X2(ik, jc) + cs[2 * a2 + 1] * X2(ik, jc - 1);
+            }
+            for (; j < half; ++j, --jc) {
+                ang += l; if (ang >= ip) ang -= ip;
+                re += cs[2 * ang] * X2(ik, j);
+                im += cs[2 * ang + 1] * X2(ik, jc);
+            }
+            Y2(ik, l) = re;
+            Y2(ik, lc) = im;
+        }
+    }
+    for (size_t ik = 0; ik < idl1; ++ik) {
+        double s = X2(ik, 0);
+        for (size_t j = 1; j < half; ++j) s += X2(ik, j);
+        Y2(ik, 0) = s;
+    }
+    /* sweep 3 */
+    for (size_t k = 0; k < l1; ++k)
+        for (size_t i = 0; i < ido; ++i) XO(i, 0, k) = Y1(i, k, 0);
+    for (size_t j = 1; j < half; ++j) {
+        const size_t jc = ip - j, j2 = 2 * j - 1;
+        for (size_t k = 0; k < l1; ++k) {
+            XO(ido - 1, j2, k) = Y1(0, k, j);
+            XO(0, j2 + 1, k) = Y1(0, k, jc);
+            for (size_t q = 0; q < nq; ++q) {
+                const size_t i = 1 + 2 * q, ic = ido - i - 2;
+                XO(i, j2 + 1, k) = Y1(i, k, j) + Y1(i, k, jc);
+                XO(ic, j2, k) = Y1(i, k, j) - Y1(i, k, jc);
+                XO(i + 1, j2 + 1, k) = Y1(i + 1, k, j) + Y1(i + 1, k, jc);
+                XO(ic + 1, j2, k) = Y1(i + 1, k, jc) - Y1(i + 1, k, j);
+            }
+        }
+    }
+#undef X1
+#undef X2
+#undef Y2
+#undef Y1
+#undef XO
+}
+
 /* in-place forward real FFT, FFTPACK half-complex output (pocketfft.c:1730-1764) */
 void orc_rfft_forward(const OrcRfftPlan *p, double *c, double *scratch)
 {
@@ -347,7 +535,8 @@ void orc_rfft_forward(const OrcRfftPlan *p, double *c, double *scratch)
         if (ip == 4) pass4(ido, l1, a, b, p->tw[k]);
         else if (ip == 2) pass2(ido, l1, a, b, p->tw[k]);
         else if (ip == 3) pass3(ido, l1, a, b, p->tw[k]);
-        else pass5(ido, l1, a, b, p->tw[k]);
+        else if (ip == 5) pass5(ido, l1, a, b, p->tw[k]);
+        else { passg(ido, ip, l1, a, b, p->tw[k], p->tws[k]); continue; }      /* (its result is in a) */
         double *t = a; a = b; b = t;
     }
     if (a != c) memcpy(c, a, n * sizeof(double));

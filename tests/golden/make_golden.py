@@ -10,7 +10,8 @@ with the repo, the reference sources do not.
                       feed-phase values, window and mel tables.
   fbank_frames.npz  : 40 single frames (random / extreme / silent PCM) -> 80 log-mel values each.
   fbank_nonpow2.npz : models with round_pow2 = 0 (the FFT length is the frame length): per geometry 24 single frames -> log-mel
-                      (400 = 4 4 5 5, 320 = 4 4 4 5, 480 = 2 4 4 3 5, 200 = 2 4 5 5 at 8 kHz, where the lowest of the 80 mel filters fall between FFT bins), and for the 400-point
+                      (400 = 4 4 5 5, 320 = 4 4 4 5, 480 = 2 4 4 3 5, 200 = 2 4 5 5 at 8 kHz, where the lowest of the 80 mel filters fall between FFT bins;
+                      882 = 2 3 3 7 7, 1102 = 2 19 29, 441 = 3 3 7 7, 220 = 4 5 11: pocketfft's generic pass, lengths that are not multiples of 4), and for the 400-point
                       one the whole online fbank on 1 s of the LCG recipe (feed chunks + both flush phases).
 """
 import os
@@ -31,7 +32,11 @@ def to_wave(pcm):
 
 # (name, RefFbank keywords, FFT length) of the round_pow2 = 0 geometries
 NONPOW2 = [("n400", dict(round_pow2=0), 400), ("n320", dict(round_pow2=0, len_ms=20), 320), ("n480", dict(round_pow2=0, len_ms=30), 480),
-           ("n200", dict(round_pow2=0, rate=8000), 200)]
+           ("n200", dict(round_pow2=0, rate=8000), 200),
+           # lengths with other factors (pocketfft's generic pass) and not multiples of 4 (the other two twiddle constructions):
+           # 882 = 2 3 3 7 7 (44.1 kHz / 20 ms), 1102 = 2 19 29 (44.1 kHz / 25 ms), 441 = 3 3 7 7 (odd), 220 = 4 5 11
+           ("n882", dict(round_pow2=0, rate=44100, len_ms=20), 882), ("n1102", dict(round_pow2=0, rate=44100), 1102),
+           ("n441", dict(round_pow2=0, rate=44100, len_ms=10), 441), ("n220", dict(round_pow2=0, rate=22050, len_ms=10), 220)]
 
 
 def run_ref(pcm, seg=3200, **kw):
@@ -79,7 +84,7 @@ def main():
     for name, kw, n in NONPOW2:
         shift = (kw.get("rate", 16000) // 100)
         frames = np.concatenate([rng.randint(-32768, 32768, size=(14, n)), rng.randint(-200, 200, size=(4, n)), np.zeros((1, n)),
-                                 np.full((1, n), -32768), np.full((1, n), 32767), np.tile(np.array([32767, -32768]), (1, n // 2)),
+                                 np.full((1, n), -32768), np.full((1, n), 32767), np.resize(np.array([32767, -32768]), n)[None],
                                  O.lcg_pcm16_fast(2 * n, seed=77).reshape(2, n)]).astype(np.int16)
         rows = []
         for f in frames:

@@ -75,9 +75,14 @@ def test_online_fbank_on_golden_lcg_10s(gm):
 
 # ------------------------------------------------------------------ round_pow2 = 0: the FFT length is the frame length
 # (src/fbank.c:135-138).  400 = 4 4 5 5, 320 = 4 4 4 5, 480 = 2 4 4 3 5, 200 = 2 4 5 5 (8 kHz): pocketfft's radix 3 / 5 passes and
-# radix 4 / 2 with an odd inner stride, on the device, against vectors generated from the reference's own fbank.c + pocketfft.c.
+# radix 4 / 2 with an odd inner stride, and (round 6) the generic pass for any other factor with all three twiddle constructions, on the
+# device, against vectors generated from the reference's own fbank.c + pocketfft.c.
 NONPOW2 = [("n400", dict(round_pow2=0), 400), ("n320", dict(round_pow2=0, length_ms=20), 320), ("n480", dict(round_pow2=0, length_ms=30), 480),
-           ("n200", dict(round_pow2=0, rate=8000), 200)]
+           ("n200", dict(round_pow2=0, rate=8000), 200),
+           # lengths with other factors (pocketfft's generic pass) and not multiples of 4 (the other two twiddle constructions):
+           # 882 = 2 3 3 7 7 (44.1 kHz / 20 ms), 1102 = 2 19 29 (44.1 kHz / 25 ms), 441 = 3 3 7 7 (odd), 220 = 4 5 11
+           ("n882", dict(round_pow2=0, rate=44100, length_ms=20), 882), ("n1102", dict(round_pow2=0, rate=44100), 1102),
+           ("n441", dict(round_pow2=0, rate=44100, length_ms=10), 441), ("n220", dict(round_pow2=0, rate=22050, length_ms=10), 220)]
 
 
 @pytest.fixture(scope="module")
@@ -124,5 +129,20 @@ def test_session_transcript_nonpow2_400(nonpow2_models, model_dir):
     got, lg1, n1 = run_gpu(nonpow2_models["n400"], pcm, 1600)
     om.close()
     assert n0 == n1
+    assert lg0.shape == lg1.shape and np.abs(lg0 - lg1).max() < 1e-3
+    assert_same_transcript(want, got)
+
+
+def test_session_transcript_nonpow2_882(nonpow2_models, model_dir):
+    """a 44.1 kHz model with 20 ms frames (882-point FFT = 2 3 3 7 7: the generic radix pass, the n mod 4 = 2 twiddle construction):
+    the whole path against the oracle session fed in 100 ms pieces of 4410 samples: the same chunk count, logits within 1e-3, the same callbacks"""
+    from oracle import orc_py as O
+    from test_gpu_parity import run_oracle, run_gpu, assert_same_transcript, speech_like_pcm
+    om = O.Model(str(model_dir / "tiny_n882.april"))
+    pcm = np.concatenate([speech_like_pcm(2.0, seed=16, rate=44100), np.zeros(44100, np.int16)])
+    want, lg0, n0 = run_oracle(om, pcm, 4410)
+    got, lg1, n1 = run_gpu(nonpow2_models["n882"], pcm, 4410)
+    om.close()
+    assert n0 == n1 and n0 > 40
     assert lg0.shape == lg1.shape and np.abs(lg0 - lg1).max() < 1e-3
     assert_same_transcript(want, got)

@@ -101,7 +101,11 @@ def test_other_geometry_against_reference(built):
 # ------------------------------------------------------------------ round_pow2 = 0: the FFT length is the frame length
 # (src/fbank.c:135-138; pocketfft's radix 3 and 5 passes, radix 4 / 2 with an odd inner stride)
 NONPOW2 = [("n400", dict(round_pow2=0), 400), ("n320", dict(round_pow2=0, len_ms=20), 320), ("n480", dict(round_pow2=0, len_ms=30), 480),
-           ("n200", dict(round_pow2=0, rate=8000), 200)]
+           ("n200", dict(round_pow2=0, rate=8000), 200),
+           # lengths with other factors (pocketfft's generic pass) and not multiples of 4 (the other two twiddle constructions):
+           # 882 = 2 3 3 7 7 (44.1 kHz / 20 ms), 1102 = 2 19 29 (44.1 kHz / 25 ms), 441 = 3 3 7 7 (odd), 220 = 4 5 11
+           ("n882", dict(round_pow2=0, rate=44100, len_ms=20), 882), ("n1102", dict(round_pow2=0, rate=44100), 1102),
+           ("n441", dict(round_pow2=0, rate=44100, len_ms=10), 441), ("n220", dict(round_pow2=0, rate=22050, len_ms=10), 220)]
 
 
 @pytest.mark.parametrize("name,kw,n", NONPOW2)
@@ -126,9 +130,14 @@ def test_golden_nonpow2_online_400(built):
 @pytest.mark.skipif(not O.ref_available(), reason="compiled reference (oracle/_ref) not present")
 @pytest.mark.parametrize("kw", [dict(round_pow2=0), dict(round_pow2=0, len_ms=20), dict(round_pow2=0, len_ms=30), dict(round_pow2=0, len_ms=10),
                                 dict(round_pow2=0, len_ms=15), dict(round_pow2=0, rate=8000, nbins=40), dict(round_pow2=0, rate=48000, nbins=80),
-                                dict(round_pow2=0, rate=8000, len_ms=30, nbins=23)])
+                                dict(round_pow2=0, rate=8000, len_ms=30, nbins=23),
+                                dict(round_pow2=0, rate=44100, len_ms=20), dict(round_pow2=0, rate=44100), dict(round_pow2=0, rate=44100, len_ms=10),
+                                dict(round_pow2=0, rate=22050, len_ms=10), dict(round_pow2=0, rate=22050), dict(round_pow2=0, rate=11025, nbins=40),
+                                dict(round_pow2=0, rate=32000, len_ms=11), dict(round_pow2=0, len_ms=13)])
 def test_nonpow2_against_compiled_reference(built, kw):
-    """FFT lengths 400, 320, 480, 160, 240, 200, 1200, 240 (8 kHz): every factor list of 4 / 2 / 3 / 5 that frame lengths produce."""
+    """FFT lengths 400, 320, 480, 160, 240, 200, 1200, 240 (8 kHz): every factor list of 4 / 2 / 3 / 5 that frame lengths produce; then
+    882 = 2 3 3 7 7, 1102 = 2 19 29, 441 = 3 3 7 7 (odd), 220 = 4 5 11, 551 = 19 29 (odd), 275 = 5 5 11 (odd), 352 = 2 4 4 11, 208 = 4 4 13:
+    pocketfft's generic pass and its three twiddle constructions (n mod 4 = 0, 2, odd)."""
     pcm = np.concatenate([O.lcg_pcm16_fast(20000, seed=5), np.zeros(1500, np.int16)])
     a = run(O.OrcFbank(**kw), pcm, 1600)
     b = run(O.RefFbank(**kw), pcm, 1600)
@@ -137,9 +146,18 @@ def test_nonpow2_against_compiled_reference(built, kw):
 
 
 def test_unsupported_fft_lengths_are_refused(built):
-    """a prime factor above 5 (pocketfft's generic pass) or a length that is not a multiple of 4: refused, not approximated"""
+    """lengths pocketfft hands to Bluestein's algorithm (a large prime factor: make_rfft_plan, pocketfft.c:2155-2182) are refused, not
+    approximated -- the compiled reference still runs them; lengths with small odd factors are accepted (generic radix pass)"""
     L = O.lib()
-    for kw in (dict(rate=22400, len_ms=25), dict(rate=16000, len_ms=13), dict(rate=44000, len_ms=21)):      # 560 = 2^4 5 7, 208 = 2^4 13, 924 = 2^2 3 7 11
+
+    def new(**kw):
         o = dict(O.APRILV0_FBANK); o.update(kw); o["round_pow2"] = 0
-        h = L.orc_fbank_new(o["rate"], o["shift_ms"], o["len_ms"], o["nbins"], 0, o["mel_lo"], o["mel_hi"], o["seg_count"], o["seg_step"])
-        assert not h
+        return L.orc_fbank_new(o["rate"], o["shift_ms"], o["len_ms"], o["nbins"], 0, o["mel_lo"], o["mel_hi"], o["seg_count"], o["seg_step"])
+    for kw in (dict(rate=40360, len_ms=25), dict(rate=80720, len_ms=25)):      # 1009 (prime), 2018 = 2 x 1009
+        assert not new(**kw)
+        if O.ref_available():
+            O.RefFbank(round_pow2=0, **kw)               # (the reference has a plan for them)
+    for kw in (dict(rate=22400, len_ms=25), dict(rate=16000, len_ms=13), dict(rate=44000, len_ms=21), dict(rate=20560, len_ms=25)):      # 560 = 2^4 5 7, 208 = 2^4 13, 924 = 2^2 3 7 11, 514 = 2 x 257 (pocketfft's cost model keeps the radix plan)
+        h = new(**kw)
+        assert h
+        L.orc_fbank_free(h)
