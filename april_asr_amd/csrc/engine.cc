@@ -167,6 +167,8 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
         }
     }
     search_stream_ = stream_;
+    HIP_CHECK(hipStreamCreateWithFlags(&pf_stream_, hipStreamNonBlocking));
+    for (hipEvent_t &e : pf_ev_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (int i = 0; i < 32; ++i) { hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); join_ev_.push_back(e); }
     {
         const char *e = getenv("APRIL_SPLIT_STREAMS");
@@ -241,6 +243,12 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
         const char *e = getenv("APRIL_F16_TILE");
         const bool want = cfg_.precision == 1 && !(e && *e && atoi(e) == 0);
         f16_tile_ = want && d.d_model % 128 == 0 && d.hidden % 128 == 0 && d.ffn % 128 == 0 && d.hidden % 16 == 0;
+        {   // weight prefetch from a side stream: MEASUREMENT FORM, off (APRIL_PREFETCH=1).  Measured round 6: configs[4] fp16 1.78 -> 2.5 ms
+            // per step, 256 sessions fp32 1.334 -> 2.10 ms -- the two cross-stream edges per launch inside the captured graph cost far
+            // more than the ~3 us of HBM latency a launch saves (tools/pp_bench `cold`)
+            const char *pe = getenv("APRIL_PREFETCH");
+            prefetch_ = pe && *pe && atoi(pe) != 0;
+        }
         if (f16_tile_) {
             kzx_hr_ = pick_kz(d.hidden, d.d_model, 32); kzx_ff2_ = pick_kz(d.ffn, d.d_model, 32);
             for (int p = 0; p < 2; ++p) y16_buf_[p] = dmalloc<uint16_t>(MB * d.d_model);
@@ -371,7 +379,7 @@ Engine::~Engine()
     for (auto &g : step_graphs_) (void)hipGraphExecDestroy(g.second);
     for (auto &g : lm_graphs_) (void)hipGraphExecDestroy(g.second);
     for (auto &g : lm_search_graphs_) (void)hipGraphExecDestroy(g.second);
-    for (auto &p : sw_plans_) { if (p.second.graph) (void)hipGraphExecDestroy(p.second.graph); for (hipGraphExec_t x : p.second.g3) if (x) (void)hipGraphExecDestroy(x); if (p.second.dev) (void)hipFree(p.second.dev); if (p.second.rdev) (void)hipFree(p.second.rdev); }
+    for (auto &p : sw_plans_) { if (p.second.graph) (void)hipGraphExecDestroy(p.second.graph); for (hipGraphExec_t x : p.second.g3) if (x) (void)hipGraphExecDestroy(x); if (p.second.dev) (void)hipFree(p.second.dev); if (p.second.rdev) (void)hipFree(p.second.rdev); if (p.second.pf_dev) (void)hipFree(p.second.pf_dev); }
     if (lm_stream_) { (void)hipStreamSynchronize(lm_stream_); (void)hipStreamDestroy(lm_stream_); }
     for (hipEvent_t e : lm_events_) (void)hipEventDestroy(e);
     if (zargs_h_) { (void)hipHostFree(zargs_h_); (void)hipFree(zargs_d_); }
@@ -395,7 +403,7 @@ Engine::~Engine()
     for (int b = 0; b < 2; ++b) if (fb_done_[b]) (void)hipEventDestroy(fb_done_[b]);
     for (int b = 0; b < 2; ++b) if (flight_done_[b]) (void)hipEventDestroy(flight_done_[b]);
     for (void *p : table_allocs_) (void)hipFree(p);
-    (void)hipStreamDestroy(stream_); (void)hipStreamDestroy(f_stream_); (void)hipStreamDestroy(s_stream_);
+    (void)hipStreamDestroy(stream_); (void)hipStreamDestroy(f_stream_); (void)hipStreamDestroy(s_stream_); if (pf_stream_) (void)hipStreamDestroy(pf_stream_); for (hipEvent_t e : pf_ev_) if (e) (void)hipEventDestroy(e);
 }
 
 void Engine::upload_tables(const FbankHostTables &ft)
@@ -1318,7 +1326,7 @@ Engine::SwPlan &Engine::sw_plan(int m, int T)
     if (sw_plans_.size() >= 64) {
         sync();
         HipLegacyLock evict_guard;                    // (see fbank())
-        for (auto &p : sw_plans_) { if (p.second.graph) (void)hipGraphExecDestroy(p.second.graph); for (hipGraphExec_t x : p.second.g3) if (x) (void)hipGraphExecDestroy(x); if (p.second.dev) (void)hipFree(p.second.dev); if (p.second.rdev) (void)hipFree(p.second.rdev); }
+        for (auto &p : sw_plans_) { if (p.second.graph) (void)hipGraphExecDestroy(p.second.graph); for (hipGraphExec_t x : p.second.g3) if (x) (void)hipGraphExecDestroy(x); if (p.second.dev) (void)hipFree(p.second.dev); if (p.second.rdev) (void)hipFree(p.second.rdev); if (p.second.pf_dev) (void)hipFree(p.second.pf_dev); }
         sw_plans_.clear();
     }
     SwPlan &p = sw_plans_[key];
@@ -1356,6 +1364,8 @@ Engine::SwPlan &Engine::sw_plan(int m, int T)
                 items.push_back(g);
             }
             SwPlan::Batch b; b.off = p.host.size(); b.n = (int)items.size(); b.macro = W; b.kind = kind; b.roff = p.rhost.size(); b.rn = (int)rows.size();
+            b.pf_off = p.pf_host.size(); b.pf_n = b.n;
+            for (const GemmArgs &g : items) { PrefetchItem pi; pi.ptr = g.wp; pi.bytes = (unsigned long long)g.N * (unsigned long long)g.K * (g.wt == 1 ? 2u : 4u); p.pf_host.push_back(pi); }
             p.host.resize(p.host.size() + items.size());
             stage_gemm_z(items.data(), b.n, p.host.data() + b.off);
             p.rhost.insert(p.rhost.end(), rows.begin(), rows.end());
@@ -1369,6 +1379,10 @@ Engine::SwPlan &Engine::sw_plan(int m, int T)
     if (!p.rhost.empty()) {
         p.rdev = dmalloc<RowArgs>(p.rhost.size());
         HIP_CHECK(hipMemcpyAsync(p.rdev, p.rhost.data(), p.rhost.size() * sizeof(RowArgs), hipMemcpyHostToDevice, stream_));
+    }
+    if (prefetch_ && !p.pf_host.empty()) {
+        p.pf_dev = dmalloc<PrefetchItem>(p.pf_host.size());
+        HIP_CHECK(hipMemcpyAsync(p.pf_dev, p.pf_host.data(), p.pf_host.size() * sizeof(PrefetchItem), hipMemcpyHostToDevice, stream_));
     }
     return p;
 }
@@ -1420,9 +1434,25 @@ void Engine::run_sw_chain(int m, int T, bool dump_logits, const SwPlan &p, int p
     }
     if (part < 0 || part == 1) {
         static const int cls_of[4] = {T_GATES, T_GEMM_OTHER, T_GEMM_OTHER, T_GEMM_OTHER};
-        for (const SwPlan::Batch &b : p.batches) {      // macro steps in order; inside one: gates, projection, FFN up, FFN down of the active layers
+        // weight prefetch (kernels.h launch_prefetch): while batch i runs, the side stream touches the weights of batch i + 1 -- released
+        // by an event in front of batch i, so it is never more than one launch ahead (the cache holds a few launches' weights, not a step's)
+        const bool pf = prefetch_ && p.pf_dev && !profiling_;
+        for (size_t bi = 0; bi < p.batches.size(); ++bi) {      // macro steps in order; inside one: gates, projection, FFN up, FFN down of the active layers
+            const SwPlan::Batch &b = p.batches[bi];
+            if (pf && bi + 1 < p.batches.size()) {
+                const SwPlan::Batch &nx = p.batches[bi + 1];
+                hipEvent_t e = pf_ev_[pf_pos_++ & 7];
+                HIP_CHECK(hipEventRecord(e, st));
+                HIP_CHECK(hipStreamWaitEvent(pf_stream_, e, 0));
+                launch_prefetch(p.pf_dev + nx.pf_off, nx.pf_n, pf_stream_);
+            }
             timed_begin(cls_of[b.kind]); launch_gemm_z(p.host.data() + b.off, b.n, p.dev + b.off, st); timed_end(cls_of[b.kind]);
             if (b.rn > 0) { timed_begin(T_ROW); launch_row_z(p.rhost.data() + b.roff, b.rn, p.rdev + b.roff, st); timed_end(T_ROW); }
+        }
+        if (pf && p.batches.size() > 1) {
+            hipEvent_t e = pf_ev_[pf_pos_++ & 7];
+            HIP_CHECK(hipEventRecord(e, pf_stream_));
+            HIP_CHECK(hipStreamWaitEvent(st, e, 0));
         }
         if (part < 0) lm_stage_proj(m, 0, T, st);
     }

@@ -189,10 +189,11 @@ private:
     void run_lm_chain(int m, int T, bool dump_logits);
     void run_lm_wavefront(int m, int T, bool dump_logits);
     struct SwPlan {                          // argument blocks + launch list of run_sw_chain for one (m, T), and its captured graph
-        struct Batch { size_t off; int n, macro, kind; size_t roff; int rn; };      // rn > 0: the GEMMs write partial planes, rn row problems finish them
+        struct Batch { size_t off; int n, macro, kind; size_t roff; int rn; size_t pf_off = 0; int pf_n = 0; };      // rn > 0: the GEMMs write partial planes, rn row problems finish them
         std::vector<GemmArgs> host; GemmArgs *dev = nullptr; std::vector<Batch> batches; hipGraphExec_t graph = nullptr; int uses = 0;
         hipGraphExec_t g3[3] = {nullptr, nullptr, nullptr};                      // split feed: front end / layers / search, one graph per stream
         std::vector<RowArgs> rhost; RowArgs *rdev = nullptr;
+        std::vector<PrefetchItem> pf_host; PrefetchItem *pf_dev = nullptr;      // weight regions of every batch (launch_prefetch of the batch AFTER the one that runs)
         std::vector<std::pair<int, long>> stamp_slots; std::vector<int> stamp_n;  // gates clock: (slot, rows) and problem count of every gates launch of a plan built while it was on
     };
     SwPlan &sw_plan(int m, int T);
@@ -254,6 +255,7 @@ private:
     bool flight_open_[2] = {false, false};     // flight_done_[p] has been recorded and not yet waited for by begin_flight (wait_flight leaves it set: waiting twice is free)
     // streams (engine.cc "streams"): front end / search beside the layer chain, the per-parity buffers that make it safe
     hipStream_t f_stream_ = nullptr, s_stream_ = nullptr, search_stream_ = nullptr;
+    hipStream_t pf_stream_ = nullptr; bool prefetch_ = false; hipEvent_t pf_ev_[8] = {}; unsigned pf_pos_ = 0;      // weight prefetch beside the layer launches (kernels.h launch_prefetch)
     std::vector<hipEvent_t> join_ev_; size_t join_pos_ = 0;
     bool f_unseen_by_m_ = false, s_unseen_by_m_ = false, m_unseen_by_f_ = false, m_unseen_by_s_ = false, flight_tail_s_ = false;
     bool overlap_hint_ = false;

@@ -333,6 +333,16 @@ void launch_conv_embed(const ConvEmbedArgs &a, hipStream_t s);
 
 // fp32 -> fp16 (round to nearest even), elementwise; used once at load for the fp16 weight copies
 void launch_cvt_f16(const float *src, void *dst, size_t n, hipStream_t s);
+
+// Weight prefetch into the memory-side cache (round 6).  The layer weights of a model do not fit the 256 MB Infinity Cache (aprilv0 fp32:
+// 0.33 GB, the larger encoder in binary16: 0.5 GB), so every launch of a step streams its weights from HBM and starts with the
+// latency of that (tools/pp_bench `cold`: +3 .. 4 us per launch against weights the launch before left behind).  launch_prefetch
+// reads one dword of every 128-byte line of n regions -- the NEXT launch's weights -- from a side stream while the current launch
+// computes: HBM is idle then (a launch's weights are in after its first third), the lines land in the memory-side cache, and the
+// next launch's first DMA stages arrive at cache latency.  No data dependency: a hint, joined only to close the graph capture.
+// MEASURED AND NOT KEPT (engine.cc, APRIL_PREFETCH=1): the cross-stream edges it needs inside the captured graph cost more than it saves.
+struct PrefetchItem { const void *ptr = nullptr; unsigned long long bytes = 0; };
+void launch_prefetch(const PrefetchItem *dev_items, int n, hipStream_t s);
 // fp32 packed weights (16-k blocks, kernels.h top) -> binary16 in the order of v_mfma_f32_16x16x32_f16's B fragment:
 //   dst[((ntile * (K / 32) + kb) * 64 + lane) * 8 + j] = W[kb * 32 + (lane >> 4) * 8 + j][ntile * 16 + (lane & 15)]
 // (one 16-byte read per lane and 32-k block; K a multiple of 32)

@@ -432,6 +432,23 @@ __global__ __launch_bounds__(256) void cvt_f16_kernel(const float *src, _Float16
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = (_Float16)src[i];
 }
 
+__global__ __launch_bounds__(256) void prefetch_kernel(const PrefetchItem *__restrict__ items)
+{
+    const PrefetchItem it = items[blockIdx.y];
+    const unsigned long long lines = it.bytes >> 7;
+    const char *p = reinterpret_cast<const char *>(it.ptr);
+    unsigned acc = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < lines; i += (unsigned long long)gridDim.x * 256)
+        acc ^= *reinterpret_cast<const volatile unsigned *>(p + (i << 7));
+    asm volatile("" :: "v"(acc));
+}
+
+void launch_prefetch(const PrefetchItem *dev_items, int n, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(prefetch_kernel, dim3(48, (unsigned)n), dim3(256), 0, s, dev_items);
+}
+
 void launch_cvt_f16(const float *src, void *dst, size_t n, hipStream_t s)
 {
     const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
