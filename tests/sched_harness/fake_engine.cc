@@ -251,6 +251,7 @@ void Engine::end_flight() { wait_flight(close_flight()); }
 void Engine::sync() {}
 void Engine::sync_streams() {}
 void Engine::set_profiling(bool on) { profiling_ = on; }
+void Engine::set_gates_clock(bool on) { gclk_ = on; }
 void Engine::reset_timing() {}
 void Engine::read_ring(int, int, int n_rows, float *out) { memset(out, 0, (size_t)n_rows * L_.dims.mel * sizeof(float)); }
 void Engine::read_greedy_state(int slot, GreedyState *out)
