@@ -69,7 +69,7 @@ template <class T> __device__ __forceinline__ __attribute__((address_space(1))) 
 template <int N> using ic = std::integral_constant<int, N>;
 __device__ __forceinline__ int seg_swz(int rq) { return (0x78 >> (2 * rq)) & 3; }      // f of the LDS image: 0, 2, 3, 1
 
-template <int EPI>
+template <int EPI, int DEF>
 __device__ __forceinline__ void gemm_pw_body(const GemmArgs &g)
 {
     using G = PWGeom;
@@ -251,10 +251,24 @@ __device__ __forceinline__ void gemm_pw_body(const GemmArgs &g)
     // One k block of one group: load phase | barrier | compute phase | barrier.  AH0 / AH1: the k blocks of this wave's pieces that may
     // stay in flight behind group 0's wait (end of the load phase: k block j + 1 landed) / group 1's (end of the compute phase: k block
     // j + 2 landed); EX: other loads in flight among them (the cell prefetch, during the first k blocks)
-    constexpr int NM = MTW * NTW, NR = MTW + NTW;
-    auto kblock = [&](const bool do_issue, auto ah0, auto ah1, auto ex0, auto ex1, f32x4 (&fa)[MTW], f32x4 (&fb)[NTW], f32x4 (&fan)[MTW], f32x4 (&fbn)[NTW]) {
+    constexpr int NR = MTW + NTW;
+    // DEF (0 = the product, 2 = measurement form, see launch_gemm_pw) rows of a wave's 4 x 6 MFMA tiles are DEFERRED: their MFMAs of k block j
+    // issue in the load phase of k block j + 1 (the fragments of k block j are still in their register set: the reads of k block j + 2
+    // that overwrite it issue behind the barrier that ends that load phase), so both waves of a SIMD issue MFMAs in every phase.  The
+    // chain of every accumulator keeps its k order.  Measured: no gain.
+    constexpr int MC = MTW - DEF;                          // rows whose MFMAs stay in the compute phase
+    auto deferred = [&](f32x4 (&fa)[MTW], f32x4 (&fb)[NTW]) {
+#pragma unroll
+        for (int mt = MC; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, fa[mt]), __builtin_bit_cast(h8, fb[nt]), acc[mt][nt], 0, 0, 0);
+    };
+    auto kblock = [&](const bool do_issue, auto first, auto ah0, auto ah1, auto ex0, auto ex1, f32x4 (&fa)[MTW], f32x4 (&fb)[NTW], f32x4 (&fan)[MTW], f32x4 (&fbn)[NTW]) {
         constexpr int AH0 = decltype(ah0)::value, AH1 = decltype(ah1)::value, EX0 = decltype(ex0)::value, EX1 = decltype(ex1)::value;
         if (do_issue) issue_kb(ib);
+        if constexpr (DEF > 0 && !decltype(first)::value) deferred(fan, fbn);      // (the set that was current one k block ago)
+        __builtin_amdgcn_sched_barrier(0);
         if (grp == 0) wait_vm<AH0 * 4 + EX0>();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -263,14 +277,16 @@ __device__ __forceinline__ void gemm_pw_body(const GemmArgs &g)
         // (the reads are unconditional -- behind the last k block they fetch a buffer nobody needs -- so that the phase is ONE scheduling region)
         read_frags(lds + rb * KBB, fan, fbn);
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt)
+        for (int mt = 0; mt < MC; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, fa[mt]), __builtin_bit_cast(h8, fb[nt]), acc[mt][nt], 0, 0, 0);
-        // issue order: MFMA, MFMA, read, ... (every accumulator takes one MFMA per k block: their order is free)
+        // issue order: MFMA(s), read, ... (every accumulator takes one MFMA per k block: their order is free)
+        constexpr int NMC = MC * NTW, PER = NMC >= 2 * NR ? 2 : 1, NI = NMC / PER < NR ? NMC / PER : NR;
 #pragma unroll
-        for (int i = 0; i < NR; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-        __builtin_amdgcn_sched_group_barrier(0x008, NM - 2 * NR, 0);
+        for (int i = 0; i < NI; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, PER, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        if constexpr (NMC > PER * NI) __builtin_amdgcn_sched_group_barrier(0x008, NMC - PER * NI, 0);
+        if constexpr (NR > NI) __builtin_amdgcn_sched_group_barrier(0x100, NR - NI, 0);
         __builtin_amdgcn_sched_barrier(0);                 // (the MFMAs stay IN FRONT of the wait: they do not depend on the reads in flight)
         wait_lgkm0();                                      // the fragments of k block j + 1 are in (and this wave's reads of their buffer are done)
         if (grp == 1) wait_vm<AH1 * 3 + EX1>();
@@ -281,21 +297,23 @@ __device__ __forceinline__ void gemm_pw_body(const GemmArgs &g)
         rb = rb == NB - 1 ? 0 : rb + 1;
         ib = ib == NB - 1 ? 0 : ib + 1;
     };
+    using T1 = std::true_type; using F0 = std::false_type;
     // k blocks 0 .. 3: the cell prefetch sits between k block 3 and k block 4 in the memory pipe.  Group 0's wait in L_j lets k blocks
     // j + 2 .. j + 4 stay out (j = 0, 1, 2: the prefetch is among them), group 1's in C_j k blocks j + 3, j + 4 (j = 0, 1).
-    kblock(true, ic<3>{}, ic<2>{}, ic<CPV>{}, ic<CPV>{}, fa0, fb0, fa1, fb1);
-    kblock(true, ic<3>{}, ic<2>{}, ic<CPV>{}, ic<CPV>{}, fa1, fb1, fa0, fb0);
-    kblock(true, ic<3>{}, ic<2>{}, ic<CPV>{}, ic<0>{}, fa0, fb0, fa1, fb1);
-    kblock(true, ic<3>{}, ic<2>{}, ic<0>{}, ic<0>{}, fa1, fb1, fa0, fb0);
+    kblock(true, T1{}, ic<3>{}, ic<2>{}, ic<CPV>{}, ic<CPV>{}, fa0, fb0, fa1, fb1);
+    kblock(true, F0{}, ic<3>{}, ic<2>{}, ic<CPV>{}, ic<CPV>{}, fa1, fb1, fa0, fb0);
+    kblock(true, F0{}, ic<3>{}, ic<2>{}, ic<CPV>{}, ic<0>{}, fa0, fb0, fa1, fb1);
+    kblock(true, F0{}, ic<3>{}, ic<2>{}, ic<0>{}, ic<0>{}, fa1, fb1, fa0, fb0);
     for (int j = 4; j + 4 < KB; j += 2) {
-        kblock(true, ic<3>{}, ic<2>{}, ic<0>{}, ic<0>{}, fa0, fb0, fa1, fb1);
-        kblock(true, ic<3>{}, ic<2>{}, ic<0>{}, ic<0>{}, fa1, fb1, fa0, fb0);
+        kblock(true, F0{}, ic<3>{}, ic<2>{}, ic<0>{}, ic<0>{}, fa0, fb0, fa1, fb1);
+        kblock(true, F0{}, ic<3>{}, ic<2>{}, ic<0>{}, ic<0>{}, fa1, fb1, fa0, fb0);
     }
     // the last four k blocks issue nothing: what may stay in flight shrinks
-    kblock(false, ic<2>{}, ic<1>{}, ic<0>{}, ic<0>{}, fa0, fb0, fa1, fb1);      // j = KB - 4: group 0 needs KB - 3 (KB - 2, KB - 1 out), group 1 KB - 2 (KB - 1 out)
-    kblock(false, ic<1>{}, ic<0>{}, ic<0>{}, ic<0>{}, fa1, fb1, fa0, fb0);
-    kblock(false, ic<0>{}, ic<0>{}, ic<0>{}, ic<0>{}, fa0, fb0, fa1, fb1);
-    kblock(false, ic<0>{}, ic<0>{}, ic<0>{}, ic<0>{}, fa1, fb1, fa0, fb0);
+    kblock(false, F0{}, ic<2>{}, ic<1>{}, ic<0>{}, ic<0>{}, fa0, fb0, fa1, fb1);      // j = KB - 4: group 0 needs KB - 3 (KB - 2, KB - 1 out), group 1 KB - 2 (KB - 1 out)
+    kblock(false, F0{}, ic<1>{}, ic<0>{}, ic<0>{}, ic<0>{}, fa1, fb1, fa0, fb0);
+    kblock(false, F0{}, ic<0>{}, ic<0>{}, ic<0>{}, ic<0>{}, fa0, fb0, fa1, fb1);
+    kblock(false, F0{}, ic<0>{}, ic<0>{}, ic<0>{}, ic<0>{}, fa1, fb1, fa0, fb0);
+    if constexpr (DEF > 0) deferred(fa1, fb1);             // the deferred rows of the last k block
     if (grp == 0) __builtin_amdgcn_s_barrier();
     if (jkb == scale_at) apply_scale();
 
@@ -355,25 +373,25 @@ __device__ __forceinline__ void gemm_pw_body(const GemmArgs &g)
     }
 }
 
-template <int EPI>
+template <int EPI, int DEF>
 __global__ __launch_bounds__(512, 1) void gemm_pw_kernel(GemmArgs g)
 {
     if constexpr (EPI == EPI_LSTM) stamp_begin(g.stamp, (blockIdx.x | blockIdx.y | blockIdx.z) == 0);
-    gemm_pw_body<EPI>(g);
+    gemm_pw_body<EPI, DEF>(g);
     if constexpr (EPI == EPI_LSTM) stamp_end(g.stamp, gridDim.x * gridDim.y * gridDim.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
 }
 
 // n independent same-shape problems in one launch (see gemm_f32_zkernel): blockIdx.z picks the argument block
-template <int EPI>
+template <int EPI, int DEF>
 __global__ __launch_bounds__(512, 1) void gemm_pw_zkernel(const GemmArgs *__restrict__ zargs)
 {
     const GemmArgs g = zargs[blockIdx.z];
     if constexpr (EPI == EPI_LSTM) stamp_begin(g.stamp, (blockIdx.x | blockIdx.y | blockIdx.z) == 0);
-    gemm_pw_body<EPI>(g);
+    gemm_pw_body<EPI, DEF>(g);
     if constexpr (EPI == EPI_LSTM) stamp_end(g.stamp, gridDim.x * gridDim.y * gridDim.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
 }
 
-template <int EPI>
+template <int EPI, int DEF>
 void launch_pw_one(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s)
 {
     using G = PWGeom;
@@ -384,12 +402,12 @@ void launch_pw_one(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream
     (void)hipGetDevice(&dev);
     const uint64_t bit = 1ull << (dev & 63);
     if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_pw_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_pw_zkernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_pw_kernel<EPI, DEF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_pw_zkernel<EPI, DEF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_devs.fetch_or(bit, std::memory_order_release);
     }
-    if (dev_args) APRIL_LAUNCH((gemm_pw_zkernel<EPI>), grid, dim3(G::NTH), (size_t)G::LDS_BYTES, s, dev_args);
-    else APRIL_LAUNCH((gemm_pw_kernel<EPI>), grid, dim3(G::NTH), (size_t)G::LDS_BYTES, s, g);
+    if (dev_args) APRIL_LAUNCH((gemm_pw_zkernel<EPI, DEF>), grid, dim3(G::NTH), (size_t)G::LDS_BYTES, s, dev_args);
+    else APRIL_LAUNCH((gemm_pw_kernel<EPI, DEF>), grid, dim3(G::NTH), (size_t)G::LDS_BYTES, s, g);
 }
 
 }  // namespace
@@ -413,8 +431,18 @@ bool gemm_pw_ok(const GemmArgs &g)
 void launch_gemm_pw(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s)
 {
     if (!gemm_pw_ok(g)) { fprintf(stderr, "libapril(mi355x): launch_gemm_pw: no kernel for epi %d (wt %d kz %d N %d K %d)\n", g.epi, g.wt, g.kz, g.N, g.K); abort(); }
-    if (g.epi == EPI_LSTM) launch_pw_one<EPI_LSTM>(g, dev_args, n, s);
-    else launch_pw_one<EPI_BIAS_DSWISH>(g, dev_args, n, s);
+    // APRIL_PW_DEFER=2: MEASUREMENT FORM (off).  Half of a wave's MFMAs of k block j issue in the load phase of k block j + 1, so that both
+    // waves of a SIMD feed the matrix pipe in every phase (two waves sustain 0.87 of it, one 0.73: tools/mfma_peak).  Bit-identical; measured
+    // 36.1 / 37.4 / 41.2 us against 35.6 / 36.6 / 39.7 (gates, 512 rows x 1 / 2 / 3): no gain -- the phases are not set by the issue rate
+    // of a lone wave (deferring one row of four: 39.9 / 41.5 / 44.5, with spills)
+    static const int defer = [] { const char *e = getenv("APRIL_PW_DEFER"); return e && *e && atoi(e) == 2 ? 2 : 0; }();
+    if (g.epi == EPI_LSTM) {
+        if (defer == 2) launch_pw_one<EPI_LSTM, 2>(g, dev_args, n, s);
+        else launch_pw_one<EPI_LSTM, 0>(g, dev_args, n, s);
+    } else {
+        if (defer == 2) launch_pw_one<EPI_BIAS_DSWISH, 2>(g, dev_args, n, s);
+        else launch_pw_one<EPI_BIAS_DSWISH, 0>(g, dev_args, n, s);
+    }
 }
 
 }  // namespace aprilx

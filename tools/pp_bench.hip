@@ -259,6 +259,9 @@ int main(int argc, char **argv)
         // what GM_PP would do there, and how a launch splits into per-tile fixed time and K-proportional time
         for (int n = 1; n <= 3; ++n) run_case("probe N768 K1536 (proj)", 512, 1536, 768, 1, n, s, iters);
         for (int n = 1; n <= 3; ++n) run_case("probe N768 K3072 (ffn-down)", 512, 3072, 768, 1, n, s, iters);
+        // what a 2-way K split of the N = d_model GEMMs on 128 x 128 ping-pong tiles would cost before its reduction: twice the workgroups, half the K
+        for (int n = 2; n <= 3; ++n) run_case("probe N768 K768 1024 rows", 1024, 768, 768, 1, n, s, iters);
+        for (int n = 2; n <= 3; ++n) run_case("probe N768 K1536 1024 rows", 1024, 1536, 768, 1, n, s, iters);
         run_case("probe gates K 1536", 512, 768, 1536, 0, 1, s, iters);
         run_case("probe gates K 3072", 512, 1536, 1536, 0, 1, s, iters);
         run_case("probe gates K 1536 x2", 512, 768, 1536, 0, 2, s, iters);
