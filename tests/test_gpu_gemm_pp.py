@@ -39,6 +39,18 @@ def test_pp_bench_every_output_bitwise(built):
     assert out.count(" same") >= 80 and "DIFF" not in out and "MISMATCH" not in r.stderr.decode()
 
 
+def test_pp_bench_stress_no_timing_dependence(built):
+    """every ping-pong form 120 times, every other run beside a 512 MB device copy (the DMA pieces land late and out of their usual
+    order): the bits of the GM_TILE form every time.  (The first 256 x 192 kernel read k block 1 before one group's pieces of it had
+    been waited for -- right in a quiet benchmark, wrong inside the engine.)"""
+    exe = os.path.join(ROOT, "tools", "pp_bench")
+    if not os.path.exists(exe):
+        subprocess.check_call(["bash", os.path.join(ROOT, "tools", "build_pp_bench.sh")], timeout=900)
+    r = subprocess.run([exe, "120", "stress"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and out.count("all same") == 7 and "DIFF" not in out, out[-2000:] + r.stderr.decode()[-1000:]
+
+
 @pytest.mark.parametrize("nsess", [96, 300])
 def test_pp_schedule_is_bit_identical_on_whole_f16_sessions(built, v0_model, nsess):
     path = v0_model["path"]

@@ -747,6 +747,41 @@ def test_config5_larger_encoder_512_sessions(large_model):
     gm.close(); om.close()
 
 
+def test_config4_2048_sessions_aprilv0_dims(v0_model):
+    """BASELINE configs[3]: 2048 concurrent sessions at aprilv0 dimensions (12 x {512, 1024, 2048}) -- the whole node's session count
+    on the ONE GPU of a test box, in 100 ms feeds (feeds of 2 / 3 chunk steps = 4096 / 6144 rows per wavefront, the GM_TILE schedules of
+    the gates / projection / FFN GEMMs).  Session 0 against the CPU oracle (token-exact, logits within 1e-3); sessions 1, 1000 and 2047
+    against themselves stepped alone (bit-identical: batch invariance across every GEMM schedule the row counts select)."""
+    import april_asr_amd as A
+    from oracle import orc_py as O
+    gm = A.Model(v0_model["path"]); om = O.Model(v0_model["path"])
+    d = gm.dims
+    assert (d.n_layers, d.d_model, d.hidden, d.ffn) == (12, 512, 1024, 2048)
+    n, secs = 2048, 0.6
+    pcms = [speech_like_pcm(secs, seed=41)] + [O.lcg_pcm16_fast(int(16000 * secs), seed=900 + i) for i in range(1, n)]
+    evs = [[] for _ in range(n)]
+    sess = [A.Session(gm, (lambda k: (lambda t, toks: evs[k].append((t, toks))))(i), raw_events=True) for i in range(n)]
+    probe = (0, 1, 1000, n - 1)
+    for i in probe:
+        sess[i].trace_logits(200)
+    grp = A.SessionGroup(sess)
+    for o in range(0, int(16000 * secs), 1600):
+        grp.feed([p[o:o + 1600] for p in pcms])
+    grp.flush()
+    assert gm.stats().max_batch_seen == n and gm.stats().replay_mismatch == 0
+    want, lg0, n0 = run_oracle(om, pcms[0], 1600)
+    assert sess[0].chunks() == n0
+    lg = sess[0].traced_logits()
+    assert lg.shape == lg0.shape and np.abs(lg - lg0).max() < 1e-3, np.abs(lg - lg0).max()
+    assert_same_transcript(want, evs[0])
+    for i in probe[1:]:
+        ev1, lg1, _ = run_gpu(gm, pcms[i], 1600)
+        assert np.array_equal(lg1, sess[i].traced_logits()) and ev1 == evs[i]
+    for s in sess:
+        s.close()
+    gm.close(); om.close()
+
+
 def test_2048_sessions_one_gpu(gpu_tiny):
     """BASELINE configs[3]'s session count on ONE GPU (tiny dimensions so that it runs in seconds): 2048 concurrent
     sessions advance in shared steps of 2048 rows; sampled sessions are bit-identical to themselves stepped alone (size-independent property:

@@ -232,6 +232,42 @@ static void run_cold_case(const char *name, int M, int d, int hidden, int kind, 
     }
 }
 
+// timing-race check: the same launch again and again while a second stream streams 512 MB copies through HBM (the DMA pieces of the
+// ping-pong tiles then land late and in a different order from run to run); every run must give the bits of the GM_TILE form
+static void run_stress(const char *name, int M, int d, int hidden, int kind, int n, int mt, hipStream_t s, int runs)
+{
+    std::vector<Problem> ps;
+    for (int i = 0; i < n; ++i) ps.push_back(make_problem(M, d, hidden, kind));
+    gemm_pp_pin(0, 0);
+    Chain ref_chain = make_chain(ps);
+    reset(ps); ref_chain.run(s); CK(hipStreamSynchronize(s));
+    const std::vector<unsigned char> ref = snapshot(ps);
+    gemm_pp_pin(1, mt);
+    Chain c = make_chain(ps);
+    hipStream_t hog; CK(hipStreamCreate(&hog));
+    char *ha = dalloc<char>((size_t)512 << 20), *hb = dalloc<char>((size_t)512 << 20);
+    int bad = 0;
+    for (int r = 0; r < runs; ++r) {
+        reset(ps);
+        if (r & 1) CK(hipMemcpyAsync(hb, ha, (size_t)512 << 20, hipMemcpyDeviceToDevice, hog));      // every other run beside a copy
+        c.run(s); CK(hipStreamSynchronize(s));
+        const std::vector<unsigned char> got = snapshot(ps);
+        if (got.size() != ref.size() || memcmp(got.data(), ref.data(), ref.size()) != 0) ++bad;
+        CK(hipStreamSynchronize(hog));
+    }
+    gemm_pp_pin(-1, 0);
+    if (bad) { ++g_fail; fprintf(stderr, "MISMATCH %s: %d of %d runs differ from the GM_TILE form\n", name, bad, runs); }
+    printf("%-28s M %5d x %d  form mt=%2d: %d runs, half of them beside a 512 MB device copy: %s\n", name, M, n, mt, runs, bad ? "DIFF" : "all same");
+    fflush(stdout);
+    CK(hipFree(ha)); CK(hipFree(hb)); CK(hipStreamDestroy(hog));
+    if (c.gd) CK(hipFree(c.gd));
+    if (ref_chain.gd) CK(hipFree(ref_chain.gd));
+    for (const Problem &p : ps) {
+        CK(hipFree(p.y16)); CK(hipFree(p.h16)); CK(hipFree(p.w16)); CK(hipFree(p.out16)); CK(hipFree(p.ssq)); CK(hipFree(p.bias));
+        CK(hipFree(p.c_state)); CK(hipFree(p.c_init)); CK(hipFree(p.p_out)); CK(hipFree(p.p_in)); CK(hipFree(p.slots));
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int iters = argc > 1 ? atoi(argv[1]) : 200;
@@ -249,6 +285,15 @@ int main(int argc, char **argv)
         run_case("large lstm h-half", 512, 768, 1536, 3, 1, s, iters);
         run_case("large ffn-up 1536 rows", 1536, 768, 3072, 1, 1, s, iters);
         run_case("large gates 100 rows", 100, 768, 1536, 0, 3, s, iters);
+    }
+    if (dims == "stress") {
+        run_stress("large gates", 512, 768, 1536, 0, 3, 12, s, iters);
+        run_stress("large gates", 437, 768, 1536, 0, 2, 12, s, iters);
+        run_stress("large gates", 512, 768, 1536, 0, 2, 16, s, iters);
+        run_stress("large gates", 512, 768, 1536, 0, 1, 8, s, iters);
+        run_stress("large ffn-up", 512, 768, 3072, 1, 3, 12, s, iters);
+        run_stress("large ffn-up", 512, 768, 3072, 1, 3, 16, s, iters);
+        run_stress("v0 gates", 1024, 512, 1024, 0, 2, 16, s, iters);
     }
     if (dims == "cold") {
         for (int n = 1; n <= 3; ++n) run_cold_case("large gates", 512, 768, 1536, 0, n, 24 / n, s, iters);
