@@ -513,6 +513,48 @@ def main():
     for s in sess:
         s.close()
 
+    # ---------------- what a client of the reference's 12 symbols alone gets (never `value`): the same number of sessions created with
+    # APRIL_CONFIG_FLAG_ASYNC_NO_RT and fed one after the other with aas_feed_pcm16 from ONE client thread (100 ms each, as fast as the
+    # calls return); the library's stepping thread gathers whatever sessions have audio queued into its ticks.  Two seconds of audio are
+    # handed over per block (an asynchronous session queues at most three, src/audio_provider.c:31), then the client waits for the block
+    # (aprilx_session_drain: the only call here that is not one of the 12 symbols -- the reference client would wait for its callbacks).
+    ref_api = None
+    if rank == 0 and world == 1 and not args.no_sweep:
+        try:
+            cnt_a = np.zeros(6, np.uint64)
+            sa = [A.Session(model, None, asynchronous=True, no_rt=True, counters=cnt_a) for _ in range(B)]
+            blocks, per_block = 3, 20
+            pa = pcm_for(B, (blocks + 1) * per_block, 70_000_000)
+            Lf = model._L
+            hs = [s_._handle for s_ in sa]
+            ptrs = [[int(p.ctypes.data) + 2 * step_samples * k for p in pa] for k in range((blocks + 1) * per_block)]
+
+            def feed_block(b0):
+                for k in range(b0 * per_block, (b0 + 1) * per_block):
+                    pk = ptrs[k]
+                    for i in range(B):
+                        Lf.aas_feed_pcm16(hs[i], pk[i], step_samples)
+                for s_ in sa:
+                    s_.drain()
+            feed_block(0)                                   # (launch chains of the tick shapes are captured here)
+            before_a = model.stats()
+            a = time.perf_counter()
+            for b0 in range(1, blocks + 1):
+                feed_block(b0)
+            el_a = time.perf_counter() - a
+            after_a = model.stats()
+            nst = blocks * per_block
+            ref_api = {"sessions": B, "steps": nst, "ms_per_step": round(el_a / nst * 1e3, 3), "rtf": round(el_a / (nst * 0.1), 5),
+                       "audio_s_per_s": round(B * nst * 0.1 / el_a, 1), "ticks": int(after_a.ticks - before_a.ticks),
+                       "cant_keep_up": int(cnt_a[3]),
+                       "what": "%d asynchronous sessions (APRIL_CONFIG_FLAG_ASYNC_NO_RT) fed by aas_feed_pcm16 alone from one Python thread, 100 ms per call, "
+                               "%d s of audio per session between waits; the library batches whatever is queued (`ticks` = GPU flights it took); includes "
+                               "the client's %d ctypes calls per step" % (B, per_block // 10, B)}
+            for s_ in sa:
+                s_.close()
+        except Exception as e:
+            ref_api = {"error": repr(e)}
+
     # ---------------- concurrency sweep (outside the timed region): RTF at other batch sizes
     sweep = None
     if rank == 0 and world == 1 and not args.no_sweep:          # single-GPU runs only (the driver computes scaling from per-N values)
@@ -664,7 +706,7 @@ def main():
             "ingest": {"mode": args.ingest, "depth": args.pipeline_depth if args.ingest == "pipelined" else 1, "what": "aprilx_feed_many_pipelined, depth 2 by default: feed k + 1 is queued (samples copied) while feed k is on the GPU, every callback "
                                                      "of the K timed feeds is delivered inside the timed region (drain before the closing barrier)"
                        if args.ingest == "pipelined" else "aprilx_feed_many: one blocking call per feed"},
-            "other_ingest": other_ingest, "deeper_pipeline": deeper, "steady": steady, "config5_f16": config5,
+            "other_ingest": other_ingest, "reference_api_async": ref_api, "deeper_pipeline": deeper, "steady": steady, "config5_f16": config5,
             "rccl_fallback": rccl_fallback, "rccl_libs_mapped": sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln}),
             "per_rank": per_rank,
             # the duration of the feed CALL: in lockstep mode that is the latency of a feed (the call returns with every callback
