@@ -14,7 +14,7 @@ for f in april_api engine session model_loader onnx_reader fbank_tables; do
 done
 $HIPCC -std=c++17 -O1 -g -fsanitize=thread -I$C -c tests/sched_harness/driver.cc -o $O/driver.o
 $HIPCC --offload-arch=gfx950 -fsanitize=thread $O/april_api.o $O/engine.o $O/session.o $O/model_loader.o $O/onnx_reader.o $O/fbank_tables.o $O/driver.o \
-  $C/build/kernels_gemm.o $C/build/kernels_gemm_tile.o $C/build/kernels_gemm_kw.o $C/build/kernels_recur.o $C/build/kernels_misc.o $C/build/kernels_fbank.o \
+  $C/build/kernels_gemm.o $C/build/kernels_gemm_tile.o $C/build/kernels_gemm_pp.o $C/build/kernels_gemm_pw.o $C/build/kernels_gemm_kw.o $C/build/kernels_recur.o $C/build/kernels_misc.o $C/build/kernels_fbank.o \
   -L/opt/rocm/lib -lrccl -lpthread -o tools/tsan_gpu_driver 2>&1 | grep -v "not currently supported" || true
 # the same under AddressSanitizer + UBSan
 A=${TMPDIR:-/tmp}/asan_objs
@@ -24,6 +24,6 @@ for f in april_api engine session model_loader onnx_reader fbank_tables; do
 done
 $HIPCC -std=c++17 -O1 -g -fsanitize=address,undefined -I$C -c tests/sched_harness/driver.cc -o $A/driver.o
 $HIPCC --offload-arch=gfx950 -fsanitize=address,undefined $A/april_api.o $A/engine.o $A/session.o $A/model_loader.o $A/onnx_reader.o $A/fbank_tables.o $A/driver.o \
-  $C/build/kernels_gemm.o $C/build/kernels_gemm_tile.o $C/build/kernels_gemm_kw.o $C/build/kernels_recur.o $C/build/kernels_misc.o $C/build/kernels_fbank.o \
+  $C/build/kernels_gemm.o $C/build/kernels_gemm_tile.o $C/build/kernels_gemm_pp.o $C/build/kernels_gemm_pw.o $C/build/kernels_gemm_kw.o $C/build/kernels_recur.o $C/build/kernels_misc.o $C/build/kernels_fbank.o \
   -L/opt/rocm/lib -lrccl -lpthread -o tools/asan_gpu_driver 2>&1 | grep -v "not currently supported" || true
 test -x tools/tsan_gpu_driver && test -x tools/asan_gpu_driver && echo built
