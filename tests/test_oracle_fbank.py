@@ -161,3 +161,37 @@ def test_unsupported_fft_lengths_are_refused(built):
         h = new(**kw)
         assert h
         L.orc_fbank_free(h)
+
+
+@pytest.mark.skipif(not O.ref_available(), reason="compiled reference (oracle/_ref) not present")
+def test_every_frame_length_against_compiled_reference(built):
+    """round_pow2 = 0 with every frame length 8 .. 1299 (sample rate 40 n, 25 ms): wherever the oracle takes the length (whatever
+    pocketfft runs through its radix passes: 1034 lengths, every factor list and all three twiddle constructions) its frames equal the
+    compiled reference's bit for bit; the rest (258 lengths: primes from 191 and their small multiples) are the ones its restatement of
+    make_rfft_plan's choice hands to Bluestein -- refused, never approximated."""
+    rng = np.random.RandomState(3)
+    same, refused = 0, []
+    for n in range(8, 1300):
+        kw = dict(round_pow2=0, rate=40 * n, nbins=23)
+        w = wave(rng.randint(-20000, 20000, size=n + 8 * (40 * n // 100)).astype(np.int16))
+        try:
+            a = O.OrcFbank(**kw)
+        except Exception:
+            refused.append(n)
+            continue
+        b = O.RefFbank(**kw)
+        a.accept(w); b.accept(w)
+        x, y = np.array(a.pull_all()), np.array(b.pull_all())
+        assert x.shape == y.shape and x.size and np.array_equal(bits(x), bits(y)), n
+        same += 1
+    assert same > 1000 and len(refused) < 300 and min(refused) > 150
+    # a refused length has a prime factor above its square root (pocketfft.c:2162) -- necessary, not sufficient (the cost comparison decides)
+    for n in refused:
+        p, m = 1, n
+        f = 2
+        while f * f <= m:
+            while m % f == 0:
+                p, m = f, m // f
+            f += 1
+        p = m if m > 1 else p
+        assert p * p > n, n
