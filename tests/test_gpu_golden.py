@@ -146,3 +146,28 @@ def test_session_transcript_nonpow2_882(nonpow2_models, model_dir):
     assert n0 == n1 and n0 > 40
     assert lg0.shape == lg1.shape and np.abs(lg0 - lg1).max() < 1e-3
     assert_same_transcript(want, got)
+
+
+MANY_LENGTHS = [14, 22, 26, 49, 63, 77, 98, 105, 121, 143, 169, 187, 198, 209, 221, 242, 245, 289, 294, 343, 361, 363, 429, 455, 462, 507, 529,
+                539, 550, 625, 637, 663, 729, 741, 847, 875, 961, 1001, 1023, 1029, 1083, 1183, 1250, 1287]
+
+
+def test_fbank_kernel_on_many_frame_lengths(model_dir, built):
+    """44 frame lengths with every kind of factor list pocketfft's radix plan produces (7, 11, 13, 17, 19, 23, 29, 31 and their squares and
+    mixes; lengths with n mod 4 = 0, 2 and odd; 49, 343, 2401-style prime powers; 961 = 31 x 31): the device's filterbank rows equal the oracle's bit
+    for bit (the oracle equals the compiled reference at every length 8 .. 1299, tests/test_oracle_fbank.py)."""
+    import april_asr_amd as A
+    from april_asr_amd import synth_model as SM
+    from oracle import orc_py as O
+    rng = np.random.RandomState(31)
+    for n in MANY_LENGTHS:
+        p = str(model_dir / ("tiny_len%d.april" % n))
+        SM.write_model(p, SM.TINY_DIMS, params=dict(round_pow2=0, rate=40 * n))
+        m = A.Model(p)
+        assert m.dims.fft_size == n
+        frames = np.concatenate([rng.randint(-32768, 32768, size=(4, n)), rng.randint(-300, 300, size=(1, n)), np.full((1, n), 32767)]).astype(np.int16)
+        got = m.run_fbank(frames)
+        fb = O.OrcFbank(round_pow2=0, rate=40 * n)
+        want = np.stack([fb.frame(f.astype(np.float32) / np.float32(32768.0)) for f in frames])
+        assert np.array_equal(bits(got), bits(want)), "frame length %d: max |diff| = %g" % (n, np.abs(got - want).max())
+        m.close()
