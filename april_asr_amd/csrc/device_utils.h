@@ -91,11 +91,15 @@ __device__ __forceinline__ float granule_ssq(const f32x4 &y)
 }
 
 // gates clock (GemmArgs::stamp): called by every thread of a workgroup at kernel entry / exit; total = workgroups of the launch.
-// Slot layout (128 words): [0] start, [1] arrivals, [2] sum of durations (10 ns ticks), [3] launches, [8 .. 71] 64 end stamps.
+// Slot layout (144 words): [0] start, [1] classes done, [2] sum of durations (10 ns ticks), [3] launches, [8 .. 71] 64 end stamps,
+// [72 .. 135] 64 arrival counters (one per class = workgroup number mod 64).
 // Contention is what a clock must not add: 512 co-resident workgroups hitting ONE L2 word with an atomic at the same moment are
 // served one after the other (~12 ns each = 6 us), and a wave's first loads retire behind its own atomic -- the first version of this
 // clock (every workgroup atomicMin on the start word, a returning atomicMax on one end word) read 43.7 us where rocprofv3 reports 36.3.
-// So: the start is workgroup 0's alone (the grid starts first to last within 0.3 .. 0.7 us), the end stamps are spread over 64 words.
+// So: the start is workgroup 0's alone (the grid starts first to last within 0.3 .. 0.7 us), the end stamps are spread over 64 words,
+// and so are the arrivals: a workgroup counts itself in on its class's word, the last of a class counts the class in on ONE word (64
+// arrivals per launch instead of one per workgroup: with a single ticket word the 1024 .. 1536 workgroups of a four- to six-problem
+// launch read 118 .. 123 us where rocprofv3 reports 82.5).
 __device__ __forceinline__ void stamp_begin(unsigned long long *slot, bool first_wg)
 {
     if (slot && first_wg && threadIdx.x == 0) __hip_atomic_store(slot, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -109,16 +113,22 @@ __device__ __forceinline__ void stamp_end(unsigned long long *slot, unsigned tot
     __syncthreads();
     if (threadIdx.x == 0) {
         // (no fences: a release fence writes back the XCD's L2 -- microseconds per workgroup.  The returned old maximum makes the wave
-        // wait until its own end stamp has landed before it takes a ticket, so the workgroup that draws the last ticket finds every end
-        // stamp in place; the ticket word is contended, but only a workgroup's retirement waits for it, after its end stamp was taken.)
-        const unsigned long long old = atomicMax(slot + STAMP_ENDS + (wg_linear & (STAMP_NENDS - 1)), (unsigned long long)wall_clock64());
+        // wait until its own end stamp has landed before it counts itself in, so whoever closes a class finds the class's end stamps in
+        // place, and whoever closes the launch every class's.)
+        const unsigned cls = wg_linear & (STAMP_NENDS - 1);
+        const unsigned long long old = atomicMax(slot + STAMP_ENDS + cls, (unsigned long long)wall_clock64());
         asm volatile("" :: "v"(old));
-        if (atomicAdd(slot + 1, 1ull) == (unsigned long long)total - 1) {      // the last workgroup of the launch closes the sample
-            unsigned long long t1 = 0;
-            for (int i = 0; i < STAMP_NENDS; ++i) { const unsigned long long e = atomicExch(slot + STAMP_ENDS + i, 0ull); t1 = e > t1 ? e : t1; }
-            const unsigned long long t0 = atomicExch(slot, 0ull);
-            atomicExch(slot + 1, 0ull);
-            if (t0 && t1 > t0) { atomicAdd(slot + 2, t1 - t0); atomicAdd(slot + 3, 1ull); }
+        const unsigned in_class = (total + STAMP_NENDS - 1 - cls) / STAMP_NENDS;             // workgroups 0 .. total - 1 with this residue
+        if (atomicAdd(slot + STAMP_SUBS + cls, 1ull) == (unsigned long long)in_class - 1) {
+            atomicExch(slot + STAMP_SUBS + cls, 0ull);
+            const unsigned classes = total < (unsigned)STAMP_NENDS ? total : (unsigned)STAMP_NENDS;
+            if (atomicAdd(slot + 1, 1ull) == (unsigned long long)classes - 1) {            // the last class of the launch closes the sample
+                unsigned long long t1 = 0;
+                for (int i = 0; i < STAMP_NENDS; ++i) { const unsigned long long e = atomicExch(slot + STAMP_ENDS + i, 0ull); t1 = e > t1 ? e : t1; }
+                const unsigned long long t0 = atomicExch(slot, 0ull);
+                atomicExch(slot + 1, 0ull);
+                if (t0 && t1 > t0) { atomicAdd(slot + 2, t1 - t0); atomicAdd(slot + 3, 1ull); }
+            }
         }
     }
 }

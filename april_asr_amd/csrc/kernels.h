@@ -76,7 +76,7 @@ struct RowScale {                  // BasicNorm scale of a row from its sum-of-s
 // last active token; src/april_session.h:32-73); see "greedy search on the device" below.
 struct GreedyState { int32_t ctx0, ctx1; int32_t last_tok; uint32_t last_emit_ms; };
 
-constexpr int STAMP_WORDS = 128, STAMP_ENDS = 8, STAMP_NENDS = 64;      // layout of a gates-clock slot (GemmArgs::stamp; device_utils.h)
+constexpr int STAMP_WORDS = 144, STAMP_ENDS = 8, STAMP_NENDS = 64, STAMP_SUBS = 72;      // layout of a gates-clock slot (GemmArgs::stamp; device_utils.h)
 
 struct GemmArgs {
     // A operand as up to two K segments with optional row indirection (slot ids)
