@@ -930,11 +930,13 @@ static TilePlan plan_tiles(int M, int N, int kz, int epi, bool force_fullk = fal
     const int zc = t.mt == 4 ? zcount : 1;
     while (t.nt > 1 && ((ntiles % t.nt) != 0 || (long)(ntiles / t.nt) * mblocks * kz * zc < 256)) t.nt >>= 1;
     // FFN up (one slab, no walking form): a launch whose 64 x 64 tiles are one and a half per CU (three 256-row problems = 384) leaves half of
-    // the CUs with two workgroups and half with one; as 64 x 32 tiles it is three per CU.  APRIL_FF1_BALANCE (round 6)
+    // the CUs with two workgroups and half with one; as 64 x 32 tiles it is three per CU.  APRIL_FF1_BALANCE (round 6): MEASUREMENT FORMS, off --
+    // 1 (three-problem launches as 64 x 32 tiles): 1.334 vs 1.333 ms per 256-session step; 2 (two-problem launches too: two workgroups per CU): 1.351 vs 1.334
     static const int ff1_balance = env_int("APRIL_FF1_BALANCE", 0);
     if (ff1_balance && epi == EPI_BIAS_DSWISH && t.mt == 4 && t.nt == 4 && kz == 1) {
         const long tiles = (long)(ntiles / 4) * mblocks * zc;
         if (tiles > 256 && tiles < 512 && tiles % 256 != 0 && (2 * tiles) % 256 == 0) t.nt = 2;
+        if (ff1_balance == 2 && tiles == 256) t.nt = 2;      // (two workgroups per CU instead of one)
     }
     if (tune && epi != EPI_PARTIAL && t.mt == 4 && (long)(ntiles / t.nt) * mblocks < 512) {
         if (tune == 1) { t.mt = 2; mblocks = (M + 31) / 32; }
