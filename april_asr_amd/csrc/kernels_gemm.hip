@@ -750,6 +750,27 @@ __global__ __launch_bounds__(256, (MT == 4 && !ASM) ? 2 : 1) void gemm_f32_zkern
     if constexpr (EPI == EPI_LSTM) stamp_end(stamp, gridDim.x, blockIdx.x);
 }
 
+// Mixed tiles for a z-batched launch whose 64 x 64 tiles are not a whole number of rounds (FFN up, three 256-row problems = 384 tiles: half
+// of the CUs get two workgroups, half one, and the launch takes as long as four problems): the first n - 1 problems on 64 x 64 tiles, the
+// last one on 64 x 32 -- 256 + 256 workgroups, every CU one of each.  One-dimensional grid, big tiles first (the dispatcher deals the
+// first 256 workgroups one per CU).  Same bodies, same arguments per tile: the sums do not depend on the tile shape.
+template <int EPI, int AOP, int MODE>
+__global__ __launch_bounds__(256, 1) void gemm_f32_zkernel_mixed(const GemmArgs *__restrict__ zargs, int gx4, int gy, int nbig_problems)
+{
+    const int nbig = gx4 * gy * nbig_problems;
+    int tile = (int)blockIdx.x;
+    if (tile < nbig) {
+        const int bx = tile % gx4, r = tile / gx4, by = r % gy, z = r / gy;
+        const GemmArgs g = zargs[z];
+        gemm_body<4, 4, EPI, AOP, 0, MODE, 1, 4>(g, 0, (unsigned)tile, bx, by, gy == 1);
+    } else {
+        tile -= nbig;
+        const int gx2 = 2 * gx4, bx = tile % gx2, by = tile / gx2;
+        const GemmArgs g = zargs[nbig_problems];
+        gemm_body<4, 2, EPI, AOP, 0, MODE, 1, 4>(g, 0, (unsigned)(nbig + tile), bx, by, gy == 1);
+    }
+}
+
 // ---------------------------------------------------------------- host side
 struct TilePlan { int mt, nt, zs, mode; };
 
@@ -1147,6 +1168,15 @@ static void launch_one_z(const GemmArgs &g, const GemmArgs *dev_args, int n, hip
                 const long ntiles = (long)grid.x * grid.y * grid.z;
                 if (walk && ntiles > 512 && ntiles < 1024) {
                     APRIL_LAUNCH((gemm_f32_zkernel_walk<MT, NT, EPI, AOP, 0, MODE, 1>), dim3(512), dim3(256), lds, s, dev_args, zdiv, (int)grid.x, (int)grid.y, (int)ntiles);
+                    return;
+                }
+            }
+            if constexpr (EPI == EPI_BIAS_DSWISH && MT == 4 && NT == 4 && MODE == GM_SLAB) {
+                // APRIL_FF1_MIXED (round 6): see gemm_f32_zkernel_mixed
+                static const int mixed = env_int("APRIL_FF1_MIXED", 1);      // 256 sessions: 1.341 -> 1.320 ms per step (three alternations on one box)
+                const long t4 = (long)grid.x * grid.y, total = t4 * n;
+                if (mixed && zdiv == 1 && n >= 2 && total % 256 != 0 && ((long)(n - 1) * t4) % 256 == 0 && (2 * t4) % 256 == 0 && g.N % 32 == 0) {
+                    APRIL_LAUNCH((gemm_f32_zkernel_mixed<EPI, AOP, MODE>), dim3((unsigned)((n - 1) * t4 + 2 * t4)), dim3(256), lds, s, dev_args, (int)grid.x, (int)grid.y, n - 1);
                     return;
                 }
             }

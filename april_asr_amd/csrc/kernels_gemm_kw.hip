@@ -563,9 +563,61 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((MT == 1 && EPI == EPI_HR) ? 6 
     gemm_kw_body<MT, NT, NW, EPI, D, CPW>(g, bx, by, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
 }
 
+// Mixed tiles for a z-batched launch whose 32-row tiles are not a whole number of rounds (three 256-row problems at N = 512: 384 tiles of
+// 32 x 32 = one and a half per CU; as 16-row tiles 768 = three per CU, the planner's choice so far): the first n - 1 problems on 32-row tiles,
+// the last one on 16-row tiles -- 256 + 256 workgroups, every CU one of each (a 16-row round costs ~0.55 of a 32-row one: 1.55 against
+// 1.65).  One-dimensional grid, the 32-row tiles first.  Same bodies, same arguments per tile: the sums do not depend on the tile shape.
+// MEASUREMENT FORM, off (APRIL_KW_MIXED=1): bit-identical, but 1.334-1.345 against 1.320 ms per 256-session step -- the 16-row workgroups of the
+// plain launch run up to six per CU and hide each other's latencies, two per CU beside a 32-row one do not (the FFN-up twin of this form pays: kernels_gemm.hip).
+template <int NT, int NW, int EPI, int D, int CPW>
+__global__ __launch_bounds__(64 * NW, 2) void gemm_kw_zkernel_mixed(const GemmArgs *__restrict__ zargs, int gx, int gy32, int nbig_problems)
+{
+    const int nbig = gx * gy32 * nbig_problems;
+    int tile = (int)blockIdx.x;
+    if (tile < nbig) {
+        const int bx = tile % gx, r = tile / gx, by = r % gy32, z = r / gy32;
+        const GemmArgs g = zargs[z];
+        gemm_kw_body<2, NT, NW, EPI, D, CPW>(g, bx, by, (unsigned)tile);
+    } else {
+        tile -= nbig;
+        const GemmArgs g = zargs[nbig_problems];
+        gemm_kw_body<1, NT, NW, EPI, D, CPW>(g, tile % gx, tile / gx, (unsigned)(nbig + tile));
+    }
+}
+
+// the mixed form applies (launch_kw_one<1, ...> asks): n problems whose 32-row tiles leave a partial round while n - 1 of them and the
+// last one's 16-row tiles are whole rounds
+template <int NT, int NW, int EPI, int D, int CPW>
+bool launch_kw_mixed(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s)
+{
+    static const int mixed = [] { const char *v = getenv("APRIL_KW_MIXED"); return v && *v ? atoi(v) : 0; }();
+    if (!mixed || !dev_args || n < 2 || g.xcd_rc != 0 || g.M % 32 != 0) return false;
+    using G2 = KwGeom<2, NT, NW, D>;
+    using G1 = KwGeom<1, NT, NW, D>;
+    const long gx = g.N / G2::BN, gy32 = g.M / 32, t32 = gx * gy32, t16 = 2 * t32;
+    if ((t32 * n) % 256 == 0 || (t32 * (n - 1)) % 256 != 0 || t16 % 256 != 0) return false;
+    const int sg = (EPI == EPI_HR && g.r_scale.ssq) ? g.r_scale.groups : 0;
+    const size_t lds2 = (size_t)G2::LDS_MAIN + (size_t)(G2::BM + (sg ? G2::BM * (sg + 1) : 0)) * sizeof(float);
+    const size_t lds1 = (size_t)G1::LDS_MAIN + (size_t)(G1::BM + (sg ? G1::BM * (sg + 1) : 0)) * sizeof(float);
+    const size_t lds = lds2 > lds1 ? lds2 : lds1;
+    static std::atomic<uint64_t> attr_devs{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kw_zkernel_mixed<NT, NW, EPI, D, CPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_devs.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((gemm_kw_zkernel_mixed<NT, NW, EPI, D, CPW>), dim3((unsigned)(t32 * (n - 1) + t16)), dim3(G2::NTH), lds, s, dev_args, (int)gx, (int)gy32, n - 1);
+    return true;
+}
+
 template <int MT, int NT, int NW, int EPI, int D, int CPW>
 void launch_kw_one(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s)
 {
+    if constexpr (MT == 1 && NW == 8 && NT == 2 && (EPI == EPI_HR || EPI == EPI_RESID_SSQ)) {
+        if (launch_kw_mixed<NT, NW, EPI, D, CPW>(g, dev_args, n, s)) return;
+    }
     using G = KwGeom<MT, NT, NW, D>;
     dim3 grid((unsigned)(g.N / G::BN), (unsigned)((g.M + G::BM - 1) / G::BM), (unsigned)std::max(1, n));
     const int sg = (EPI == EPI_HR && g.r_scale.ssq) ? g.r_scale.groups : ((EPI == EPI_LSTM && g.x_scale.ssq) ? g.x_scale.groups : 0);
