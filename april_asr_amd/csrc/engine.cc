@@ -1316,6 +1316,12 @@ void Engine::run_lm_wavefront(int m, int T, bool dump_logits)
 // planner picks larger tiles for the N = d_model GEMMs (32x32 instead of 16x32 at 256 rows: 1.5 x fewer operand bytes per
 // flop, the bound of those kernels) and co-resident workgroups overlap each other's prologue / epilogue.
 // The argument blocks depend on (m, T) only: built once per shape, kept in device memory, and the whole chain is one graph.
+static bool lm_gates_split_on()
+{
+    static const bool on = [] { const char *e = getenv("APRIL_GATES_SPLIT"); return !(e && *e && atoi(e) == 0); }();
+    return on;
+}
+
 Engine::SwPlan &Engine::sw_plan(int m, int T)
 {
     // (the argument blocks point into the parity's buffers; plans built under the gates clock carry stamp slots and are kept apart:
@@ -1351,10 +1357,6 @@ Engine::SwPlan &Engine::sw_plan(int m, int T)
                 if (t < 0 || t >= T) continue;
                 GemmArgs g = kind == 0 ? sw_args_gates(l, m, t) : kind == 1 ? lm_args_whr(l, m, t) : kind == 2 ? lm_args_ff1(l, m, t, t + 1) : lm_args_ff2(l, m, t, t + 1);
                 if (kind == 0 && cfg_.precision == 0) g.tile_ok = gates_tile_rows((long)m * n_act) ? 2 : 0;
-                if (kind == 0 && gclk_ && gclk_slots_ && gclk_used_ < GCLK_SLOTS) {      // one slot per gates LAUNCH: all its problems point at it
-                    if (items.empty()) { p.stamp_slots.push_back(std::make_pair(gclk_used_, (long)m * n_act)); p.stamp_n.push_back(n_act); ++gclk_used_; }
-                    g.stamp = gclk_slots_ + (size_t)p.stamp_slots.back().first * STAMP_WORDS;
-                }
                 if (kind == 2 && cfg_.precision == 0) g.tile_ok = ff1_tile_rows((long)m * n_act) ? 2 : 0;
                 if (split) {
                     float *ws = ws_ + (size_t)t * m * d.d_model;
@@ -1363,13 +1365,35 @@ Engine::SwPlan &Engine::sw_plan(int m, int T)
                 } else if (tk == 2) g.force_fullk = 0;
                 items.push_back(g);
             }
-            SwPlan::Batch b; b.off = p.host.size(); b.n = (int)items.size(); b.macro = W; b.kind = kind; b.roff = p.rhost.size(); b.rn = (int)rows.size();
-            b.pf_off = p.pf_host.size(); b.pf_n = b.n;
-            for (const GemmArgs &g : items) { PrefetchItem pi; pi.ptr = g.wp; pi.bytes = (unsigned long long)g.N * (unsigned long long)g.K * (g.wt == 1 ? 2u : 4u); p.pf_host.push_back(pi); }
-            p.host.resize(p.host.size() + items.size());
-            stage_gemm_z(items.data(), b.n, p.host.data() + b.off);
-            p.rhost.insert(p.rhost.end(), rows.begin(), rows.end());
-            p.batches.push_back(b);
+            // The gates launch of four and more problems (merged flights: two feeds stepped as one wavefront of up to seven chunk steps) goes
+            // out as launches of two or three: the hand-scheduled 64 x 64 kernel holds 512 workgroups at a time, two problems are exactly one
+            // round and three run on walking workgroups, while four to six in one grid measured 82.5 / 110 / 125 us against 76.8 / 97.3 / 117.8
+            // for the pieces (rocprofv3 by grid size, round 6) -- and every launch of a kernel name then holds one problem count, which is
+            // what makes a per-kernel trace comparable with the gates clock.  (fp32, below the GM_TILE row count only.)
+            std::vector<int> groups;
+            {
+                int left = (int)items.size();
+                const bool cut = kind == 0 && cfg_.precision == 0 && left >= 4 && !gates_tile_rows((long)m * n_act) && lm_gates_split_on();
+                while (cut && left > 0) { const int take = (left == 4 || left == 2) ? 2 : (left >= 3 ? 3 : left); groups.push_back(take); left -= take; }
+                if (groups.empty()) groups.push_back((int)items.size());
+            }
+            size_t first = 0;
+            for (size_t gi = 0; gi < groups.size(); ++gi) {
+                const int gn = groups[gi];
+                if (kind == 0 && gclk_ && gclk_slots_ && gclk_used_ < GCLK_SLOTS) {      // one slot per gates LAUNCH: all its problems point at it
+                    p.stamp_slots.push_back(std::make_pair(gclk_used_, (long)m * gn)); p.stamp_n.push_back(gn);
+                    for (int i = 0; i < gn; ++i) items[first + (size_t)i].stamp = gclk_slots_ + (size_t)gclk_used_ * STAMP_WORDS;
+                    ++gclk_used_;
+                }
+                SwPlan::Batch b; b.off = p.host.size(); b.n = gn; b.macro = W; b.kind = kind; b.roff = p.rhost.size(); b.rn = gi == 0 ? (int)rows.size() : 0;
+                b.pf_off = p.pf_host.size(); b.pf_n = b.n;
+                for (int i = 0; i < gn; ++i) { const GemmArgs &g = items[first + (size_t)i]; PrefetchItem pi; pi.ptr = g.wp; pi.bytes = (unsigned long long)g.N * (unsigned long long)g.K * (g.wt == 1 ? 2u : 4u); p.pf_host.push_back(pi); }
+                p.host.resize(p.host.size() + (size_t)gn);
+                stage_gemm_z(items.data() + first, gn, p.host.data() + b.off);
+                if (gi == 0) p.rhost.insert(p.rhost.end(), rows.begin(), rows.end());
+                p.batches.push_back(b);
+                first += (size_t)gn;
+            }
         }
     }
     p.dev = dmalloc<GemmArgs>(p.host.size());
