@@ -12,3 +12,15 @@ def test_every_mutant_of_the_state_machine_is_killed(built, tiny_model):
     assert not survivors, "mutants of oracle/orc_session.c that pass every hand-derived case: %r" % [n for n, _ in survivors]
     assert not eq_killed, "mutants listed as equivalent that a case does catch (the argument is wrong): %r" % eq_killed
     assert len(killed) == len(M.MUTANTS) >= 25
+
+
+def test_every_mutant_of_the_product_state_machine_is_killed(built, tiny_model):
+    """the same kind of single edits in the PRODUCT's transcription (csrc/session.cc `Greedy`), each built into its own library and run
+    through aprilx_greedy_* on the host (tests/mutate_product_state_machine.py): the oracle and the product are sibling transcriptions, so
+    the fixtures have to catch a slip in either"""
+    import mutate_product_state_machine as PM
+    killed, survivors, eq_killed, failures = PM.run_all(model_path=tiny_model["path"])
+    assert not failures, failures
+    assert not survivors, "mutants of csrc/session.cc that pass every hand-derived case: %r" % [n for n, _ in survivors]
+    assert not eq_killed, "mutants listed as equivalent that a case does catch (the argument is wrong): %r" % eq_killed
+    assert len(killed) == len(PM.MUTANTS) >= 40
