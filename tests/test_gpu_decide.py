@@ -130,3 +130,16 @@ def test_device_decision_matches_host_state_machine_on_random_rounds(gpu_tiny, t
                 break
     L.aprilx_greedy_free(g)
     assert n_blank > 100 and n_tok > 100
+
+
+def test_every_mutant_of_the_device_decision_is_killed(built, tiny_model):
+    """24 single-edit mutants of decide_kernel (csrc/kernels_misc.hip: tie order, the comparisons and constants of the blank decision, the punctuation
+    override and the digit-dot rule, the context push, the silence rule), each compiled and linked into its own library on this box and run through
+    aprilx_run_decide against the hand-derived cases (tests/mutate_device_decide.py): none may pass them all -- the device's copy is the third
+    transcription of src/april_session.c:306-429 beside the oracle's and the host's"""
+    import mutate_device_decide as DM
+    killed, survivors, eq_killed, failures = DM.run_all(model_path=tiny_model["path"])
+    assert not failures, failures
+    assert not survivors, "mutants of decide_kernel that pass every hand-derived case: %r" % [n for n, _ in survivors]
+    assert not eq_killed, "mutants listed as equivalent that a case does catch (the argument is wrong): %r" % eq_killed
+    assert len(killed) == len(DM.MUTANTS) >= 20
