@@ -305,7 +305,7 @@ private:
     // profiling
     bool profiling_ = false;
     bool gclk_ = false; unsigned long long *gclk_slots_ = nullptr; int gclk_used_ = 0;      // gates clock (set_gates_clock): 8-word device slots
-    static constexpr int GCLK_SLOTS = 2048;       // launch sites x 1 KB (STAMP_WORDS, device_utils.h)
+    static constexpr int GCLK_SLOTS = 2048;       // launch sites x 1152 B (STAMP_WORDS, device_utils.h)
     double gclk_ms_ = 0; long gclk_launches_ = 0, gclk_rows_ = 0; double gclk_ms_n_[4] = {0, 0, 0, 0}; long gclk_launches_n_[4] = {0, 0, 0, 0};
     struct Ev { hipEvent_t a, b; int cls; };
     std::vector<Ev> ev_pool_; size_t ev_used_ = 0;

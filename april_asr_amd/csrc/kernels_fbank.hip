@@ -25,6 +25,7 @@
 //   (https://gitlab.mpcdf.mpg.de/mtr/pocketfft/-/blob/81d171a6/LICENSE.md); the full text, including the
 //   disclaimer, is in THIRD_PARTY_NOTICES.md at the repository root.
 #include "kernels.h"
+#include <atomic>
 
 namespace aprilx {
 
@@ -368,6 +369,16 @@ void launch_fbank(const FbankArgs &a, hipStream_t s)
 {
     if (a.n_frames <= 0) return;
     const size_t lds = sizeof(double) * 2 * (size_t)a.t.padded;
+    if (lds > 64 * 1024) {          // frames above 4096 samples (the tables go up to 8192): dynamic LDS beyond 64 KB has to be announced, per device
+        static std::atomic<uint64_t> attr_devs{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fbank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_devs.fetch_or(bit, std::memory_order_release);
+        }
+    }
     hipLaunchKernelGGL(fbank_kernel, dim3((unsigned)a.n_frames), dim3(64), lds, s, a);
 }
 

@@ -171,3 +171,23 @@ def test_fbank_kernel_on_many_frame_lengths(model_dir, built):
         want = np.stack([fb.frame(f.astype(np.float32) / np.float32(32768.0)) for f in frames])
         assert np.array_equal(bits(got), bits(want)), "frame length %d: max |diff| = %g" % (n, np.abs(got - want).max())
         m.close()
+
+
+def test_fbank_kernel_on_frames_above_4096_samples(model_dir, built):
+    """frames of 4400, 6000 and 8192 samples (100 ms at 44 / 60 / 81.92 kHz): the two fp64 LDS buffers of a frame pass 64 KB, which a launch has to
+    announce (csrc/kernels_fbank.hip launch_fbank) -- the sequential DC sum of frames above 512 samples, the generic radix pass (4400 = 2 4 5 5 11) and
+    the power of two 8192 against the oracle, bit for bit"""
+    import april_asr_amd as A
+    from april_asr_amd import synth_model as SM
+    from oracle import orc_py as O
+    for n in (4400, 6000, 8192):
+        p = str(model_dir / ("tiny_long%d.april" % n))
+        SM.write_model(p, SM.TINY_DIMS, params=dict(round_pow2=0, rate=10 * n, length_ms=100))
+        m = A.Model(p)
+        assert m.dims.fft_size == n
+        frames = np.random.RandomState(n).randint(-32768, 32768, size=(3, n)).astype(np.int16)
+        got = m.run_fbank(frames)
+        fb = O.OrcFbank(round_pow2=0, rate=10 * n, len_ms=100)
+        want = np.stack([fb.frame(f.astype(np.float32) / np.float32(32768.0)) for f in frames])
+        assert np.array_equal(bits(got), bits(want)), "frame length %d: max |diff| = %g" % (n, np.abs(got - want).max())
+        m.close()
