@@ -59,7 +59,7 @@ struct HostModel {
 // reference src/april_model.c:25-40,65-72,99-102).
 bool load_april_file(const char *path, HostModel &out, std::string &err);
 
-// Layer widths that are multiples of 16 but not of 64 (the MFMA kernels' tile: 4 waves x 16 columns, 64-k stages): every width --
+// Layer widths that are not multiples of 64 (the MFMA kernels' tile: 4 waves x 16 columns, 64-k stages), multiples of 16 or not: every width --
 // d_model, cell, ffn, joiner, the third conv's channels -- is rounded up to the next multiple of 64 with zero weights and biases.
 // Padded units compute exact zeros (LSTM cell: sigma(0) c + sigma(0) tanh(0); DoubleSwish(0) = 0; tanh(0) = 0 in the joiner) and feed
 // zero rows of the next matrix, so the real outputs are the file's network; the one place the true width shows is the BasicNorm mean

@@ -161,6 +161,9 @@ MEDIUM_DIMS = dict(n_layers=3, d_model=192, hidden=320, ffn=448, joiner=192, voc
 # widths that are multiples of 16 but not of 64 (the loader pads them: csrc/model_loader.cc pad_host_model)
 NARROW_DIMS = dict(n_layers=2, d_model=144, hidden=208, ffn=304, joiner=80, vocab=60, mel=80, seg=9,
                    context=2, dec_groups=36, conv_ch=(8, 16, 48))
+# widths that are not even multiples of 16 (the zero padding does not care): d 100, cell 150, ffn 210, joiner 70, 20 conv channels
+ODD_DIMS = dict(n_layers=2, d_model=100, hidden=150, ffn=210, joiner=70, vocab=45, mel=80, seg=9,
+                context=2, dec_groups=25, conv_ch=(8, 12, 20))
 LARGE_DIMS = dict(n_layers=16, d_model=768, hidden=1536, ffn=3072, joiner=768, vocab=500, mel=80, seg=9,
                   context=2, dec_groups=192, conv_ch=(8, 32, 128))
 

@@ -714,6 +714,26 @@ def test_widths_padded_at_load_match_the_oracle(narrow_model):
     gm.close(); om.close()
 
 
+def test_any_width_is_padded_at_load(model_dir, built):
+    """d 100, cell 150, ffn 210, joiner 70, 20 conv-3 channels -- not even multiples of 16: padded to 128 / 192 / 256 / 128 / 64 at load; a full
+    session (logits within 1e-3, transcript) against the oracle, which runs the file's widths"""
+    import april_asr_amd as A
+    from april_asr_amd import synth_model as SM
+    from oracle import orc_py as O
+    p = str(model_dir / "odd100.april")
+    SM.write_model(p, SM.ODD_DIMS, seed=9)
+    gm = A.Model(p); om = O.Model(p)
+    d = gm.dims
+    assert (d.d_model, d.hidden, d.ffn, d.joiner, d.vocab, d.d_model_file) == (128, 192, 256, 128, 45, 100)
+    pcm = speech_like_pcm(3.0, seed=28, silence=(1.0, 1.4))
+    want, lg0, n0 = run_oracle(om, pcm, 1600)
+    got, lg1, n1 = run_gpu(gm, pcm, 1600)
+    assert n0 == n1 and lg0.shape == lg1.shape and lg1.shape[1] == 45
+    assert np.abs(lg0 - lg1).max() < 1e-3
+    assert_same_transcript(want, got)
+    gm.close(); om.close()
+
+
 def test_config5_larger_encoder_512_sessions(large_model):
     """BASELINE configs[4] shape (fp32 here): the larger encoder (16 x {768, 1536, 3072}), 512 concurrent sessions in
     100 ms feeds on one GPU.  Session 0 against the CPU oracle (token-exact, logits within 1e-3); sessions 1 and 511
