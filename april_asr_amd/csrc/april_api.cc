@@ -132,7 +132,7 @@ bool create_engines(Model &m, const float *blob_host, const float *blob_device)
         return false;
     }
     if (m.layout.dims.embed_in % 64 || m.layout.dims.d_model % 64 || m.layout.dims.hidden % 64 || m.layout.dims.ffn % 64 || m.layout.dims.joiner % 64 || m.layout.dims.conv_ch[2] % 16) {
-        LOGE("aam: layer widths must be multiples of 64 for the MFMA kernels (pad_host_model rounds multiples of 16 up at load)");
+        LOGE("aam: layer widths must be multiples of 64 for the MFMA kernels (pad_host_model rounds a file's widths up at load: this model did not come through it)");
         return false;
     }
     if (m.layout.dims.d_model > 2048) { LOGE("aam: d_model > 2048 unsupported (row scales are staged for at most 64 column groups)"); return false; }

@@ -23,7 +23,7 @@ typedef struct AprilxDims {
     int32_t n_layers, d_model, hidden, ffn, joiner, vocab, mel, seg, seg_step, context;
     int32_t fft_size, frame_shift, sample_rate, blank_id, n_devices;
     int32_t precision;          /* 0: fp32 GEMMs (default); 1: fp16 operands, fp32 accumulate (env APRIL_PRECISION=f16) */
-    int32_t d_model_file;       /* 0, or the model file's d_model when its layer widths (multiples of 16) were rounded up to multiples of
+    int32_t d_model_file;       /* 0, or the model file's d_model when its layer widths (any that are not multiples of 64) were rounded up to multiples of
                                    64 at load: d_model, hidden, ffn, joiner above are then the padded widths the engine runs */
     int64_t param_count;
 } AprilxDims;
