@@ -795,6 +795,13 @@ bool Scheduler::step_chunks(std::vector<Session *> &ready)
     static const bool f16_lm = !(getenv("APRIL_F16_LM") && atoi(getenv("APRIL_F16_LM")) == 0);
     const bool lm_ok = lm_min_chunks_ > 0 && lm_min_chunks_ <= MB && (!eng_->f16_tile() || f16_lm);
     for (Session *s : ready) ((lm_ok && waiting(s) >= lm_min_chunks_) ? lm : one).push_back(s);
+    // ... a FEW sessions: layer-major pays while the rows of a time step are a handful (the recurrent pair of a step as weight streams,
+    // everything else batched over time); from ~48 sessions with a backlog the successive feed wavefronts of up to wave_max_chunks_
+    // chunks are faster (aprilv0 dims, 2 .. 10 s handed over at once, ms per 100 ms of all sessions, layer-major vs wavefronts: 1 session
+    // 0.13 vs 0.33, 32: 0.33 vs 0.49, 64: 0.73 vs 0.60, 256: 1.74 vs 1.31 -- round 6; an asynchronous client that runs ahead of the GPU
+    // is the case: bench.py `reference_api_async` 1.93 -> 1.45 ms per step)
+    static const size_t lm_max_sessions = (size_t)env_us("APRIL_LM_MAX_SESSIONS", 48);
+    if (lm.size() > lm_max_sessions && wave_min_chunks_ > 0) { one.insert(one.end(), lm.begin(), lm.end()); lm.clear(); }
     if (!lm.empty()) {
         const int per = std::max(1, MB / lm_min_chunks_);
         std::vector<Session *> group;
