@@ -133,6 +133,23 @@ __device__ __forceinline__ void stamp_end(unsigned long long *slot, unsigned tot
     }
 }
 
+// First-round start skew of the kernels that run two (or three) workgroups per CU over several rounds (GemmArgs::skew, x 4096 cycles; 0 = off,
+// the default: a MEASUREMENT FORM).  The workgroups a CU gets at the start of a launch run in lock step -- all in their prologues, all in the
+// K loop, all in their epilogues with the matrix pipe idle -- and their successors inherit the phase, because the slots free up together.  A
+// phase offset, once established, is kept by the same mechanism: the odd threadgroup slot of every CU (HW_ID.TG_ID bit 0; tools/cu_pair_probe:
+// the two workgroups of a first-round pair always differ in it, and they are 256 apart in dispatch order) sleeps once, and only workgroups of
+// the first round (linear id < first_round) ever do.  Round 1's form of this slept in EVERY second block of 256 workgroup ids, every round, and
+// lost.  This one is neutral (profiles/r06_first_round_skew.txt: gates at 4608 rows 323 us at any delay of 3 .. 12 x 4096 cycles): a
+// workgroup alone on a CU drives the matrix pipe at ~0.55 of its rate (its own barriers and fragment waits), so what de-phasing wins in
+// overlapped epilogues it loses in K loops that run alone.  Speed only, never correctness.
+__device__ __forceinline__ void first_round_skew(int skew, unsigned wg_linear, unsigned first_round)
+{
+    if (skew <= 0 || wg_linear >= first_round) return;
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    if ((hw >> 16) & 1) for (int i = 0; i < skew; ++i) __builtin_amdgcn_s_sleep(64);
+}
+
 // sigma and tanh on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each); absolute error ~1e-7, far inside
 // the 1e-4 per-call parity tolerance, and ~10x fewer VALU instructions than libm's expf/tanhf
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }

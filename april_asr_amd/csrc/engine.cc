@@ -262,6 +262,20 @@ Engine::Engine(const EngineConfig &cfg, const PackedLayout &layout, const float 
     const size_t ws_n = (size_t)std::max({kz_embed_ * d.d_model, kz_hr_ * d.d_model, kz_ff2_ * d.d_model, kz_proj_ * d.joiner, kz_out_ * L_.vocab_pad});
     ws_ = dmalloc<float>(ws_n * MB);
     ws_g_ = dmalloc<float>((size_t)std::max(kz_proj_ * d.joiner, kz_out_ * L_.vocab_pad) * MB);    // the search's own workspace: it runs beside encoder stages
+    {   // K-cut hand-over of the projection / FFN-down stream kernels (<= 16 rows): [layer][which][d_model / granule][kz][16 rows][granule columns]
+        // floats = d_model * kz * 16 per problem, one counter word per granule (zero between launches: the last workgroup re-arms it).
+        // Not in APRIL_CHAIN_STREAMS mode: there the chunks of one layer run beside each other on their own streams.
+        const bool chains = getenv("APRIL_CHAIN_STREAMS") && atoi(getenv("APRIL_CHAIN_STREAMS")) != 0;
+        const bool ks_on = getenv("APRIL_RECUR_KSPLIT") && atoi(getenv("APRIL_RECUR_KSPLIT")) != 0;      // (a measurement form, off by default: kernels_recur.hip recur_ksplit)
+        if (ks_on && !chains && cfg_.precision == 0) {
+            ks_ws_stride_ = (size_t)d.d_model * (size_t)std::max(kz_hr_, kz_ff2_) * 16;
+            ks_cnt_stride_ = (size_t)d.d_model / 16;
+            ks_ws_ = dmalloc<float>(2 * (size_t)d.n_layers * ks_ws_stride_);
+            ks_cnt_ = dmalloc<unsigned>(2 * (size_t)d.n_layers * ks_cnt_stride_);
+            HipLegacyLock legacy;
+            HIP_CHECK(hipMemset(ks_cnt_, 0, 2 * (size_t)d.n_layers * ks_cnt_stride_ * sizeof(unsigned)));
+        }
+    }
     xin_ = dmalloc<float>(MB * d.embed_in);
     a3_ = dmalloc<float>(MB * d.f_out * L_.k3);
     HIP_CHECK(hipMemset(a3_, 0, MB * d.f_out * L_.k3 * 4));      // padded k columns (if any) stay zero
@@ -386,6 +400,8 @@ Engine::~Engine()
     for (int i = 0; i < 3; ++i) if (zargs_done_[i]) (void)hipEventDestroy(zargs_done_[i]);
     for (void *p : {(void *)lm_now_d_, (void *)lm_rows_d_, (void *)lm_rec_off_d_}) if (p) (void)hipFree(p);
     if (ws_g_) (void)hipFree(ws_g_);
+    if (ks_ws_) (void)hipFree(ks_ws_);
+    if (ks_cnt_) (void)hipFree(ks_cnt_);
     if (dec_table_) (void)hipFree(dec_table_);
     if (p_lm_) (void)hipFree(p_lm_);
     for (int p = 0; p < 2; ++p)
@@ -700,11 +716,12 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
         timed_begin(T_CONV); launch_gemm(g, stream_); timed_end(T_CONV);
     }
     // y = A x W + bias (+ residual) with sums of squares: fused into the GEMM where its tiles own all of K, else split-K + row kernel
-    auto resid_ssq = [&](const float *a, int K, size_t w_off, int kz, const float *bias, const float *resid) {
+    auto resid_ssq = [&](const float *a, int K, size_t w_off, int kz, const float *bias, const float *resid, int ks_layer = -1) {
         GemmArgs g; g.a0 = a; g.lda0 = K; g.K0 = K; lin(g, w_off);
         g.M = n; g.N = d.d_model; g.K = K; g.kz = kz; g.tile_ok = tile_ok();
         if (gemm_fullk(n, d.d_model, kz, false, 1, tile_ok())) {
             g.epi = EPI_RESID_SSQ; g.bias = bias; g.resid = resid; g.ldr = d.d_model; g.out = y_; g.ldo = d.d_model; g.ssq_out = ssq_;
+            if (ks_layer >= 0) attach_ksplit(g, ks_layer, 1);
             timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
             return;
         }
@@ -747,6 +764,7 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
             g.M = n; g.N = d.d_model; g.K = d.hidden; g.kz = kz_hr_; g.tile_ok = tile_ok();
             if (gemm_fullk(n, d.d_model, kz_hr_, false, 1, tile_ok())) {
                 g.epi = EPI_HR; g.state = h_l; g.ld_state = d.d_model; g.slot_idx = d_slots; g.resid = y_; g.ldr = d.d_model; g.r_scale = xs; g.out = xb_; g.ldo = d.d_model;
+                attach_ksplit(g, l, 0);
                 timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
             } else {
                 g.epi = EPI_PARTIAL; g.out = ws_; g.m_stride = ws_mstride_;
@@ -762,7 +780,7 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
             timed_begin(T_GEMM_OTHER); launch_gemm(g, stream_); timed_end(T_GEMM_OTHER);
         }
         // FFN down + bias + residual -> y (the last reader of the previous y was the projection above)
-        resid_ssq(ff_, d.ffn, o.wff2, kz_ff2_, w_ + o.bff2, xb_);
+        resid_ssq(ff_, d.ffn, o.wff2, kz_ff2_, w_ + o.bff2, xb_, l);
         eps_in = L_.norm_eps[(size_t)l];
     }
     {   // encoder_proj(norm(y)) -> eout[slot]
@@ -992,6 +1010,13 @@ GemmArgs Engine::sw_args_gates(int l, int m, int t) const
     return g;
 }
 
+void Engine::attach_ksplit(GemmArgs &g, int l, int which) const
+{
+    if (!ks_ws_) return;
+    g.ks_ws = ks_ws_ + ((size_t)l * 2 + (size_t)which) * ks_ws_stride_;
+    g.ks_cnt = ks_cnt_ + ((size_t)l * 2 + (size_t)which) * ks_cnt_stride_;
+}
+
 GemmArgs Engine::lm_args_whr(int l, int m, int t) const
 {   // h' = u x Whr ; state write + residual, in one launch however few workgroups (sequential step)
     const NetDims &d = L_.dims;
@@ -1004,6 +1029,7 @@ GemmArgs Engine::lm_args_whr(int l, int m, int t) const
     g.epi = EPI_HR; g.state = h_ + (size_t)l * S * d.d_model; g.ld_state = d.d_model; g.slot_idx = step_d_; g.resid = y_ + r0 * d.d_model; g.ldr = d.d_model;
     g.r_scale.ssq = ssq_ + r0 * G; g.r_scale.groups = G; g.r_scale.inv_n = 1.0f / (float)(d.d_norm ? d.d_norm : d.d_model); g.r_scale.eps = l == 0 ? L_.embed_eps : L_.norm_eps[(size_t)l - 1];
     g.out = xb_ + r0 * d.d_model; g.ldo = d.d_model;
+    attach_ksplit(g, l, 0);
     if (f16_tile_) {
         g.a0 = reinterpret_cast<const float *>(u16_ + r0 * d.hidden); lin16(g, o.whr); g.kz = kzx_hr_;
         g.state16 = h16_ + (size_t)l * S * d.d_model; g.out16 = xb16_ + r0 * d.d_model;
@@ -1032,6 +1058,7 @@ GemmArgs Engine::lm_args_ff2(int l, int m, int t0, int t1) const
     GemmArgs g; g.a0 = ff_ + b0 * d.ffn; g.lda0 = d.ffn; g.K0 = d.ffn; lin(g, o.wff2);
     g.M = (t1 - t0) * m; g.N = d.d_model; g.K = d.ffn; g.kz = kz_ff2_; g.tile_ok = tile_ok(); g.force_fullk = 1;
     g.epi = EPI_RESID_SSQ; g.bias = w_ + o.bff2; g.resid = xb_ + b0 * d.d_model; g.ldr = d.d_model; g.out = y_ + b0 * d.d_model; g.ldo = d.d_model; g.ssq_out = ssq_ + b0 * G;
+    attach_ksplit(g, l, 1);
     if (f16_tile_) { g.a0 = reinterpret_cast<const float *>(ff16_ + b0 * d.ffn); lin16(g, o.wff2); g.kz = kzx_ff2_; g.out16 = y16_ + b0 * d.d_model; }
     return g;
 }

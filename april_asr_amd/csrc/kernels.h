@@ -127,7 +127,12 @@ struct GemmArgs {
     int tile_ok = 0;                       // the caller planned this GEMM with gemm_fullk / gemm_partials(..., tile_ok): 1 = GM_TILE may be chosen by
                                            // the planner's occupancy rule (fp32 A in one K segment, N % 64 == 0, row epilogue or partial planes);
                                            // 2 = GM_TILE always (the fp16 tile path of an fp16 engine: every batch size runs the same chains)
-    int skew = 0;                          // start delay (x 4096 cycles) for every second generation of workgroups
+    // (measurement form, APRIL_RECUR_KSPLIT, off by default) the row forms of kernels_recur.hip (<= 16 rows, EPI_HR / EPI_RESID_SSQ) cut K across `ksplit` workgroups per column granule when the caller
+    // lends them a workspace: ks_ws = [N / granule columns][kz][16][granule columns] floats, ks_cnt = one zeroed word per granule, both
+    // private to this problem among everything that can run beside it (the engine: per layer).  ksplit is set by launch_gemm / stage_gemm_z.
+    float *ks_ws = nullptr; unsigned *ks_cnt = nullptr; int ksplit = 1;
+    int skew = 0;                          // first-round start skew (x 4096 cycles; APRIL_GEMM_SKEW, off: device_utils.h first_round_skew; GM_KW: its own meaning, APRIL_KW_SKEW)
+    int skew_wgs = 0;                      // workgroups of the first round (the chip's slots for this kernel); set by launch_gemm with skew
     int xcd_rc = 0;                        // GM_KW: 2 = tiles dealt to the XCDs as 2 row halves x 4 column quarters (APRIL_KW_XCD; 0 = column tiles round robin)
     int asm_loop = 0;                      // != 0: hand-scheduled K loop (gemm_mainloop_asm.inc) in the fused-epilogue 64x64 fp32 tiles
     unsigned long long *trace = nullptr;   // measurement only: per-workgroup s_memtime stamps [wg][8] (wave 0, lane 0)
@@ -166,6 +171,8 @@ void gemm_kw_pin(int enable, int mt, int ff1);
 // (internal) the recurrent GEMMs of a long feed at <= 16 rows as weight streams (kernels_recur.hip): recur_form says whether g is
 // one of them (1 gates h-half + cell, 2 projection), launch_recur runs n same-shape problems (dev_args) or g itself (dev_args == null)
 int recur_form(const GemmArgs &g);
+void recur_ksplit_pin(int s);                    // measurement only (tools/kw_bench): -1 = environment default (APRIL_RECUR_KSPLIT), 0 = off, 1 = planner, > 1 = that cut
+int recur_ksplit(const GemmArgs &g, int n);      // workgroups per column granule for the row forms (1 = whole K in one workgroup)
 void launch_recur(const GemmArgs &g, int form, const GemmArgs *dev_args, int n, hipStream_t s);
 // n independent GEMMs of ONE shape (same M, N, K, kz, epilogue; any pointers) in one launch.  stage_gemm_z finalizes the
 // argument blocks on the host; launch_gemm_z launches once they are in device memory at dev_args (in stream order).

@@ -91,13 +91,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, const int zg, const
     const int nt0 = bx * NT;
     const int m0 = by * Cfg::BM;
     // zg (GM_SLAB): this workgroup owns slabs [zg*zs, (zg+1)*zs)
-    if (g.skew > 0) {
-        // Two workgroups share a CU.  Dispatched together they run in lock-step: both stream MFMAs (halving each
-        // other's rate), then both sit in their epilogues while the matrix pipe idles.  Delaying every second
-        // "generation" of workgroups once, by about one epilogue, interleaves the phases for the rest of the launch.
-        // Placement is only a heuristic here (speed, never correctness).
-        if ((wg_linear >> 8) & 1) for (int i = 0; i < g.skew; ++i) __builtin_amdgcn_s_sleep(64);
-    }
+    first_round_skew(g.skew, (unsigned)wg_linear, (unsigned)g.skew_wgs);      // (measurement form, off by default: device_utils.h)
     const int KB = g.K >> 4;
 
     const int mrow = lane & 15, kq = lane >> 4;
@@ -1088,7 +1082,7 @@ static TilePlan finalize_gemm(GemmArgs &g)
 {
     static const int dbg = env_int("APRIL_GEMM_DEBUG", 0);
     g.debug = dbg;
-    static const int skew = env_int("APRIL_GEMM_SKEW", 0);        // round 2: no start skew (measured below)
+    static const int skew = env_int("APRIL_GEMM_SKEW", 0);        // first-round start skew, x 4096 cycles (below; measured neutral, off)
     static const int asm_loop = env_int("APRIL_GEMM_ASM", 1);     // 0 = compiler-scheduled loop everywhere (A/B)
     static const int z_tiles = env_int("APRIL_Z_TILES", 2);      // A/B: 0 = plan z-batched problems as if each had the chip to itself, 1 = hint everywhere, 2 = fused-epilogue slab tiles only, 3 = full-K tiles only
     const int zc = std::max(1, g.zcount);
@@ -1113,7 +1107,15 @@ static TilePlan finalize_gemm(GemmArgs &g)
     //   hand loop, no skew 42.2 / 85.6 / 159.2   hand loop, skew 2: 85.5 / 174.3   compiler loop, skew 2 (round-1 choice at two
     //   workgroups per CU): 91.3 / 170.4   compiler loop, no skew: 56.5 / 100.7 / 180.2;  FFN-up [2048,512]x[512,2048]: 42.3 vs 45.7
     g.asm_loop = asm_loop != 0;
-    g.skew = (long)(g.N / (16 * t.nt)) * ((g.M + 16 * t.mt - 1) / (16 * t.mt)) * (t.mode == GM_FULLK ? 1 : g.kz / g.zs) >= 512 ? skew : 0;   // two workgroups per CU
+    // first-round start skew (device_utils.h first_round_skew; measured neutral, off): launches of several rounds of the fused-epilogue
+    // K-split tiles and of the four-wave GM_TILE tiles.  APRIL_GEMM_SKEW = delay in units of 4096 cycles, APRIL_SKEW_MIN_WGS = smallest launch.
+    {
+        static const int skew_min_wgs = env_int("APRIL_SKEW_MIN_WGS", 1536), skew_slots = env_int("APRIL_SKEW_SLOTS", 512);
+        const long wgs = (long)(g.N / (16 * t.nt)) * ((g.M + 16 * t.mt - 1) / (16 * t.mt)) * (t.mode == GM_FULLK ? 1 : g.kz / g.zs) * zc;
+        const bool several_per_cu = (t.mode == GM_TILE && t.nt == 4 && (t.mt == 4 || t.mt == 2)) || ((t.mode == GM_SLAB || t.mode == GM_FULLK) && is_slab_epi);
+        g.skew = (several_per_cu && wgs >= skew_min_wgs) ? skew : 0;
+        g.skew_wgs = skew_slots;
+    }
     static const int kw_skew = env_int("APRIL_KW_SKEW", 0);      // GM_KW: start delay of the second half of a workgroup's waves, x 64 cycles (measured: no effect; kernels_gemm_kw.hip)
     if (t.mode == GM_KW) g.skew = kw_skew;
     if (t.mode == GM_PP) g.skew = 0;
@@ -1135,6 +1137,7 @@ static bool kw_before_recur(const GemmArgs &g)
 void launch_gemm(const GemmArgs &g_in, hipStream_t s)
 {
     GemmArgs g = g_in;
+    g.ksplit = kw_before_recur(g) ? 1 : recur_ksplit(g, 1);
     if (!kw_before_recur(g)) if (const int rf = recur_form(g)) { launch_recur(g, rf, nullptr, 1, s); return; }
     const TilePlan t = finalize_gemm(g);
     if (t.mode == GM_PP) { if (t.nt == 12) launch_gemm_pw(g, nullptr, 0, s); else launch_gemm_pp(g, t.mt, nullptr, 0, s); return; }
@@ -1205,6 +1208,7 @@ void stage_gemm_z(const GemmArgs *items, int n, GemmArgs *staged)
     for (int i = 0; i < n; ++i) {
         staged[i] = items[i];
         staged[i].zcount = n;
+        staged[i].ksplit = 1;
         const TilePlan t = finalize_gemm(staged[i]);
         if (i == 0) t0 = t;
         const GemmArgs &a = staged[i], &b = staged[0];
@@ -1212,6 +1216,12 @@ void stage_gemm_z(const GemmArgs *items, int n, GemmArgs *staged)
             a.a_op != AOP_NONE || a.x_scale.groups != b.x_scale.groups || a.r_scale.groups != b.r_scale.groups || (a.x_scale.ssq == nullptr) != (b.x_scale.ssq == nullptr)) {
             fprintf(stderr, "libapril(mi355x): stage_gemm_z: the problems of one launch must have one shape\n"); abort();
         }
+    }
+    // the K cut of the <= 16-row stream kernels (kernels_recur.hip): one value for the launch, only when every problem brings its workspace
+    if (n > 0 && !kw_before_recur(staged[0])) {
+        int S = recur_ksplit(staged[0], n);
+        for (int i = 1; i < n && S > 1; ++i) if (recur_ksplit(staged[i], n) != S) S = 1;
+        for (int i = 0; i < n; ++i) staged[i].ksplit = S;
     }
 }
 

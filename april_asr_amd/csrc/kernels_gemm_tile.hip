@@ -87,6 +87,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs &g, const int zg)
     char *lds = reinterpret_cast<char *>(red);
 
     if (g.run_flag && *g.run_flag != g.run_gen) return;
+    if constexpr (NWM * NWN == 4) first_round_skew(g.skew, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), (unsigned)g.skew_wgs);      // (measurement form, off by default: device_utils.h)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / NWN, wn = wave % NWN;

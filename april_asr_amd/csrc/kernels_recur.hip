@@ -196,15 +196,19 @@ __device__ __forceinline__ void recur_row_body(const GemmArgs &g)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = (int)(blockDim.x >> 6);
-    const int KB = g.K >> 4, nch = 4 * g.kz, c = KB / nch, cpw = NTILE * nch / nw;      // (checked on the host: cpw * c == TB)
+    // K cut across S workgroups (g.ksplit; 1 = the whole K here): a column granule's chunks are dealt to S consecutive workgroups in slab
+    // order, kz / S whole slabs each -- see the hand-over below
+    const int S = g.ksplit > 1 ? g.ksplit : 1;
+    const int gran = (int)blockIdx.x / S, slice = (int)blockIdx.x - gran * S;
+    const int KB = g.K >> 4, nchk = 4 * g.kz, nch = nchk / S, c = KB / nchk, cpw = NTILE * nch / nw;      // nch: chunks per column tile in THIS workgroup (checked on the host: cpw * c == TB)
     float *red = dyn, *part = dyn + (size_t)NTILE * nch * RPLANE;
     const int first = wave * cpw;                                         // this wave's chains: tile first / nch, chunks first % nch ..
-    const int ct = blockIdx.x * NTILE + first / nch, kb0 = (first % nch) * c;
+    const int ct = gran * NTILE + first / nch, kb0 = (slice * nch + first % nch) * c;
     // epilogue operands.  RF_HR: threads 0..63 = (row, quad).  RF_RESID_SSQ: threads 0..127 = (row, 8 quads of the 32-column granule)
     const int erow = FORM == RF_HR ? (int)threadIdx.x >> 2 : (int)threadIdx.x >> 3, eq = FORM == RF_HR ? (threadIdx.x & 3) : (threadIdx.x & 7);
     const bool e_on = (int)threadIdx.x < 64 * NTILE, e_ok = e_on && erow < g.M;
     const int em = erow < g.M ? erow : g.M - 1;
-    const int en = blockIdx.x * NTILE * 16 + eq * 4;
+    const int en = gran * NTILE * 16 + eq * 4;
     int eslot = 0;
     f32x4 eres = {0.f, 0.f, 0.f, 0.f}, ebias = {0.f, 0.f, 0.f, 0.f};
     ScalePart sp;
@@ -225,16 +229,65 @@ __device__ __forceinline__ void recur_row_body(const GemmArgs &g)
     stream_chains<TB, ((TB > 16 || (FORM == RF_HR && TB > 12)) ? 12 : 16), (FORM == RF_RESID_SSQ || TB > 12) ? 8 : 16>(ap, ao, bp, (uint32_t)lane * 16u, c, [&](int q, const f32x4 &acc) { plane_store(mine + q * RPLANE, lane, acc); });
     if (FORM == RF_HR && threadIdx.x < 64) scale_park(part, sp);
     __syncthreads();
+    const int tile = FORM == RF_HR ? 0 : eq >> 2;
+    const int o = erow * RLD + (eq & 3) * 4;
+    // slab sums ((c0 + c1) + c2) + c3 (z: slab number within this workgroup), then the balanced tree in slab order
+    auto slab = [&](int z) {
+        const float *p = red + (size_t)(tile * nch + 4 * z) * RPLANE + o;
+        return ((*reinterpret_cast<const f32x4 *>(p) + *reinterpret_cast<const f32x4 *>(p + RPLANE)) + *reinterpret_cast<const f32x4 *>(p + 2 * RPLANE)) + *reinterpret_cast<const f32x4 *>(p + 3 * RPLANE);
+    };
+    f32x4 sl[8];
+#pragma unroll
+    for (int z = 0; z < 8; ++z) sl[z] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (S > 1) {
+        // Hand-over between the S workgroups of a granule, without a spin and without a fence: every workgroup leaves its slab sums (rows < M
+        // only: 16 bytes per row, quad and slab) in the launch's workspace with agent-scope stores (they pass the XCD's L2, which is not
+        // coherent with the other seven), waits until they have been acknowledged, and counts itself in on the granule's word; whoever finds
+        // S - 1 there is the last one, re-arms the word, fetches all kz slab sums (agent-scope loads) and finishes tree + epilogue exactly as
+        // the one-workgroup form does.  The others are done.  Same slab sums, same tree => the same bits as S = 1.
+        const int zs = g.kz / S, ncol = 16 * NTILE;
+        using gfloat = __attribute__((address_space(1))) float;
+        using guint = __attribute__((address_space(1))) unsigned;
+        gfloat *wsg = (gfloat *)(g.ks_ws) + (size_t)gran * g.kz * 16 * ncol;
+        guint *cnt = (guint *)(g.ks_cnt) + gran;
+        if (e_ok) {
+            for (int z = 0; z < zs; ++z) {
+                const f32x4 t = slab(z);
+                gfloat *q = wsg + ((size_t)(slice * zs + z) * 16 + erow) * ncol + tile * 16 + (eq & 3) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) __hip_atomic_store(q + j, t[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0): this wave's stores have been acknowledged
+        asm volatile("" ::: "memory");
+        __shared__ int ks_last;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == (unsigned)(S - 1);
+            if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ks_last = last;
+        }
+        __syncthreads();
+        if (!ks_last) return;
+        if (e_ok) {
+            for (int z = 0; z < g.kz; ++z) {
+                const gfloat *q = wsg + ((size_t)z * 16 + erow) * ncol + tile * 16 + (eq & 3) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sl[z][j] = __hip_atomic_load(q + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
     if (e_on) {
-        const int tile = FORM == RF_HR ? 0 : eq >> 2;
-        const int o = erow * RLD + (eq & 3) * 4;
-        // slab sums ((c0 + c1) + c2) + c3, then the balanced tree in slab order
-        auto slab = [&](int z) {
-            const float *p = red + (size_t)(tile * nch + 4 * z) * RPLANE + o;
-            return ((*reinterpret_cast<const f32x4 *>(p) + *reinterpret_cast<const f32x4 *>(p + RPLANE)) + *reinterpret_cast<const f32x4 *>(p + 2 * RPLANE)) + *reinterpret_cast<const f32x4 *>(p + 3 * RPLANE);
-        };
         f32x4 v;
-        if (g.kz == 8) v = ((slab(0) + slab(1)) + (slab(2) + slab(3))) + ((slab(4) + slab(5)) + (slab(6) + slab(7)));
+        if (S > 1) {
+            // the last of the granule's S workgroups (the hand-over above) holds every slab sum in sl[]
+            if (g.kz == 8) v = ((sl[0] + sl[1]) + (sl[2] + sl[3])) + ((sl[4] + sl[5]) + (sl[6] + sl[7]));
+            else if (g.kz == 4) v = (sl[0] + sl[1]) + (sl[2] + sl[3]);
+            else v = sl[0] + sl[1];
+        }
+        else if (g.kz == 8) v = ((slab(0) + slab(1)) + (slab(2) + slab(3))) + ((slab(4) + slab(5)) + (slab(6) + slab(7)));
         else if (g.kz == 4) v = (slab(0) + slab(1)) + (slab(2) + slab(3));
         else if (g.kz == 2) v = slab(0) + slab(1);
         else v = slab(0);
@@ -277,7 +330,7 @@ bool row_tb_ok(int tb) {
 #undef X
     return false;
 }
-int row_waves(const GemmArgs &g, int ntile) { const int chains = 4 * g.kz * ntile, cap = ntile == 2 ? 16 : 8; return chains < cap ? chains : cap; }
+int row_waves(const GemmArgs &g, int ntile) { const int chains = 4 * g.kz * ntile / (g.ksplit > 1 ? g.ksplit : 1), cap = ntile == 2 ? 16 : 8; return chains < cap ? chains : cap; }
 
 int recur_enabled()
 {
@@ -303,8 +356,9 @@ template <int FORM>
 void launch_row(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStream_t s)
 {
     constexpr int NTILE = FORM == RF_RESID_SSQ ? 2 : 1;
-    const int nw = row_waves(g, NTILE), chains = 4 * g.kz * NTILE;
-    const dim3 grid((unsigned)(g.N / (16 * NTILE)), (unsigned)(dev_args ? n : 1), 1);
+    const int S = g.ksplit > 1 ? g.ksplit : 1;
+    const int nw = row_waves(g, NTILE), chains = 4 * g.kz * NTILE / S;      // (chains of ONE workgroup)
+    const dim3 grid((unsigned)(g.N / (16 * NTILE) * S), (unsigned)(dev_args ? n : 1), 1);
     const size_t lds = ((size_t)chains * RPLANE + 16 * (MAX_GROUPS + 1)) * sizeof(float);
     switch (g.K / 16 / (4 * g.kz) * (chains / nw)) {
 #define X(tb) case tb: { \
@@ -347,9 +401,39 @@ int recur_form(const GemmArgs &g)
     if (g.epi == EPI_XPART && halves && g.wave_mask == 0x3 && !g.p_add && xs_ok && g.N % 32 == 0) return RECUR_XPART;
     if (g.epi == EPI_BIAS_DSWISH && g.wave_mask == 0xF && g.kz == 1 && g.K1 == 0 && cell_tb_ok(KB / 4) && g.out && g.N % 16 == 0) return RECUR_DSWISH;
     if (g.wave_mask != 0xF || g.K1 != 0 || !kz_ok || KB % (4 * g.kz) != 0) return 0;
-    if (g.epi == EPI_HR && g.N % 16 == 0 && g.r_scale.ssq && g.r_scale.groups <= MAX_GROUPS && row_tb_ok(KB / row_waves(g, 1))) return RECUR_HR;
-    if (g.epi == EPI_RESID_SSQ && g.N % 32 == 0 && g.ssq_out && row_tb_ok(2 * KB / row_waves(g, 2))) return RECUR_RESID_SSQ;
+    const int S = g.ksplit > 1 ? g.ksplit : 1;
+    if (S > 1 && (g.kz % S != 0 || g.kz / S < 1 || !g.ks_ws || !g.ks_cnt)) return 0;      // (recur_ksplit only hands out divisors of kz)
+    if (g.epi == EPI_HR && g.N % 16 == 0 && g.r_scale.ssq && g.r_scale.groups <= MAX_GROUPS && row_tb_ok(KB / S / row_waves(g, 1))) return RECUR_HR;
+    if (g.epi == EPI_RESID_SSQ && g.N % 32 == 0 && g.ssq_out && row_tb_ok(2 * KB / S / row_waves(g, 2))) return RECUR_RESID_SSQ;
     return 0;
+}
+
+// K cut of the row forms across workgroups (GemmArgs::ksplit) -- a MEASUREMENT FORM, off by default.  N = d_model gives 16 (FFN down: 32-column
+// granules) or 32 (projection) workgroups per problem; the 4 MB of FFN-down weights of one session's step take 9.8 us in 16 workgroups
+// beside 4.9 us for the same bytes of FFN up in 128.  Cutting K across S workgroups per granule with the in-launch hand-over of
+// recur_row_body (agent-scope stores, one counter word, the last arriver finishes: no spin, no fence; bit-identical) was built and measured
+// in round 6 (tools/kw_bench, profiles/r06_ksplit_bench.txt): the hand-over itself costs 2.7 .. 4 us -- store acknowledgement, the counter's
+// round trip, the fetch of the slab sums, three dependent trips to the memory side -- against 1 .. 2 us saved on the stream: projection
+// 4.4 -> 7.0 us, FFN down 8.8 -> 10.1 us at one row, 11.8 -> 11.9 at sixteen.  So the whole-K form stays.  S = the power of two that brings
+// the launch to ~128 workgroups, at most kz (whole slabs per workgroup); needs the caller's workspace (ks_ws / ks_cnt).
+// APRIL_RECUR_KSPLIT: 0 = off (default), 1 = planner, N > 1 = pin S.
+static int g_ksplit_pin = -1;
+void recur_ksplit_pin(int s) { g_ksplit_pin = s; }
+int recur_ksplit(const GemmArgs &g, int n)
+{
+    static const int env_mode = [] { const char *e = getenv("APRIL_RECUR_KSPLIT"); return e && *e ? atoi(e) : 0; }();
+    const int mode = g_ksplit_pin >= 0 ? g_ksplit_pin : env_mode;
+    static const int target = [] { const char *e = getenv("APRIL_RECUR_KSPLIT_WGS"); return e && *e ? atoi(e) : 128; }();
+    if (!mode || !recur_enabled() || !g.ks_ws || !g.ks_cnt || g.M < 1 || g.M > 16 || g.kz < 2 || (g.epi != EPI_HR && g.epi != EPI_RESID_SSQ)) return 1;
+    const int wgs = g.N / (g.epi == EPI_RESID_SSQ ? 32 : 16) * (n > 0 ? n : 1);
+    int S = 1;
+    if (mode > 1) S = mode; else while (S * 2 <= g.kz && wgs * S < target) S *= 2;
+    while (S > 1 && (S > g.kz || g.kz % S != 0)) S >>= 1;
+    if (S > 1) {      // (a cut without a kernel for its blocks per wave: keep the whole-K form)
+        GemmArgs t = g; t.ksplit = S;
+        if (!recur_form(t)) return 1;
+    }
+    return S;
 }
 
 // n problems of one shape (dev_args: their argument blocks in device memory) or one problem by value (dev_args == null)

@@ -48,6 +48,7 @@ int main(int argc, char **argv)
         g.c_state = cst; g.slot_idx = idx; g.hidden = N / 4; g.ldo = N / 4;
         g.x_scale.ssq = ssq; g.x_scale.groups = (K / 2) / 32; g.x_scale.inv_n = 1.0f / (K / 2); g.x_scale.eps = 0.25f;
     }
+    if (getenv("GB_TILE_OK")) g.tile_ok = atoi(getenv("GB_TILE_OK"));      // 2 = the GM_TILE form (the engine's choice for gates launches from 2048 rows)
     hipStream_t s; hipStreamCreate(&s);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 20; ++i) launch_gemm(g, s);
@@ -63,6 +64,13 @@ int main(int argc, char **argv)
         g.trace = tr; g.wp = w; launch_gemm(g, s); hipStreamSynchronize(s); g.trace = nullptr;
         std::vector<unsigned long long> ht((size_t)nwg * 8);
         hipMemcpy(ht.data(), tr, ht.size() * 8, hipMemcpyDeviceToHost);
+        if (getenv("GB_TILE_OK")) {   // GM_TILE (kernels_gemm_tile.hip built with -DAPRIL_GEMM_TRACE): per-workgroup SUMS of phase intervals, [7] = stages
+            double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int nw = 0;
+            for (int i = 0; i < nwg; ++i) if (ht[(size_t)i * 8 + 7]) { ++nw; for (int k = 0; k < 8; ++k) acc[k] += (double)ht[(size_t)i * 8 + k]; }
+            if (nw) printf("  tile trace (%d workgroups, %.0f stages each; s_memtime ticks per stage): first k block %.0f | chunk ends %.0f | wait+barrier %.0f | issue + second k block %.0f | loop total %.0f ; fragment waits + prologue %.0f, fragment waits + epilogue %.0f ticks per workgroup\n",
+                           nw, acc[7] / nw, acc[0] / acc[7], acc[1] / acc[7], acc[2] / acc[7], acc[3] / acc[7], acc[4] / acc[7], acc[5] / nw, acc[6] / nw);
+            return 0;
+        }
         unsigned long long t0 = ~0ull, t1 = 0; int n = 0;
         for (int i = 0; i < nwg; ++i) if (ht[(size_t)i * 8]) { ++n; t0 = std::min(t0, ht[(size_t)i * 8]); t1 = std::max(t1, ht[(size_t)i * 8 + 4]); }
         double seg[5] = {0, 0, 0, 0, 0}, start_spread = 0;

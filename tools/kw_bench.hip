@@ -22,6 +22,7 @@ struct Problem {
     int M, N, K, kz, epi; bool a_indexed = false;      // a_indexed: the activation rows are reached through the row -> slot indirection (aidx0)
     float *a, *w, *bias, *resid, *ssq_in, *out, *state, *ssq_out, *cst = nullptr, *cst0 = nullptr;      // cst: cell state (gates), cst0: its initial values
     int *slots;
+    float *ks_ws = nullptr; unsigned *ks_cnt = nullptr;      // workspace of the K-cut stream kernels (<= 16 rows; kernels_recur.hip)
 };
 static void fill(std::vector<float> &h, unsigned seed, float scale)
 {
@@ -42,6 +43,7 @@ static Problem make_problem(int M, int N, int K, int kz, int epi, unsigned seed)
     std::vector<int> perm((size_t)M); for (int i = 0; i < M; ++i) perm[(size_t)i] = i;
     unsigned s = seed; for (int i = M - 1; i > 0; --i) { s = s * 1664525u + 1013904223u; std::swap(perm[(size_t)i], perm[(size_t)((s >> 8) % (unsigned)(i + 1))]); }
     p.slots = dalloc<int>((size_t)M); CK(hipMemcpy(p.slots, perm.data(), (size_t)M * 4, hipMemcpyHostToDevice));
+    if (M <= 16 && (epi == EPI_HR || epi == EPI_RESID_SSQ)) { p.ks_ws = dalloc<float>((size_t)N * kz * 16); p.ks_cnt = dalloc<unsigned>((size_t)N / 16); CK(hipMemset(p.ks_cnt, 0, (size_t)N / 16 * 4)); }
     if (epi == EPI_LSTM) {      // gates: A = [y (M x K/2, rows) | h (M x K/2, by slot)], c state [M][N/4]
         h.resize((size_t)M * (N / 4)); fill(h, seed + 5, 1.0f); p.cst0 = upload(h); p.cst = dalloc<float>(h.size());
         h.resize((size_t)M * (K / 64)); fill(h, seed + 6, 1.0f); for (auto &v : h) v = v * v + 0.1f;
@@ -49,6 +51,7 @@ static Problem make_problem(int M, int N, int K, int kz, int epi, unsigned seed)
     }
     return p;
 }
+static bool g_ks_attach = false;      // hand the K-cut workspace to the GEMMs (the engine always does; off for the reference runs)
 static GemmArgs gemm_of(const Problem &p, int zcount, int tile_ok = 0)
 {
     GemmArgs g; g.tile_ok = tile_ok;
@@ -62,6 +65,7 @@ static GemmArgs gemm_of(const Problem &p, int zcount, int tile_ok = 0)
     else if (p.epi == EPI_HR) { g.state = p.state; g.ld_state = p.N; g.slot_idx = p.slots; g.resid = p.resid; g.ldr = p.N;
                            g.r_scale.ssq = p.ssq_in; g.r_scale.groups = p.N / 32; g.r_scale.inv_n = 1.0f / p.N; g.r_scale.eps = 0.25f; g.bias = nullptr; g.force_fullk = 1; }
     else if (p.epi == EPI_RESID_SSQ) { g.resid = p.resid; g.ldr = p.N; g.ssq_out = p.ssq_out; g.force_fullk = 1; }
+    if (g_ks_attach) { g.ks_ws = p.ks_ws; g.ks_cnt = p.ks_cnt; }
     return g;
 }
 struct Chain {
@@ -117,6 +121,14 @@ int main(int argc, char **argv)
     hipStream_t s; CK(hipStreamCreate(&s));
     struct Shape { const char *name; int M, N, K, kz, epi, n; bool idx = false; };
     const Shape shapes[] = {
+        {"proj    1x1", 1, 512, 1024, 4, EPI_HR, 1},                     // one session streaming: 1 .. 3 problems of one row
+        {"proj    1x2", 1, 512, 1024, 4, EPI_HR, 2},
+        {"proj    1x3", 1, 512, 1024, 4, EPI_HR, 3},
+        {"ffdn    1x1", 1, 512, 2048, 8, EPI_RESID_SSQ, 1},
+        {"ffdn    1x2", 1, 512, 2048, 8, EPI_RESID_SSQ, 2},
+        {"ffdn    1x3", 1, 512, 2048, 8, EPI_RESID_SSQ, 3},
+        {"ffdn    2x3", 2, 512, 2048, 8, EPI_RESID_SSQ, 3},
+        {"proj   1x12", 1, 512, 1024, 4, EPI_HR, 12},                    // the recurrent pair of a long feed: twelve layers per launch
         {"proj    4x3", 4, 512, 1024, 8, EPI_HR, 3},                     // <= 16 rows: the reference is the weight-stream kernel of kernels_recur.hip
         {"ffdn    8x2", 8, 512, 2048, 8, EPI_RESID_SSQ, 2},
         {"proj   16x3", 16, 512, 1024, 8, EPI_HR, 3},
@@ -177,6 +189,26 @@ int main(int argc, char **argv)
         const std::vector<float> want = snapshot(ps);
         const double t_ref = time_chain(ref, s, iters);
         printf("%-13s M=%d N=%d K=%d kz=%d x%d | round-4 schedule (mode %d): %7.2f us (%.3f of peak)\n", sh.name, sh.M, sh.N, sh.K, sh.kz, sh.n, ref.gh[0].mode, t_ref, flops / (t_ref * 1e-6) / 157.3e12);
+        if (sh.M <= 16 && (sh.epi == EPI_HR || sh.epi == EPI_RESID_SSQ)) {
+            // the stream kernel with K cut across workgroups (in-launch hand-over, kernels_recur.hip): planner's cut, then every pinned one
+            for (int cut : {1, 2, 4, 8}) {
+                if (cut > sh.kz) continue;
+                g_ks_attach = true; recur_ksplit_pin(cut); gemm_kw_pin(0, 0, 0);
+                Chain c = make_chain(ps);
+                g_ks_attach = false;
+                const int got_cut = c.n == 1 ? recur_ksplit(c.gh[0], 1) : c.gh[0].ksplit;      // (launch_gemm plans a single problem again at every launch: the pin stays)
+                clear_outputs(ps); c.run(s); CK(hipStreamSynchronize(s));
+                const std::vector<float> got = snapshot(ps);
+                size_t diff = 0; for (size_t i = 0; i < want.size(); ++i) if (memcmp(&want[i], &got[i], 4) != 0) ++diff;
+                const double t = time_chain(c, s, iters);
+                clear_outputs(ps); for (int i = 0; i < 7; ++i) c.run(s); CK(hipStreamSynchronize(s));      // back-to-back: the counters re-arm
+                recur_ksplit_pin(-1);
+                const std::vector<float> got2 = snapshot(ps);
+                size_t diff2 = 0; for (size_t i = 0; i < want.size(); ++i) if (memcmp(&want[i], &got2[i], 4) != 0) ++diff2;
+                printf("    stream kernel, K cut %s-> %d workgroups per granule : %7.2f us (%.2fx)  %s\n", cut == 1 ? "(planner) " : "", got_cut, t, t_ref / t, (diff || diff2) ? "MISMATCH" : "bit-identical");
+                if (diff || diff2) { ++bad; printf("      mismatching floats: %zu / %zu of %zu\n", diff, diff2, want.size()); }
+            }
+        }
         if (sh.epi != EPI_BIAS_DSWISH && gemm_tile_planned(sh.M, sh.N, sh.kz, sh.n) && gemm_fullk(sh.M, sh.N, sh.kz, true, sh.n, 1)) {
             // GM_TILE with the row work fused, where the engine's planner would take it (for the crossover between the two)
             gemm_kw_pin(0, 0, 0);

@@ -174,10 +174,19 @@ int main(int argc, char **argv)
         {"ffdn 2048x2", 2048, 512, 2048, 8, EPI_RESID_SSQ, 2},
         {"ffdn 2048x3", 2048, 512, 2048, 8, EPI_RESID_SSQ, 3},
         {"ffdn 512x3 L", 512, 768, 3072, 8, EPI_RESID_SSQ, 3},          // larger encoder (configs[4] dims)
+        {"proj 2560x2", 2560, 512, 1024, 4, EPI_HR, 2},                 // the capacity boundary (2560 .. 2816 sessions): 640 .. 1056 tiles of 64 x 64
+        {"proj 2560x3", 2560, 512, 1024, 4, EPI_HR, 3},
+        {"ffdn 2560x2", 2560, 512, 2048, 8, EPI_RESID_SSQ, 2},
+        {"ffdn 2560x3", 2560, 512, 2048, 8, EPI_RESID_SSQ, 3},
+        {"proj 2816x2", 2816, 512, 1024, 4, EPI_HR, 2},
+        {"proj 2816x3", 2816, 512, 1024, 4, EPI_HR, 3},
+        {"ffdn 2816x2", 2816, 512, 2048, 8, EPI_RESID_SSQ, 2},
+        {"ffdn 2816x3", 2816, 512, 2048, 8, EPI_RESID_SSQ, 3},
     };
     int bad = 0;
     for (const Shape &sh : shapes) {
         if (only >= 0 && (&sh - shapes) != only) continue;
+        if (getenv("TB_FIRST") && (&sh - shapes) < atoi(getenv("TB_FIRST"))) continue;
         std::vector<Problem> ps;
         for (int i = 0; i < sh.n; ++i) ps.push_back(make_problem(sh.M, sh.N, sh.K, sh.kz, sh.epi, 1000u * (unsigned)(&sh - shapes) + 10u * (unsigned)i));
         const double flops = 2.0 * sh.M * sh.N * sh.K * sh.n;
