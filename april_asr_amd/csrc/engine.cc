@@ -341,6 +341,12 @@ void Engine::finish_weights()
         }
         HIP_CHECK(hipDeviceSynchronize());
     }
+    if (!conv_wt_) {   // the many-chunk form of the conv front end reads its weights channel-fastest (kernels_misc.hip conv12_wide_kernel)
+        const NetDims &d = L_.dims;
+        conv_wt_ = dmalloc<float>((size_t)9 * d.conv_ch[0] + (size_t)9 * d.conv_ch[0] * d.conv_ch[1]);
+        launch_conv_weight_transpose(w_ + L_.conv_w[0], w_ + L_.conv_w[1], d.conv_ch[0], d.conv_ch[1], conv_wt_, conv_wt_ + (size_t)9 * d.conv_ch[0], nullptr);
+        HIP_CHECK(hipDeviceSynchronize());
+    }
     build_dec_table();
 }
 
@@ -401,6 +407,7 @@ Engine::~Engine()
     for (void *p : {(void *)lm_now_d_, (void *)lm_rows_d_, (void *)lm_rec_off_d_}) if (p) (void)hipFree(p);
     if (ws_g_) (void)hipFree(ws_g_);
     if (ks_ws_) (void)hipFree(ks_ws_);
+    if (conv_wt_) (void)hipFree(conv_wt_);
     if (ks_cnt_) (void)hipFree(ks_cnt_);
     if (dec_table_) (void)hipFree(dec_table_);
     if (p_lm_) (void)hipFree(p_lm_);
@@ -709,6 +716,7 @@ void Engine::run_encoder_rows(int n, const int *d_slots, const int *d_tails, con
     ca.ch1_per_group = 1;                                 // largest divisor of the second conv's channel count that is <= 8
     for (int k = 8; k > 1; --k) if (d.conv_ch[1] % k == 0) { ca.ch1_per_group = k; break; }
     ca.out = a3_; ca.ldo = L_.k3; ca.M = n;
+    if (conv_wt_) { ca.w0t = conv_wt_; ca.w1t = conv_wt_ + (size_t)9 * d.conv_ch[0]; }
     timed_begin(T_CONV); launch_conv_embed(ca, stream_); timed_end(T_CONV);
     {   // third conv: [n*f_out, k3] x [k3, c2] + bias, DoubleSwish -> xin[n][f_out*c2]
         GemmArgs g; g.a0 = a3_; g.lda0 = L_.k3; g.K0 = L_.k3; g.wp = w_ + L_.conv_w[2];
@@ -903,6 +911,7 @@ void Engine::lm_stage_embed(int m, int t0, int t1, hipStream_t st, bool own_ws)
     ca.ch1_per_group = 1;
     for (int k = 8; k > 1; --k) if (d.conv_ch[1] % k == 0) { ca.ch1_per_group = k; break; }
     ca.out = a3_ + r0 * d.f_out * L_.k3; ca.ldo = L_.k3; ca.M = rows;
+    if (conv_wt_) { ca.w0t = conv_wt_; ca.w1t = conv_wt_ + (size_t)9 * d.conv_ch[0]; }
     timed_begin(T_CONV); launch_conv_embed(ca, st); timed_end(T_CONV);
     {
         GemmArgs g; g.a0 = a3_ + r0 * d.f_out * L_.k3; g.lda0 = L_.k3; g.K0 = L_.k3; g.wp = w_ + L_.conv_w[2];

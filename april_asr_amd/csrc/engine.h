@@ -286,6 +286,7 @@ private:
     // gemm split factors (fixed per shape => batch-invariant numerics)
     int kz_embed_ = 1, kz_hr_ = 1, kz_ff2_ = 1, kz_proj_ = 1, kz_out_ = 1;
     int ws_mstride_ = 0;
+    float *conv_wt_ = nullptr;      // transposed weights of the first two convolutions: [9][ch0] then [ch0 * 9][ch1] (finish_weights)
     // workspace of the K-cut stream kernels at <= 16 rows (kernels.h GemmArgs::ks_ws / ks_cnt): per layer, projection and FFN down apart
     float *ks_ws_ = nullptr; unsigned *ks_cnt_ = nullptr; size_t ks_ws_stride_ = 0, ks_cnt_stride_ = 0;
     void attach_ksplit(GemmArgs &g, int l, int which) const;

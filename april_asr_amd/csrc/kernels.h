@@ -335,8 +335,10 @@ struct ConvEmbedArgs {
     float *out = nullptr; int ldo = 0;     // im2col rows of the third conv: [M * f_out][ldo], k = ci*9 + i*3 + j
     int M = 0;
     const float *x_direct = nullptr;       // debug path: x given as [M][seg][mel] instead of the ring
+    const float *w0t = nullptr, *w1t = nullptr;      // optional: the first two convs' weights transposed (launch_conv_weight_transpose): [9][ch0], [ch0 * 9][ch1] -- the many-chunk form needs them
 };
 void launch_conv_embed(const ConvEmbedArgs &a, hipStream_t s);
+void launch_conv_weight_transpose(const float *w0, const float *w1, int c0, int c1, float *w0t, float *w1t, hipStream_t s);
 
 // fp32 -> fp16 (round to nearest even), elementwise; used once at load for the fp16 weight copies
 void launch_cvt_f16(const float *src, void *dst, size_t n, hipStream_t s);

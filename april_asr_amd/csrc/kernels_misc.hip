@@ -417,8 +417,157 @@ __global__ __launch_bounds__(256) void conv12_kernel(ConvEmbedArgs a)
     }
 }
 
+// The same front end for MANY chunks (round 6): one workgroup per chunk computes ALL second-conv channels -- the first conv once instead
+// of once per channel group (a quarter of the old form's multiplies were that recomputation), CPS channels of a position per thread with
+// the weights transposed once at load ([ci][k][channel]: a position's channels sit side by side at wave-uniform addresses, i.e. scalar
+// loads, no LDS traffic for weights) so that two channels share one
+// packed multiply and one packed add (v_pk_mul_f32 / v_pk_add_f32: the build keeps multiply and add apart, -ffp-contract=off, as the
+// oracle's C does).  Every output is the same chain as in conv12_kernel -- input channel, kernel row, kernel column, bias last -- so the
+// two forms agree bit for bit (tests/test_gpu_golden.py runs both).  At 2048 sessions the old form took 239 us per 100 ms step.
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+constexpr int pad4(int n) { return (n + 3) & ~3; }
+// (channel counts and the subset count are compile-time: the index arithmetic of the im2col rows and the channel loops is then
+// multiplications and shifts -- with run-time divisors it was a third of the kernel's instructions)
+template <int C0, int C1, int NSUB>
+__global__ __launch_bounds__(256) void conv12_wide_kernel(ConvEmbedArgs a)
+{
+    constexpr int CPS = C1 / NSUB;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int m = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int H0 = a.seg, W0 = a.mel;
+    const int s0 = a.stride[0], s1 = a.stride[1], s2 = a.stride[2];
+    const int H1 = (H0 - 3) / s0 + 1, W1 = (W0 - 3) / s0 + 1;
+    const int H2 = (H1 - 3) / s1 + 1, W2 = (W1 - 3) / s1 + 1;
+    const int W3 = (W2 - 3) / s2 + 1;
+    constexpr int c0 = C0, c1 = C1, WS = C1;
+    const int NP = H2 * W2;
+    float *x = lds;                              // H0*W0
+    float *a1 = x + pad4(H0 * W0);               // c0*H1*W1
+    float *a2 = a1 + pad4(c0 * H1 * W1);         // c1*NP
+    // the weights come transposed from the engine (launch_conv_weight_transpose): w1t[ci * 9 + k][c1], w0t[k][c0] -- a position's channels
+    // are consecutive, their addresses uniform over the wave: scalar loads, the products take them straight from SGPR pairs
+    const float *__restrict__ wl = a.w1t, *__restrict__ w0l = a.w0t;
+
+    if (a.x_direct) {
+        for (int i = tid; i < H0 * W0; i += 256) x[i] = a.x_direct[(size_t)m * H0 * W0 + i];
+    } else {
+        // eight rows x 32-column strides per pass: no divisions (the ring row wraps at most once: tail < ring_frames, H0 <= ring_frames)
+        const int slot = a.slot_idx[m];
+        const int tail = a.ring_tail[m];
+        const float *ring = a.ring + (size_t)slot * a.ring_frames * W0;
+        for (int row = tid >> 5; row < H0; row += 8) {
+            int rr = tail + row;
+            if (rr >= a.ring_frames) rr -= a.ring_frames;
+            for (int col = tid & 31; col < W0; col += 32) x[row * W0 + col] = ring[(size_t)rr * W0 + col];
+        }
+    }
+    __syncthreads();
+    for (int p = tid; p < H1 * W1; p += 256) {
+        const int oh = p / W1, ow = p % W1;
+        float patch[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) patch[i * 3 + j] = x[(oh * s0 + i) * W0 + ow * s0 + j];
+        for (int cq = 0; cq < c0; cq += 4) {                               // four channels at a time (c0 % 4 == 0, checked on the host)
+            f32x2 lo = f32x2{0.0f, 0.0f}, hi = f32x2{0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(w0l + k * c0 + cq);
+                const f32x2 pk = f32x2{patch[k], patch[k]};
+                lo = lo + pk * f32x2{w.x, w.y};
+                hi = hi + pk * f32x2{w.z, w.w};
+            }
+            a1[(cq + 0) * H1 * W1 + p] = dswish_dev(lo.x + a.b[0][cq + 0]);
+            a1[(cq + 1) * H1 * W1 + p] = dswish_dev(lo.y + a.b[0][cq + 1]);
+            a1[(cq + 2) * H1 * W1 + p] = dswish_dev(hi.x + a.b[0][cq + 2]);
+            a1[(cq + 3) * H1 * W1 + p] = dswish_dev(hi.y + a.b[0][cq + 3]);
+        }
+    }
+    __syncthreads();
+    {
+        // threads = (channel subset, position): `per` positions (whole waves) x 256 / per subsets of CPS channels (checked on the host)
+        constexpr int per = 256 / NSUB;                                    // (>= NP, whole waves: checked on the host)
+        const int sub = __builtin_amdgcn_readfirstlane(tid / per);
+        const int pq = tid % per, pc = pq < NP ? pq : NP - 1;              // (idle lanes recompute the last position; never stored)
+        const int oh = pc / W2, ow = pc % W2;
+        const int cbase = sub * CPS;
+        f32x2 acc[CPS / 2];
+#pragma unroll
+        for (int q = 0; q < CPS / 2; ++q) acc[q] = f32x2{0.0f, 0.0f};
+        for (int ci = 0; ci < c0; ++ci) {
+            const float *src = a1 + ci * H1 * W1 + (oh * s1) * W1 + ow * s1;
+            float patch[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) patch[i * 3 + j] = src[i * W1 + j];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const f32x4 *wq = reinterpret_cast<const f32x4 *>(wl + (ci * 9 + k) * WS + cbase);
+                const f32x2 pk = f32x2{patch[k], patch[k]};
+#pragma unroll
+                for (int q = 0; q < CPS / 4; ++q) {
+                    const f32x4 w = wq[q];
+                    acc[2 * q] = acc[2 * q] + pk * f32x2{w.x, w.y};
+                    acc[2 * q + 1] = acc[2 * q + 1] + pk * f32x2{w.z, w.w};
+                }
+            }
+        }
+        if (pq < NP) {
+#pragma unroll
+            for (int q = 0; q < CPS / 2; ++q) {
+                const int cl = cbase + 2 * q;
+                a2[cl * NP + pq] = dswish_dev(acc[q].x + a.b[1][cl]);
+                a2[(cl + 1) * NP + pq] = dswish_dev(acc[q].y + a.b[1][cl + 1]);
+            }
+        }
+    }
+    __syncthreads();
+    // im2col rows of the third conv: consecutive threads write consecutive k (whole rows of c1*9 floats)
+    constexpr int krow = c1 * 9;
+    for (int e = tid; e < W3 * krow; e += 256) {
+        const int ow = e / krow, kl = e % krow;
+        const int cl = kl / 9, i = (kl % 9) / 3, j = kl % 3;
+        a.out[((size_t)m * W3 + ow) * a.ldo + kl] = a2[cl * NP + i * W2 + ow * s2 + j];
+    }
+}
+
+// w1 [c1][c0][9] -> w1t [c0 * 9][c1], w0 [c0][9] -> w0t [9][c0] (once, at load)
+__global__ __launch_bounds__(256) void conv_weight_transpose_kernel(const float *w0, const float *w1, int c0, int c1, float *w0t, float *w1t)
+{
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < c1 * c0 * 9; i += gridDim.x * 256) w1t[(i % (c0 * 9)) * c1 + i / (c0 * 9)] = w1[i];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < c0 * 9; i += gridDim.x * 256) w0t[(i % 9) * c0 + i / 9] = w0[i];
+}
+void launch_conv_weight_transpose(const float *w0, const float *w1, int c0, int c1, float *w0t, float *w1t, hipStream_t s)
+{
+    hipLaunchKernelGGL(conv_weight_transpose_kernel, dim3(8), dim3(256), 0, s, w0, w1, c0, c1, w0t, w1t);
+}
+
+// the wide form where it exists, from APRIL_CONV_WIDE_MIN (default 48; -1 = never) chunks per launch (below that the channel groups of
+// conv12_kernel are what fills the chip)
+static bool conv_wide_ok(const ConvEmbedArgs &a)
+{
+    static const int min_chunks = [] { const char *e = getenv("APRIL_CONV_WIDE_MIN"); return e && *e ? atoi(e) : 48; }();
+    if (min_chunks < 0 || a.M < min_chunks || !a.w1t || !a.w0t) return false;
+    const int H1 = (a.seg - 3) / a.stride[0] + 1, W1 = (a.mel - 3) / a.stride[0] + 1;
+    const int H2 = (H1 - 3) / a.stride[1] + 1, W2 = (W1 - 3) / a.stride[1] + 1;
+    const int NP = H2 * W2;
+    const size_t lds = sizeof(float) * ((size_t)pad4(a.seg * a.mel) + pad4(a.ch[0] * H1 * W1) + pad4(a.ch[1] * NP));
+    // the instantiated shape: 8 -> 32 channels, the second conv's positions in two waves (aprilv0 and the larger encoder: 80 mel bins, 9 frames)
+    return H2 == 3 && a.ch[0] == 8 && a.ch[1] == 32 && NP > 64 && NP <= 128 && a.seg <= a.ring_frames && lds <= 64 * 1024;
+}
+
 void launch_conv_embed(const ConvEmbedArgs &a, hipStream_t s)
 {
+    if (conv_wide_ok(a)) {
+        const int H1 = (a.seg - 3) / a.stride[0] + 1, W1 = (a.mel - 3) / a.stride[0] + 1;
+        const int H2 = (H1 - 3) / a.stride[1] + 1, W2 = (W1 - 3) / a.stride[1] + 1;
+        const size_t lds = sizeof(float) * ((size_t)pad4(a.seg * a.mel) + pad4(a.ch[0] * H1 * W1) + pad4(a.ch[1] * H2 * W2));
+        hipLaunchKernelGGL((conv12_wide_kernel<8, 32, 2>), dim3((unsigned)a.M), dim3(256), lds, s, a);
+        return;
+    }
     const int H1 = (a.seg - 3) / a.stride[0] + 1, W1 = (a.mel - 3) / a.stride[0] + 1;
     const int H2 = (H1 - 3) / a.stride[1] + 1, W2 = (W1 - 3) / a.stride[1] + 1;
     const size_t lds = sizeof(float) * ((size_t)a.seg * a.mel + (size_t)a.ch[0] * H1 * W1 + (size_t)a.ch1_per_group * H2 * W2);
