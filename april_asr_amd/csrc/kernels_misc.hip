@@ -486,6 +486,7 @@ __global__ __launch_bounds__(256) void conv12_wide_kernel(ConvEmbedArgs a)
         }
     }
     __syncthreads();
+    for (int kl = tid; kl < c1 * 9; kl += 256) reinterpret_cast<int *>(x)[kl] = (kl / 9) * NP + ((kl % 9) / 3) * W2 + kl % 3;      // (x is free now; read behind the next barrier)
     {
         // threads = (channel subset, position): `per` positions (whole waves) x 256 / per subsets of CPS channels (checked on the host)
         constexpr int per = 256 / NSUB;                                    // (>= NP, whole waves: checked on the host)
@@ -525,12 +526,17 @@ __global__ __launch_bounds__(256) void conv12_wide_kernel(ConvEmbedArgs a)
         }
     }
     __syncthreads();
-    // im2col rows of the third conv: consecutive threads write consecutive k (whole rows of c1*9 floats)
-    constexpr int krow = c1 * 9;
-    for (int e = tid; e < W3 * krow; e += 256) {
-        const int ow = e / krow, kl = e % krow;
-        const int cl = kl / 9, i = (kl % 9) / 3, j = kl % 3;
-        a.out[((size_t)m * W3 + ow) * a.ldo + kl] = a2[cl * NP + i * W2 + ow * s2 + j];
+    // im2col rows of the third conv, four consecutive k per thread and store (rows of c1 * 9 floats, 16-byte aligned: ldo % 4 == 0 is
+    // checked on the host): where k = cl * 9 + i * 3 + j reads from is looked up in a table built once per workgroup (x's space, free
+    // since the first conv) -- decoding k per element was a third of this kernel's instructions
+    constexpr int krow = c1 * 9, qrow = krow / 4;
+    const int *koff = reinterpret_cast<const int *>(x);
+    for (int e = tid; e < W3 * qrow; e += 256) {
+        const int ow = e / qrow, q = e - ow * qrow;
+        const int4 o = *reinterpret_cast<const int4 *>(koff + 4 * q);
+        const int sh = ow * s2;
+        const f32x4 v = {a2[o.x + sh], a2[o.y + sh], a2[o.z + sh], a2[o.w + sh]};
+        *reinterpret_cast<f32x4 *>(a.out + (size_t)((unsigned)(m * W3 + ow) * (unsigned)a.ldo + 4u * (unsigned)q)) = v;
     }
 }
 
@@ -556,7 +562,7 @@ static bool conv_wide_ok(const ConvEmbedArgs &a)
     const int NP = H2 * W2;
     const size_t lds = sizeof(float) * ((size_t)pad4(a.seg * a.mel) + pad4(a.ch[0] * H1 * W1) + pad4(a.ch[1] * NP));
     // the instantiated shape: 8 -> 32 channels, the second conv's positions in two waves (aprilv0 and the larger encoder: 80 mel bins, 9 frames)
-    return H2 == 3 && a.ch[0] == 8 && a.ch[1] == 32 && NP > 64 && NP <= 128 && a.seg <= a.ring_frames && lds <= 64 * 1024;
+    return H2 == 3 && a.ch[0] == 8 && a.ch[1] == 32 && NP > 64 && NP <= 128 && a.seg <= a.ring_frames && a.ldo % 4 == 0 && a.seg * a.mel >= a.ch[1] * 9 && lds <= 64 * 1024;
 }
 
 void launch_conv_embed(const ConvEmbedArgs &a, hipStream_t s)
