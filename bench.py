@@ -492,7 +492,8 @@ def main():
                     if rk:      # the same kernels' execution time under rocprofv3 (committed summary of the default invocation): no event brackets, graph replay
                         rl["kernel_time_rocprof"] = {"weighted_avg_us_per_launch": rk["weighted_avg_us_per_launch"], "tflops": rk["weighted_tflops"],
                                                      "frac": rk["frac_of_157.3"], "source": rk["source"].split(" (")[0],
-                                                     "what": "committed rocprofv3 kernel durations of the two gates kernels of an earlier round, for comparison; `achieved` / `frac` above are live and on the same clock (dispatch time stamps)"}
+                                                     "by_problems_per_launch": rk.get("by_problems_per_launch"),
+                                                     "what": "committed rocprofv3 kernel durations of the gates launches of the default invocation (profiles/, per problem count where the trace was split by grid size), for comparison; `achieved` / `frac` above are live, on the kernels' own clock"}
             except Exception:
                 pass
         rl["algorithmic_bytes_per_launch"] = int(wbytes + sbytes)

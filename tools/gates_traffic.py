@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""usage: tools/gates_traffic.py <pmc_summary.txt> <pipelined_kernel_stats.csv> <tag> [bench line of the traced run] > profiles/<tag>_gates_traffic.json
+"""usage: tools/gates_traffic.py <pmc_summary.txt> <pipelined_kernel_stats.csv> <tag> [bench line of the traced run] [trace_by_grid output of the same trace] > profiles/<tag>_gates_traffic.json
 HBM-side traffic of the fp32 gates kernels at the bench default (256 sessions, aprilv0 dims) from a committed rocprofv3 PMC pass
 (tools/pmc_pass.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, kernel-trace only), in the schema bench.py reads
 (roofline.traffic), and the same kernels' durations from the kernel trace of the default (pipelined) invocation."""
@@ -56,10 +56,24 @@ def main():
             bl = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])
             rows = float(bl["roofline"]["gates_clock"]["rows_per_launch"])
             rows_src = "rows per launch from the launch plans of the same run (%s: roofline.gates_clock)" % sys.argv[4]
+        per_class = None
+        if len(sys.argv) > 5:      # tools/trace_by_grid.py output of the same trace: the z-batched kernel holds one- AND two-problem launches; the grid's z tells them apart
+            per_class = {}
+            for line in open(sys.argv[5]):
+                m = re.match(r"(.*?)\s+grid (\S+)\s+n\s+(\d+)\s+mean\s+([\d.]+) us", line)
+                if not m or "4, 4, 1, 0, 0, 0, 1" not in m.group(1):
+                    continue
+                probs = 3 if "walk" in m.group(1) else int(m.group(2).split("x")[2])
+                per_class[str(probs)] = {"launches": int(m.group(3)), "avg_us": float(m.group(4)), "rows": 256 * probs}
+            calls = sum(v["launches"] for v in per_class.values())
+            us = sum(v["launches"] * v["avg_us"] for v in per_class.values()) / calls
+            rows = sum(v["launches"] * v["rows"] for v in per_class.values()) / calls
+            rows_src = "256 rows per problem, problems per launch from the grid sizes of the same trace (%s)" % sys.argv[5]
         tf = 2.0 * rows * (2 * D) * (4 * H) / (us * 1e-6) / 1e12
         rk = {"source": stats + " (rocprofv3 --kernel-trace --stats of the default, pipelined invocation)", "weighted_avg_us_per_launch": round(us, 2),
               "rows_per_launch": round(rows, 1), "rows_source": rows_src, "weighted_tflops": round(tf, 2), "frac_of_157.3": round(tf / 157.3, 4),
-              "per_kernel_us": {w: {"calls": c, "avg_us": round(t, 2)} for w, (c, t) in times.items()}}
+              "per_kernel_us": {w: {"calls": c, "avg_us": round(t, 2)} for w, (c, t) in times.items()},
+              "by_problems_per_launch": per_class}
     out = {"source": "%s (rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, tools/pmc_pass.sh %s_b256 --ingest lockstep --steps 4 --warmup 2 --no-sweep --no-cpu-baseline --no-config5 --steady-steps 0 --profile-steps 1)" % (pmc, tag),
            "kernel": "gemm_f32_kernel / gemm_f32_zkernel / gemm_f32_zkernel_walk <4, 4, 1, ...>: LSTM gates GEMM + BasicNorm row scale + cell, hand-scheduled K-split loop",
            "sessions_per_gpu": SESS, "rows_per_launch": round(tot_rows / tot_n, 1), "layers_per_launch": round(tot_rows / tot_n / SESS, 3),
