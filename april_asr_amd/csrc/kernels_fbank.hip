@@ -359,7 +359,16 @@ __global__ __launch_bounds__(64) void fbank_kernel(FbankArgs a)
         const float *w = a.t.mel + (size_t)m * nfft;
         float val = 0.0f;
         const int hi = a.t.mel_hi[m];
-        for (int k = a.t.mel_lo[m]; k < hi; ++k) val += pw[k] * w[k];
+        // eight taps' weights (global memory) and powers (LDS) are fetched together, then added in bin order: the sum is the same sequence
+        // of products, but a filter of thirty taps waits for four round trips instead of thirty (the loop with one load per tap was
+        // half of a frame's latency, and the frames in flight per CU are bounded by LDS)
+        for (int k0 = a.t.mel_lo[m]; k0 < hi; k0 += 8) {
+            float wv[8], pv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const int k = k0 + i < hi ? k0 + i : hi - 1; wv[i] = w[k]; pv[i] = pw[k]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (k0 + i < hi) val += pv[i] * wv[i];
+        }
         const float v = kFloor > val ? kFloor : val;
         out[m] = (float)log((double)v);
     }
