@@ -61,7 +61,7 @@ template <int MT, int NT = 4, int NWM = 2, int NWN = 2, int NS_ = TILE_STAGES> s
     static constexpr int MTW = MT / NWM, NTW = NT / NWN;                  // MFMA tiles per wave
     static constexpr int PLANE_FLOATS = BM * LDR;
     static constexpr int LDS_MAIN = (NS * STAGE_BYTES > PLANE_FLOATS * 4) ? NS * STAGE_BYTES : PLANE_FLOATS * 4;
-    static_assert(NS == 3 || NS == 4, "the tail of the K loop counts in-flight stages for 3 or 4 buffers");
+    static_assert(NS >= 3 && NS <= 8, "three to eight stage buffers (the tail of the K loop settles every outstanding stage once fewer than NS - 3 remain)");
     static_assert(PIECES % NW == 0 && MT % NWM == 0 && NT % NWN == 0, "pieces and tiles are dealt evenly to the waves");
 };
 
@@ -672,7 +672,11 @@ void launch_tile_one(const GemmArgs &g, const GemmArgs *dev_args, int n, hipStre
 #ifndef APRIL_TILE_STAGES_F16
 #define APRIL_TILE_STAGES_F16 4
 #endif
-    constexpr int NSB = (WT && NT <= 8) ? APRIL_TILE_STAGES_F16 : TILE_STAGES;      // (128 x 192 tiles: 40 KB per stage, three stages fit the LDS)
+#ifndef APRIL_TILE_STAGES_F16_MT2
+#define APRIL_TILE_STAGES_F16_MT2 4
+#endif
+    // (32-row four-wave tiles: 12 KB per stage, so two workgroups per CU could hold six each; 128 x 192 tiles: 40 KB per stage, three fit the LDS)
+    constexpr int NSB = (WT && NT <= 8) ? ((MT == 2 && NWM * NWN == 4) ? APRIL_TILE_STAGES_F16_MT2 : APRIL_TILE_STAGES_F16) : TILE_STAGES;
     using G = TileGeom<MT, NT, NWM, NWN, NSB>;
     const int zdiv = g.kz / g.zs;
     dim3 grid((unsigned)(g.N / G::BN), (unsigned)((g.M + G::BM - 1) / G::BM), (unsigned)(zdiv * std::max(1, n)));
