@@ -888,7 +888,23 @@ static bool plan_tile(int M, int N, int kz, int zcount, bool force_full, TilePla
         }
     }
     t.mt = mt; t.nt = 4; t.zs = zs; t.mode = GM_TILE;
-    if (wide_ok && N % 128 == 0 && M >= 48 && pin_mt == 0) {
+    if (always && wide_ok && zs == kz && N % 96 == 0 && pin_mt == 0) {
+        // MEASUREMENT FORM, off (APRIL_TILE_NT6=1).  fp16 projection / FFN down, all of K in the workgroup: if these launches took as long as the
+        // operand bytes of their busiest CU (tools/pp_bench probe: 32 x 64 tiles three per CU, 128 x 128 and 256 x 128 ping-pong tiles one per
+        // CU all read ~63 GB/s per CU), 96-column tiles (N = 768 = 8 x 96: 192 / 256 tiles for three / two 512-row problems, one per CU,
+        // where 64 columns give 576 / 384) would take a third off them.  Built (64 x 96 / 32 x 96, four waves), bit-identical
+        // (tests/test_gpu_f16.py), measured: configs[4] 1.75 -> 1.81 ms per step (the N = d_model class 4.55 -> 4.80 ms per ten steps).
+        static const int nt6 = env_int("APRIL_TILE_NT6", 0);
+        if (nt6) {
+            long best = -1;
+            for (int cm : {2, 4}) for (int cn : {4, 6}) {
+                const long tl = (long)(N / (16 * cn)) * ((M + 16 * cm - 1) / (16 * cm)) * zc;
+                const long cost = ((tl + 255) / 256) * (16L * cm + 16L * cn) * 1000 + (cn == 4 && cm == mt ? 0 : 1);      // (ties keep the 64-column rule)
+                if (best < 0 || cost < best) { best = cost; t.mt = cm; t.nt = cn; }
+            }
+        }
+    }
+    if (wide_ok && N % 128 == 0 && M >= 48 && pin_mt == 0 && t.nt == 4) {
         // fp16 projection / FFN down: 64 x 128 tiles, eight waves -- half the operand bytes per flop of 32 x 64; the cost model again,
         // on those tiles
         static const int wide = env_int("APRIL_TILE_WIDE", 0);      // measured: no gain (projection + FFN down 10.94 vs 11.02 ms per 10 feeds, more row-kernel work) -> off

@@ -722,6 +722,17 @@ void launch_gemm_tile(const GemmArgs &g, int mt, int nt, const GemmArgs *dev_arg
         else if (g.wt == 1 && g.epi == EPI_HR) { launch_tile_one<4, EPI_HR, 1, 8, 2, 4>(g, dev_args, n, s); ok = true; }
         else if (g.wt == 1 && g.epi == EPI_RESID_SSQ) { launch_tile_one<4, EPI_RESID_SSQ, 1, 8, 2, 4>(g, dev_args, n, s); ok = true; }
     }
+    else if (nt == 6) {                   // 64 x 96 / 32 x 96, four waves (wave tile 32 x 48 / 16 x 48): the fp16 N = d_model GEMMs where N is a multiple of 96 (plan_tile)
+        if (g.wt == 1 && mt == 4) {
+            if (g.epi == EPI_PARTIAL) { launch_tile_one<4, EPI_PARTIAL, 1, 6>(g, dev_args, n, s); ok = true; }
+            else if (g.epi == EPI_HR) { launch_tile_one<4, EPI_HR, 1, 6>(g, dev_args, n, s); ok = true; }
+            else if (g.epi == EPI_RESID_SSQ) { launch_tile_one<4, EPI_RESID_SSQ, 1, 6>(g, dev_args, n, s); ok = true; }
+        } else if (g.wt == 1 && mt == 2) {
+            if (g.epi == EPI_PARTIAL) { launch_tile_one<2, EPI_PARTIAL, 1, 6>(g, dev_args, n, s); ok = true; }
+            else if (g.epi == EPI_HR) { launch_tile_one<2, EPI_HR, 1, 6>(g, dev_args, n, s); ok = true; }
+            else if (g.epi == EPI_RESID_SSQ) { launch_tile_one<2, EPI_RESID_SSQ, 1, 6>(g, dev_args, n, s); ok = true; }
+        }
+    }
     else if (mt == 8 && nt == 12) {       // 128 x 192, eight waves (wave tile 64 x 48): 77 flop per operand byte; N a multiple of 192
         if (g.wt == 1 && g.epi == EPI_LSTM) { launch_tile_one<8, EPI_LSTM, 1, 12, 2, 4>(g, dev_args, n, s); ok = true; }
         else if (g.wt == 1 && g.epi == EPI_BIAS_DSWISH) { launch_tile_one<8, EPI_BIAS_DSWISH, 1, 12, 2, 4>(g, dev_args, n, s); ok = true; }
