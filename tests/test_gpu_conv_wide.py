@@ -30,3 +30,4 @@ def test_wide_conv_front_end_equals_grouped_form(built, tiny_model, medium_model
     b = run(path, 0, nsess, secs)
     assert a[1] == b[1] and a[1] > 0 and a[3] == 0 and b[3] == 0, (a, b)
     assert a[0] == b[0], "the two forms of the conv front end differ"
+

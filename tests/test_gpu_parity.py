@@ -88,6 +88,23 @@ def test_encoder_matches_oracle(which, request):
         assert np.abs(c2[i] - c0[:, 0, :]).max() < 1e-4
 
 
+def test_wide_conv_front_end_matches_oracle(gpu_v0, orc_v0):
+    """64 rows through the encoder entry (x handed over directly): the launch is large enough for the one-workgroup-per-chunk form
+    (>= 48 chunks); a few of its rows against the CPU oracle's encoder, tolerance as in tests/test_gpu_parity.py."""
+    d = gpu_v0.dims
+    rng = np.random.RandomState(55)
+    n = 64
+    x = rng.uniform(-16, 8, size=(n, d.seg, d.mel)).astype(np.float32)
+    h = rng.uniform(-0.5, 0.5, size=(n, d.n_layers, d.d_model)).astype(np.float32)
+    c = rng.uniform(-1, 1, size=(n, d.n_layers, d.hidden)).astype(np.float32)
+    eout, h2, c2 = gpu_v0.run_encoder(x, h, c)
+    for i in (0, 31, 63):
+        e0, h0, c0 = orc_v0.encoder(x[i:i + 1], h[i][:, None, :], c[i][:, None, :])
+        assert np.abs(eout[i] - e0.ravel()).max() < 1e-4
+        assert np.abs(h2[i] - h0[:, 0, :]).max() < 1e-4
+        assert np.abs(c2[i] - c0[:, 0, :]).max() < 1e-4
+
+
 @pytest.mark.parametrize("which", ["tiny", "v0"])
 def test_decoder_and_joiner_match_oracle(which, request):
     gm = request.getfixturevalue("gpu_" + which); om = request.getfixturevalue("orc_" + which)
